@@ -1,0 +1,82 @@
+"""Loader for the *real* reference classes (YaqiangCao/cLoops at /root/reference).
+
+Test infrastructure only.  The reference is Python-2 code that exists only in the
+build container (never on the GPU box), so everything here degrades to "absent"
+when /root/reference is missing and the tests that need it skip.
+
+Nothing of the reference is copied into this repository: cDBSCAN.py and
+blockDBSCAN.py are imported in place; cDBSCAN2.py needs the mechanical
+`.iteritems()` -> `.items()` substitution to run on Python 3, which is applied
+to the source text *in memory* and exec'd into a throw-away module object
+(SURVEY.md Appendix A).
+"""
+import os
+import sys
+import types
+
+REF_ROOT = os.environ.get("CLOOPS_REFERENCE", "/root/reference")
+
+
+def available():
+    return os.path.isfile(os.path.join(REF_ROOT, "cLoops", "cDBSCAN2.py"))
+
+
+_cache = {}
+
+
+def _load_text_module(name, relpath, subst=()):
+    with open(os.path.join(REF_ROOT, relpath)) as fh:
+        src = fh.read()
+    for a, b in subst:
+        src = src.replace(a, b)
+    mod = types.ModuleType(name)
+    exec(compile(src, relpath, "exec"), mod.__dict__)
+    return mod
+
+
+def ref_classes():
+    """-> dict(v1=class, v2=class, block=class) of the reference's own classes."""
+    if "cls" in _cache:
+        return _cache["cls"]
+    if not available():
+        raise RuntimeError("reference not present at %s" % REF_ROOT)
+    v1 = _load_text_module("_ref_cDBSCAN", "cLoops/cDBSCAN.py")
+    v2 = _load_text_module("_ref_cDBSCAN2", "cLoops/cDBSCAN2.py",
+                           subst=((".iteritems()", ".items()"),))
+    bl = _load_text_module("_ref_blockDBSCAN", "cLoops/blockDBSCAN.py")
+    _cache["cls"] = {"v1": v1.cDBSCAN, "v2": v2.cDBSCAN, "block": bl.blockDBSCAN}
+    return _cache["cls"]
+
+
+def ref_ests():
+    """The reference's cut estimator (cLoops/ests.py:36-61), imported in place."""
+    if "ests" in _cache:
+        return _cache["ests"]
+    src_path = os.path.join(REF_ROOT, "cLoops", "ests.py")
+    with open(src_path) as fh:
+        src = fh.read()
+    # ests.py does `from .utils import cFlush` (unused on this path); neutralise the
+    # relative import so the file can be exec'd standalone.
+    src = src.replace("from .utils import cFlush", "cFlush = None")
+    mod = types.ModuleType("_ref_ests")
+    exec(compile(src, src_path, "exec"), mod.__dict__)
+    _cache["ests"] = mod
+    return mod
+
+
+def ref_labels(variant, mat, eps, minPts):
+    """Run the real reference class; return its `.labels` dict (ids -> cluster id)."""
+    import numpy as np
+    cls = ref_classes()[variant]
+    db = cls(np.asarray(mat), eps, minPts)
+    return db.labels
+
+
+def labels_dict_to_array(labels, ids):
+    """dict {id: cid} -> int32 array aligned with `ids` (noise = -1)."""
+    import numpy as np
+    out = np.full(len(ids), -1, dtype=np.int32)
+    pos = {int(k): i for i, k in enumerate(ids)}
+    for k, v in labels.items():
+        out[pos[int(k)]] = int(v)
+    return out
