@@ -1,0 +1,95 @@
+"""ctypes binding of libcloops_hip.so (C ABI: include/cloops_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or no MI355X is
+visible, every entry point raises.  (The CPU oracle under oracle/ is test infrastructure
+and is never imported from here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libcloops_hip.so")
+
+CL_OK = 0
+CL_ERR_ARG = -1
+CL_ERR_HIP = -2
+CL_ERR_EMPTY = -3
+CL_ERR_DOMAIN = -4
+CL_ERR_GRID = -5
+CL_ERR_NODEVICE = -6
+
+VARIANT_CDBSCAN1 = 1
+VARIANT_CDBSCAN2 = 2
+VARIANT_BLOCK = 3
+
+# every symbol include/cloops_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "cl_last_error", "cl_device_count", "cl_chrom_create", "cl_chrom_destroy", "cl_chrom_size",
+    "cl_cluster", "cl_get_boxes", "cl_neighbor_counts", "cl_labels_device", "cl_set_profiling",
+    "cl_get_timing", "cl_version",
+]
+
+
+class ClBox(ctypes.Structure):
+    _fields_ = [("min_x", ctypes.c_int32), ("max_x", ctypes.c_int32), ("min_y", ctypes.c_int32),
+                ("max_y", ctypes.c_int32), ("count", ctypes.c_int32)]
+
+
+class ClTiming(ctypes.Structure):
+    _fields_ = [("ms_keys", ctypes.c_float), ("ms_sort", ctypes.c_float), ("ms_region", ctypes.c_float),
+                ("ms_union", ctypes.c_float), ("ms_border", ctypes.c_float), ("ms_table", ctypes.c_float),
+                ("ms_d2h", ctypes.c_float), ("ms_total", ctypes.c_float), ("n_in", ctypes.c_int64),
+                ("n_strips", ctypes.c_int64)]
+
+
+class CloopsHipError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libcloops_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it has not been built -- see cloops_amd/build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            "libcloops_hip.so is missing (%s). Build it with `python -m cloops_amd.build` "
+            "(needs hipcc); there is no CPU fallback." % SO_PATH)
+    lib = ctypes.CDLL(SO_PATH)
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    vp = ctypes.c_void_p
+    lib.cl_last_error.restype = ctypes.c_char_p
+    lib.cl_last_error.argtypes = []
+    lib.cl_device_count.restype = ctypes.c_int
+    lib.cl_version.restype = ctypes.c_int
+    lib.cl_chrom_create.restype = ctypes.c_int
+    lib.cl_chrom_create.argtypes = [ctypes.c_int, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.cl_chrom_destroy.restype = None
+    lib.cl_chrom_destroy.argtypes = [vp]
+    lib.cl_chrom_size.restype = ctypes.c_int64
+    lib.cl_chrom_size.argtypes = [vp]
+    lib.cl_cluster.restype = ctypes.c_int
+    lib.cl_cluster.argtypes = [vp, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, i32p, i32p]
+    lib.cl_get_boxes.restype = ctypes.c_int
+    lib.cl_get_boxes.argtypes = [vp, vp]
+    lib.cl_neighbor_counts.restype = ctypes.c_int
+    lib.cl_neighbor_counts.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp]
+    lib.cl_labels_device.restype = vp
+    lib.cl_labels_device.argtypes = [vp]
+    lib.cl_set_profiling.restype = None
+    lib.cl_set_profiling.argtypes = [vp, ctypes.c_int]
+    lib.cl_get_timing.restype = ctypes.c_int
+    lib.cl_get_timing.argtypes = [vp, ctypes.POINTER(ClTiming)]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != CL_OK:
+        msg = load().cl_last_error()
+        raise CloopsHipError(rc, msg.decode() if msg else "")

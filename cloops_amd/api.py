@@ -1,0 +1,120 @@
+"""Array-level host API over the C ABI: a chromosome resident in HBM and clustering runs on it.
+
+This is what the reference-shaped wrappers (cDBSCAN.py, cDBSCAN2.py, blockDBSCAN.py,
+pipe.py) and bench.py are built on.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+VARIANTS = {"v1": _lib.VARIANT_CDBSCAN1, "cDBSCAN": _lib.VARIANT_CDBSCAN1, 1: 1,
+            "v2": _lib.VARIANT_CDBSCAN2, "cDBSCAN2": _lib.VARIANT_CDBSCAN2, 2: 2,
+            "block": _lib.VARIANT_BLOCK, "blockDBSCAN": _lib.VARIANT_BLOCK, 3: 3}
+
+BOX_DTYPE = np.dtype([("min_x", "<i4"), ("max_x", "<i4"), ("min_y", "<i4"), ("max_y", "<i4"), ("count", "<i4")])
+
+
+def device_count():
+    return _lib.load().cl_device_count()
+
+
+def _as_i32(a, name):
+    a = np.asarray(a)
+    if a.ndim != 1:
+        raise ValueError("%s must be one-dimensional" % name)
+    if a.dtype.kind == "f":
+        if a.size and not np.all(a == np.floor(a)):
+            raise TypeError("%s: integer coordinates required (the reference's PET mid-points are ints)" % name)
+    elif a.dtype.kind not in "iu":
+        raise TypeError("%s: integer coordinates required" % name)
+    if a.size and (a.min() <= -(1 << 29) or a.max() >= (1 << 29)):
+        raise _lib.CloopsHipError(_lib.CL_ERR_DOMAIN, "coordinates must satisfy |X|,|Y| < 2^29")
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class ClusterResult(object):
+    """labels: int32[n] aligned to the input rows (-1 = not in the reference's `.labels`);
+    boxes: structured array indexed by cluster id (count == 0 marks an id gap of variant 1)."""
+    __slots__ = ("labels", "n_clusters", "max_label", "boxes", "timing")
+
+    def __init__(self, labels, n_clusters, max_label, boxes, timing):
+        self.labels = labels
+        self.n_clusters = n_clusters
+        self.max_label = max_label
+        self.boxes = boxes
+        self.timing = timing
+
+
+class Chromosome(object):
+    """One chromosome's PET coordinates resident in HBM (cl_chrom of include/cloops_hip.h)."""
+
+    def __init__(self, X, Y, device=0, stream=None):
+        lib = _lib.load()
+        self._lib = lib
+        self._h = ctypes.c_void_p()
+        X = _as_i32(X, "X")
+        Y = _as_i32(Y, "Y")
+        if X.shape != Y.shape:
+            raise ValueError("X and Y differ in length")
+        self.n = int(X.shape[0])
+        self.device = device
+        _lib.check(lib.cl_chrom_create(int(device), ctypes.c_void_p(stream), X.ctypes.data_as(ctypes.c_void_p),
+                                       Y.ctypes.data_as(ctypes.c_void_p), self.n, 0, ctypes.byref(self._h)))
+        self._profiling = False
+
+    @classmethod
+    def from_device_pointers(cls, x_ptr, y_ptr, n, device=0, stream=None, keepalive=None):
+        """Wrap int32 device arrays (e.g. torch tensors' data_ptr()) without copying."""
+        self = cls.__new__(cls)
+        lib = _lib.load()
+        self._lib = lib
+        self._h = ctypes.c_void_p()
+        self.n = int(n)
+        self.device = device
+        self._keepalive = keepalive
+        self._profiling = False
+        _lib.check(lib.cl_chrom_create(int(device), ctypes.c_void_p(stream), ctypes.c_void_p(x_ptr),
+                                       ctypes.c_void_p(y_ptr), self.n, 1, ctypes.byref(self._h)))
+        return self
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.cl_chrom_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_profiling(self, on=True):
+        self._profiling = bool(on)
+        self._lib.cl_set_profiling(self._h, 1 if on else 0)
+
+    def timing(self):
+        t = _lib.ClTiming()
+        _lib.check(self._lib.cl_get_timing(self._h, ctypes.byref(t)))
+        return {k: getattr(t, k) for k, _ in _lib.ClTiming._fields_}
+
+    def cluster(self, variant, eps, minPts, cut=0, want_labels=True, want_boxes=True):
+        v = VARIANTS[variant]
+        labels = np.empty(self.n, dtype=np.int32) if want_labels else None
+        nc = ctypes.c_int32(0)
+        ml = ctypes.c_int32(-1)
+        lp = labels.ctypes.data_as(ctypes.c_void_p) if want_labels else None
+        _lib.check(self._lib.cl_cluster(self._h, v, int(eps), int(minPts), int(cut), lp,
+                                        ctypes.byref(nc), ctypes.byref(ml)))
+        boxes = None
+        if want_boxes:
+            boxes = np.zeros(ml.value + 1, dtype=BOX_DTYPE)
+            if ml.value >= 0:
+                _lib.check(self._lib.cl_get_boxes(self._h, boxes.ctypes.data_as(ctypes.c_void_p)))
+        return ClusterResult(labels, nc.value, ml.value, boxes, self.timing() if self._profiling else None)
+
+    def neighbor_counts(self, eps, cut=0):
+        out = np.full(self.n, -1, dtype=np.int32)
+        _lib.check(self._lib.cl_neighbor_counts(self._h, int(eps), int(cut), out.ctypes.data_as(ctypes.c_void_p)))
+        return out

@@ -1,0 +1,1033 @@
+// cloops_hip.hip -- MI355X (gfx950 / CDNA4) implementation of the cDBSCAN hot path of
+// YaqiangCao/cLoops behind the C ABI of include/cloops_hip.h.
+//
+// Not a port: the reference (cLoops/cDBSCAN.py, cLoops/cDBSCAN2.py, cLoops/blockDBSCAN.py)
+// is sequential, visit-order dependent Python over dicts.  This file implements the
+// ORDER-FREE closed forms of those three algorithms
+// as data-parallel integer kernels, and reproduces the reference's cluster ids bit-exactly.
+//
+// Data layout (variants 1 and 2).  The city-block ball |dX|+|dY| <= eps is the square
+// max(|da|,|dv|) <= eps in the rotated coordinates a = Y-X, v = X+Y (cDBSCAN2.py:67-68).
+// PETs are radix-sorted by the 64-bit key (strip(a) << 32 | v) where strip(a) = a / eps:
+// a *strip* is an eps-wide band of `a`, internally ordered by v.  For a query point in
+// strip s, every neighbour lies in strips s-1, s, s+1, and inside each strip in one
+// CONTIGUOUS v-window [v-eps, v+eps] -- three coalesced candidate ranges per point instead
+// of nine cells; inside the own strip the `a` test is implied, so its contribution to the
+// neighbour count is a pure index difference.  A dense table strip_start[] (one int per
+// strip) replaces every hash/dict lookup of the reference.
+//
+// Kernels (names as in DESIGN.md):
+//   K0 k_make_keys      cut filter (pipe.py:59-63) + sort keys
+//   K1 rocPRIM radix sort, k_gather_sorted, k_strip_table
+//   K2 k_region_count   neighbour counts -> core flags           (the roofline kernel)
+//   K3 k_union_cores    lock-free union-find over core-core edges; k_flatten
+//   K4 k_border         border ownership per variant rule; v2 release fix-up
+//   K5 k_rank_flags / scan / k_final_labels   reference cluster ids + cluster table
+//   K6 block variant    cell table, links, cell-level union (blockDBSCAN.py)
+#include <cstring>
+#include <cstdlib>
+#include <cstdio>
+#include <climits>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/cloops_hip.h"
+
+#define CL_VERSION_NUM 100   // 0.1.0
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char* what, const char* detail = nullptr)
+{
+    g_err = what;
+    if (detail) { g_err += ": "; g_err += detail; }
+    return code;
+}
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) return fail(CL_ERR_HIP, #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char* cl_last_error(void) { return g_err.c_str(); }
+extern "C" int cl_version(void) { return CL_VERSION_NUM; }
+
+extern "C" int cl_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+#define TPB 256
+
+struct GridParams {
+    int eps;      // cell / strip width (cDBSCAN.py:29, cDBSCAN2.py:30: cw = eps)
+    int minPts;
+    int cut;      // pipe.py:59-63 pre-filter, 0 = off
+    int A0;       // offset subtracted from a = Y - X  (0 for variant 2: absolute cells)
+    int V0;       // offset subtracted from v = X + Y  (0 for variant 2)
+    int s0;       // strip index of the first table row
+    int S;        // number of strips in the table; key strip S marks filtered rows
+    int variant;
+};
+
+__device__ __forceinline__ int sat_add(int a, int b)
+{
+    long long s = (long long)a + (long long)b;
+    return s > INT_MAX ? INT_MAX : (s < INT_MIN ? INT_MIN : (int)s);
+}
+
+// first index in [lo,hi) with sv[idx] >= val
+__device__ __forceinline__ int lower_bound_i(const int* __restrict__ sv, int lo, int hi, int val)
+{
+    while (lo < hi) {
+        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+        if (sv[mid] < val) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// first index in [lo,hi) with sv[idx] > val
+__device__ __forceinline__ int upper_bound_i(const int* __restrict__ sv, int lo, int hi, int val)
+{
+    while (lo < hi) {
+        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+        if (sv[mid] <= val) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// Galloping variants anchored at position i (sv[i] is known to satisfy the predicate):
+// windows are short (tens of PETs), so doubling from i beats a full-strip bisect.
+__device__ __forceinline__ int gallop_left(const int* __restrict__ sv, int b, int i, int val)
+{   // first idx in [b,i] with sv[idx] >= val, given sv[i] >= val
+    int step = 1, hi = i, lo = i - 1;
+    while (lo >= b && sv[lo] >= val) { hi = lo; lo -= step; step <<= 1; }
+    if (lo < b) lo = b - 1;
+    // answer in (lo, hi]
+    return lower_bound_i(sv, lo + 1, hi, val);
+}
+__device__ __forceinline__ int gallop_right(const int* __restrict__ sv, int i, int e, int val)
+{   // first idx in (i,e] with sv[idx] > val (or e), given sv[i] <= val
+    int step = 1, lo = i, hi = i + 1;
+    while (hi < e && sv[hi] <= val) { lo = hi; hi += step; step <<= 1; }
+    if (hi > e) hi = e;
+    // answer in (lo, hi]
+    return upper_bound_i(sv, lo + 1, hi, val);
+}
+
+__device__ __forceinline__ int strip_of(const GridParams& g, int arel) { return arel / g.eps - g.s0; }
+
+// Visit every j != i with max(|a_j-a_i|, |v_j-v_i|) <= eps.  `which` selects the strips:
+// bit0 = strip s-1, bit1 = own strip (both directions), bit2 = strip s+1.
+template <typename F>
+__device__ __forceinline__ void for_each_neighbor(const GridParams& g, const int* __restrict__ sv,
+                                                  const int* __restrict__ sa,
+                                                  const int* __restrict__ strip_start, int i, int which, F&& f)
+{
+    const int vi = sv[i], ai = sa[i];
+    const int s = strip_of(g, ai);
+    const int vlo = sat_add(vi, -g.eps), vhi = sat_add(vi, g.eps);
+    if (which & 2) {
+        const int b = strip_start[s], e = strip_start[s + 1];
+        for (int j = i - 1; j >= b && sv[j] >= vlo; --j) f(j);
+        for (int j = i + 1; j < e && sv[j] <= vhi; ++j) f(j);
+    }
+#pragma unroll
+    for (int d = -1; d <= 1; d += 2) {
+        if (!(which & (d < 0 ? 1 : 4))) continue;
+        const int t = s + d;
+        if (t < 0 || t >= g.S) continue;
+        const int b = strip_start[t], e = strip_start[t + 1];
+        if (b == e) continue;
+        int j = lower_bound_i(sv, b, e, vlo);
+        for (; j < e; ++j) {
+            const int vj = sv[j];
+            if (vj > vhi) break;
+            const int da = sa[j] - ai;
+            if ((da < 0 ? -da : da) <= g.eps) f(j);
+        }
+    }
+}
+
+// ---- lock-free union-find (roots = smallest sorted index of the component) ---------------
+// parent[] is read with agent-scope relaxed atomics: per-CU L1s are not coherent and the
+// per-XCD L2s are not coherent with each other, plain loads could spin on a stale root.
+__device__ __forceinline__ int uf_load(int* parent, int i)
+{
+    return __hip_atomic_load(parent + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int uf_find(int* parent, int x)
+{
+    for (;;) {
+        int p = uf_load(parent, x);
+        if (p == x) return x;
+        int gp = uf_load(parent, p);
+        if (gp == p) return p;
+        __hip_atomic_store(parent + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // path halving
+        x = gp;
+    }
+}
+__device__ __forceinline__ void uf_unite(int* parent, int a, int b)
+{
+    for (;;) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        int old = atomicCAS(parent + a, a, b);      // hook the larger root under the smaller
+        if (old == a) return;
+        a = old;                                    // lost the race: continue from the new parent
+    }
+}
+__device__ __forceinline__ int uf_find_ro(const int* __restrict__ parent, int x)
+{   // after the union kernel has completed (kernel boundary = coherent), plain loads
+    int p = parent[x];
+    while (p != x) { x = p; p = parent[x]; }
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------
+// chromosome statistics (once per upload)
+// ------------------------------------------------------------------------------------------
+struct Stats { int amin, amax, vmin, vmax, xmin, xmax, ymin, ymax; };
+
+__global__ void k_stats(const int* __restrict__ X, const int* __restrict__ Y, long long n, Stats* out)
+{
+    int amin = INT_MAX, amax = INT_MIN, vmin = INT_MAX, vmax = INT_MIN;
+    int xmin = INT_MAX, xmax = INT_MIN, ymin = INT_MAX, ymax = INT_MIN;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        int x = X[i], y = Y[i];
+        xmin = min(xmin, x); xmax = max(xmax, x); ymin = min(ymin, y); ymax = max(ymax, y);
+        // |x|,|y| < 2^29 is validated from xmin..ymax afterwards; clamp here to stay defined
+        long long a = (long long)y - x, v = (long long)y + x;
+        int ai = (int)max(min(a, (long long)INT_MAX), (long long)INT_MIN);
+        int vi = (int)max(min(v, (long long)INT_MAX), (long long)INT_MIN);
+        amin = min(amin, ai); amax = max(amax, ai); vmin = min(vmin, vi); vmax = max(vmax, vi);
+    }
+    // wave reduction, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        amin = min(amin, __shfl_down(amin, off)); amax = max(amax, __shfl_down(amax, off));
+        vmin = min(vmin, __shfl_down(vmin, off)); vmax = max(vmax, __shfl_down(vmax, off));
+        xmin = min(xmin, __shfl_down(xmin, off)); xmax = max(xmax, __shfl_down(xmax, off));
+        ymin = min(ymin, __shfl_down(ymin, off)); ymax = max(ymax, __shfl_down(ymax, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&out->amin, amin); atomicMax(&out->amax, amax);
+        atomicMin(&out->vmin, vmin); atomicMax(&out->vmax, vmax);
+        atomicMin(&out->xmin, xmin); atomicMax(&out->xmax, xmax);
+        atomicMin(&out->ymin, ymin); atomicMax(&out->ymax, ymax);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K0: keys
+// ------------------------------------------------------------------------------------------
+__global__ void k_make_keys(const int* __restrict__ X, const int* __restrict__ Y, int n, GridParams g,
+                            u64* __restrict__ keys, u32* __restrict__ vals)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int x = X[r], y = Y[r];
+    int a = y - x;
+    bool valid = (g.cut <= 0) || (a >= g.cut);            // pipe.py:59-62  d >= cut
+    int arel = a - g.A0;
+    u32 vrel = (u32)(x + y - g.V0);
+    u64 key = valid ? (((u64)(u32)strip_of(g, arel) << 32) | vrel) : ((u64)(u32)g.S << 32);
+    keys[r] = key;
+    vals[r] = (u32)r;
+}
+
+// K1b: sorted coordinates (gather through the sorted row ids)
+__global__ void k_gather_sorted(const int* __restrict__ X, const int* __restrict__ Y, int n, GridParams g,
+                                const u64* __restrict__ skeys, const u32* __restrict__ srow,
+                                int* __restrict__ sv, int* __restrict__ sa)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 k = skeys[i];
+    if ((int)(k >> 32) >= g.S) { sv[i] = INT_MAX; sa[i] = 0; return; }
+    u32 r = srow[i];
+    sv[i] = (int)(u32)(k & 0xffffffffu);
+    sa[i] = Y[r] - X[r] - g.A0;
+}
+
+// K1c: strip_start[t] = first sorted index whose strip >= t, t = 0..S+1
+// (strip_start[S] = M = number of rows that entered DBSCAN, strip_start[S+1] = n)
+__global__ void k_strip_table(const u64* __restrict__ skeys, int n, int S, int* __restrict__ strip_start)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > S + 1) return;
+    if (t == S + 1) { strip_start[t] = n; return; }
+    u64 target = (u64)(u32)t << 32;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+        if (skeys[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    strip_start[t] = lo;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: region query  (cDBSCAN.py:186-205 regionQuery / cDBSCAN2.py:304-334 neighbour count)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB)
+k_region_count(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
+               const int* __restrict__ strip_start, int* __restrict__ cnt)
+{
+    const int M = strip_start[g.S];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int vi = sv[i], ai = sa[i];
+    const int s = strip_of(g, ai);
+    const int vlo = sat_add(vi, -g.eps), vhi = sat_add(vi, g.eps);
+    // own strip: every PET of the v-window is a neighbour (|da| < eps inside a strip)
+    const int b = strip_start[s], e = strip_start[s + 1];
+    int c = gallop_right(sv, i, e, vhi) - gallop_left(sv, b, i, vlo);
+#pragma unroll
+    for (int d = -1; d <= 1; d += 2) {
+        const int t = s + d;
+        if (t < 0 || t >= g.S) continue;
+        const int tb = strip_start[t], te = strip_start[t + 1];
+        if (tb == te) continue;
+        int j = lower_bound_i(sv, tb, te, vlo);
+        for (; j < te; ++j) {
+            const int vj = sv[j];
+            if (vj > vhi) break;
+            const int da = sa[j] - ai;
+            c += ((da < 0 ? -da : da) <= g.eps) ? 1 : 0;
+        }
+    }
+    cnt[i] = c;
+}
+
+// scatter counts back to input-row order (cl_neighbor_counts)
+__global__ void k_scatter_counts(const int* __restrict__ strip_start, int S, const u32* __restrict__ srow,
+                                 const int* __restrict__ cnt, int* __restrict__ out)
+{
+    const int M = strip_start[S];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    out[srow[i]] = cnt[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// per-run initialisation of the per-point / per-root arrays
+// ------------------------------------------------------------------------------------------
+__global__ void k_init_arrays(int n, int* __restrict__ parent, int* __restrict__ compkey, int* __restrict__ ncore,
+                              int* __restrict__ bsize, int* __restrict__ cellfirst, int* __restrict__ flag,
+                              int* __restrict__ state, int* __restrict__ counters)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 16 && counters) counters[i] = 0;
+    if (i > n) return;
+    flag[i] = 0;                       // n+1 entries
+    if (i == n) return;
+    parent[i] = i;
+    compkey[i] = INT_MAX;
+    ncore[i] = 0;
+    bsize[i] = 0;
+    cellfirst[i] = INT_MAX;
+    state[i] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// v2: cellfirst(cell) = smallest input row of ANY point of the rotated cell
+// (cDBSCAN2.py:69-71,117: start cells are visited in dict insertion order)
+// ------------------------------------------------------------------------------------------
+__global__ void k_cell_heads(const u64* __restrict__ skeys, const int* __restrict__ strip_start, GridParams g,
+                             int* __restrict__ headidx)
+{
+    const int M = strip_start[g.S];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    bool head = true;
+    if (i > 0) {
+        u64 k = skeys[i], kp = skeys[i - 1];
+        // variant 2: V0 == 0 so the low word IS v = X + Y; cell column = trunc(v / eps)
+        head = ((k >> 32) != (kp >> 32)) || ((u32)(k & 0xffffffffu) / (u32)g.eps != (u32)(kp & 0xffffffffu) / (u32)g.eps);
+    }
+    headidx[i] = head ? i : 0;
+}
+__global__ void k_cell_first(const int* __restrict__ strip_start, int S, const int* __restrict__ head,
+                             const u32* __restrict__ srow, int* __restrict__ cellfirst)
+{
+    const int M = strip_start[S];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    atomicMin(&cellfirst[head[i]], (int)srow[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: union of core points
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB)
+k_union_cores(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
+              const int* __restrict__ strip_start, const int* __restrict__ cnt, int* parent)
+{
+    const int M = strip_start[g.S];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    if (cnt[i] < g.minPts) return;
+    const int vi = sv[i], ai = sa[i];
+    const int s = strip_of(g, ai);
+    const int vlo = sat_add(vi, -g.eps), vhi = sat_add(vi, g.eps);
+    // own strip: cores within eps in v form a chain, linking to the previous core suffices
+    const int b = strip_start[s];
+    for (int j = i - 1; j >= b && sv[j] >= vlo; --j)
+        if (cnt[j] >= g.minPts) { uf_unite(parent, i, j); break; }
+    // strip s-1 (pairs with strip s+1 are united by the other endpoint)
+    const int t = s - 1;
+    if (t >= 0) {
+        const int tb = strip_start[t], te = strip_start[t + 1];
+        int j = lower_bound_i(sv, tb, te, vlo);
+        for (; j < te; ++j) {
+            const int vj = sv[j];
+            if (vj > vhi) break;
+            const int da = sa[j] - ai;
+            if ((da < 0 ? -da : da) <= g.eps && cnt[j] >= g.minPts) uf_unite(parent, i, j);
+        }
+    }
+}
+
+// K3b: root per core point, component keys and core counts.
+//   variant 1: key = smallest input row of a core point = the component's start point
+//              (cDBSCAN.py:134-137)
+//   variant 2: key = smallest cellfirst over the cells holding its core points
+//              (cDBSCAN2.py:117-140)
+__global__ void k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ cnt,
+                          const int* __restrict__ parent, const u32* __restrict__ srow,
+                          const int* __restrict__ head, const int* __restrict__ cellfirst,
+                          int* __restrict__ root, int* __restrict__ compkey, int* __restrict__ ncore)
+{
+    const int M = strip_start[g.S];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    if (cnt[i] < g.minPts) { root[i] = -1; return; }
+    int r = uf_find_ro(parent, i);
+    root[i] = r;
+    int key = (g.variant == CL_VARIANT_CDBSCAN2) ? cellfirst[head[i]] : (int)srow[i];
+    atomicMin(&compkey[r], key);
+    atomicAdd(&ncore[r], 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: border points
+//   variant 2 (R2): the lowest-key adjacent component (first come, cDBSCAN2.py:130,212,352)
+//   variant 1 (R1): max over adjacent components whose START POINT is a neighbour
+//                   (unconditional overwrite, cDBSCAN.py:172-173), else the lowest-key
+//                   adjacent component (first come, cDBSCAN.py:179-182)
+// owner[i] = root of the owning component (cores: their own root), -1 = noise
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB)
+k_border(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
+         const int* __restrict__ strip_start, const int* __restrict__ root, const int* __restrict__ compkey,
+         const u32* __restrict__ srow, int* __restrict__ owner, int* __restrict__ bsize)
+{
+    const int M = strip_start[g.S];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    int ri = root[i];
+    if (ri >= 0) { owner[i] = ri; return; }
+    int bestk = INT_MAX, best = -1, tk = -1, tbest = -1;
+    const bool v1 = g.variant == CL_VARIANT_CDBSCAN1;
+    for_each_neighbor(g, sv, sa, strip_start, i, 7, [&](int j) {
+        int r = root[j];
+        if (r < 0) return;
+        int k = compkey[r];
+        if (k < bestk) { bestk = k; best = r; }
+        if (v1 && (int)srow[j] == k && k > tk) { tk = k; tbest = r; }
+    });
+    int o = (v1 && tbest >= 0) ? tbest : best;
+    owner[i] = o;
+    if (o >= 0) atomicAdd(&bsize[o], 1);
+}
+
+// ---- variant 2 release rule (cDBSCAN2.py:180-183) ------------------------------------------
+// A component is surely live if cores + first-come borders >= minPts (its share can only grow
+// when lower components die).  The rest form the small uncertain set U, resolved in key order.
+enum { ST_LIVE = 0, ST_DEAD = 1, ST_UNKNOWN = 2 };
+enum { CTR_NU = 0, CTR_NREC = 1, CTR_OVERFLOW = 2 };
+
+__global__ void k_mark_uncertain(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ root,
+                                 const int* __restrict__ ncore, const int* __restrict__ bsize,
+                                 int* __restrict__ state, int* __restrict__ ulist, int* __restrict__ counters)
+{
+    const int M = strip_start[g.S];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    if (root[i] != i) return;
+    if (ncore[i] + bsize[i] < g.minPts) {
+        state[i] = ST_UNKNOWN;
+        int k = atomicAdd(&counters[CTR_NU], 1);
+        ulist[k] = i;
+    }
+}
+
+// records: for every border point adjacent to an uncertain component, its (<= 4, geometric
+// bound) distinct adjacent components in ascending key order
+struct Rec { int pt; int r[4]; };
+
+__global__ void __launch_bounds__(TPB)
+k_emit_records(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
+               const int* __restrict__ strip_start, const int* __restrict__ root, const int* __restrict__ compkey,
+               const int* __restrict__ state, const int* __restrict__ owner, Rec* __restrict__ recs, int rec_cap,
+               int* __restrict__ counters)
+{
+    if (counters[CTR_NU] == 0) return;
+    const int M = strip_start[g.S];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    if (root[i] >= 0 || owner[i] < 0) return;
+    int rr[4] = {-1, -1, -1, -1};
+    int kk[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
+    int nr = 0;
+    bool any_u = false, overflow = false;
+    for_each_neighbor(g, sv, sa, strip_start, i, 7, [&](int j) {
+        int r = root[j];
+        if (r < 0) return;
+        for (int q = 0; q < 4; ++q) if (rr[q] == r) return;
+        if (nr == 4) { overflow = true; return; }
+        int k = compkey[r];
+        int q = nr++;
+        while (q > 0 && kk[q - 1] > k) { kk[q] = kk[q - 1]; rr[q] = rr[q - 1]; --q; }
+        kk[q] = k; rr[q] = r;
+        if (state[r] == ST_UNKNOWN) any_u = true;
+    });
+    if (overflow) atomicExch(&counters[CTR_OVERFLOW], 1);
+    if (!any_u) return;
+    int idx = atomicAdd(&counters[CTR_NREC], 1);
+    if (idx >= rec_cap) { atomicExch(&counters[CTR_OVERFLOW], 2); return; }
+    Rec rec; rec.pt = i;
+    for (int q = 0; q < 4; ++q) rec.r[q] = rr[q];
+    recs[idx] = rec;
+}
+
+// one workgroup; rounds until every uncertain component is decided.  lo = borders surely
+// available (every lower-key adjacent component dead), hi = possibly available (none live).
+__global__ void __launch_bounds__(1024)
+k_resolve_release(int minPts, const int* __restrict__ ncore, int* state, const int* __restrict__ ulist,
+                  const Rec* __restrict__ recs, int* lo, int* hi, const int* __restrict__ counters)
+{
+    const int nU = counters[CTR_NU];
+    if (nU == 0) return;
+    const int nrec = counters[CTR_NREC];
+    __shared__ int remaining;
+    for (;;) {
+        for (int u = threadIdx.x; u < nU; u += blockDim.x) { int c = ulist[u]; lo[c] = 0; hi[c] = 0; }
+        if (threadIdx.x == 0) remaining = 0;
+        __syncthreads();
+        for (int q = threadIdx.x; q < nrec; q += blockDim.x) {
+            const Rec rec = recs[q];
+            bool allDead = true, noneLive = true;
+            for (int k = 0; k < 4; ++k) {
+                int c = rec.r[k];
+                if (c < 0) break;
+                int st = state[c];
+                if (st == ST_UNKNOWN) {
+                    if (allDead) atomicAdd(&lo[c], 1);
+                    if (noneLive) atomicAdd(&hi[c], 1);
+                }
+                if (st != ST_DEAD) allDead = false;
+                if (st == ST_LIVE) noneLive = false;
+            }
+        }
+        __syncthreads();
+        for (int u = threadIdx.x; u < nU; u += blockDim.x) {
+            int c = ulist[u];
+            if (state[c] != ST_UNKNOWN) continue;
+            if (ncore[c] + lo[c] >= minPts) state[c] = ST_LIVE;
+            else if (ncore[c] + hi[c] < minPts) state[c] = ST_DEAD;
+            else atomicAdd(&remaining, 1);
+        }
+        __syncthreads();
+        if (remaining == 0) break;
+        __syncthreads();
+    }
+}
+
+__global__ void k_apply_records(const Rec* __restrict__ recs, const int* __restrict__ state,
+                                int* __restrict__ owner, const int* __restrict__ counters)
+{
+    const int nrec = counters[CTR_NREC];
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nrec) return;
+    const Rec rec = recs[q];
+    int o = -1;
+    for (int k = 0; k < 4; ++k) {
+        int c = rec.r[k];
+        if (c < 0) break;
+        if (state[c] != ST_DEAD) { o = c; break; }
+    }
+    owner[rec.pt] = o;
+}
+
+// ------------------------------------------------------------------------------------------
+// K5: cluster ids = rank of the component key among the kept components; labels; table
+// ------------------------------------------------------------------------------------------
+__global__ void k_rank_flags(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ root,
+                             const int* __restrict__ compkey, const int* __restrict__ state, int* __restrict__ flag)
+{
+    const int M = strip_start[g.S];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    if (root[i] != i) return;
+    // variant 2: released components do not consume an id (cDBSCAN2.py:183-185);
+    // variant 1: every component consumes one, dropped clusters leave gaps (cDBSCAN.py:136-152)
+    if (g.variant == CL_VARIANT_CDBSCAN2 && state[i] == ST_DEAD) return;
+    flag[compkey[i]] = 1;
+}
+
+struct Table { int* count; int* minx; int* maxx; int* miny; int* maxy; };
+
+__global__ void k_init_table(Table t, const int* __restrict__ rankscan, int n)
+{
+    const int K = rankscan[n];      // total number of ids handed out
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    t.count[k] = 0; t.minx[k] = INT_MAX; t.maxx[k] = INT_MIN; t.miny[k] = INT_MAX; t.maxy[k] = INT_MIN;
+}
+
+__global__ void __launch_bounds__(TPB)
+k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ sv,
+               const int* __restrict__ sa, const u32* __restrict__ srow, const int* __restrict__ owner,
+               const int* __restrict__ compkey, const int* __restrict__ ncore, const int* __restrict__ bsize,
+               const int* __restrict__ state, const int* __restrict__ rankscan, int* __restrict__ labels, Table t)
+{
+    const int M = strip_start[g.S];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    int o = owner[i];
+    int lab = -1;
+    if (o >= 0) {
+        bool keep = (g.variant == CL_VARIANT_CDBSCAN2) ? (state[o] != ST_DEAD)
+                                                       : (ncore[o] + bsize[o] >= g.minPts);   // cDBSCAN.py:149-152
+        if (keep) lab = rankscan[compkey[o]];
+    }
+    labels[srow[i]] = lab;
+    if (lab >= 0) {
+        // X = (v - a) / 2, Y = (v + a) / 2 exactly (v and a have equal parity)
+        int a = sa[i] + g.A0, v = sv[i] + g.V0;
+        int x = (v - a) / 2, y = (v + a) / 2;
+        atomicAdd(&t.count[lab], 1);
+        atomicMin(&t.minx[lab], x); atomicMax(&t.maxx[lab], x);
+        atomicMin(&t.miny[lab], y); atomicMax(&t.maxy[lab], y);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return CL_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        size_t want = need + need / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "hipMalloc", hipGetErrorString(e));
+        bytes = want;
+        return CL_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <typename T> T* as() { return (T*)p; }
+};
+
+struct cl_chrom {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t n = 0;
+    int *d_x = nullptr, *d_y = nullptr;
+    bool own_xy = false;
+    Stats st{};
+    // workspace
+    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, scan_tmp;
+    DevBuf sv, sa, strip, cnt, parent, root, head, headidx, cellfirst, compkey, ncore, bsize, owner, state;
+    DevBuf flag, rankscan, labels, table, ulist, lo, hi, recs, counters;
+    int* h_pinned = nullptr;          // small pinned staging (counters, K)
+    // last result
+    int last_K = 0;                   // ids handed out (max_label + 1 upper bound)
+    bool have_result = false;
+    // profiling
+    bool profiling = false;
+    cl_timing timing{};
+    hipEvent_t ev[10]{};
+    bool ev_ready = false;
+};
+
+static void free_chrom(cl_chrom* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->sv, &c->sa,
+                      &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
+                      &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->labels, &c->table,
+                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters};
+    for (DevBuf* b : bufs) b->release();
+    if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->ev_ready) for (auto& e : c->ev) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" void cl_chrom_destroy(cl_chrom* c) { free_chrom(c); }
+extern "C" int64_t cl_chrom_size(const cl_chrom* c) { return c ? c->n : -1; }
+extern "C" void cl_set_profiling(cl_chrom* c, int enabled) { if (c) c->profiling = enabled != 0; }
+extern "C" int cl_get_timing(const cl_chrom* c, cl_timing* out)
+{
+    if (!c || !out) return fail(CL_ERR_ARG, "cl_get_timing: null argument");
+    *out = c->timing;
+    return CL_OK;
+}
+extern "C" const int32_t* cl_labels_device(const cl_chrom* c) { return c ? (const int32_t*)c->labels.p : nullptr; }
+
+static inline int nblocks(long long n, int tpb = TPB) { return (int)((n + tpb - 1) / tpb); }
+
+extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const int32_t* y, int64_t n,
+                               int on_device, cl_chrom** out)
+{
+    if (!out) return fail(CL_ERR_ARG, "cl_chrom_create: out is null");
+    *out = nullptr;
+    if (n < 0 || n > (1LL << 30)) return fail(CL_ERR_ARG, "cl_chrom_create: n out of range (0 .. 2^30)");
+    if (n > 0 && (!x || !y)) return fail(CL_ERR_ARG, "cl_chrom_create: null coordinates");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(CL_ERR_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(CL_ERR_ARG, "cl_chrom_create: bad device index");
+    HIP_TRY(hipSetDevice(device));
+    cl_chrom* c = new cl_chrom();
+    c->device = device;
+    c->n = n;
+    int rc = CL_OK;
+    do {
+        if (stream) c->stream = (hipStream_t)stream;
+        else {
+            if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipStreamCreate"); break; }
+            c->own_stream = true;
+        }
+        if (hipHostMalloc((void**)&c->h_pinned, 4096, hipHostMallocDefault) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipHostMalloc"); break; }
+        if (on_device) { c->d_x = (int*)x; c->d_y = (int*)y; }
+        else if (n > 0) {
+            c->own_xy = true;
+            if (hipMalloc((void**)&c->d_x, n * 4) != hipSuccess || hipMalloc((void**)&c->d_y, n * 4) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipMalloc X/Y"); break; }
+            if (hipMemcpyAsync(c->d_x, x, n * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                hipMemcpyAsync(c->d_y, y, n * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipMemcpy X/Y"); break; }
+        }
+        if (n > 0) {
+            if ((rc = c->counters.ensure(256))) break;
+            Stats init = {INT_MAX, INT_MIN, INT_MAX, INT_MIN, INT_MAX, INT_MIN, INT_MAX, INT_MIN};
+            Stats* hs = (Stats*)c->h_pinned;
+            *hs = init;
+            if (hipMemcpyAsync(c->counters.p, hs, sizeof(Stats), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(CL_ERR_HIP, "stats init"); break; }
+            int grid = std::min(nblocks(n), 2048);
+            hipLaunchKernelGGL(k_stats, dim3(grid), dim3(TPB), 0, c->stream, c->d_x, c->d_y, (long long)n, (Stats*)c->counters.p);
+            if (hipMemcpyAsync(hs, c->counters.p, sizeof(Stats), hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(CL_ERR_HIP, "stats readback"); break; }
+            hipError_t e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { rc = fail(CL_ERR_HIP, "stats sync", hipGetErrorString(e)); break; }
+            c->st = *hs;
+            const int LIM = 1 << 29;
+            if (c->st.xmin <= -LIM || c->st.xmax >= LIM || c->st.ymin <= -LIM || c->st.ymax >= LIM) {
+                rc = fail(CL_ERR_DOMAIN, "coordinates must satisfy |X|,|Y| < 2^29");
+                break;
+            }
+        }
+    } while (0);
+    if (rc != CL_OK) { std::string keep = g_err; free_chrom(c); g_err = keep; return rc; }
+    *out = c;
+    return CL_OK;
+}
+
+// workspace for a run over n rows
+static int ensure_workspace(cl_chrom* c, int S)
+{
+    const size_t n = (size_t)c->n;
+    int rc;
+#define ENS(buf, bytes) if ((rc = c->buf.ensure(bytes))) return rc
+    ENS(keys_in, n * 8); ENS(keys_out, n * 8); ENS(vals_in, n * 4); ENS(vals_out, n * 4);
+    ENS(sv, n * 4); ENS(sa, n * 4); ENS(strip, ((size_t)S + 2) * 4); ENS(cnt, n * 4);
+    ENS(parent, n * 4); ENS(root, n * 4); ENS(head, n * 4); ENS(headidx, n * 4); ENS(cellfirst, n * 4);
+    ENS(compkey, n * 4); ENS(ncore, n * 4); ENS(bsize, n * 4); ENS(owner, n * 4); ENS(state, n * 4);
+    ENS(flag, (n + 1) * 4); ENS(rankscan, (n + 1) * 4); ENS(labels, n * 4); ENS(table, (n + 1) * 5 * 4);
+    ENS(ulist, n * 4); ENS(lo, n * 4); ENS(hi, n * 4); ENS(recs, n * sizeof(Rec)); ENS(counters, 256);
+#undef ENS
+    // rocPRIM temporary storage
+    size_t sort_bytes = 0, scan_bytes = 0, scan2 = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr,
+                                             n, 0, 64, c->stream);
+    if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs size query", hipGetErrorString(e));
+    e = rocprim::inclusive_scan(nullptr, scan_bytes, (int*)nullptr, (int*)nullptr, n, rocprim::maximum<int>(), c->stream);
+    if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan size query", hipGetErrorString(e));
+    e = rocprim::exclusive_scan(nullptr, scan2, (int*)nullptr, (int*)nullptr, 0, n + 1, rocprim::plus<int>(), c->stream);
+    if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan size query", hipGetErrorString(e));
+    if ((rc = c->sort_tmp.ensure(std::max<size_t>(sort_bytes, 16)))) return rc;
+    if ((rc = c->scan_tmp.ensure(std::max<size_t>(std::max(scan_bytes, scan2), 16)))) return rc;
+    return CL_OK;
+}
+
+static int bits_for(unsigned v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
+
+// Build GridParams for the rotated-strip layout (variants 1 and 2)
+static int make_grid(cl_chrom* c, int variant, int eps, int minPts, int cut, GridParams* g)
+{
+    g->eps = eps; g->minPts = minPts; g->cut = cut; g->variant = variant;
+    if (variant == CL_VARIANT_CDBSCAN2) {
+        // absolute rotated cells (cDBSCAN2.py:67-70); exact only for 0 <= X <= Y
+        if (c->st.amin < 0 || c->st.xmin < 0) return fail(CL_ERR_DOMAIN, "variant 2 (cDBSCAN2) needs 0 <= X <= Y for every PET");
+        g->A0 = 0; g->V0 = 0;
+    } else {
+        g->A0 = c->st.amin; g->V0 = c->st.vmin;
+    }
+    long long lo = ((long long)c->st.amin - g->A0) / eps;
+    long long hi = ((long long)c->st.amax - g->A0) / eps;
+    long long S = hi - lo + 1;
+    if (S > (1LL << 28)) return fail(CL_ERR_GRID, "eps too small for the coordinate extent (strip table > 2^28 rows)");
+    g->s0 = (int)lo; g->S = (int)S;
+    return CL_OK;
+}
+
+#define LAUNCH(kernel, nthreads, ...) \
+    hipLaunchKernelGGL(kernel, dim3(nblocks(nthreads)), dim3(TPB), 0, c->stream, __VA_ARGS__)
+
+static void ev_record(cl_chrom* c, int k)
+{
+    if (c->profiling) (void)hipEventRecord(c->ev[k], c->stream);
+}
+
+// K0 + K1 + K2: keys, sort, strip table, neighbour counts.  Leaves sorted arrays in the workspace.
+static int run_sort_and_count(cl_chrom* c, const GridParams& g)
+{
+    const int n = (int)c->n;
+    ev_record(c, 0);
+    LAUNCH(k_make_keys, n, c->d_x, c->d_y, n, g, c->keys_in.as<u64>(), c->vals_in.as<u32>());
+    ev_record(c, 1);
+    size_t tmp_bytes = c->sort_tmp.bytes;
+    int end_bit = 32 + std::max(1, bits_for((unsigned)g.S));
+    hipError_t e = rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->keys_in.as<u64>(), c->keys_out.as<u64>(),
+                                             c->vals_in.as<u32>(), c->vals_out.as<u32>(), (size_t)n, 0, end_bit, c->stream);
+    if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs", hipGetErrorString(e));
+    LAUNCH(k_gather_sorted, n, c->d_x, c->d_y, n, g, c->keys_out.as<u64>(), c->vals_out.as<u32>(), c->sv.as<int>(), c->sa.as<int>());
+    LAUNCH(k_strip_table, g.S + 2, c->keys_out.as<u64>(), n, g.S, c->strip.as<int>());
+    ev_record(c, 2);
+    LAUNCH(k_region_count, n, g, c->sv.as<int>(), c->sa.as<int>(), c->strip.as<int>(), c->cnt.as<int>());
+    ev_record(c, 3);
+    HIP_TRY(hipGetLastError());
+    return CL_OK;
+}
+
+static int ensure_events(cl_chrom* c)
+{
+    if (c->profiling && !c->ev_ready) {
+        for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+        c->ev_ready = true;
+    }
+    return CL_OK;
+}
+
+static int check_args(cl_chrom* c, int eps, int minPts, int cut)
+{
+    if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
+    if (eps <= 0) return fail(CL_ERR_ARG, "eps must be > 0 (the reference divides by it: ZeroDivisionError)");
+    if (eps >= (1 << 30)) return fail(CL_ERR_ARG, "eps must be < 2^30");
+    if (minPts < 0) return fail(CL_ERR_ARG, "minPts must be >= 0");
+    (void)cut;
+    return CL_OK;
+}
+
+extern "C" int cl_neighbor_counts(cl_chrom* c, int32_t eps, int32_t cut, int32_t* counts_out)
+{
+    int rc = check_args(c, eps, 1, cut);
+    if (rc) return rc;
+    if (c->n == 0) return CL_OK;
+    if (!counts_out) return fail(CL_ERR_ARG, "counts_out is null");
+    HIP_TRY(hipSetDevice(c->device));
+    GridParams g;
+    if ((rc = make_grid(c, CL_VARIANT_CDBSCAN1, eps, 1, cut, &g))) return rc;
+    if ((rc = ensure_workspace(c, g.S))) return rc;
+    if ((rc = ensure_events(c))) return rc;
+    if ((rc = run_sort_and_count(c, g))) return rc;
+    const int n = (int)c->n;
+    HIP_TRY(hipMemsetAsync(c->labels.p, 0xFF, (size_t)n * 4, c->stream));
+    LAUNCH(k_scatter_counts, n, c->strip.as<int>(), g.S, c->vals_out.as<u32>(), c->cnt.as<int>(), c->labels.as<int>());
+    HIP_TRY(hipMemcpyAsync(counts_out, c->labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->profiling) {
+        memset(&c->timing, 0, sizeof(c->timing));
+        (void)hipEventElapsedTime(&c->timing.ms_keys, c->ev[0], c->ev[1]);
+        (void)hipEventElapsedTime(&c->timing.ms_sort, c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&c->timing.ms_region, c->ev[2], c->ev[3]);
+        c->timing.n_strips = g.S + 2;
+    }
+    c->have_result = false;
+    return CL_OK;
+}
+
+static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, int32_t* labels_out,
+                       int32_t* n_clusters, int32_t* max_label);
+
+extern "C" int cl_cluster(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut,
+                          int32_t* labels_out, int32_t* n_clusters, int32_t* max_label)
+{
+    int rc = check_args(c, eps, min_pts, cut);
+    if (rc) return rc;
+    if (n_clusters) *n_clusters = 0;
+    if (max_label) *max_label = -1;
+    c->have_result = false;
+    c->last_K = 0;
+    if (variant != CL_VARIANT_CDBSCAN1 && variant != CL_VARIANT_CDBSCAN2 && variant != CL_VARIANT_BLOCK)
+        return fail(CL_ERR_ARG, "unknown variant");
+    if (c->n == 0) {
+        // cDBSCAN.py:77 / blockDBSCAN.py:74: mat[0] on an empty mat raises; cDBSCAN2 returns {}
+        if (variant != CL_VARIANT_CDBSCAN2 && cut <= 0) return fail(CL_ERR_EMPTY, "empty input (reference raises IndexError)");
+        c->have_result = true;
+        return CL_OK;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    if (variant == CL_VARIANT_BLOCK) return fail(CL_ERR_ARG, "variant 3 (blockDBSCAN) not built into this library yet");
+    return run_rotated(c, variant, eps, min_pts, cut, labels_out, n_clusters, max_label);
+}
+
+static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, int32_t* labels_out,
+                       int32_t* n_clusters, int32_t* max_label)
+{
+    int rc;
+    GridParams g;
+    if ((rc = make_grid(c, variant, eps, minPts, cut, &g))) return rc;
+    if ((rc = ensure_workspace(c, g.S))) return rc;
+    if ((rc = ensure_events(c))) return rc;
+    const int n = (int)c->n;
+    int* strip = c->strip.as<int>();
+    int* sv = c->sv.as<int>();
+    int* sa = c->sa.as<int>();
+    int* cnt = c->cnt.as<int>();
+    u32* srow = c->vals_out.as<u32>();
+    int* counters = c->counters.as<int>();
+
+    LAUNCH(k_init_arrays, n + 1, n, c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
+           c->cellfirst.as<int>(), c->flag.as<int>(), c->state.as<int>(), counters);
+    HIP_TRY(hipMemsetAsync(c->labels.p, 0xFF, (size_t)n * 4, c->stream));
+    if ((rc = run_sort_and_count(c, g))) return rc;
+
+    // K3
+    if (variant == CL_VARIANT_CDBSCAN2) {
+        LAUNCH(k_cell_heads, n, c->keys_out.as<u64>(), strip, g, c->headidx.as<int>());
+        size_t tb = c->scan_tmp.bytes;
+        hipError_t e = rocprim::inclusive_scan(c->scan_tmp.p, tb, c->headidx.as<int>(), c->head.as<int>(), (size_t)n,
+                                               rocprim::maximum<int>(), c->stream);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan", hipGetErrorString(e));
+        LAUNCH(k_cell_first, n, strip, g.S, c->head.as<int>(), srow, c->cellfirst.as<int>());
+    }
+    LAUNCH(k_union_cores, n, g, sv, sa, strip, cnt, c->parent.as<int>());
+    LAUNCH(k_flatten, n, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
+           c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>());
+    ev_record(c, 4);
+    // K4
+    LAUNCH(k_border, n, g, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>());
+    if (variant == CL_VARIANT_CDBSCAN2) {
+        const int rec_cap = n;
+        LAUNCH(k_mark_uncertain, n, g, strip, c->root.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->state.as<int>(),
+               c->ulist.as<int>(), counters);
+        LAUNCH(k_emit_records, n, g, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(), c->state.as<int>(),
+               c->owner.as<int>(), c->recs.as<Rec>(), rec_cap, counters);
+        hipLaunchKernelGGL(k_resolve_release, dim3(1), dim3(1024), 0, c->stream, minPts, c->ncore.as<int>(), c->state.as<int>(),
+                           c->ulist.as<int>(), c->recs.as<Rec>(), c->lo.as<int>(), c->hi.as<int>(), counters);
+        LAUNCH(k_apply_records, n, c->recs.as<Rec>(), c->state.as<int>(), c->owner.as<int>(), counters);
+    }
+    ev_record(c, 5);
+    // K5
+    LAUNCH(k_rank_flags, n, g, strip, c->root.as<int>(), c->compkey.as<int>(), c->state.as<int>(), c->flag.as<int>());
+    {
+        size_t tb = c->scan_tmp.bytes;
+        hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, c->flag.as<int>(), c->rankscan.as<int>(), 0, (size_t)n + 1,
+                                               rocprim::plus<int>(), c->stream);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan", hipGetErrorString(e));
+    }
+    Table t;
+    {
+        int* base = c->table.as<int>();
+        size_t stride = (size_t)n + 1;
+        t.count = base; t.minx = base + stride; t.maxx = base + 2 * stride; t.miny = base + 3 * stride; t.maxy = base + 4 * stride;
+    }
+    LAUNCH(k_init_table, n + 1, t, c->rankscan.as<int>(), n);
+    LAUNCH(k_final_labels, n, g, strip, sv, sa, srow, c->owner.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(),
+           c->bsize.as<int>(), c->state.as<int>(), c->rankscan.as<int>(), c->labels.as<int>(), t);
+    ev_record(c, 6);
+    HIP_TRY(hipGetLastError());
+    // results to host
+    int* hp = c->h_pinned;
+    HIP_TRY(hipMemcpyAsync(hp, c->rankscan.as<int>() + n, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hp + 1, counters, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hp + 8, strip + g.S, 4, hipMemcpyDeviceToHost, c->stream));
+    if (labels_out) HIP_TRY(hipMemcpyAsync(labels_out, c->labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ev_record(c, 7);
+    const int K = hp[0];
+    if (hp[1 + CTR_OVERFLOW] != 0)
+        return fail(CL_ERR_HIP, "internal: release-record overflow (border point with > 4 adjacent components)");
+    c->last_K = K;
+    c->have_result = true;
+    // n_clusters / max_label need the per-id counts (variant 1 leaves gaps)
+    int nc = 0, ml = -1;
+    if (K > 0) {
+        std::vector<int> counts((size_t)K);
+        HIP_TRY(hipMemcpyAsync(counts.data(), t.count, (size_t)K * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int k = 0; k < K; ++k) if (counts[k] > 0) { ++nc; ml = k; }
+    }
+    if (n_clusters) *n_clusters = nc;
+    if (max_label) *max_label = ml;
+    c->last_K = ml + 1;
+    if (c->profiling) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipEventSynchronize(c->ev[7]));
+        cl_timing& tm = c->timing;
+        memset(&tm, 0, sizeof(tm));
+        (void)hipEventElapsedTime(&tm.ms_keys, c->ev[0], c->ev[1]);
+        (void)hipEventElapsedTime(&tm.ms_sort, c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&tm.ms_region, c->ev[2], c->ev[3]);
+        (void)hipEventElapsedTime(&tm.ms_union, c->ev[3], c->ev[4]);
+        (void)hipEventElapsedTime(&tm.ms_border, c->ev[4], c->ev[5]);
+        (void)hipEventElapsedTime(&tm.ms_table, c->ev[5], c->ev[6]);
+        (void)hipEventElapsedTime(&tm.ms_d2h, c->ev[6], c->ev[7]);
+        (void)hipEventElapsedTime(&tm.ms_total, c->ev[0], c->ev[7]);
+        tm.n_in = hp[8];
+        tm.n_strips = g.S + 2;
+    }
+    return CL_OK;
+}
+
+extern "C" int cl_get_boxes(cl_chrom* c, cl_box* boxes_out)
+{
+    if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
+    if (!c->have_result) return fail(CL_ERR_ARG, "cl_get_boxes: no clustering result available");
+    const int K = c->last_K;
+    if (K <= 0) return CL_OK;
+    if (!boxes_out) return fail(CL_ERR_ARG, "boxes_out is null");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t stride = (size_t)c->n + 1;
+    std::vector<int> h((size_t)K * 5);
+    for (int f = 0; f < 5; ++f)
+        HIP_TRY(hipMemcpyAsync(h.data() + (size_t)f * K, c->table.as<int>() + f * stride, (size_t)K * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < K; ++k) {
+        cl_box b;
+        b.count = h[k]; b.min_x = h[(size_t)K + k]; b.max_x = h[(size_t)2 * K + k];
+        b.min_y = h[(size_t)3 * K + k]; b.max_y = h[(size_t)4 * K + k];
+        if (b.count == 0) { b.min_x = b.max_x = b.min_y = b.max_y = 0; }
+        boxes_out[k] = b;
+    }
+    return CL_OK;
+}

@@ -1,0 +1,137 @@
+/*
+ * cloops_hip.h -- C ABI of libcloops_hip.so, the MI355X (gfx950) implementation of the
+ * cDBSCAN / cDBSCAN2 / blockDBSCAN hot path of YaqiangCao/cLoops.
+ *
+ * Plain C: opaque handles, plain pointers and sizes, integer error codes; no exceptions
+ * and no torch / numpy types cross this boundary.  Every entry point cites the reference
+ * interface it replaces (paths relative to the reference checkout).
+ *
+ * The reference classes take `mat` = int64[N,3] rows [pointId, X, Y] (cLoops/io.py:192-217)
+ * and produce `.labels` = {pointId: clusterId} for clustered points only.  Here a
+ * chromosome's X and Y live in HBM as two int32 arrays (|X|,|Y| < 2^30) and labels come
+ * back as an int32 array ALIGNED TO THE INPUT ROWS (-1 = absent from `.labels`); the host
+ * wrapper (cloops_amd/) turns that into the dict lazily.
+ */
+#ifndef CLOOPS_HIP_H
+#define CLOOPS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (return values; 0 = success) ------------------------------------- */
+#define CL_OK             0
+#define CL_ERR_ARG       -1   /* bad argument (null pointer, eps <= 0, unknown variant ...)   */
+#define CL_ERR_HIP       -2   /* a HIP runtime call failed; see cl_last_error()               */
+#define CL_ERR_EMPTY     -3   /* empty input where the reference raises IndexError
+                                 (cLoops/cDBSCAN.py:77, cLoops/blockDBSCAN.py:74)             */
+#define CL_ERR_DOMAIN    -4   /* coordinates outside the supported domain: |X|,|Y| >= 2^30, or
+                                 (variant 2) X > Y / negative coordinate, where cDBSCAN2's
+                                 trunc-toward-zero cell rule (cLoops/cDBSCAN2.py:69-70) stops
+                                 being an exact grid                                          */
+#define CL_ERR_GRID      -5   /* eps so small that the strip/row table would exceed 2^28 rows */
+#define CL_ERR_NODEVICE  -6   /* no usable HIP device                                         */
+
+/* ---- clustering variants ---------------------------------------------------------- */
+#define CL_VARIANT_CDBSCAN1  1   /* cLoops/cDBSCAN.py:6      class cDBSCAN      (scripts/callStripes:29,
+                                    scripts/jd2saturation:23)                                  */
+#define CL_VARIANT_CDBSCAN2  2   /* cLoops/cDBSCAN2.py:7     class cDBSCAN      (production, pipe.py:42) */
+#define CL_VARIANT_BLOCK     3   /* cLoops/blockDBSCAN.py:6  class blockDBSCAN  (pipe.py:43)   */
+
+/* A chromosome's PETs resident in HBM (+ the reusable device workspace and the result of
+ * the last clustering run on it).  Replaces the per-step `joblib.load` of the .jd file
+ * (cLoops/io.py:206-217, called at cLoops/pipe.py:58): X,Y cross PCIe once per chromosome,
+ * not once per (eps, minPts) step. */
+typedef struct cl_chrom cl_chrom;
+
+/* One candidate-loop row: what cLoops/pipe.py:78-102 derives per cluster label. */
+typedef struct {
+    int32_t min_x, max_x, min_y, max_y;   /* bounding box of the member PETs            */
+    int32_t count;                        /* number of member PETs                       */
+} cl_box;
+
+/* Per-kernel device timings of the last cl_cluster() call, HIP-event measured on the
+ * stream the kernels ran on (only filled when profiling is enabled, see cl_set_profiling). */
+typedef struct {
+    float ms_keys;        /* K0  filter + key build                                      */
+    float ms_sort;        /* K1  radix sort + gather + strip table                       */
+    float ms_region;      /* K2  region query (neighbour count)  <- the roofline kernel  */
+    float ms_union;       /* K3  core union-find + flatten + component keys              */
+    float ms_border;      /* K4  border assignment (+ release fix-up / small-cluster drop) */
+    float ms_table;       /* K5  ranks, labels scatter, cluster table                    */
+    float ms_d2h;         /* labels + table to host                                      */
+    float ms_total;       /* first kernel -> results on host                             */
+    int64_t n_in;         /* PETs that entered DBSCAN (after the cut filter)             */
+    int64_t n_strips;     /* rows of the strip table (C+1 term of the algorithmic bytes) */
+} cl_timing;
+
+/* Human-readable description of the last error on the calling thread. */
+const char* cl_last_error(void);
+
+/* Number of visible HIP devices (0 if none / no driver). */
+int cl_device_count(void);
+
+/*
+ * Upload one chromosome.  `x`, `y`: n int32 coordinates (anchor mid-points, the X and Y
+ * columns of the reference's `mat`, cLoops/io.py:49-57,192-203), host pointers if
+ * `on_device` == 0, else device pointers on `device` that must stay valid for the life of
+ * the handle (no copy is made).  `stream`: a hipStream_t to run on, or NULL for a private
+ * stream.  n may be 0.
+ */
+int cl_chrom_create(int device, void* stream, const int32_t* x, const int32_t* y, int64_t n,
+                    int on_device, cl_chrom** out);
+void cl_chrom_destroy(cl_chrom* c);
+int64_t cl_chrom_size(const cl_chrom* c);
+
+/*
+ * One clustering run = `DBSCAN(mat, eps, minPts)` of cLoops/pipe.py:70 preceded by the
+ * distance pre-filter of cLoops/pipe.py:59-63 (`cut` > 0 keeps rows with Y-X >= cut; pass 0
+ * for the bare class constructors cLoops/cDBSCAN.py:12, cLoops/cDBSCAN2.py:13,
+ * cLoops/blockDBSCAN.py:13).
+ *
+ *   labels_out   n int32, host memory (or NULL to leave labels on the device):
+ *                cluster id of every input row, -1 for rows that are filtered, noise, or
+ *                otherwise absent from the reference's `.labels`.  Ids are exactly the
+ *                reference's ids (variant 1 keeps its gaps).
+ *   n_clusters   number of distinct cluster ids;   max_label: largest id (or -1).
+ *
+ * Errors: CL_ERR_EMPTY for variants 1/3 when no row survives the filter and cut == 0
+ * (the reference's IndexError); with cut > 0 an empty survivor set is not an error
+ * (cLoops/pipe.py:64-65 returns early) and yields zero clusters.
+ */
+int cl_cluster(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut,
+               int32_t* labels_out, int32_t* n_clusters, int32_t* max_label);
+
+/*
+ * Cluster table of the last run, indexed by cluster id 0..max_label (count == 0 for the
+ * id gaps of variant 1): bounding box + size per label, the inputs of cLoops/pipe.py:83-102.
+ * `boxes_out`: (max_label+1) rows of host memory.
+ */
+int cl_get_boxes(cl_chrom* c, cl_box* boxes_out);
+
+/*
+ * Region query alone (kernel K2): neighbour counts |{q : |Xp-Xq|+|Yp-Yq| <= eps}|, self
+ * included, per input row (-1 for rows removed by `cut`) -- the quantity the reference
+ * compares with minPts (cLoops/cDBSCAN.py:168,177 `len(regionQuery)`,
+ * cLoops/cDBSCAN2.py:333-334 `n + cell_pt_num`).  Exposed for parity tests and for the
+ * roofline measurement of bench.py.
+ */
+int cl_neighbor_counts(cl_chrom* c, int32_t eps, int32_t cut, int32_t* counts_out);
+
+/* Device pointer to the labels of the last run (n int32, row aligned) -- lets the caller
+ * keep results on the GPU (e.g. to hand them to RCCL) without a host round trip. */
+const int32_t* cl_labels_device(const cl_chrom* c);
+
+/* Enable (1) / disable (0) HIP-event timing of the kernels of subsequent runs. */
+void cl_set_profiling(cl_chrom* c, int enabled);
+int cl_get_timing(const cl_chrom* c, cl_timing* out);
+
+/* Library version: major*10000 + minor*100 + patch. */
+int cl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLOOPS_HIP_H */

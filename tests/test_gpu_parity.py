@@ -1,0 +1,90 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the committed golden vectors
+(made from the REAL reference) and against the CPU oracle on seeded inputs.  Bit-exact."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle
+from cloops_amd import api
+
+pytestmark = pytest.mark.gpu
+
+ROT = ["v2", "v1"]
+
+
+def gpu_labels(variant, X, Y, eps, minPts, cut=0):
+    ch = api.Chromosome(X, Y)
+    try:
+        return ch.cluster(variant, eps, minPts, cut)
+    finally:
+        ch.close()
+
+
+def test_library_loaded_and_device_present():
+    assert api.device_count() >= 1
+
+
+@pytest.mark.parametrize("eps", [7, 100, 2000])
+def test_neighbor_counts_bruteforce(eps):
+    rng = np.random.default_rng(eps)
+    n = 3000
+    X = rng.integers(0, 40 * eps, n)
+    Y = X + rng.integers(0, 30 * eps, n)
+    ch = api.Chromosome(X, Y)
+    got = ch.neighbor_counts(eps)
+    ch.close()
+    assert np.array_equal(got, oracle.neighbor_counts(X, Y, eps))
+
+
+@pytest.mark.parametrize("variant", ROT)
+@pytest.mark.parametrize("family", ["adversarial", "plain", "clumpy"])
+def test_families_golden(variant, family):
+    for k, ids, X, Y, eps, minPts, gold in G.family_cases(family):
+        res = gpu_labels(variant, X, Y, eps, minPts)
+        assert np.array_equal(res.labels, gold[variant]), (family, k, variant, eps, minPts)
+
+
+@pytest.mark.parametrize("variant", ROT)
+@pytest.mark.parametrize("eps,minPts", [(500, 5), (1000, 5), (2000, 5), (5000, 20)])
+def test_chr21_golden(variant, eps, minPts):
+    X, Y = G.chr21_xy()
+    res = gpu_labels(variant, X, Y, eps, minPts)
+    gold = G.chr21_labels(variant, eps, minPts)
+    assert np.array_equal(res.labels, gold)
+    m = G.meta()["chr21_%s_%d_%d" % (variant, eps, minPts)]
+    assert res.n_clusters == m["clusters"]
+    # cluster table against a host recomputation from the labels
+    for c in np.unique(gold[gold >= 0])[:50]:
+        sel = gold == c
+        b = res.boxes[c]
+        assert (b["count"], b["min_x"], b["max_x"], b["min_y"], b["max_y"]) == (
+            sel.sum(), X[sel].min(), X[sel].max(), Y[sel].min(), Y[sel].max())
+
+
+@pytest.mark.parametrize("variant", ROT)
+def test_chr21_chain_with_cut(variant):
+    """config 1 (-m 1): the cut pre-filter of pipe.py:59-63 runs on the GPU."""
+    X, Y = G.chr21_xy()
+    for step in G.meta()["chr21_chain_" + variant]:
+        res = gpu_labels(variant, X, Y, step["eps"], step["minPts"], step["cut_in"])
+        assert np.array_equal(res.labels, G.chr21_chain_labels(variant, step["eps"])), step
+        assert res.n_clusters == step["clusters"]
+
+
+@pytest.mark.parametrize("variant", ROT)
+def test_synth150k_golden(variant):
+    X, Y, z = G.synth150k()
+    for eps, minPts in ((2000, 5), (5000, 20)):
+        res = gpu_labels(variant, X, Y, eps, minPts)
+        assert np.array_equal(res.labels, z["%s_%d_%d" % (variant, eps, minPts)])
+
+
+@pytest.mark.parametrize("variant", ROT)
+def test_oracle_midsize(variant):
+    """2 M synthetic PETs against the C oracle (sizes the oracle finishes in seconds)."""
+    from cloops_amd.synth import synth_chrom
+    X, Y = synth_chrom(2000000, 248956422, 77)
+    for eps, minPts in ((2000, 5), (5000, 20)):
+        res = gpu_labels(variant, X, Y, eps, minPts)
+        want = oracle.labels(variant, X, Y, eps, minPts)
+        assert np.array_equal(res.labels, want), (variant, eps, minPts, int((res.labels != want).sum()))
