@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""bench.py -- PETs clustered / s on MI355X for the cDBSCAN hot path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one pass of the hot path over one batch: ONE clustering run
+(variant cDBSCAN2 = the production class, cLoops/pipe.py:42) of a 5 M-PET synthetic
+chromosome (BASELINE.json configs[1]: "Synthetic 5 M cis PETs, one chromosome, single
+eps=2000 minPts=5"), timed from "X,Y resident in HBM" to "labels + cluster table on the
+host".  With N > 1 every rank owns its own 5 M-PET chromosome (weak scaling, chromosomes
+are independent units -- cLoops/pipe.py:117) and the per-step candidate-loop tables are
+all-gathered over RCCL (the only exchange of the path, cLoops/pipe.py:119-127).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  "roofline"      K2 region-query kernel: algorithmic bytes / HIP-event measured duration
+  "cpu_baseline"  the CPU oracle (C port of cDBSCAN2) timed on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_PETS = 5000000
+CHROM_LEN = 248956422          # chr1 (cfg2 = one chromosome, L = chr1)
+EPS, MINPTS = 2000, 5
+VARIANT = "v2"
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = world > 1
+    import numpy as np
+    torch = None
+    dist = None
+    if use_dist:
+        # torch first: its bundled HIP runtime then also serves libcloops_hip.so (same SONAME)
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from cloops_amd import api
+    from cloops_amd.synth import synth_chrom
+    from cloops_amd.dist import gather_tables
+
+    device = local_rank if use_dist else 0
+    # weak scaling: every rank has its own chromosome (seed differs per rank)
+    X, Y = synth_chrom(N_PETS, CHROM_LEN, 2000 + rank)
+    chrom = api.Chromosome(X, Y, device=device)
+    chrom.set_profiling(True)
+    tdev = torch.device("cuda", local_rank) if use_dist else None
+
+    def sync_all():
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        res = chrom.cluster(VARIANT, EPS, MINPTS, 0, pinned=True)
+        if use_dist:
+            b = res.boxes
+            tab = np.stack([b["min_x"], b["max_x"], b["min_y"], b["max_y"], b["count"]], 1) if len(b) else np.zeros((0, 5), np.int32)
+            gather_tables(tab, device=tdev)
+        return res
+
+    for _ in range(args.warmup):
+        res = step()
+    sync_all()
+    t0 = time.perf_counter()
+    k2_ms = []
+    for _ in range(args.steps):
+        res = step()
+        k2_ms.append(res.timing["ms_region"])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    timing = res.timing
+    n_in = int(timing["n_in"])
+    total_pets = n_in * args.steps * world
+    value = total_pets / elapsed
+
+    if rank == 0:
+        k2 = float(np.mean(k2_ms))
+        alg_bytes = n_in * 12 + int(timing["n_strips"]) * 4        # N*(8+4) + (C+1)*4
+        achieved = alg_bytes / (k2 * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "k2_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as fh:
+                    tj = json.load(fh)
+                if tj.get("workload") == "synthetic-5M-chr1-eps2000-minPts5":
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "PETs clustered/sec (whole node)",
+            "value": value,
+            "unit": "PETs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": "synthetic-5M-chr1-eps2000-minPts5 (BASELINE.json configs[1])",
+                       "variant": "cDBSCAN2", "pets_per_gpu": n_in, "eps": EPS, "minPts": MINPTS,
+                       "clusters": int(res.n_clusters), "parallelism": "chromosome-per-gpu x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_region_count", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k2},
+            "kernel_ms": {k[3:]: round(float(v), 4) for k, v in timing.items() if k.startswith("ms_")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(X, Y, res)
+        print(json.dumps(line), flush=True)
+    chrom.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(X, Y, res):
+    """The CPU oracle (single-threaded C port of cLoops/cDBSCAN2.py) on the SAME 5 M PETs;
+    doubles as a full-size parity check of the GPU labels."""
+    import numpy as np
+    import oracle
+    oracle.build()
+    t0 = time.perf_counter()
+    want = oracle.labels(VARIANT, X, Y, EPS, MINPTS)
+    dt = time.perf_counter() - t0
+    same = bool(np.array_equal(want, res.labels))
+    return {"value": len(X) / dt, "unit": "PETs/s", "cores": 1, "kind": "port",
+            "sample": "the full workload once: %d PETs, cDBSCAN2 eps=%d minPts=%d, C oracle, 1 thread, %.1f s" % (len(X), EPS, MINPTS, dt),
+            "labels_match_gpu": same,
+            "note": "the Python reference itself runs ~1e5 PETs/s/core (BASELINE.md section 2); the C port is far faster than the reference"}
+
+
+if __name__ == "__main__":
+    main()

@@ -26,7 +26,7 @@ VARIANT_BLOCK = 3
 SYMBOLS = [
     "cl_last_error", "cl_device_count", "cl_chrom_create", "cl_chrom_destroy", "cl_chrom_size",
     "cl_cluster", "cl_get_boxes", "cl_neighbor_counts", "cl_labels_device", "cl_set_profiling",
-    "cl_get_timing", "cl_version",
+    "cl_get_timing", "cl_version", "cl_host_alloc", "cl_host_free",
 ]
 
 
@@ -85,6 +85,10 @@ def load():
     lib.cl_set_profiling.argtypes = [vp, ctypes.c_int]
     lib.cl_get_timing.restype = ctypes.c_int
     lib.cl_get_timing.argtypes = [vp, ctypes.POINTER(ClTiming)]
+    lib.cl_host_alloc.restype = vp
+    lib.cl_host_alloc.argtypes = [ctypes.c_int64]
+    lib.cl_host_free.restype = None
+    lib.cl_host_free.argtypes = [vp]
     _lib = lib
     return lib
 

@@ -83,6 +83,19 @@ class Chromosome(object):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.cl_chrom_destroy(self._h)
             self._h = ctypes.c_void_p()
+        if getattr(self, "_pinned", None):
+            self._lib.cl_host_free(ctypes.c_void_p(self._pinned))
+            self._pinned = None
+
+    def _pinned_labels(self):
+        """A page-locked int32[n] result buffer owned by this object, reused by every run."""
+        if not getattr(self, "_pinned", None):
+            p = self._lib.cl_host_alloc(max(4, self.n * 4))
+            if not p:
+                raise MemoryError("cl_host_alloc failed")
+            self._pinned = p
+            self._pinned_arr = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_int32)), shape=(self.n,))
+        return self._pinned_arr
 
     def __del__(self):
         try:
@@ -99,9 +112,14 @@ class Chromosome(object):
         _lib.check(self._lib.cl_get_timing(self._h, ctypes.byref(t)))
         return {k: getattr(t, k) for k, _ in _lib.ClTiming._fields_}
 
-    def cluster(self, variant, eps, minPts, cut=0, want_labels=True, want_boxes=True):
+    def cluster(self, variant, eps, minPts, cut=0, want_labels=True, want_boxes=True, pinned=False):
+        """`pinned=True` returns labels as a VIEW of a reusable page-locked buffer (valid until
+        the next run on this chromosome) -- the fast path used by the sweep driver and bench."""
         v = VARIANTS[variant]
-        labels = np.empty(self.n, dtype=np.int32) if want_labels else None
+        if want_labels:
+            labels = self._pinned_labels() if pinned else np.empty(self.n, dtype=np.int32)
+        else:
+            labels = None
         nc = ctypes.c_int32(0)
         ml = ctypes.c_int32(-1)
         lp = labels.ctypes.data_as(ctypes.c_void_p) if want_labels else None

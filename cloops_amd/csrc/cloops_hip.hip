@@ -62,6 +62,15 @@ static int fail(int code, const char* what, const char* detail = nullptr)
 extern "C" const char* cl_last_error(void) { return g_err.c_str(); }
 extern "C" int cl_version(void) { return CL_VERSION_NUM; }
 
+extern "C" void* cl_host_alloc(int64_t bytes)
+{
+    void* p = nullptr;
+    if (bytes <= 0) return nullptr;
+    if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { fail(CL_ERR_HIP, "hipHostMalloc"); return nullptr; }
+    return p;
+}
+extern "C" void cl_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 extern "C" int cl_device_count(void)
 {
     int n = 0;
@@ -163,20 +172,21 @@ __device__ __forceinline__ void for_each_neighbor(const GridParams& g, const int
 }
 
 // ---- lock-free union-find (roots = smallest sorted index of the component) ---------------
-// parent[] is read with agent-scope relaxed atomics: per-CU L1s are not coherent and the
-// per-XCD L2s are not coherent with each other, plain loads could spin on a stale root.
-__device__ __forceinline__ int uf_load(int* parent, int i)
-{
-    return __hip_atomic_load(parent + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// Invariant: parent[x] <= x, so the forest is acyclic whatever the interleaving.  parent[]
+// is read with PLAIN (L1-cacheable) loads: a stale value is always an earlier parent of the
+// same node, i.e. still an ancestor, so a find that stops early merely returns a non-root
+// ancestor.  Only the hook is an atomic: atomicCAS succeeds only on a true root, and when it
+// fails it returns the true parent, which is strictly smaller -- every retry makes
+// progress.  (Agent-scope atomic loads here serialise millions of lanes on the one L2
+// channel holding a giant component's root: 77 ms vs 1 ms on a 16 M-PET chromosome.)
 __device__ __forceinline__ int uf_find(int* parent, int x)
 {
     for (;;) {
-        int p = uf_load(parent, x);
+        int p = parent[x];
         if (p == x) return x;
-        int gp = uf_load(parent, p);
+        int gp = parent[p];
         if (gp == p) return p;
-        __hip_atomic_store(parent + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // path halving
+        parent[x] = gp;                             // path halving (benign race: gp is an ancestor)
         x = gp;
     }
 }
@@ -189,7 +199,7 @@ __device__ __forceinline__ void uf_unite(int* parent, int a, int b)
         if (a < b) { int t = a; a = b; b = t; }
         int old = atomicCAS(parent + a, a, b);      // hook the larger root under the smaller
         if (old == a) return;
-        a = old;                                    // lost the race: continue from the new parent
+        a = old;                                    // not a root any more: continue from its true parent
     }
 }
 __device__ __forceinline__ int uf_find_ro(const int* __restrict__ parent, int x)
@@ -373,6 +383,43 @@ __global__ void k_cell_first(const int* __restrict__ strip_start, int S, const i
 // ------------------------------------------------------------------------------------------
 // K3: union of core points
 // ------------------------------------------------------------------------------------------
+// Inside a strip every pair is within eps in `a`, so core points whose v-gaps are <= eps
+// form a CHAIN.  Chains are resolved without union-find: chainflag[i] = i+1 for a core that
+// opens a chain (no earlier core of its strip within eps), 0 otherwise; an inclusive
+// max-scan then gives every core its chain head.  The union-find forest starts flat
+// (parent = chain head), so no million-long pointer chains ever exist -- dense diagonals
+// (self-ligation PETs) become one chain per strip.
+__global__ void __launch_bounds__(TPB)
+k_chain_flags(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
+              const int* __restrict__ strip_start, const int* __restrict__ cnt, int* __restrict__ chainflag)
+{
+    const int M = strip_start[g.S];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    int f = 0;
+    if (cnt[i] >= g.minPts) {
+        const int vi = sv[i];
+        const int vlo = sat_add(vi, -g.eps);
+        const int b = strip_start[strip_of(g, sa[i])];
+        f = i + 1;
+        for (int j = i - 1; j >= b && sv[j] >= vlo; --j)
+            if (cnt[j] >= g.minPts) { f = 0; break; }
+    }
+    chainflag[i] = f;
+}
+__global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const int* __restrict__ cnt, int minPts,
+                               const int* __restrict__ chainhead, int* __restrict__ parent)
+{
+    const int M = strip_start[S];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    parent[i] = (cnt[i] >= minPts) ? chainhead[i] - 1 : i;
+}
+
+// Cross-strip edges: a core i of strip s against the cores of strip s-1 in its window (the
+// pairs with strip s+1 are handled from the other endpoint).  One union per chain segment
+// of strip s-1 suffices: consecutive cores of the window with v-gap <= eps are already in
+// one chain.
 __global__ void __launch_bounds__(TPB)
 k_union_cores(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
               const int* __restrict__ strip_start, const int* __restrict__ cnt, int* parent)
@@ -382,23 +429,23 @@ k_union_cores(GridParams g, const int* __restrict__ sv, const int* __restrict__ 
     if (i >= M) return;
     if (cnt[i] < g.minPts) return;
     const int vi = sv[i], ai = sa[i];
-    const int s = strip_of(g, ai);
+    const int t = strip_of(g, ai) - 1;
+    if (t < 0) return;
     const int vlo = sat_add(vi, -g.eps), vhi = sat_add(vi, g.eps);
-    // own strip: cores within eps in v form a chain, linking to the previous core suffices
-    const int b = strip_start[s];
-    for (int j = i - 1; j >= b && sv[j] >= vlo; --j)
-        if (cnt[j] >= g.minPts) { uf_unite(parent, i, j); break; }
-    // strip s-1 (pairs with strip s+1 are united by the other endpoint)
-    const int t = s - 1;
-    if (t >= 0) {
-        const int tb = strip_start[t], te = strip_start[t + 1];
-        int j = lower_bound_i(sv, tb, te, vlo);
-        for (; j < te; ++j) {
-            const int vj = sv[j];
-            if (vj > vhi) break;
-            const int da = sa[j] - ai;
-            if ((da < 0 ? -da : da) <= g.eps && cnt[j] >= g.minPts) uf_unite(parent, i, j);
-        }
+    const int tb = strip_start[t], te = strip_start[t + 1];
+    if (tb == te) return;
+    int j = lower_bound_i(sv, tb, te, vlo);
+    bool linked = false, have_prev = false;
+    int prev_v = 0;
+    for (; j < te; ++j) {
+        const int vj = sv[j];
+        if (vj > vhi) break;
+        if (cnt[j] < g.minPts) continue;
+        if (have_prev && vj - prev_v > g.eps) linked = false;      // a new chain of strip s-1 starts
+        have_prev = true; prev_v = vj;
+        if (linked) continue;
+        const int da = sa[j] - ai;
+        if ((da < 0 ? -da : da) <= g.eps) { uf_unite(parent, i, j); linked = true; }
     }
 }
 
@@ -407,20 +454,42 @@ k_union_cores(GridParams g, const int* __restrict__ sv, const int* __restrict__ 
 //              (cDBSCAN.py:134-137)
 //   variant 2: key = smallest cellfirst over the cells holding its core points
 //              (cDBSCAN2.py:117-140)
-__global__ void k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ cnt,
-                          const int* __restrict__ parent, const u32* __restrict__ srow,
-                          const int* __restrict__ head, const int* __restrict__ cellfirst,
-                          int* __restrict__ root, int* __restrict__ compkey, int* __restrict__ ncore)
+__global__ void __launch_bounds__(TPB)
+k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ cnt,
+          int* parent, const u32* __restrict__ srow,
+          const int* __restrict__ head, const int* __restrict__ cellfirst,
+          int* __restrict__ root, int* __restrict__ compkey, int* __restrict__ ncore)
 {
     const int M = strip_start[g.S];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    if (cnt[i] < g.minPts) { root[i] = -1; return; }
-    int r = uf_find_ro(parent, i);
-    root[i] = r;
-    int key = (g.variant == CL_VARIANT_CDBSCAN2) ? cellfirst[head[i]] : (int)srow[i];
-    atomicMin(&compkey[r], key);
-    atomicAdd(&ncore[r], 1);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = -1, key = INT_MAX;
+    if (i < M) {
+        if (cnt[i] >= g.minPts) {
+            r = uf_find(parent, i);
+            key = (g.variant == CL_VARIANT_CDBSCAN2) ? cellfirst[head[i]] : (int)srow[i];
+        }
+        root[i] = r;
+    }
+    // per-wave pre-reduction by root (a giant component would otherwise take one atomic
+    // per PET on a single address)
+    const int lane = threadIdx.x & 63;
+    unsigned long long pending = __ballot(r >= 0);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int R = __shfl(r, leader);
+        const unsigned long long m = __ballot(r == R);
+        const bool mine = r == R;
+        const int cm = __popcll(m);
+        if (cm >= 4) {
+            int mk = mine ? key : INT_MAX;
+            for (int o = 32; o > 0; o >>= 1) mk = min(mk, __shfl_xor(mk, o));
+            if (lane == leader) { atomicMin(&compkey[R], mk); atomicAdd(&ncore[R], cm); }
+        } else if (mine) {
+            atomicMin(&compkey[R], key);
+            atomicAdd(&ncore[R], 1);
+        }
+        pending &= ~m;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -600,6 +669,13 @@ __global__ void k_init_table(Table t, const int* __restrict__ rankscan, int n)
     t.count[k] = 0; t.minx[k] = INT_MAX; t.maxx[k] = INT_MIN; t.miny[k] = INT_MAX; t.maxy[k] = INT_MIN;
 }
 
+__device__ __forceinline__ int wave_min_i(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ int wave_max_i(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
+
+// Labels are scattered to input-row order; the cluster table (pipe.py:78-102) is reduced
+// per wave first: sorted order keeps a cluster's PETs in neighbouring lanes, so a wave
+// usually carries a handful of labels and a giant cluster costs 5 atomics per wave, not
+// 5 per PET.
 __global__ void __launch_bounds__(TPB)
 k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ sv,
                const int* __restrict__ sa, const u32* __restrict__ srow, const int* __restrict__ owner,
@@ -607,23 +683,42 @@ k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __r
                const int* __restrict__ state, const int* __restrict__ rankscan, int* __restrict__ labels, Table t)
 {
     const int M = strip_start[g.S];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    int o = owner[i];
-    int lab = -1;
-    if (o >= 0) {
-        bool keep = (g.variant == CL_VARIANT_CDBSCAN2) ? (state[o] != ST_DEAD)
-                                                       : (ncore[o] + bsize[o] >= g.minPts);   // cDBSCAN.py:149-152
-        if (keep) lab = rankscan[compkey[o]];
-    }
-    labels[srow[i]] = lab;
-    if (lab >= 0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int lab = -1, x = 0, y = 0;
+    if (i < M) {
+        int o = owner[i];
+        if (o >= 0) {
+            bool keep = (g.variant == CL_VARIANT_CDBSCAN2) ? (state[o] != ST_DEAD)
+                                                           : (ncore[o] + bsize[o] >= g.minPts);   // cDBSCAN.py:149-152
+            if (keep) lab = rankscan[compkey[o]];
+        }
+        labels[srow[i]] = lab;
         // X = (v - a) / 2, Y = (v + a) / 2 exactly (v and a have equal parity)
         int a = sa[i] + g.A0, v = sv[i] + g.V0;
-        int x = (v - a) / 2, y = (v + a) / 2;
-        atomicAdd(&t.count[lab], 1);
-        atomicMin(&t.minx[lab], x); atomicMax(&t.maxx[lab], x);
-        atomicMin(&t.miny[lab], y); atomicMax(&t.maxy[lab], y);
+        x = (v - a) / 2; y = (v + a) / 2;
+    }
+    const int lane = threadIdx.x & 63;
+    unsigned long long pending = __ballot(lab >= 0);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int L = __shfl(lab, leader);
+        const unsigned long long m = __ballot(lab == L);
+        const bool mine = lab == L;
+        const int cm = __popcll(m);
+        if (cm >= 6) {
+            int mnx = wave_min_i(mine ? x : INT_MAX), mxx = wave_max_i(mine ? x : INT_MIN);
+            int mny = wave_min_i(mine ? y : INT_MAX), mxy = wave_max_i(mine ? y : INT_MIN);
+            if (lane == leader) {
+                atomicAdd(&t.count[L], cm);
+                atomicMin(&t.minx[L], mnx); atomicMax(&t.maxx[L], mxx);
+                atomicMin(&t.miny[L], mny); atomicMax(&t.maxy[L], mxy);
+            }
+        } else if (mine) {
+            atomicAdd(&t.count[L], 1);
+            atomicMin(&t.minx[L], x); atomicMax(&t.maxx[L], x);
+            atomicMin(&t.miny[L], y); atomicMax(&t.maxy[L], y);
+        }
+        pending &= ~m;
     }
 }
 
@@ -657,7 +752,7 @@ struct cl_chrom {
     // workspace
     DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, scan_tmp;
     DevBuf sv, sa, strip, cnt, parent, root, head, headidx, cellfirst, compkey, ncore, bsize, owner, state;
-    DevBuf flag, rankscan, labels, table, ulist, lo, hi, recs, counters;
+    DevBuf flag, rankscan, labels, table, ulist, lo, hi, recs, counters, chainflag, chainhead;
     int* h_pinned = nullptr;          // small pinned staging (counters, K)
     // last result
     int last_K = 0;                   // ids handed out (max_label + 1 upper bound)
@@ -676,7 +771,7 @@ static void free_chrom(cl_chrom* c)
     DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->labels, &c->table,
-                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters};
+                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead};
     for (DevBuf* b : bufs) b->release();
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -763,6 +858,7 @@ static int ensure_workspace(cl_chrom* c, int S)
     ENS(compkey, n * 4); ENS(ncore, n * 4); ENS(bsize, n * 4); ENS(owner, n * 4); ENS(state, n * 4);
     ENS(flag, (n + 1) * 4); ENS(rankscan, (n + 1) * 4); ENS(labels, n * 4); ENS(table, (n + 1) * 5 * 4);
     ENS(ulist, n * 4); ENS(lo, n * 4); ENS(hi, n * 4); ENS(recs, n * sizeof(Rec)); ENS(counters, 256);
+    ENS(chainflag, n * 4); ENS(chainhead, n * 4);
 #undef ENS
     // rocPRIM temporary storage
     size_t sort_bytes = 0, scan_bytes = 0, scan2 = 0;
@@ -929,6 +1025,17 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
                                                rocprim::maximum<int>(), c->stream);
         if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan", hipGetErrorString(e));
         LAUNCH(k_cell_first, n, strip, g.S, c->head.as<int>(), srow, c->cellfirst.as<int>());
+    }
+    {
+        // own-strip chains by scan (headidx / head buffers are free again here for variant 2:
+        // k_cell_first has consumed them into cellfirst... they are still needed by k_flatten,
+        // so the chain scan uses its own pair of buffers)
+        LAUNCH(k_chain_flags, n, g, sv, sa, strip, cnt, c->chainflag.as<int>());
+        size_t tb = c->scan_tmp.bytes;
+        hipError_t e = rocprim::inclusive_scan(c->scan_tmp.p, tb, c->chainflag.as<int>(), c->chainhead.as<int>(), (size_t)n,
+                                               rocprim::maximum<int>(), c->stream);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan(chain)", hipGetErrorString(e));
+        LAUNCH(k_chain_parent, n, strip, g.S, cnt, g.minPts, c->chainhead.as<int>(), c->parent.as<int>());
     }
     LAUNCH(k_union_cores, n, g, sv, sa, strip, cnt, c->parent.as<int>());
     LAUNCH(k_flatten, n, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),

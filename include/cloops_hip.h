@@ -128,6 +128,12 @@ const int32_t* cl_labels_device(const cl_chrom* c);
 void cl_set_profiling(cl_chrom* c, int enabled);
 int cl_get_timing(const cl_chrom* c, cl_timing* out);
 
+/* Page-locked host memory for result buffers (labels_out / boxes_out / counts_out): D2H
+ * copies into pinned memory run at PCIe rate instead of through a staging buffer.  Plain
+ * malloc'ed memory works everywhere too, only slower. */
+void* cl_host_alloc(int64_t bytes);
+void cl_host_free(void* p);
+
 /* Library version: major*10000 + minor*100 + patch. */
 int cl_version(void);
 
