@@ -669,8 +669,40 @@ __global__ void k_init_table(Table t, const int* __restrict__ rankscan, int n)
     t.count[k] = 0; t.minx[k] = INT_MAX; t.maxx[k] = INT_MIN; t.miny[k] = INT_MAX; t.maxy[k] = INT_MIN;
 }
 
+__device__ __forceinline__ int je_minus(const int* __restrict__ cstart, int j) { return cstart[j + 1] - cstart[j]; }
 __device__ __forceinline__ int wave_min_i(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ int wave_max_i(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
+
+// Per-wave pre-reduction of the cluster table (pipe.py:78-102): sorted order keeps a
+// cluster's PETs in neighbouring lanes, so a wave usually carries a handful of labels and
+// a giant cluster costs 5 atomics per wave, not 5 per PET.  Must be called by all 64 lanes.
+__device__ __forceinline__ void table_accumulate(const Table& t, int lab, int x, int y)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long pending = __ballot(lab >= 0);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int L = __shfl(lab, leader);
+        const unsigned long long m = __ballot(lab == L);
+        const bool mine = lab == L;
+        const int cm = __popcll(m);
+        if (cm >= 6) {
+            int mnx = wave_min_i(mine ? x : INT_MAX), mxx = wave_max_i(mine ? x : INT_MIN);
+            int mny = wave_min_i(mine ? y : INT_MAX), mxy = wave_max_i(mine ? y : INT_MIN);
+            if (lane == leader) {
+                atomicAdd(&t.count[L], cm);
+                atomicMin(&t.minx[L], mnx); atomicMax(&t.maxx[L], mxx);
+                atomicMin(&t.miny[L], mny); atomicMax(&t.maxy[L], mxy);
+            }
+        } else if (mine) {
+            atomicAdd(&t.count[L], 1);
+            atomicMin(&t.minx[L], x); atomicMax(&t.maxx[L], x);
+            atomicMin(&t.miny[L], y); atomicMax(&t.maxy[L], y);
+        }
+        pending &= ~m;
+    }
+}
+
 
 // Labels are scattered to input-row order; the cluster table (pipe.py:78-102) is reduced
 // per wave first: sorted order keeps a cluster's PETs in neighbouring lanes, so a wave
@@ -697,29 +729,252 @@ k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __r
         int a = sa[i] + g.A0, v = sv[i] + g.V0;
         x = (v - a) / 2; y = (v + a) / 2;
     }
-    const int lane = threadIdx.x & 63;
-    unsigned long long pending = __ballot(lab >= 0);
-    while (pending) {
-        const int leader = __ffsll((long long)pending) - 1;
-        const int L = __shfl(lab, leader);
-        const unsigned long long m = __ballot(lab == L);
-        const bool mine = lab == L;
-        const int cm = __popcll(m);
-        if (cm >= 6) {
-            int mnx = wave_min_i(mine ? x : INT_MAX), mxx = wave_max_i(mine ? x : INT_MIN);
-            int mny = wave_min_i(mine ? y : INT_MAX), mxy = wave_max_i(mine ? y : INT_MIN);
-            if (lane == leader) {
-                atomicAdd(&t.count[L], cm);
-                atomicMin(&t.minx[L], mnx); atomicMax(&t.maxx[L], mxx);
-                atomicMin(&t.miny[L], mny); atomicMax(&t.maxy[L], mxy);
-            }
-        } else if (mine) {
-            atomicAdd(&t.count[L], 1);
-            atomicMin(&t.minx[L], x); atomicMax(&t.maxx[L], x);
-            atomicMin(&t.miny[L], y); atomicMax(&t.maxy[L], y);
-        }
-        pending &= ~m;
+    table_accumulate(t, lab, x, y);
+}
+
+
+// ==========================================================================================
+// K6: blockDBSCAN (cLoops/blockDBSCAN.py) -- DBSCAN over grid CELLS
+// ==========================================================================================
+// Closed form: unrotated eps-grid anchored at the filtered set's (minX,minY)
+// (:74-82); cells whose 9-cell population is < minPts and whose existing neighbours are all
+// like that are deleted (:101-122); two surviving 8-adjacent cells are LINKED iff their
+// float64 centroids are within eps (city block) or some point pair is (:204-239); a cell is
+// CORE iff own + linked population >= minPts (:181,191); components of core cells are ranked
+// by their first cell in insertion order (= smallest input row of the cell's first point,
+// :148-152); a non-core cell linked to core cells takes the LARGEST adjacent rank
+// (unconditional overwrite, :195-198); points inherit their cell's label (:154-168).
+struct BlkParams {
+    int eps, minPts, cut;
+    int R;            // rows of the cell-row table; key row R marks filtered PETs
+    int n;
+};
+struct BlkScalars { int minx, miny, M, C; };
+
+__global__ void k_blk_minmax(const int* __restrict__ X, const int* __restrict__ Y, int n, int cut, BlkScalars* sc)
+{
+    int mx = INT_MAX, my = INT_MAX;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int x = X[i], y = Y[i];
+        if (cut > 0 && y - x < cut) continue;
+        mx = min(mx, x); my = min(my, y);
     }
+    for (int o = 32; o > 0; o >>= 1) { mx = min(mx, __shfl_down(mx, o)); my = min(my, __shfl_down(my, o)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&sc->minx, mx); atomicMin(&sc->miny, my); }
+}
+
+__global__ void k_blk_keys(const int* __restrict__ X, const int* __restrict__ Y, BlkParams p, const BlkScalars* __restrict__ sc,
+                           u64* __restrict__ keys, u32* __restrict__ vals)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.n) return;
+    int x = X[r], y = Y[r];
+    bool valid = (p.cut <= 0) || (y - x >= p.cut);
+    // nx = int((X - minX) / cw) + 1 (:81-82); the +1 is dropped (cells are only compared)
+    u32 nx = valid ? (u32)((x - sc->minx) / p.eps) : (u32)p.R;
+    u32 ny = valid ? (u32)((y - sc->miny) / p.eps) : 0u;
+    keys[r] = ((u64)nx << 32) | ny;
+    vals[r] = (u32)r;
+}
+
+__global__ void k_blk_gather(const int* __restrict__ X, const int* __restrict__ Y, BlkParams p,
+                             const u64* __restrict__ skeys, const u32* __restrict__ srow,
+                             int* __restrict__ sx, int* __restrict__ sy, int* __restrict__ headflag, BlkScalars* sc)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    u64 k = skeys[i];
+    bool valid = (u32)(k >> 32) < (u32)p.R;
+    u32 r = srow[i];
+    sx[i] = X[r]; sy[i] = Y[r];
+    bool head = valid && (i == 0 || skeys[i - 1] != k);
+    headflag[i] = head ? 1 : 0;
+    if (!valid && (i == 0 || (u32)(skeys[i - 1] >> 32) < (u32)p.R)) sc->M = i;   // first filtered row
+    if (valid && i == p.n - 1) sc->M = p.n;
+}
+
+// cid[i] = (inclusive prefix sum of headflag)[i] - 1 ; per-cell arrays
+__global__ void k_blk_cells(BlkParams p, const u64* __restrict__ skeys, const int* __restrict__ headflag,
+                            const int* __restrict__ cidp1, const u32* __restrict__ srow, BlkScalars* sc,
+                            int* __restrict__ cstart, u64* __restrict__ ckey, int* __restrict__ cfirst)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = sc->M;
+    if (i >= M) return;
+    if (headflag[i]) {
+        int c = cidp1[i] - 1;
+        cstart[c] = i;
+        ckey[c] = skeys[i];
+        cfirst[c] = (int)srow[i];       // stable sort: first of the run = smallest input row
+    }
+    if (i == M - 1) { int C = cidp1[i]; sc->C = C; cstart[C] = M; }
+}
+
+// rowcell[r] = first cell index whose row >= r, r = 0..R
+__global__ void k_blk_rowtable(BlkParams p, const BlkScalars* __restrict__ sc, const u64* __restrict__ ckey,
+                               int* __restrict__ rowcell)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > p.R) return;
+    const int C = sc->C;
+    u64 target = (u64)(u32)r << 32;
+    int lo = 0, hi = C;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (ckey[mid] < target) lo = mid + 1; else hi = mid; }
+    rowcell[r] = lo;
+}
+
+__device__ __forceinline__ int blk_find_cell(const u64* __restrict__ ckey, const int* __restrict__ rowcell, int R,
+                                             long long nx, long long ny)
+{
+    if (nx < 0 || nx >= R || ny < 0) return -1;
+    u64 target = ((u64)(u32)nx << 32) | (u32)ny;
+    int lo = rowcell[nx], hi = rowcell[nx + 1];
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (ckey[mid] < target) lo = mid + 1; else hi = mid; }
+    return (lo < rowcell[nx + 1] && ckey[lo] == target) ? lo : -1;
+}
+
+// neighbour indices (8 per cell), 9-cell population test, centroids
+__global__ void k_blk_neighbors(BlkParams p, const BlkScalars* __restrict__ sc, const u64* __restrict__ ckey,
+                                const int* __restrict__ rowcell, const int* __restrict__ cstart,
+                                const int* __restrict__ sx, const int* __restrict__ sy,
+                                int* __restrict__ nb, int* __restrict__ low, double* __restrict__ cx, double* __restrict__ cy)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= sc->C) return;
+    u64 k = ckey[c];
+    long long nx = (long long)(u32)(k >> 32), ny = (long long)(u32)(k & 0xffffffffu);
+    int tot = cstart[c + 1] - cstart[c];
+    int q = 0;
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy) {
+            if (!dx && !dy) continue;
+            int j = blk_find_cell(ckey, rowcell, p.R, nx + dx, ny + dy);
+            nb[(size_t)c * 8 + q++] = j;
+            if (j >= 0) tot += cstart[j + 1] - cstart[j];
+        }
+    low[c] = tot < p.minPts ? 1 : 0;
+    long long sumx = 0, sumy = 0;
+    for (int t = cstart[c]; t < cstart[c + 1]; ++t) { sumx += sx[t]; sumy += sy[t]; }
+    double m = (double)(cstart[c + 1] - cstart[c]);
+    cx[c] = (double)sumx / m;          // true division of Python ints (:136-137)
+    cy[c] = (double)sumy / m;
+}
+
+__global__ void k_blk_alive(const BlkScalars* __restrict__ sc, const int* __restrict__ nb, const int* __restrict__ low,
+                            int* __restrict__ alive)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= sc->C) return;
+    int a = 1;
+    if (low[c]) {
+        a = 0;
+        for (int q = 0; q < 8; ++q) { int j = nb[(size_t)c * 8 + q]; if (j >= 0 && !low[j]) { a = 1; break; } }
+    }
+    alive[c] = a;
+}
+
+// link bits + population sum + core flag
+__global__ void k_blk_links(BlkParams p, const BlkScalars* __restrict__ sc, const int* __restrict__ nb,
+                            const int* __restrict__ alive, const int* __restrict__ cstart,
+                            const int* __restrict__ sx, const int* __restrict__ sy,
+                            const double* __restrict__ cx, const double* __restrict__ cy,
+                            int* __restrict__ linkbits, int* __restrict__ corec)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= sc->C) return;
+    int bits = 0, core = 0;
+    if (alive[c]) {
+        const int cb = cstart[c], ce = cstart[c + 1];
+        int psum = ce - cb;
+        const double epsd = (double)p.eps;
+        for (int q = 0; q < 8; ++q) {
+            int j = nb[(size_t)c * 8 + q];
+            if (j < 0 || !alive[j]) continue;
+            bool linked = (fabs(cx[c] - cx[j]) + fabs(cy[c] - cy[j])) <= epsd;        // :232
+            if (!linked) {                                                            // getGridDist :204-213
+                const int jb = cstart[j], je = cstart[j + 1];
+                for (int s = cb; s < ce && !linked; ++s) {
+                    const int x = sx[s], y = sy[s];
+                    for (int t = jb; t < je; ++t) {
+                        int dx = x - sx[t], dy = y - sy[t];
+                        if ((dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy) <= p.eps) { linked = true; break; }
+                    }
+                }
+            }
+            if (linked) { bits |= 1 << q; psum += je_minus(cstart, j); }
+        }
+        core = psum >= p.minPts ? 1 : 0;
+    }
+    linkbits[c] = bits;
+    corec[c] = core;
+}
+
+__global__ void k_blk_union(const BlkScalars* __restrict__ sc, const int* __restrict__ nb, const int* __restrict__ linkbits,
+                            const int* __restrict__ corec, int* parent)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= sc->C) return;
+    if (!corec[c]) return;
+    int bits = linkbits[c];
+    for (int q = 0; q < 8; ++q) {
+        if (!(bits & (1 << q))) continue;
+        int j = nb[(size_t)c * 8 + q];
+        if (j < c && corec[j]) uf_unite(parent, c, j);
+    }
+}
+
+__global__ void k_blk_flatten(const BlkScalars* __restrict__ sc, const int* __restrict__ corec, int* parent,
+                              const int* __restrict__ cfirst, int* __restrict__ root, int* __restrict__ compkey)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= sc->C) return;
+    int r = -1;
+    if (corec[c]) { r = uf_find(parent, c); atomicMin(&compkey[r], cfirst[c]); }
+    root[c] = r;
+}
+
+__global__ void k_blk_rank_flags(const BlkScalars* __restrict__ sc, const int* __restrict__ root,
+                                 const int* __restrict__ compkey, int* __restrict__ flag)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= sc->C) return;
+    if (root[c] == c) flag[compkey[c]] = 1;
+}
+
+__global__ void k_blk_cell_labels(const BlkScalars* __restrict__ sc, const int* __restrict__ nb,
+                                  const int* __restrict__ linkbits, const int* __restrict__ alive,
+                                  const int* __restrict__ root, const int* __restrict__ compkey,
+                                  const int* __restrict__ rankscan, int* __restrict__ clab)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= sc->C) return;
+    int lab = -1;
+    if (root[c] >= 0) lab = rankscan[compkey[root[c]]];
+    else if (alive[c]) {
+        int bits = linkbits[c];
+        for (int q = 0; q < 8; ++q) {
+            if (!(bits & (1 << q))) continue;
+            int j = nb[(size_t)c * 8 + q];
+            if (root[j] >= 0) lab = max(lab, rankscan[compkey[root[j]]]);     // :195-198 last writer = highest rank
+        }
+    }
+    clab[c] = lab;
+}
+
+__global__ void __launch_bounds__(TPB)
+k_blk_point_labels(BlkParams p, const BlkScalars* __restrict__ sc, const int* __restrict__ cidp1,
+                   const int* __restrict__ clab, const u32* __restrict__ srow, const int* __restrict__ sx,
+                   const int* __restrict__ sy, int* __restrict__ labels, Table t)
+{
+    const int M = sc->M;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int lab = -1, x = 0, y = 0;
+    if (i < M) {
+        lab = clab[cidp1[i] - 1];
+        labels[srow[i]] = lab;
+        x = sx[i]; y = sy[i];
+    }
+    table_accumulate(t, lab, x, y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -752,7 +1007,7 @@ struct cl_chrom {
     // workspace
     DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, scan_tmp;
     DevBuf sv, sa, strip, cnt, parent, root, head, headidx, cellfirst, compkey, ncore, bsize, owner, state;
-    DevBuf flag, rankscan, labels, table, ulist, lo, hi, recs, counters, chainflag, chainhead;
+    DevBuf flag, rankscan, labels, table, ulist, lo, hi, recs, counters, chainflag, chainhead, b_cstart, b_ckey, b_nb, b_cx, b_cy;
     int* h_pinned = nullptr;          // small pinned staging (counters, K)
     // last result
     int last_K = 0;                   // ids handed out (max_label + 1 upper bound)
@@ -771,7 +1026,7 @@ static void free_chrom(cl_chrom* c)
     DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->labels, &c->table,
-                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead};
+                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy};
     for (DevBuf* b : bufs) b->release();
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -971,8 +1226,155 @@ extern "C" int cl_neighbor_counts(cl_chrom* c, int32_t eps, int32_t cut, int32_t
     return CL_OK;
 }
 
+// Shared tail of every variant: ids handed out (K), labels + per-id counts to the host.
+static int finish_run(cl_chrom* c, int n_strips, const int* d_M, const Table& t, int32_t* labels_out,
+                      int32_t* n_clusters, int32_t* max_label)
+{
+    const int n = (int)c->n;
+    int* counters = c->counters.as<int>();
+    int* hp = c->h_pinned;
+    HIP_TRY(hipMemcpyAsync(hp, c->rankscan.as<int>() + n, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hp + 1, counters, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hp + 8, d_M, 4, hipMemcpyDeviceToHost, c->stream));
+    if (labels_out) HIP_TRY(hipMemcpyAsync(labels_out, c->labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ev_record(c, 7);
+    const int K = hp[0];
+    if (hp[1 + CTR_OVERFLOW] != 0)
+        return fail(CL_ERR_HIP, "internal: release-record overflow (border point with > 4 adjacent components)");
+    c->last_K = K;
+    c->have_result = true;
+    // n_clusters / max_label need the per-id counts (variant 1 leaves gaps)
+    int nc = 0, ml = -1;
+    if (K > 0) {
+        std::vector<int> counts((size_t)K);
+        HIP_TRY(hipMemcpyAsync(counts.data(), t.count, (size_t)K * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int k = 0; k < K; ++k) if (counts[k] > 0) { ++nc; ml = k; }
+    }
+    if (n_clusters) *n_clusters = nc;
+    if (max_label) *max_label = ml;
+    c->last_K = ml + 1;
+    if (c->profiling) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipEventSynchronize(c->ev[7]));
+        cl_timing& tm = c->timing;
+        memset(&tm, 0, sizeof(tm));
+        (void)hipEventElapsedTime(&tm.ms_keys, c->ev[0], c->ev[1]);
+        (void)hipEventElapsedTime(&tm.ms_sort, c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&tm.ms_region, c->ev[2], c->ev[3]);
+        (void)hipEventElapsedTime(&tm.ms_union, c->ev[3], c->ev[4]);
+        (void)hipEventElapsedTime(&tm.ms_border, c->ev[4], c->ev[5]);
+        (void)hipEventElapsedTime(&tm.ms_table, c->ev[5], c->ev[6]);
+        (void)hipEventElapsedTime(&tm.ms_d2h, c->ev[6], c->ev[7]);
+        (void)hipEventElapsedTime(&tm.ms_total, c->ev[0], c->ev[7]);
+        tm.n_in = hp[8];
+        tm.n_strips = n_strips;
+    }
+    return CL_OK;
+}
+
+static Table make_table(cl_chrom* c)
+{
+    Table t;
+    int* base = c->table.as<int>();
+    size_t stride = (size_t)c->n + 1;
+    t.count = base; t.minx = base + stride; t.maxx = base + 2 * stride; t.miny = base + 3 * stride; t.maxy = base + 4 * stride;
+    return t;
+}
+
 static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, int32_t* labels_out,
                        int32_t* n_clusters, int32_t* max_label);
+
+// ---- variant 3 host driver -----------------------------------------------------------------
+static int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_out,
+                     int32_t* n_clusters, int32_t* max_label)
+{
+    int rc;
+    const int n = (int)c->n;
+    long long R = ((long long)c->st.xmax - c->st.xmin) / eps + 1;
+    if (R > (1LL << 28)) return fail(CL_ERR_GRID, "eps too small for the coordinate extent (cell-row table > 2^28 rows)");
+    if ((rc = ensure_workspace(c, (int)R))) return rc;
+    if ((rc = ensure_events(c))) return rc;
+#define ENSB(buf, bytes) if ((rc = c->buf.ensure(bytes))) return rc
+    ENSB(b_cstart, ((size_t)n + 1) * 4); ENSB(b_ckey, (size_t)n * 8); ENSB(b_nb, (size_t)n * 32);
+    ENSB(b_cx, (size_t)n * 8); ENSB(b_cy, (size_t)n * 8);
+#undef ENSB
+    BlkParams p; p.eps = eps; p.minPts = minPts; p.cut = cut; p.R = (int)R; p.n = n;
+    int* counters = c->counters.as<int>();
+    BlkScalars* sc = (BlkScalars*)(counters + 32);
+    LAUNCH(k_init_arrays, n + 1, n, c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
+           c->cellfirst.as<int>(), c->flag.as<int>(), c->state.as<int>(), counters);
+    HIP_TRY(hipMemsetAsync(c->labels.p, 0xFF, (size_t)n * 4, c->stream));
+    BlkScalars* hsc = (BlkScalars*)(c->h_pinned + 64);
+    hsc->minx = INT_MAX; hsc->miny = INT_MAX; hsc->M = 0; hsc->C = 0;
+    HIP_TRY(hipMemcpyAsync(sc, hsc, sizeof(BlkScalars), hipMemcpyHostToDevice, c->stream));
+    ev_record(c, 0);
+    hipLaunchKernelGGL(k_blk_minmax, dim3(std::min(nblocks(n), 2048)), dim3(TPB), 0, c->stream, c->d_x, c->d_y, n, cut, sc);
+    LAUNCH(k_blk_keys, n, c->d_x, c->d_y, p, sc, c->keys_in.as<u64>(), c->vals_in.as<u32>());
+    ev_record(c, 1);
+    {
+        size_t tmp_bytes = c->sort_tmp.bytes;
+        int end_bit = 32 + std::max(1, bits_for((unsigned)p.R));
+        hipError_t e = rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->keys_in.as<u64>(), c->keys_out.as<u64>(),
+                                                 c->vals_in.as<u32>(), c->vals_out.as<u32>(), (size_t)n, 0, end_bit, c->stream);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs", hipGetErrorString(e));
+    }
+    u64* skeys = c->keys_out.as<u64>();
+    u32* srow = c->vals_out.as<u32>();
+    int* sx = c->sv.as<int>();
+    int* sy = c->sa.as<int>();
+    int* headflag = c->chainflag.as<int>();
+    int* cidp1 = c->chainhead.as<int>();
+    LAUNCH(k_blk_gather, n, c->d_x, c->d_y, p, skeys, srow, sx, sy, headflag, sc);
+    {
+        size_t tb = c->scan_tmp.bytes;
+        hipError_t e = rocprim::inclusive_scan(c->scan_tmp.p, tb, headflag, cidp1, (size_t)n, rocprim::plus<int>(), c->stream);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan(cells)", hipGetErrorString(e));
+    }
+    int* cstart = c->b_cstart.as<int>();
+    u64* ckey = c->b_ckey.as<u64>();
+    int* cfirst = c->cellfirst.as<int>();
+    int* rowcell = c->strip.as<int>();
+    LAUNCH(k_blk_cells, n, p, skeys, headflag, cidp1, srow, sc, cstart, ckey, cfirst);
+    LAUNCH(k_blk_rowtable, p.R + 1, p, sc, ckey, rowcell);
+    ev_record(c, 2);
+    int* nb = c->b_nb.as<int>();
+    int* low = c->ncore.as<int>();
+    int* alive = c->bsize.as<int>();
+    double* cx = c->b_cx.as<double>();
+    double* cy = c->b_cy.as<double>();
+    int* linkbits = c->owner.as<int>();
+    int* corec = c->state.as<int>();
+    LAUNCH(k_blk_neighbors, n, p, sc, ckey, rowcell, cstart, sx, sy, nb, low, cx, cy);
+    LAUNCH(k_blk_alive, n, sc, nb, low, alive);
+    LAUNCH(k_blk_links, n, p, sc, nb, alive, cstart, sx, sy, cx, cy, linkbits, corec);
+    ev_record(c, 3);
+    LAUNCH(k_blk_union, n, sc, nb, linkbits, corec, c->parent.as<int>());
+    LAUNCH(k_blk_flatten, n, sc, corec, c->parent.as<int>(), cfirst, c->root.as<int>(), c->compkey.as<int>());
+    ev_record(c, 4);
+    LAUNCH(k_blk_rank_flags, n, sc, c->root.as<int>(), c->compkey.as<int>(), c->flag.as<int>());
+    {
+        size_t tb = c->scan_tmp.bytes;
+        hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, c->flag.as<int>(), c->rankscan.as<int>(), 0, (size_t)n + 1,
+                                               rocprim::plus<int>(), c->stream);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan", hipGetErrorString(e));
+    }
+    ev_record(c, 5);
+    Table t = make_table(c);
+    LAUNCH(k_init_table, n + 1, t, c->rankscan.as<int>(), n);
+    int* clab = c->cnt.as<int>();
+    LAUNCH(k_blk_cell_labels, n, sc, nb, linkbits, alive, c->root.as<int>(), c->compkey.as<int>(), c->rankscan.as<int>(), clab);
+    LAUNCH(k_blk_point_labels, n, p, sc, cidp1, clab, srow, sx, sy, c->labels.as<int>(), t);
+    ev_record(c, 6);
+    HIP_TRY(hipGetLastError());
+    rc = finish_run(c, p.R + 1, &sc->M, t, labels_out, n_clusters, max_label);
+    if (rc) return rc;
+    // blockDBSCAN.py:74: an empty (fully filtered) mat raises only when the class is called
+    // on it; pipe.py:64-65 returns before that, so cut > 0 with no survivors is just empty.
+    return CL_OK;
+}
+
 
 extern "C" int cl_cluster(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut,
                           int32_t* labels_out, int32_t* n_clusters, int32_t* max_label)
@@ -992,7 +1394,7 @@ extern "C" int cl_cluster(cl_chrom* c, int variant, int32_t eps, int32_t min_pts
         return CL_OK;
     }
     HIP_TRY(hipSetDevice(c->device));
-    if (variant == CL_VARIANT_BLOCK) return fail(CL_ERR_ARG, "variant 3 (blockDBSCAN) not built into this library yet");
+    if (variant == CL_VARIANT_BLOCK) return run_block(c, eps, min_pts, cut, labels_out, n_clusters, max_label);
     return run_rotated(c, variant, eps, min_pts, cut, labels_out, n_clusters, max_label);
 }
 
@@ -1062,58 +1464,13 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
                                                rocprim::plus<int>(), c->stream);
         if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan", hipGetErrorString(e));
     }
-    Table t;
-    {
-        int* base = c->table.as<int>();
-        size_t stride = (size_t)n + 1;
-        t.count = base; t.minx = base + stride; t.maxx = base + 2 * stride; t.miny = base + 3 * stride; t.maxy = base + 4 * stride;
-    }
+    Table t = make_table(c);
     LAUNCH(k_init_table, n + 1, t, c->rankscan.as<int>(), n);
     LAUNCH(k_final_labels, n, g, strip, sv, sa, srow, c->owner.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(),
            c->bsize.as<int>(), c->state.as<int>(), c->rankscan.as<int>(), c->labels.as<int>(), t);
     ev_record(c, 6);
     HIP_TRY(hipGetLastError());
-    // results to host
-    int* hp = c->h_pinned;
-    HIP_TRY(hipMemcpyAsync(hp, c->rankscan.as<int>() + n, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(hp + 1, counters, 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(hp + 8, strip + g.S, 4, hipMemcpyDeviceToHost, c->stream));
-    if (labels_out) HIP_TRY(hipMemcpyAsync(labels_out, c->labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    ev_record(c, 7);
-    const int K = hp[0];
-    if (hp[1 + CTR_OVERFLOW] != 0)
-        return fail(CL_ERR_HIP, "internal: release-record overflow (border point with > 4 adjacent components)");
-    c->last_K = K;
-    c->have_result = true;
-    // n_clusters / max_label need the per-id counts (variant 1 leaves gaps)
-    int nc = 0, ml = -1;
-    if (K > 0) {
-        std::vector<int> counts((size_t)K);
-        HIP_TRY(hipMemcpyAsync(counts.data(), t.count, (size_t)K * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        for (int k = 0; k < K; ++k) if (counts[k] > 0) { ++nc; ml = k; }
-    }
-    if (n_clusters) *n_clusters = nc;
-    if (max_label) *max_label = ml;
-    c->last_K = ml + 1;
-    if (c->profiling) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipEventSynchronize(c->ev[7]));
-        cl_timing& tm = c->timing;
-        memset(&tm, 0, sizeof(tm));
-        (void)hipEventElapsedTime(&tm.ms_keys, c->ev[0], c->ev[1]);
-        (void)hipEventElapsedTime(&tm.ms_sort, c->ev[1], c->ev[2]);
-        (void)hipEventElapsedTime(&tm.ms_region, c->ev[2], c->ev[3]);
-        (void)hipEventElapsedTime(&tm.ms_union, c->ev[3], c->ev[4]);
-        (void)hipEventElapsedTime(&tm.ms_border, c->ev[4], c->ev[5]);
-        (void)hipEventElapsedTime(&tm.ms_table, c->ev[5], c->ev[6]);
-        (void)hipEventElapsedTime(&tm.ms_d2h, c->ev[6], c->ev[7]);
-        (void)hipEventElapsedTime(&tm.ms_total, c->ev[0], c->ev[7]);
-        tm.n_in = hp[8];
-        tm.n_strips = g.S + 2;
-    }
-    return CL_OK;
+    return finish_run(c, g.S + 2, strip + g.S, t, labels_out, n_clusters, max_label);
 }
 
 extern "C" int cl_get_boxes(cl_chrom* c, cl_box* boxes_out)
