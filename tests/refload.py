@@ -80,3 +80,36 @@ def labels_dict_to_array(labels, ids):
     for k, v in labels.items():
         out[pos[int(k)]] = int(v)
     return out
+
+
+def ref_pipe_namespace(variant="v2"):
+    """The reference's OWN dispatch functions (cLoops/pipe.py: singleDBSCAN :52-110,
+    runDBSCAN :113-127, filterClusterByDis :130-143, combineTwice :155-174), extracted from
+    the parsed module (pipe.py cannot be imported: it pulls seaborn and the py2-only io.py)
+    and exec'd in a namespace wired to the real clustering class, the real parseJd
+    (cLoops/io.py:206-217, sliced out of the py2-only file) and the real estIntSelCutFrag."""
+    import ast
+    import sys as _sys
+    import numpy as np
+    import pandas as pd
+    import joblib
+    from joblib import Parallel, delayed
+    key = "pipe_" + variant
+    if key in _cache:
+        return _cache[key]
+    ns = {"np": np, "pd": pd, "sys": _sys, "os": os, "joblib": joblib, "Parallel": Parallel, "delayed": delayed,
+          "DBSCAN": ref_classes()[variant], "estIntSelCutFrag": ref_ests().estIntSelCutFrag}
+    # parseJd: slice `def parseJd` ... up to the next top-level def out of io.py
+    with open(os.path.join(REF_ROOT, "cLoops", "io.py")) as fh:
+        lines = fh.read().split("\n")
+    start = [i for i, l in enumerate(lines) if l.startswith("def parseJd")][0]
+    end = [i for i, l in enumerate(lines) if i > start and l.startswith("def ")][0]
+    exec(compile("\n".join(lines[start:end]), "io.py:parseJd", "exec"), ns)
+    with open(os.path.join(REF_ROOT, "cLoops", "pipe.py")) as fh:
+        tree = ast.parse(fh.read())
+    want = {"singleDBSCAN", "runDBSCAN", "filterClusterByDis", "checkSameLoop", "combineTwice"}
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    mod = ast.Module(body=body, type_ignores=[])
+    exec(compile(mod, "pipe.py:dispatch", "exec"), ns)
+    _cache[key] = ns
+    return ns

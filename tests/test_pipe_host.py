@@ -1,0 +1,56 @@
+"""CPU: host logic of cloops_amd.pipe (dispatch, record classification, report lines, sweep
+chain, combine/filter) against the reference-made golden vectors, with the GPU replaced by
+the oracle-backed FakeChromosome (tests/fake_backend.py)."""
+import numpy as np
+import pytest
+
+import fake_backend
+import pipe_checks
+import refload
+from cloops_amd import api, pipe
+
+
+@pytest.fixture()
+def cpu_pipe(monkeypatch, tmp_path):
+    monkeypatch.setattr(api, "Chromosome", fake_backend.FakeChromosome)
+    monkeypatch.setattr(api, "device_count", lambda: 1)
+    pipe.CACHE.clear()
+    f = pipe_checks.write_chr21_jd(tmp_path)
+    yield pipe, f
+    pipe.CACHE.clear()
+
+
+def test_run_dbscan_matches_reference_outputs(cpu_pipe):
+    p, f = cpu_pipe
+    pipe_checks.check_run_dbscan_chain(p, f)
+
+
+def test_sweep_chain_combine_filter(cpu_pipe):
+    p, f = cpu_pipe
+    pipe_checks.check_sweep(p, f)
+
+
+def test_single_dbscan_all_filtered(cpu_pipe):
+    p, f = cpu_pipe
+    key, ff, dataI, dataS, dis, dss = p.singleDBSCAN(f, 500, 5, cut=10 ** 9)     # pipe.py:64-65
+    assert key == ("chr21", "chr21") and dataI == [] and dataS == [] and dis == []
+    assert len(dss) == 99674
+
+
+def test_filter_uses_floor_division():
+    data = {("c", "c"): {"f": "x", "records": [["c", 0, 3, "c", 10, 13], ["c", 0, 3, "c", 10, 12]]}}
+    out = pipe.filterClusterByDis(data, 10)          # (10+13)//2 - (0+3)//2 = 10 ; (10+12)//2 - 1 = 10
+    assert len(out[("c", "c")]["records"]) == 2
+    out = pipe.filterClusterByDis(data, 11)
+    assert len(out[("c", "c")]["records"]) == 0
+
+
+@pytest.mark.skipif(not refload.available(), reason="reference checkout not present")
+def test_ests_matches_reference_function():
+    from cloops_amd.ests import estIntSelCutFrag
+    ref = refload.ref_ests().estIntSelCutFrag
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        di = np.exp(rng.normal(10, 1.5, 3000)).astype(np.int64).astype(float)
+        ds = np.exp(rng.normal(6, 1.0, 5000)).astype(np.int64).astype(float)
+        assert estIntSelCutFrag(di, ds) == ref(di, ds)
