@@ -87,11 +87,15 @@ struct GridParams {
     int eps;      // cell / strip width (cDBSCAN.py:29, cDBSCAN2.py:30: cw = eps)
     int minPts;
     int cut;      // pipe.py:59-63 pre-filter, 0 = off
-    int A0;       // offset subtracted from a = Y - X  (0 for variant 2: absolute cells)
-    int V0;       // offset subtracted from v = X + Y  (0 for variant 2)
+    int A0;       // offset subtracted from the STRIP coordinate  (0 for variant 2: absolute cells)
+    int V0;       // offset subtracted from the IN-STRIP (sorted) coordinate (0 for variant 2)
+    int swap;     // 0: strips are bands of a = Y-X ordered by v = X+Y;  1: bands of v ordered by a
     int s0;       // strip index of the first table row
     int S;        // number of strips in the table; key strip S marks filtered rows
     int variant;
+    int dbg;      // developer knobs (CLOOPS_DBG env), 0 in production
+    u32 magic;    // strip(a) = a / eps by multiply-shift (Granlund-Montgomery, exact for all u32)
+    int sh1, sh2;
 };
 
 __device__ __forceinline__ int sat_add(int a, int b)
@@ -137,7 +141,12 @@ __device__ __forceinline__ int gallop_right(const int* __restrict__ sv, int i, i
     return upper_bound_i(sv, lo + 1, hi, val);
 }
 
-__device__ __forceinline__ int strip_of(const GridParams& g, int arel) { return arel / g.eps - g.s0; }
+__device__ __forceinline__ int strip_of(const GridParams& g, int arel)
+{
+    const u32 n = (u32)arel;                       // arel >= 0 by construction
+    const u32 t1 = __umulhi(g.magic, n);
+    return (int)((t1 + ((n - t1) >> g.sh1)) >> g.sh2) - g.s0;
+}
 
 // Visit every j != i with max(|a_j-a_i|, |v_j-v_i|) <= eps.  `which` selects the strips:
 // bit0 = strip s-1, bit1 = own strip (both directions), bit2 = strip s+1.
@@ -253,8 +262,9 @@ __global__ void k_make_keys(const int* __restrict__ X, const int* __restrict__ Y
     int x = X[r], y = Y[r];
     int a = y - x;
     bool valid = (g.cut <= 0) || (a >= g.cut);            // pipe.py:59-62  d >= cut
-    int arel = a - g.A0;
-    u32 vrel = (u32)(x + y - g.V0);
+    int v = x + y;
+    int arel = (g.swap ? v : a) - g.A0;                   // strip coordinate
+    u32 vrel = (u32)((g.swap ? a : v) - g.V0);            // in-strip coordinate
     u64 key = valid ? (((u64)(u32)strip_of(g, arel) << 32) | vrel) : ((u64)(u32)g.S << 32);
     keys[r] = key;
     vals[r] = (u32)r;
@@ -271,7 +281,7 @@ __global__ void k_gather_sorted(const int* __restrict__ X, const int* __restrict
     if ((int)(k >> 32) >= g.S) { sv[i] = INT_MAX; sa[i] = 0; return; }
     u32 r = srow[i];
     sv[i] = (int)(u32)(k & 0xffffffffu);
-    sa[i] = Y[r] - X[r] - g.A0;
+    sa[i] = (g.swap ? (Y[r] + X[r]) : (Y[r] - X[r])) - g.A0;
 }
 
 // K1c: strip_start[t] = first sorted index whose strip >= t, t = 0..S+1
@@ -293,34 +303,200 @@ __global__ void k_strip_table(const u64* __restrict__ skeys, int n, int S, int* 
 // ------------------------------------------------------------------------------------------
 // K2: region query  (cDBSCAN.py:186-205 regionQuery / cDBSCAN2.py:304-334 neighbour count)
 // ------------------------------------------------------------------------------------------
+// 4-way lower bound: three independent probes per step -- half the dependent memory round
+// trips of a bisect (the global path is latency bound: one L2/HBM round trip per step).
+__device__ __forceinline__ int lower_bound_4(const int* pv, int lo, int hi, int val)
+{
+    while (hi - lo > 4) {
+        const int q = (hi - lo) >> 2;
+        const int m1 = lo + q, m2 = m1 + q, m3 = m2 + q;
+        const int v1 = pv[m1], v2 = pv[m2], v3 = pv[m3];
+        if (v1 >= val) hi = m1;
+        else if (v2 >= val) { lo = m1 + 1; hi = m2; }
+        else if (v3 >= val) { lo = m2 + 1; hi = m3; }
+        else lo = m3 + 1;
+    }
+    while (lo < hi && pv[lo] < val) ++lo;
+    return lo;
+}
+
+// Branch-free bounded searches on an LDS window of (q,p) pairs: fixed 8 steps, no divergence
+// (a wave pays the LONGEST trip count of its lanes, so data-dependent loops cost far more
+// instructions than the average lane needs).  Valid for hi - lo <= 255.
+// first idx in [lo,hi) with w[idx].x >= val (or hi)
+__device__ __forceinline__ int lds_lower_bound8(const int2* w, int lo, int hi, int val)
+{
+    int pos = lo;
+#pragma unroll
+    for (int step = 128; step >= 1; step >>= 1) {
+        const int idx = pos + step - 1;
+        const int v = w[min(idx, hi - 1)].x;
+        pos = (idx < hi && v < val) ? pos + step : pos;
+    }
+    return pos;
+}
+// first idx in [lo,hi) with w[idx].x > val (or hi)
+__device__ __forceinline__ int lds_upper_bound8(const int2* w, int lo, int hi, int val)
+{
+    int pos = lo;
+#pragma unroll
+    for (int step = 128; step >= 1; step >>= 1) {
+        const int idx = pos + step - 1;
+        const int v = w[min(idx, hi - 1)].x;
+        pos = (idx < hi && v <= val) ? pos + step : pos;
+    }
+    return pos;
+}
+
+// Count the candidates j of [j,te) with q[j] <= qhi (q ascending) and |p[j]-pi| <= eps, in chunks
+// whose loads are all issued before the first compare (an element-at-a-time `while (q <= qhi)`
+// loop costs one full memory latency per candidate).
+template <bool EXACT, int CH>
+__device__ __forceinline__ int k2_count_lds(const int2* w, int j, int te, int qhi, int pi, int eps, int minPts, int c)
+{
+    while (j < te) {
+        int2 v[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) v[k] = w[min(j + k, te - 1)];
+        bool out = false;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const bool in = (j + k < te) && (v[k].x <= qhi);
+            out |= !in;
+            const int da = v[k].y - pi;
+            c += (in && (da < 0 ? -da : da) <= eps) ? 1 : 0;
+        }
+        if (out || (!EXACT && c >= minPts)) break;
+        j += CH;
+    }
+    return c;
+}
+template <bool EXACT, int CH>
+__device__ __forceinline__ int k2_count_glb(const int* __restrict__ pq, const int* __restrict__ pp, int j, int te,
+                                            int qhi, int pi, int eps, int minPts, int c)
+{
+    while (j < te) {
+        int v[CH], a[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) { const int idx = min(j + k, te - 1); v[k] = pq[idx]; a[k] = pp[idx]; }
+        bool out = false;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const bool in = (j + k < te) && (v[k] <= qhi);
+            out |= !in;
+            const int da = a[k] - pi;
+            c += (in && (da < 0 ? -da : da) <= eps) ? 1 : 0;
+        }
+        if (out || (!EXACT && c >= minPts)) break;
+        j += CH;
+    }
+    return c;
+}
+
+#define K2_HALO 128
+#define K2_WIN (TPB + 2 * K2_HALO)
+#define K2_SPAN 120      // own-strip window searched branch-free within +-K2_SPAN positions
+#define K2_RUN 8         // consecutive tiles given to one XCD (halo reuse in that XCD's L2)
+
+// One workgroup = a tile of 256 consecutive sorted PETs.  The tile plus a halo of K2_HALO PETs
+// on both sides is staged in LDS as (q,p) pairs with coalesced loads.  With strips laid along
+// v (a few tens of PETs per strip, uniformly) the three strips of a query sit next to each
+// other in sorted order, so the whole region query runs out of LDS:
+//   phase 1  own strip: every PET of the in-strip window [q-eps, q+eps] is a neighbour (the
+//            strip coordinate differs by < eps), so that part of the count is an index
+//            difference found by two branch-free 8-step searches -- no candidate is touched;
+//   phase 2  strips s-1 / s+1, only for points not yet known to be core (DBSCAN needs
+//            `count >= minPts`, not the count: EXACT = false saturates; cl_neighbor_counts()
+//            instantiates EXACT = true).  Those points are first COMPACTED inside the
+//            workgroup so that whole waves drop out instead of running at ~45 % lane use.
+// Windows that leave the staged range (pile-ups of hundreds of PETs) continue in global memory.
+// Workgroup b runs on XCD b % 8 (observed placement, used for speed only): each XCD is handed
+// runs of K2_RUN consecutive tiles so that halos are re-read from its own L2.
+template <bool EXACT>
 __global__ void __launch_bounds__(TPB)
-k_region_count(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
+k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
                const int* __restrict__ strip_start, int* __restrict__ cnt)
 {
+    __shared__ int2 lw[K2_WIN];
+    __shared__ int l_c[TPB];
+    __shared__ short l_list[TPB];
+    __shared__ int l_wcount[TPB / 64];
     const int M = strip_start[g.S];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    const int vi = sv[i], ai = sa[i];
-    const int s = strip_of(g, ai);
-    const int vlo = sat_add(vi, -g.eps), vhi = sat_add(vi, g.eps);
-    // own strip: every PET of the v-window is a neighbour (|da| < eps inside a strip)
-    const int b = strip_start[s], e = strip_start[s + 1];
-    int c = gallop_right(sv, i, e, vhi) - gallop_left(sv, b, i, vlo);
-#pragma unroll
-    for (int d = -1; d <= 1; d += 2) {
-        const int t = s + d;
-        if (t < 0 || t >= g.S) continue;
-        const int tb = strip_start[t], te = strip_start[t + 1];
-        if (tb == te) continue;
-        int j = lower_bound_i(sv, tb, te, vlo);
-        for (; j < te; ++j) {
-            const int vj = sv[j];
-            if (vj > vhi) break;
-            const int da = sa[j] - ai;
-            c += ((da < 0 ? -da : da) <= g.eps) ? 1 : 0;
-        }
+    const int xcd = blockIdx.x & 7, kseq = blockIdx.x >> 3;
+    const int tile = ((kseq / K2_RUN) * 8 + xcd) * K2_RUN + (kseq % K2_RUN);
+    const int t0 = tile * TPB;
+    if (tile >= ntiles || t0 >= M) return;
+    const int base = t0 - K2_HALO;                 // global index of lw[0]
+    for (int k = threadIdx.x; k < K2_WIN; k += TPB) {
+        const int gi = base + k;
+        const bool in = gi >= 0 && gi < M;
+        lw[k] = in ? make_int2(sv[gi], sa[gi]) : make_int2(0, 0);
     }
-    cnt[i] = c;
+    __syncthreads();
+    const int2* w = lw - base;                     // w[global sorted index] = (in-strip coord q, strip coord p)
+    const int wbeg = max(base, 0), wend = min(base + K2_WIN, M);
+    const int i = t0 + threadIdx.x;
+    const bool valid = i < M;
+    bool needy = false;
+    if (valid) {
+        const int2 me = w[i];
+        const int qi = me.x, pi = me.y;
+        const int s = strip_of(g, pi);
+        const int qlo = sat_add(qi, -g.eps), qhi = sat_add(qi, g.eps);
+        const int b = strip_start[s], e = strip_start[s + 1];
+        const int L = max(max(b, wbeg), i - K2_SPAN);
+        int lo = lds_lower_bound8(w, L, i + 1, qlo);
+        if (lo == L && L > b) lo = lower_bound_4(sv, b, L, qlo);           // window leaves the staged span
+        const int R = min(min(e, wend), i + 1 + K2_SPAN);
+        int hi = lds_upper_bound8(w, i + 1, R, qhi);
+        if (hi == R && R < e) hi = lower_bound_4(sv, R, e, sat_add(qhi, 1));
+        const int c = hi - lo;
+        needy = EXACT || c < g.minPts;
+        if (needy) l_c[threadIdx.x] = c; else cnt[i] = c;
+    }
+    // ---- workgroup compaction of the points that still need their neighbour strips ------------
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(needy);
+    if (lane == 0) l_wcount[wv] = __popcll(bal);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < TPB / 64; ++k) { const int t = l_wcount[k]; off += (k < wv) ? t : 0; total += t; }
+    if (needy) l_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (short)threadIdx.x;
+    __syncthreads();
+    if ((int)threadIdx.x >= total) return;
+    // ---- phase 2: neighbour strips ------------------------------------------------------------
+    {
+        const int tix = l_list[threadIdx.x];
+        const int ii = t0 + tix;
+        const int2 me = w[ii];
+        const int qi = me.x, pi = me.y;
+        const int s = strip_of(g, pi);
+        const int qlo = sat_add(qi, -g.eps), qhi = sat_add(qi, g.eps);
+        const int b = strip_start[s], e = strip_start[s + 1];
+        const int tb = s > 0 ? strip_start[s - 1] : b;
+        const int te = s + 1 < g.S ? strip_start[s + 2] : e;
+        int c = l_c[tix];
+        if (tb < b) {                                                      // strip s-1 = [tb, b)
+            if (tb >= wbeg && b - tb <= 255) {
+                const int j = lds_lower_bound8(w, tb, b, qlo);
+                c = k2_count_lds<EXACT, 4>(w, j, b, qhi, pi, g.eps, g.minPts, c);
+            } else {
+                const int j = lower_bound_4(sv, tb, b, qlo);
+                c = k2_count_glb<EXACT, 8>(sv, sa, j, b, qhi, pi, g.eps, g.minPts, c);
+            }
+        }
+        if ((EXACT || c < g.minPts) && e < te) {                           // strip s+1 = [e, te)
+            if (te <= wend && te - e <= 255) {
+                const int j = lds_lower_bound8(w, e, te, qlo);
+                c = k2_count_lds<EXACT, 4>(w, j, te, qhi, pi, g.eps, g.minPts, c);
+            } else {
+                const int j = lower_bound_4(sv, e, te, qlo);
+                c = k2_count_glb<EXACT, 8>(sv, sa, j, te, qhi, pi, g.eps, g.minPts, c);
+            }
+        }
+        cnt[ii] = c;
+    }
 }
 
 // scatter counts back to input-row order (cl_neighbor_counts)
@@ -726,7 +902,8 @@ k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __r
         }
         labels[srow[i]] = lab;
         // X = (v - a) / 2, Y = (v + a) / 2 exactly (v and a have equal parity)
-        int a = sa[i] + g.A0, v = sv[i] + g.V0;
+        int pp = sa[i] + g.A0, qq = sv[i] + g.V0;
+        int a = g.swap ? qq : pp, v = g.swap ? pp : qq;
         x = (v - a) / 2; y = (v + a) / 2;
     }
     table_accumulate(t, lab, x, y);
@@ -1135,15 +1312,24 @@ static int bits_for(unsigned v) { int b = 0; while (v) { ++b; v >>= 1; } return 
 static int make_grid(cl_chrom* c, int variant, int eps, int minPts, int cut, GridParams* g)
 {
     g->eps = eps; g->minPts = minPts; g->cut = cut; g->variant = variant;
+    { const char* e = getenv("CLOOPS_DBG"); g->dbg = e ? atoi(e) : 0; }
+    g->swap = (g->dbg & 16) ? 0 : 1;
+    {
+        const unsigned d = (unsigned)eps;
+        int l = 0; while ((1ull << l) < d) ++l;                          // ceil(log2 d)
+        g->magic = (u32)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+        g->sh1 = l < 1 ? l : 1; g->sh2 = l > 1 ? l - 1 : 0;
+    }
     if (variant == CL_VARIANT_CDBSCAN2) {
         // absolute rotated cells (cDBSCAN2.py:67-70); exact only for 0 <= X <= Y
         if (c->st.amin < 0 || c->st.xmin < 0) return fail(CL_ERR_DOMAIN, "variant 2 (cDBSCAN2) needs 0 <= X <= Y for every PET");
         g->A0 = 0; g->V0 = 0;
     } else {
-        g->A0 = c->st.amin; g->V0 = c->st.vmin;
+        g->A0 = g->swap ? c->st.vmin : c->st.amin; g->V0 = g->swap ? c->st.amin : c->st.vmin;
     }
-    long long lo = ((long long)c->st.amin - g->A0) / eps;
-    long long hi = ((long long)c->st.amax - g->A0) / eps;
+    const int pmin = g->swap ? c->st.vmin : c->st.amin, pmax = g->swap ? c->st.vmax : c->st.amax;
+    long long lo = ((long long)pmin - g->A0) / eps;
+    long long hi = ((long long)pmax - g->A0) / eps;
     long long S = hi - lo + 1;
     if (S > (1LL << 28)) return fail(CL_ERR_GRID, "eps too small for the coordinate extent (strip table > 2^28 rows)");
     g->s0 = (int)lo; g->S = (int)S;
@@ -1159,7 +1345,7 @@ static void ev_record(cl_chrom* c, int k)
 }
 
 // K0 + K1 + K2: keys, sort, strip table, neighbour counts.  Leaves sorted arrays in the workspace.
-static int run_sort_and_count(cl_chrom* c, const GridParams& g)
+static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
 {
     const int n = (int)c->n;
     ev_record(c, 0);
@@ -1173,7 +1359,12 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g)
     LAUNCH(k_gather_sorted, n, c->d_x, c->d_y, n, g, c->keys_out.as<u64>(), c->vals_out.as<u32>(), c->sv.as<int>(), c->sa.as<int>());
     LAUNCH(k_strip_table, g.S + 2, c->keys_out.as<u64>(), n, g.S, c->strip.as<int>());
     ev_record(c, 2);
-    LAUNCH(k_region_count, n, g, c->sv.as<int>(), c->sa.as<int>(), c->strip.as<int>(), c->cnt.as<int>());
+    {
+        const int ntiles = nblocks(n);
+        const int grid = ((ntiles + 8 * K2_RUN - 1) / (8 * K2_RUN)) * (8 * K2_RUN);
+        if (exact) hipLaunchKernelGGL(k_region_count<true>, dim3(grid), dim3(TPB), 0, c->stream, g, ntiles, c->sv.as<int>(), c->sa.as<int>(), c->strip.as<int>(), c->cnt.as<int>());
+        else hipLaunchKernelGGL(k_region_count<false>, dim3(grid), dim3(TPB), 0, c->stream, g, ntiles, c->sv.as<int>(), c->sa.as<int>(), c->strip.as<int>(), c->cnt.as<int>());
+    }
     ev_record(c, 3);
     HIP_TRY(hipGetLastError());
     return CL_OK;
@@ -1209,7 +1400,7 @@ extern "C" int cl_neighbor_counts(cl_chrom* c, int32_t eps, int32_t cut, int32_t
     if ((rc = make_grid(c, CL_VARIANT_CDBSCAN1, eps, 1, cut, &g))) return rc;
     if ((rc = ensure_workspace(c, g.S))) return rc;
     if ((rc = ensure_events(c))) return rc;
-    if ((rc = run_sort_and_count(c, g))) return rc;
+    if ((rc = run_sort_and_count(c, g, true))) return rc;
     const int n = (int)c->n;
     HIP_TRY(hipMemsetAsync(c->labels.p, 0xFF, (size_t)n * 4, c->stream));
     LAUNCH(k_scatter_counts, n, c->strip.as<int>(), g.S, c->vals_out.as<u32>(), c->cnt.as<int>(), c->labels.as<int>());
@@ -1417,7 +1608,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     LAUNCH(k_init_arrays, n + 1, n, c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
            c->cellfirst.as<int>(), c->flag.as<int>(), c->state.as<int>(), counters);
     HIP_TRY(hipMemsetAsync(c->labels.p, 0xFF, (size_t)n * 4, c->stream));
-    if ((rc = run_sort_and_count(c, g))) return rc;
+    if ((rc = run_sort_and_count(c, g, false))) return rc;
 
     // K3
     if (variant == CL_VARIANT_CDBSCAN2) {
