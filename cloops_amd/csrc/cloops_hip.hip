@@ -320,11 +320,21 @@ __device__ __forceinline__ int lower_bound_4(const int* pv, int lo, int hi, int 
     return lo;
 }
 
+struct LdsPairs {       // LDS window of (q = in-strip coord, p = strip coord), addressed by GLOBAL sorted index
+    const int2* a; int base;
+    __device__ __forceinline__ int2 operator[](int j) const { return a[j - base]; }
+};
+struct LdsInts {
+    const int* a; int base;
+    __device__ __forceinline__ int operator[](int j) const { return a[j - base]; }
+};
+
 // Branch-free bounded searches on an LDS window of (q,p) pairs: fixed 8 steps, no divergence
 // (a wave pays the LONGEST trip count of its lanes, so data-dependent loops cost far more
 // instructions than the average lane needs).  Valid for hi - lo <= 255.
 // first idx in [lo,hi) with w[idx].x >= val (or hi)
-__device__ __forceinline__ int lds_lower_bound8(const int2* w, int lo, int hi, int val)
+template <typename W>
+__device__ __forceinline__ int lds_lower_bound8(const W& w, int lo, int hi, int val)
 {
     int pos = lo;
 #pragma unroll
@@ -336,7 +346,8 @@ __device__ __forceinline__ int lds_lower_bound8(const int2* w, int lo, int hi, i
     return pos;
 }
 // first idx in [lo,hi) with w[idx].x > val (or hi)
-__device__ __forceinline__ int lds_upper_bound8(const int2* w, int lo, int hi, int val)
+template <typename W>
+__device__ __forceinline__ int lds_upper_bound8(const W& w, int lo, int hi, int val)
 {
     int pos = lo;
 #pragma unroll
@@ -351,8 +362,8 @@ __device__ __forceinline__ int lds_upper_bound8(const int2* w, int lo, int hi, i
 // Count the candidates j of [j,te) with q[j] <= qhi (q ascending) and |p[j]-pi| <= eps, in chunks
 // whose loads are all issued before the first compare (an element-at-a-time `while (q <= qhi)`
 // loop costs one full memory latency per candidate).
-template <bool EXACT, int CH>
-__device__ __forceinline__ int k2_count_lds(const int2* w, int j, int te, int qhi, int pi, int eps, int minPts, int c)
+template <bool EXACT, int CH, typename W>
+__device__ __forceinline__ int k2_count_lds(const W& w, int j, int te, int qhi, int pi, int eps, int minPts, int c)
 {
     while (j < te) {
         int2 v[CH];
@@ -433,7 +444,7 @@ k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
         lw[k] = in ? make_int2(sv[gi], sa[gi]) : make_int2(0, 0);
     }
     __syncthreads();
-    const int2* w = lw - base;                     // w[global sorted index] = (in-strip coord q, strip coord p)
+    LdsPairs w; w.a = lw; w.base = base;           // w[global sorted index] = (in-strip coord q, strip coord p)
     const int wbeg = max(base, 0), wend = min(base + K2_WIN, M);
     const int i = t0 + threadIdx.x;
     const bool valid = i < M;
@@ -499,6 +510,111 @@ k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS tile framework shared by the traversal kernels K3 (chains, union) and K4 (border, records)
+// ------------------------------------------------------------------------------------------
+// Same tiling as K2: a workgroup owns 256 consecutive sorted PETs and stages them plus a halo
+// as (q,p) pairs and one int of per-PET payload (neighbour count or component root).  Strip
+// segments inside the staged range are walked in LDS; anything else falls back to global memory.
+#define T_HALO 128
+#define T_WIN (TPB + 2 * T_HALO)
+
+struct Tile {
+    LdsPairs w;         // (q, p), indexed by global sorted index
+    LdsInts x;          // payload, indexed by global sorted index
+    int wbeg, wend;     // staged index range [wbeg, wend)
+    int t0;             // first PET of the tile
+};
+
+__device__ __forceinline__ int tile_of_block(int bid)
+{
+    const int xcd = bid & 7, kseq = bid >> 3;
+    return ((kseq / K2_RUN) * 8 + xcd) * K2_RUN + (kseq % K2_RUN);
+}
+static inline int tile_grid(int ntiles) { return ((ntiles + 8 * K2_RUN - 1) / (8 * K2_RUN)) * (8 * K2_RUN); }
+
+// all threads of the workgroup; returns false (for the whole workgroup) if the tile is empty
+__device__ __forceinline__ bool tile_stage(Tile& t, int2* lw, int* lx, int ntiles, int M,
+                                           const int* __restrict__ gq, const int* __restrict__ gp,
+                                           const int* __restrict__ gx)
+{
+    const int tile = tile_of_block(blockIdx.x);
+    t.t0 = tile * TPB;
+    if (tile >= ntiles || t.t0 >= M) return false;
+    const int base = t.t0 - T_HALO;
+    for (int k = threadIdx.x; k < T_WIN; k += TPB) {
+        const int gi = base + k;
+        const bool in = gi >= 0 && gi < M;
+        lw[k] = in ? make_int2(gq[gi], gp[gi]) : make_int2(0, 0);
+        lx[k] = in ? gx[gi] : 0;
+    }
+    __syncthreads();
+    t.w.a = lw; t.w.base = base; t.x.a = lx; t.x.base = base;
+    t.wbeg = max(base, 0); t.wend = min(base + T_WIN, M);
+    return true;
+}
+
+// Workgroup compaction: slot list of the threads with `active`; returns their number.  Whole
+// waves fall out of the expensive phase instead of running it at partial lane occupancy.
+__device__ __forceinline__ int block_compact(bool active, short* l_list, int* l_wcount)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(active);
+    if (lane == 0) l_wcount[wv] = __popcll(bal);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < TPB / 64; ++k) { const int c = l_wcount[k]; off += (k < wv) ? c : 0; total += c; }
+    if (active) l_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (short)threadIdx.x;
+    __syncthreads();
+    return total;
+}
+
+// visit, in ascending order, every j of the strip segment [sb,se) with q_j in [qlo,qhi]:
+// f(j, q_j, p_j, x_j)
+template <typename F>
+__device__ __forceinline__ void tile_visit_segment(const Tile& t, const int* __restrict__ gq, const int* __restrict__ gp,
+                                                   const int* __restrict__ gx, int sb, int se, int qlo, int qhi, F&& f)
+{
+    if (sb >= se) return;
+    if (sb >= t.wbeg && se <= t.wend && se - sb <= 255) {
+        int j = lds_lower_bound8(t.w, sb, se, qlo);
+        for (; j < se; ++j) {
+            const int2 c = t.w[j];
+            if (c.x > qhi) break;
+            f(j, c.x, c.y, t.x[j]);
+        }
+    } else {
+        int j = lower_bound_4(gq, sb, se, qlo);
+        for (; j < se; ++j) {
+            const int q = gq[j];
+            if (q > qhi) break;
+            f(j, q, gp[j], gx[j]);
+        }
+    }
+}
+// own strip: walk left from i-1 down to b while q >= qlo, then right from i+1 up to e while
+// q <= qhi; f(j, x_j) returns true to stop that direction early.  `dirs`: bit0 left, bit1 right.
+template <typename F>
+__device__ __forceinline__ void tile_visit_own(const Tile& t, const int* __restrict__ gq, const int* __restrict__ gx,
+                                               int i, int b, int e, int qlo, int qhi, int dirs, F&& f)
+{
+    if (dirs & 1)
+        for (int j = i - 1; j >= b; --j) {
+            const bool in = j >= t.wbeg;
+            const int q = in ? t.w[j].x : gq[j];
+            if (q < qlo) break;
+            if (f(j, in ? t.x[j] : gx[j])) break;
+        }
+    if (dirs & 2)
+        for (int j = i + 1; j < e; ++j) {
+            const bool in = j < t.wend;
+            const int q = in ? t.w[j].x : gq[j];
+            if (q > qhi) break;
+            if (f(j, in ? t.x[j] : gx[j])) break;
+        }
+}
+
 // scatter counts back to input-row order (cl_neighbor_counts)
 __global__ void k_scatter_counts(const int* __restrict__ strip_start, int S, const u32* __restrict__ srow,
                                  const int* __restrict__ cnt, int* __restrict__ out)
@@ -513,8 +629,8 @@ __global__ void k_scatter_counts(const int* __restrict__ strip_start, int S, con
 // per-run initialisation of the per-point / per-root arrays
 // ------------------------------------------------------------------------------------------
 __global__ void k_init_arrays(int n, int* __restrict__ parent, int* __restrict__ compkey, int* __restrict__ ncore,
-                              int* __restrict__ bsize, int* __restrict__ cellfirst, int* __restrict__ flag,
-                              int* __restrict__ state, int* __restrict__ counters)
+                              int* __restrict__ bsize, int* __restrict__ usize, int* __restrict__ cellfirst,
+                              int* __restrict__ flag, int* __restrict__ state, int* __restrict__ counters)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 16 && counters) counters[i] = 0;
@@ -525,6 +641,7 @@ __global__ void k_init_arrays(int n, int* __restrict__ parent, int* __restrict__
     compkey[i] = INT_MAX;
     ncore[i] = 0;
     bsize[i] = 0;
+    usize[i] = 0;
     cellfirst[i] = INT_MAX;
     state[i] = 0;
 }
@@ -566,20 +683,23 @@ __global__ void k_cell_first(const int* __restrict__ strip_start, int S, const i
 // (parent = chain head), so no million-long pointer chains ever exist -- dense diagonals
 // (self-ligation PETs) become one chain per strip.
 __global__ void __launch_bounds__(TPB)
-k_chain_flags(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
+k_chain_flags(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
               const int* __restrict__ strip_start, const int* __restrict__ cnt, int* __restrict__ chainflag)
 {
+    __shared__ int2 lw[T_WIN];
+    __shared__ int lx[T_WIN];
     const int M = strip_start[g.S];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    Tile t;
+    if (!tile_stage(t, lw, lx, ntiles, M, sv, sa, cnt)) return;
+    const int i = t.t0 + threadIdx.x;
     if (i >= M) return;
     int f = 0;
-    if (cnt[i] >= g.minPts) {
-        const int vi = sv[i];
-        const int vlo = sat_add(vi, -g.eps);
-        const int b = strip_start[strip_of(g, sa[i])];
+    if (t.x[i] >= g.minPts) {
+        const int2 me = t.w[i];
+        const int b = strip_start[strip_of(g, me.y)];
         f = i + 1;
-        for (int j = i - 1; j >= b && sv[j] >= vlo; --j)
-            if (cnt[j] >= g.minPts) { f = 0; break; }
+        tile_visit_own(t, sv, cnt, i, b, 0, sat_add(me.x, -g.eps), 0, 1,
+                       [&](int, int cj) { if (cj >= g.minPts) { f = 0; return true; } return false; });
     }
     chainflag[i] = f;
 }
@@ -597,32 +717,35 @@ __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const
 // of strip s-1 suffices: consecutive cores of the window with v-gap <= eps are already in
 // one chain.
 __global__ void __launch_bounds__(TPB)
-k_union_cores(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
+k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
               const int* __restrict__ strip_start, const int* __restrict__ cnt, int* parent)
 {
+    __shared__ int2 lw[T_WIN];
+    __shared__ int lx[T_WIN];
+    __shared__ short l_list[TPB];
+    __shared__ int l_wcount[TPB / 64];
     const int M = strip_start[g.S];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    if (cnt[i] < g.minPts) return;
-    const int vi = sv[i], ai = sa[i];
-    const int t = strip_of(g, ai) - 1;
-    if (t < 0) return;
-    const int vlo = sat_add(vi, -g.eps), vhi = sat_add(vi, g.eps);
-    const int tb = strip_start[t], te = strip_start[t + 1];
-    if (tb == te) return;
-    int j = lower_bound_i(sv, tb, te, vlo);
+    Tile t;
+    if (!tile_stage(t, lw, lx, ntiles, M, sv, sa, cnt)) return;
+    const int i0 = t.t0 + threadIdx.x;
+    const int total = block_compact(i0 < M && t.x[i0 < M ? i0 : t.t0] >= g.minPts, l_list, l_wcount);
+    if ((int)threadIdx.x >= total) return;
+    const int i = t.t0 + l_list[threadIdx.x];
+    const int2 me = t.w[i];
+    const int s = strip_of(g, me.y);
+    if (s == 0) return;
+    const int tb = strip_start[s - 1], b = strip_start[s];
     bool linked = false, have_prev = false;
-    int prev_v = 0;
-    for (; j < te; ++j) {
-        const int vj = sv[j];
-        if (vj > vhi) break;
-        if (cnt[j] < g.minPts) continue;
-        if (have_prev && vj - prev_v > g.eps) linked = false;      // a new chain of strip s-1 starts
-        have_prev = true; prev_v = vj;
-        if (linked) continue;
-        const int da = sa[j] - ai;
+    int prev_q = 0;
+    tile_visit_segment(t, sv, sa, cnt, tb, b, sat_add(me.x, -g.eps), sat_add(me.x, g.eps),
+                       [&](int j, int qj, int pj, int cj) {
+        if (cj < g.minPts) return;
+        if (have_prev && qj - prev_q > g.eps) linked = false;      // a new chain of strip s-1 starts
+        have_prev = true; prev_q = qj;
+        if (linked) return;
+        const int da = pj - me.y;
         if ((da < 0 ? -da : da) <= g.eps) { uf_unite(parent, i, j); linked = true; }
-    }
+    });
 }
 
 // K3b: root per core point, component keys and core counts.
@@ -676,28 +799,58 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
 //                   adjacent component (first come, cDBSCAN.py:179-182)
 // owner[i] = root of the owning component (cores: their own root), -1 = noise
 // ------------------------------------------------------------------------------------------
+#define OWNER_CONTESTED 0x40000000
+__device__ __forceinline__ int owner_root(int o) { return o < 0 ? -1 : (o & (OWNER_CONTESTED - 1)); }
+
 __global__ void __launch_bounds__(TPB)
-k_border(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
+k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
          const int* __restrict__ strip_start, const int* __restrict__ root, const int* __restrict__ compkey,
-         const u32* __restrict__ srow, int* __restrict__ owner, int* __restrict__ bsize)
+         const u32* __restrict__ srow, int* __restrict__ owner, int* __restrict__ bsize, int* __restrict__ usize)
 {
+    __shared__ int2 lw[T_WIN];
+    __shared__ int lx[T_WIN];
+    __shared__ short l_list[TPB];
+    __shared__ int l_wcount[TPB / 64];
     const int M = strip_start[g.S];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    int ri = root[i];
-    if (ri >= 0) { owner[i] = ri; return; }
-    int bestk = INT_MAX, best = -1, tk = -1, tbest = -1;
+    Tile t;
+    if (!tile_stage(t, lw, lx, ntiles, M, sv, sa, root)) return;
+    const int i0 = t.t0 + threadIdx.x;
+    bool border = false;
+    if (i0 < M) {
+        const int ri = t.x[i0];
+        if (ri >= 0) owner[i0] = ri; else border = true;
+    }
+    const int total = block_compact(border, l_list, l_wcount);
+    if ((int)threadIdx.x >= total) return;
+    const int i = t.t0 + l_list[threadIdx.x];
+    const int2 me = t.w[i];
+    const int s = strip_of(g, me.y);
+    const int qlo = sat_add(me.x, -g.eps), qhi = sat_add(me.x, g.eps);
+    const int b = strip_start[s], e = strip_start[s + 1];
+    const int tb = s > 0 ? strip_start[s - 1] : b;
+    const int te = s + 1 < g.S ? strip_start[s + 2] : e;
     const bool v1 = g.variant == CL_VARIANT_CDBSCAN1;
-    for_each_neighbor(g, sv, sa, strip_start, i, 7, [&](int j) {
-        int r = root[j];
+    int bestk = INT_MAX, best = -1, tk = -1, tbest = -1, lastr = -1, lastk = 0, first = -1;
+    bool contested = false;
+    auto see = [&](int j, int r) {
         if (r < 0) return;
-        int k = compkey[r];
+        if (first < 0) first = r; else if (r != first) contested = true;
+        int k;
+        if (r == lastr) k = lastk; else { k = compkey[r]; lastr = r; lastk = k; }
         if (k < bestk) { bestk = k; best = r; }
-        if (v1 && (int)srow[j] == k && k > tk) { tk = k; tbest = r; }
-    });
-    int o = (v1 && tbest >= 0) ? tbest : best;
-    owner[i] = o;
-    if (o >= 0) atomicAdd(&bsize[o], 1);
+        if (v1 && (int)srow[j] == k && k > tk) { tk = k; tbest = r; }     // j is its component's start point
+    };
+    tile_visit_own(t, sv, root, i, b, e, qlo, qhi, 3, [&](int j, int r) { see(j, r); return false; });
+    tile_visit_segment(t, sv, sa, root, tb, b, qlo, qhi, [&](int j, int, int pj, int r) {
+        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.eps) see(j, r); });
+    tile_visit_segment(t, sv, sa, root, e, te, qlo, qhi, [&](int j, int, int pj, int r) {
+        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.eps) see(j, r); });
+    const int o = (v1 && tbest >= 0) ? tbest : best;
+    owner[i] = o < 0 ? -1 : (contested ? (o | OWNER_CONTESTED) : o);
+    if (o >= 0) {
+        atomicAdd(&bsize[o], 1);
+        if (!contested) atomicAdd(&usize[o], 1);
+    }
 }
 
 // ---- variant 2 release rule (cDBSCAN2.py:180-183) ------------------------------------------
@@ -726,34 +879,53 @@ __global__ void k_mark_uncertain(GridParams g, const int* __restrict__ strip_sta
 struct Rec { int pt; int r[4]; };
 
 __global__ void __launch_bounds__(TPB)
-k_emit_records(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
+k_emit_records(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
                const int* __restrict__ strip_start, const int* __restrict__ root, const int* __restrict__ compkey,
                const int* __restrict__ state, const int* __restrict__ owner, Rec* __restrict__ recs, int rec_cap,
                int* __restrict__ counters)
 {
+    __shared__ int2 lw[T_WIN];
+    __shared__ int lx[T_WIN];
+    __shared__ short l_list[TPB];
+    __shared__ int l_wcount[TPB / 64];
     if (counters[CTR_NU] == 0) return;
     const int M = strip_start[g.S];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    if (root[i] >= 0 || owner[i] < 0) return;
+    Tile t;
+    if (!tile_stage(t, lw, lx, ntiles, M, sv, sa, root)) return;
+    const int i0 = t.t0 + threadIdx.x;
+    // only CONTESTED border points can change hands when a component is released
+    const bool act = i0 < M && t.x[i0] < 0 && owner[i0] >= 0 && (owner[i0] & OWNER_CONTESTED);
+    const int total = block_compact(act, l_list, l_wcount);
+    if ((int)threadIdx.x >= total) return;
+    const int i = t.t0 + l_list[threadIdx.x];
+    const int2 me = t.w[i];
+    const int s = strip_of(g, me.y);
+    const int qlo = sat_add(me.x, -g.eps), qhi = sat_add(me.x, g.eps);
+    const int b = strip_start[s], e = strip_start[s + 1];
+    const int tb = s > 0 ? strip_start[s - 1] : b;
+    const int te = s + 1 < g.S ? strip_start[s + 2] : e;
     int rr[4] = {-1, -1, -1, -1};
     int kk[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
     int nr = 0;
     bool any_u = false, overflow = false;
-    for_each_neighbor(g, sv, sa, strip_start, i, 7, [&](int j) {
-        int r = root[j];
+    auto see = [&](int r) {
         if (r < 0) return;
         for (int q = 0; q < 4; ++q) if (rr[q] == r) return;
         if (nr == 4) { overflow = true; return; }
-        int k = compkey[r];
+        const int k = compkey[r];
         int q = nr++;
         while (q > 0 && kk[q - 1] > k) { kk[q] = kk[q - 1]; rr[q] = rr[q - 1]; --q; }
         kk[q] = k; rr[q] = r;
         if (state[r] == ST_UNKNOWN) any_u = true;
-    });
+    };
+    tile_visit_own(t, sv, root, i, b, e, qlo, qhi, 3, [&](int, int r) { see(r); return false; });
+    tile_visit_segment(t, sv, sa, root, tb, b, qlo, qhi, [&](int, int, int pj, int r) {
+        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.eps) see(r); });
+    tile_visit_segment(t, sv, sa, root, e, te, qlo, qhi, [&](int, int, int pj, int r) {
+        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.eps) see(r); });
     if (overflow) atomicExch(&counters[CTR_OVERFLOW], 1);
     if (!any_u) return;
-    int idx = atomicAdd(&counters[CTR_NREC], 1);
+    const int idx = atomicAdd(&counters[CTR_NREC], 1);
     if (idx >= rec_cap) { atomicExch(&counters[CTR_OVERFLOW], 2); return; }
     Rec rec; rec.pt = i;
     for (int q = 0; q < 4; ++q) rec.r[q] = rr[q];
@@ -763,15 +935,17 @@ k_emit_records(GridParams g, const int* __restrict__ sv, const int* __restrict__
 // one workgroup; rounds until every uncertain component is decided.  lo = borders surely
 // available (every lower-key adjacent component dead), hi = possibly available (none live).
 __global__ void __launch_bounds__(1024)
-k_resolve_release(int minPts, const int* __restrict__ ncore, int* state, const int* __restrict__ ulist,
-                  const Rec* __restrict__ recs, int* lo, int* hi, const int* __restrict__ counters)
+k_resolve_release(int minPts, const int* __restrict__ ncore, const int* __restrict__ usize, int* state,
+                  const int* __restrict__ ulist, const Rec* __restrict__ recs, int* lo, int* hi,
+                  const int* __restrict__ counters)
 {
     const int nU = counters[CTR_NU];
     if (nU == 0) return;
     const int nrec = counters[CTR_NREC];
     __shared__ int remaining;
     for (;;) {
-        for (int u = threadIdx.x; u < nU; u += blockDim.x) { int c = ulist[u]; lo[c] = 0; hi[c] = 0; }
+        // uncontested borders are always available to their only adjacent component
+        for (int u = threadIdx.x; u < nU; u += blockDim.x) { int c = ulist[u]; lo[c] = usize[c]; hi[c] = usize[c]; }
         if (threadIdx.x == 0) remaining = 0;
         __syncthreads();
         for (int q = threadIdx.x; q < nrec; q += blockDim.x) {
@@ -894,7 +1068,7 @@ k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __r
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int lab = -1, x = 0, y = 0;
     if (i < M) {
-        int o = owner[i];
+        int o = owner_root(owner[i]);
         if (o >= 0) {
             bool keep = (g.variant == CL_VARIANT_CDBSCAN2) ? (state[o] != ST_DEAD)
                                                            : (ncore[o] + bsize[o] >= g.minPts);   // cDBSCAN.py:149-152
@@ -1184,7 +1358,7 @@ struct cl_chrom {
     // workspace
     DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, scan_tmp;
     DevBuf sv, sa, strip, cnt, parent, root, head, headidx, cellfirst, compkey, ncore, bsize, owner, state;
-    DevBuf flag, rankscan, labels, table, ulist, lo, hi, recs, counters, chainflag, chainhead, b_cstart, b_ckey, b_nb, b_cx, b_cy;
+    DevBuf flag, rankscan, labels, table, ulist, lo, hi, recs, counters, chainflag, chainhead, usize, b_cstart, b_ckey, b_nb, b_cx, b_cy;
     int* h_pinned = nullptr;          // small pinned staging (counters, K)
     // last result
     int last_K = 0;                   // ids handed out (max_label + 1 upper bound)
@@ -1203,7 +1377,7 @@ static void free_chrom(cl_chrom* c)
     DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->labels, &c->table,
-                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy};
+                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy};
     for (DevBuf* b : bufs) b->release();
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -1290,7 +1464,7 @@ static int ensure_workspace(cl_chrom* c, int S)
     ENS(compkey, n * 4); ENS(ncore, n * 4); ENS(bsize, n * 4); ENS(owner, n * 4); ENS(state, n * 4);
     ENS(flag, (n + 1) * 4); ENS(rankscan, (n + 1) * 4); ENS(labels, n * 4); ENS(table, (n + 1) * 5 * 4);
     ENS(ulist, n * 4); ENS(lo, n * 4); ENS(hi, n * 4); ENS(recs, n * sizeof(Rec)); ENS(counters, 256);
-    ENS(chainflag, n * 4); ENS(chainhead, n * 4);
+    ENS(chainflag, n * 4); ENS(chainhead, n * 4); ENS(usize, n * 4);
 #undef ENS
     // rocPRIM temporary storage
     size_t sort_bytes = 0, scan_bytes = 0, scan2 = 0;
@@ -1495,7 +1669,7 @@ static int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_
     int* counters = c->counters.as<int>();
     BlkScalars* sc = (BlkScalars*)(counters + 32);
     LAUNCH(k_init_arrays, n + 1, n, c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
-           c->cellfirst.as<int>(), c->flag.as<int>(), c->state.as<int>(), counters);
+           c->usize.as<int>(), c->cellfirst.as<int>(), c->flag.as<int>(), c->state.as<int>(), counters);
     HIP_TRY(hipMemsetAsync(c->labels.p, 0xFF, (size_t)n * 4, c->stream));
     BlkScalars* hsc = (BlkScalars*)(c->h_pinned + 64);
     hsc->minx = INT_MAX; hsc->miny = INT_MAX; hsc->M = 0; hsc->C = 0;
@@ -1604,9 +1778,11 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     int* cnt = c->cnt.as<int>();
     u32* srow = c->vals_out.as<u32>();
     int* counters = c->counters.as<int>();
+    const int ntiles = nblocks(n);
+    const int tgrid = tile_grid(ntiles);
 
     LAUNCH(k_init_arrays, n + 1, n, c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
-           c->cellfirst.as<int>(), c->flag.as<int>(), c->state.as<int>(), counters);
+           c->usize.as<int>(), c->cellfirst.as<int>(), c->flag.as<int>(), c->state.as<int>(), counters);
     HIP_TRY(hipMemsetAsync(c->labels.p, 0xFF, (size_t)n * 4, c->stream));
     if ((rc = run_sort_and_count(c, g, false))) return rc;
 
@@ -1623,26 +1799,27 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         // own-strip chains by scan (headidx / head buffers are free again here for variant 2:
         // k_cell_first has consumed them into cellfirst... they are still needed by k_flatten,
         // so the chain scan uses its own pair of buffers)
-        LAUNCH(k_chain_flags, n, g, sv, sa, strip, cnt, c->chainflag.as<int>());
+        hipLaunchKernelGGL(k_chain_flags, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, cnt, c->chainflag.as<int>());
         size_t tb = c->scan_tmp.bytes;
         hipError_t e = rocprim::inclusive_scan(c->scan_tmp.p, tb, c->chainflag.as<int>(), c->chainhead.as<int>(), (size_t)n,
                                                rocprim::maximum<int>(), c->stream);
         if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan(chain)", hipGetErrorString(e));
         LAUNCH(k_chain_parent, n, strip, g.S, cnt, g.minPts, c->chainhead.as<int>(), c->parent.as<int>());
     }
-    LAUNCH(k_union_cores, n, g, sv, sa, strip, cnt, c->parent.as<int>());
+    hipLaunchKernelGGL(k_union_cores, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, cnt, c->parent.as<int>());
     LAUNCH(k_flatten, n, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
            c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>());
     ev_record(c, 4);
     // K4
-    LAUNCH(k_border, n, g, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>());
+    hipLaunchKernelGGL(k_border, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(),
+                       srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>());
     if (variant == CL_VARIANT_CDBSCAN2) {
         const int rec_cap = n;
         LAUNCH(k_mark_uncertain, n, g, strip, c->root.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->state.as<int>(),
                c->ulist.as<int>(), counters);
-        LAUNCH(k_emit_records, n, g, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(), c->state.as<int>(),
-               c->owner.as<int>(), c->recs.as<Rec>(), rec_cap, counters);
-        hipLaunchKernelGGL(k_resolve_release, dim3(1), dim3(1024), 0, c->stream, minPts, c->ncore.as<int>(), c->state.as<int>(),
+        hipLaunchKernelGGL(k_emit_records, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, c->root.as<int>(),
+                           c->compkey.as<int>(), c->state.as<int>(), c->owner.as<int>(), c->recs.as<Rec>(), rec_cap, counters);
+        hipLaunchKernelGGL(k_resolve_release, dim3(1), dim3(1024), 0, c->stream, minPts, c->ncore.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                            c->ulist.as<int>(), c->recs.as<Rec>(), c->lo.as<int>(), c->hi.as<int>(), counters);
         LAUNCH(k_apply_records, n, c->recs.as<Rec>(), c->state.as<int>(), c->owner.as<int>(), counters);
     }
