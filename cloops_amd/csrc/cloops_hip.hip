@@ -96,6 +96,8 @@ struct GridParams {
     int dbg;      // developer knobs (CLOOPS_DBG env), 0 in production
     u32 magic;    // strip(a) = a / eps by multiply-shift (Granlund-Montgomery, exact for all u32)
     int sh1, sh2;
+    int qbits;    // sort key = strip << (qbits+rbits) | q << rbits | (p mod eps): both coordinates ride
+    int rbits;    //   in the key, so the sorted (q,p) arrays are DECODED, not gathered through row ids
 };
 
 __device__ __forceinline__ int sat_add(int a, int b)
@@ -141,12 +143,13 @@ __device__ __forceinline__ int gallop_right(const int* __restrict__ sv, int i, i
     return upper_bound_i(sv, lo + 1, hi, val);
 }
 
-__device__ __forceinline__ int strip_of(const GridParams& g, int arel)
+__device__ __forceinline__ int div_eps(const GridParams& g, int arel)
 {
     const u32 n = (u32)arel;                       // arel >= 0 by construction
     const u32 t1 = __umulhi(g.magic, n);
-    return (int)((t1 + ((n - t1) >> g.sh1)) >> g.sh2) - g.s0;
+    return (int)((t1 + ((n - t1) >> g.sh1)) >> g.sh2);
 }
+__device__ __forceinline__ int strip_of(const GridParams& g, int arel) { return div_eps(g, arel) - g.s0; }
 
 // Visit every j != i with max(|a_j-a_i|, |v_j-v_i|) <= eps.  `which` selects the strips:
 // bit0 = strip s-1, bit1 = own strip (both directions), bit2 = strip s+1.
@@ -263,35 +266,38 @@ __global__ void k_make_keys(const int* __restrict__ X, const int* __restrict__ Y
     int a = y - x;
     bool valid = (g.cut <= 0) || (a >= g.cut);            // pipe.py:59-62  d >= cut
     int v = x + y;
-    int arel = (g.swap ? v : a) - g.A0;                   // strip coordinate
-    u32 vrel = (u32)((g.swap ? a : v) - g.V0);            // in-strip coordinate
-    u64 key = valid ? (((u64)(u32)strip_of(g, arel) << 32) | vrel) : ((u64)(u32)g.S << 32);
+    int prel = (g.swap ? v : a) - g.A0;                   // strip coordinate
+    u32 qrel = (u32)((g.swap ? a : v) - g.V0);            // in-strip coordinate
+    const int sabs = div_eps(g, prel);
+    const u32 rem = (u32)(prel - sabs * g.eps);           // p mod eps
+    const int sh = g.qbits + g.rbits;
+    u64 key = valid ? (((u64)(u32)(sabs - g.s0) << sh) | ((u64)qrel << g.rbits) | rem) : ((u64)(u32)g.S << sh);
     keys[r] = key;
     vals[r] = (u32)r;
 }
 
-// K1b: sorted coordinates (gather through the sorted row ids)
-__global__ void k_gather_sorted(const int* __restrict__ X, const int* __restrict__ Y, int n, GridParams g,
-                                const u64* __restrict__ skeys, const u32* __restrict__ srow,
+// K1b: sorted coordinates, decoded from the sorted keys (coalesced; no gather through row ids)
+__global__ void k_decode_sorted(int n, GridParams g, const u64* __restrict__ skeys,
                                 int* __restrict__ sv, int* __restrict__ sa)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    u64 k = skeys[i];
-    if ((int)(k >> 32) >= g.S) { sv[i] = INT_MAX; sa[i] = 0; return; }
-    u32 r = srow[i];
-    sv[i] = (int)(u32)(k & 0xffffffffu);
-    sa[i] = (g.swap ? (Y[r] + X[r]) : (Y[r] - X[r])) - g.A0;
+    const u64 k = skeys[i];
+    const int sh = g.qbits + g.rbits;
+    const int strip = (int)(k >> sh);
+    if (strip >= g.S) { sv[i] = INT_MAX; sa[i] = 0; return; }
+    sv[i] = (int)((k >> g.rbits) & ((1ull << g.qbits) - 1ull));
+    sa[i] = (strip + g.s0) * g.eps + (int)(k & ((1ull << g.rbits) - 1ull));
 }
 
 // K1c: strip_start[t] = first sorted index whose strip >= t, t = 0..S+1
 // (strip_start[S] = M = number of rows that entered DBSCAN, strip_start[S+1] = n)
-__global__ void k_strip_table(const u64* __restrict__ skeys, int n, int S, int* __restrict__ strip_start)
+__global__ void k_strip_table(const u64* __restrict__ skeys, int n, int S, int shift, int* __restrict__ strip_start)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > S + 1) return;
     if (t == S + 1) { strip_start[t] = n; return; }
-    u64 target = (u64)(u32)t << 32;
+    u64 target = (u64)(u32)t << shift;
     int lo = 0, hi = n;
     while (lo < hi) {
         int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
@@ -650,27 +656,19 @@ __global__ void k_init_arrays(int n, int* __restrict__ parent, int* __restrict__
 // v2: cellfirst(cell) = smallest input row of ANY point of the rotated cell
 // (cDBSCAN2.py:69-71,117: start cells are visited in dict insertion order)
 // ------------------------------------------------------------------------------------------
-__global__ void k_cell_heads(const u64* __restrict__ skeys, const int* __restrict__ strip_start, GridParams g,
-                             int* __restrict__ headidx)
+__global__ void k_cell_heads(int n, const int* __restrict__ sv, const int* __restrict__ sa, const int* __restrict__ strip_start,
+                             GridParams g, int* __restrict__ headidx)
 {
     const int M = strip_start[g.S];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
+    if (i >= n) return;
+    if (i >= M) { headidx[i] = i; return; }           // filtered tail: singleton segments
     bool head = true;
     if (i > 0) {
-        u64 k = skeys[i], kp = skeys[i - 1];
-        // variant 2: V0 == 0 so the low word IS v = X + Y; cell column = trunc(v / eps)
-        head = ((k >> 32) != (kp >> 32)) || ((u32)(k & 0xffffffffu) / (u32)g.eps != (u32)(kp & 0xffffffffu) / (u32)g.eps);
+        // a rotated cell = (strip, q / eps); variant 2 runs with A0 = V0 = 0, so q IS the absolute coordinate
+        head = (div_eps(g, sa[i]) != div_eps(g, sa[i - 1])) || (div_eps(g, sv[i]) != div_eps(g, sv[i - 1]));
     }
     headidx[i] = head ? i : 0;
-}
-__global__ void k_cell_first(const int* __restrict__ strip_start, int S, const int* __restrict__ head,
-                             const u32* __restrict__ srow, int* __restrict__ cellfirst)
-{
-    const int M = strip_start[S];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    atomicMin(&cellfirst[head[i]], (int)srow[i]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1476,7 +1474,11 @@ static int ensure_workspace(cl_chrom* c, int S)
     e = rocprim::exclusive_scan(nullptr, scan2, (int*)nullptr, (int*)nullptr, 0, n + 1, rocprim::plus<int>(), c->stream);
     if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan size query", hipGetErrorString(e));
     if ((rc = c->sort_tmp.ensure(std::max<size_t>(sort_bytes, 16)))) return rc;
-    if ((rc = c->scan_tmp.ensure(std::max<size_t>(std::max(scan_bytes, scan2), 16)))) return rc;
+    size_t scan3 = 0;
+    e = rocprim::inclusive_scan_by_key(nullptr, scan3, rocprim::make_reverse_iterator((int*)nullptr), rocprim::make_reverse_iterator((int*)nullptr),
+                                       rocprim::make_reverse_iterator((int*)nullptr), n, rocprim::minimum<int>(), rocprim::equal_to<int>(), c->stream);
+    if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan_by_key size query", hipGetErrorString(e));
+    if ((rc = c->scan_tmp.ensure(std::max<size_t>(std::max(std::max(scan_bytes, scan2), scan3), 16)))) return rc;
     return CL_OK;
 }
 
@@ -1507,6 +1509,10 @@ static int make_grid(cl_chrom* c, int variant, int eps, int minPts, int cut, Gri
     long long S = hi - lo + 1;
     if (S > (1LL << 28)) return fail(CL_ERR_GRID, "eps too small for the coordinate extent (strip table > 2^28 rows)");
     g->s0 = (int)lo; g->S = (int)S;
+    const int qmin = g->swap ? c->st.amin : c->st.vmin, qmax = g->swap ? c->st.amax : c->st.vmax;
+    (void)qmin;
+    g->qbits = std::max(1, bits_for((unsigned)((long long)qmax - g->V0)));
+    g->rbits = bits_for((unsigned)(eps - 1));
     return CL_OK;
 }
 
@@ -1526,12 +1532,12 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     LAUNCH(k_make_keys, n, c->d_x, c->d_y, n, g, c->keys_in.as<u64>(), c->vals_in.as<u32>());
     ev_record(c, 1);
     size_t tmp_bytes = c->sort_tmp.bytes;
-    int end_bit = 32 + std::max(1, bits_for((unsigned)g.S));
+    int end_bit = g.qbits + g.rbits + std::max(1, bits_for((unsigned)g.S));
     hipError_t e = rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->keys_in.as<u64>(), c->keys_out.as<u64>(),
                                              c->vals_in.as<u32>(), c->vals_out.as<u32>(), (size_t)n, 0, end_bit, c->stream);
     if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs", hipGetErrorString(e));
-    LAUNCH(k_gather_sorted, n, c->d_x, c->d_y, n, g, c->keys_out.as<u64>(), c->vals_out.as<u32>(), c->sv.as<int>(), c->sa.as<int>());
-    LAUNCH(k_strip_table, g.S + 2, c->keys_out.as<u64>(), n, g.S, c->strip.as<int>());
+    LAUNCH(k_decode_sorted, n, n, g, c->keys_out.as<u64>(), c->sv.as<int>(), c->sa.as<int>());
+    LAUNCH(k_strip_table, g.S + 2, c->keys_out.as<u64>(), n, g.S, g.qbits + g.rbits, c->strip.as<int>());
     ev_record(c, 2);
     {
         const int ntiles = nblocks(n);
@@ -1788,12 +1794,19 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
 
     // K3
     if (variant == CL_VARIANT_CDBSCAN2) {
-        LAUNCH(k_cell_heads, n, c->keys_out.as<u64>(), strip, g, c->headidx.as<int>());
+        LAUNCH(k_cell_heads, n, n, sv, sa, strip, g, c->headidx.as<int>());
         size_t tb = c->scan_tmp.bytes;
         hipError_t e = rocprim::inclusive_scan(c->scan_tmp.p, tb, c->headidx.as<int>(), c->head.as<int>(), (size_t)n,
                                                rocprim::maximum<int>(), c->stream);
         if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan", hipGetErrorString(e));
-        LAUNCH(k_cell_first, n, strip, g.S, c->head.as<int>(), srow, c->cellfirst.as<int>());
+        // cellfirst: segmented suffix-min of the input rows, keyed by the cell's head index, so that
+        // cellfirst[head] = smallest row of the whole cell (replaces one atomicMin per PET)
+        tb = c->scan_tmp.bytes;
+        e = rocprim::inclusive_scan_by_key(c->scan_tmp.p, tb, rocprim::make_reverse_iterator(c->head.as<int>() + n),
+                                           rocprim::make_reverse_iterator((int*)srow + n),
+                                           rocprim::make_reverse_iterator(c->cellfirst.as<int>() + n), (size_t)n,
+                                           rocprim::minimum<int>(), rocprim::equal_to<int>(), c->stream);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan_by_key", hipGetErrorString(e));
     }
     {
         // own-strip chains by scan (headidx / head buffers are free again here for variant 2:
