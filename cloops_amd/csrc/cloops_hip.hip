@@ -746,17 +746,40 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     });
 }
 
+// ------------------------------------------------------------------------------------------
+// Two-level reduce-by-key in front of global atomics.  A giant component (the self-ligation
+// diagonal at large eps: millions of PETs in ONE cluster) would otherwise put one atomic per
+// wave on the same few addresses, which the L2 serialises at ~2 ns each (2.5 ms per kernel on a
+// 16 M-PET chromosome).  Level 1: lanes of a wave sharing a key are reduced with ballots and
+// shuffles.  Level 2: the per-wave results of a 1024-thread workgroup meet in a small LDS hash
+// table; one global atomic per key per WORKGROUP remains.
+// ------------------------------------------------------------------------------------------
+#define BIGTPB 1024
+#define AGG_H 512
+__device__ __forceinline__ int agg_slot(int* keys, int key)
+{
+    unsigned h = ((unsigned)key * 2654435761u) >> 23;            // 9 bits
+    for (;;) {
+        const int old = atomicCAS(&keys[h], -1, key);
+        if (old == -1 || old == key) return (int)h;
+        h = (h + 1) & (AGG_H - 1);
+    }
+}
+
 // K3b: root per core point, component keys and core counts.
 //   variant 1: key = smallest input row of a core point = the component's start point
 //              (cDBSCAN.py:134-137)
 //   variant 2: key = smallest cellfirst over the cells holding its core points
 //              (cDBSCAN2.py:117-140)
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(BIGTPB)
 k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ cnt,
           int* parent, const u32* __restrict__ srow,
           const int* __restrict__ head, const int* __restrict__ cellfirst,
           int* __restrict__ root, int* __restrict__ compkey, int* __restrict__ ncore)
 {
+    __shared__ int hkey[AGG_H], hmin[AGG_H], hcnt[AGG_H];
+    if (threadIdx.x < AGG_H) { hkey[threadIdx.x] = -1; hmin[threadIdx.x] = INT_MAX; hcnt[threadIdx.x] = 0; }
+    __syncthreads();
     const int M = strip_start[g.S];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int r = -1, key = INT_MAX;
@@ -767,8 +790,6 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
         }
         root[i] = r;
     }
-    // per-wave pre-reduction by root (a giant component would otherwise take one atomic
-    // per PET on a single address)
     const int lane = threadIdx.x & 63;
     unsigned long long pending = __ballot(r >= 0);
     while (pending) {
@@ -780,12 +801,20 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
         if (cm >= 4) {
             int mk = mine ? key : INT_MAX;
             for (int o = 32; o > 0; o >>= 1) mk = min(mk, __shfl_xor(mk, o));
-            if (lane == leader) { atomicMin(&compkey[R], mk); atomicAdd(&ncore[R], cm); }
+            if (lane == leader) {
+                const int sl = agg_slot(hkey, R);
+                atomicMin(&hmin[sl], mk); atomicAdd(&hcnt[sl], cm);
+            }
         } else if (mine) {
             atomicMin(&compkey[R], key);
             atomicAdd(&ncore[R], 1);
         }
         pending &= ~m;
+    }
+    __syncthreads();
+    if (threadIdx.x < AGG_H && hkey[threadIdx.x] >= 0) {
+        atomicMin(&compkey[hkey[threadIdx.x]], hmin[threadIdx.x]);
+        atomicAdd(&ncore[hkey[threadIdx.x]], hcnt[threadIdx.x]);
     }
 }
 
@@ -845,9 +874,21 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
         const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.eps) see(j, r); });
     const int o = (v1 && tbest >= 0) ? tbest : best;
     owner[i] = o < 0 ? -1 : (contested ? (o | OWNER_CONTESTED) : o);
-    if (o >= 0) {
-        atomicAdd(&bsize[o], 1);
-        if (!contested) atomicAdd(&usize[o], 1);
+    // counts per owning component, reduced over the lanes of the wave that share the owner
+    {
+        const int lane = threadIdx.x & 63;
+        unsigned long long pending = __ballot(o >= 0);
+        while (pending) {
+            const int leader = __ffsll((long long)pending) - 1;
+            const int O = __shfl(o, leader);
+            const unsigned long long m = __ballot(o == O);
+            const unsigned long long mu = __ballot(o == O && !contested);
+            if (lane == leader) {
+                atomicAdd(&bsize[O], __popcll(m));
+                if (mu) atomicAdd(&usize[O], __popcll(mu));
+            }
+            pending &= ~m;
+        }
     }
 }
 
@@ -1021,10 +1062,20 @@ __device__ __forceinline__ int je_minus(const int* __restrict__ cstart, int j) {
 __device__ __forceinline__ int wave_min_i(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ int wave_max_i(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
 
-// Per-wave pre-reduction of the cluster table (pipe.py:78-102): sorted order keeps a
-// cluster's PETs in neighbouring lanes, so a wave usually carries a handful of labels and
-// a giant cluster costs 5 atomics per wave, not 5 per PET.  Must be called by all 64 lanes.
-__device__ __forceinline__ void table_accumulate(const Table& t, int lab, int x, int y)
+// Cluster table (pipe.py:78-102) by the two-level reduce-by-key above; called by all threads
+// of a BIGTPB workgroup (sorted order keeps a cluster's PETs in neighbouring lanes, so a wave
+// usually carries a handful of labels).
+struct TableLds { int key[AGG_H], cnt[AGG_H], mnx[AGG_H], mxx[AGG_H], mny[AGG_H], mxy[AGG_H]; };
+
+__device__ __forceinline__ void table_lds_init(TableLds& h)
+{
+    if (threadIdx.x < AGG_H) {
+        const int k = threadIdx.x;
+        h.key[k] = -1; h.cnt[k] = 0; h.mnx[k] = INT_MAX; h.mxx[k] = INT_MIN; h.mny[k] = INT_MAX; h.mxy[k] = INT_MIN;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void table_accumulate(const Table& t, TableLds& h, int lab, int x, int y)
 {
     const int lane = threadIdx.x & 63;
     unsigned long long pending = __ballot(lab >= 0);
@@ -1038,9 +1089,10 @@ __device__ __forceinline__ void table_accumulate(const Table& t, int lab, int x,
             int mnx = wave_min_i(mine ? x : INT_MAX), mxx = wave_max_i(mine ? x : INT_MIN);
             int mny = wave_min_i(mine ? y : INT_MAX), mxy = wave_max_i(mine ? y : INT_MIN);
             if (lane == leader) {
-                atomicAdd(&t.count[L], cm);
-                atomicMin(&t.minx[L], mnx); atomicMax(&t.maxx[L], mxx);
-                atomicMin(&t.miny[L], mny); atomicMax(&t.maxy[L], mxy);
+                const int sl = agg_slot(h.key, L);
+                atomicAdd(&h.cnt[sl], cm);
+                atomicMin(&h.mnx[sl], mnx); atomicMax(&h.mxx[sl], mxx);
+                atomicMin(&h.mny[sl], mny); atomicMax(&h.mxy[sl], mxy);
             }
         } else if (mine) {
             atomicAdd(&t.count[L], 1);
@@ -1049,6 +1101,13 @@ __device__ __forceinline__ void table_accumulate(const Table& t, int lab, int x,
         }
         pending &= ~m;
     }
+    __syncthreads();
+    if (threadIdx.x < AGG_H && h.key[threadIdx.x] >= 0) {
+        const int k = threadIdx.x, L = h.key[k];
+        atomicAdd(&t.count[L], h.cnt[k]);
+        atomicMin(&t.minx[L], h.mnx[k]); atomicMax(&t.maxx[L], h.mxx[k]);
+        atomicMin(&t.miny[L], h.mny[k]); atomicMax(&t.maxy[L], h.mxy[k]);
+    }
 }
 
 
@@ -1056,12 +1115,14 @@ __device__ __forceinline__ void table_accumulate(const Table& t, int lab, int x,
 // per wave first: sorted order keeps a cluster's PETs in neighbouring lanes, so a wave
 // usually carries a handful of labels and a giant cluster costs 5 atomics per wave, not
 // 5 per PET.
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(BIGTPB)
 k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ sv,
                const int* __restrict__ sa, const u32* __restrict__ srow, const int* __restrict__ owner,
                const int* __restrict__ compkey, const int* __restrict__ ncore, const int* __restrict__ bsize,
                const int* __restrict__ state, const int* __restrict__ rankscan, int* __restrict__ labels, Table t)
 {
+    __shared__ TableLds h;
+    table_lds_init(h);
     const int M = strip_start[g.S];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int lab = -1, x = 0, y = 0;
@@ -1078,7 +1139,7 @@ k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __r
         int a = g.swap ? qq : pp, v = g.swap ? pp : qq;
         x = (v - a) / 2; y = (v + a) / 2;
     }
-    table_accumulate(t, lab, x, y);
+    table_accumulate(t, h, lab, x, y);
 }
 
 
@@ -1310,11 +1371,13 @@ __global__ void k_blk_cell_labels(const BlkScalars* __restrict__ sc, const int* 
     clab[c] = lab;
 }
 
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(BIGTPB)
 k_blk_point_labels(BlkParams p, const BlkScalars* __restrict__ sc, const int* __restrict__ cidp1,
                    const int* __restrict__ clab, const u32* __restrict__ srow, const int* __restrict__ sx,
                    const int* __restrict__ sy, int* __restrict__ labels, Table t)
 {
+    __shared__ TableLds h;
+    table_lds_init(h);
     const int M = sc->M;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int lab = -1, x = 0, y = 0;
@@ -1323,7 +1386,7 @@ k_blk_point_labels(BlkParams p, const BlkScalars* __restrict__ sc, const int* __
         labels[srow[i]] = lab;
         x = sx[i]; y = sy[i];
     }
-    table_accumulate(t, lab, x, y);
+    table_accumulate(t, h, lab, x, y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1736,7 +1799,7 @@ static int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_
     LAUNCH(k_init_table, n + 1, t, c->rankscan.as<int>(), n);
     int* clab = c->cnt.as<int>();
     LAUNCH(k_blk_cell_labels, n, sc, nb, linkbits, alive, c->root.as<int>(), c->compkey.as<int>(), c->rankscan.as<int>(), clab);
-    LAUNCH(k_blk_point_labels, n, p, sc, cidp1, clab, srow, sx, sy, c->labels.as<int>(), t);
+    hipLaunchKernelGGL(k_blk_point_labels, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, p, sc, cidp1, clab, srow, sx, sy, c->labels.as<int>(), t);
     ev_record(c, 6);
     HIP_TRY(hipGetLastError());
     rc = finish_run(c, p.R + 1, &sc->M, t, labels_out, n_clusters, max_label);
@@ -1820,7 +1883,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         LAUNCH(k_chain_parent, n, strip, g.S, cnt, g.minPts, c->chainhead.as<int>(), c->parent.as<int>());
     }
     hipLaunchKernelGGL(k_union_cores, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, cnt, c->parent.as<int>());
-    LAUNCH(k_flatten, n, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
+    hipLaunchKernelGGL(k_flatten, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
            c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>());
     ev_record(c, 4);
     // K4
@@ -1847,7 +1910,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     }
     Table t = make_table(c);
     LAUNCH(k_init_table, n + 1, t, c->rankscan.as<int>(), n);
-    LAUNCH(k_final_labels, n, g, strip, sv, sa, srow, c->owner.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(),
+    hipLaunchKernelGGL(k_final_labels, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow, c->owner.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(),
            c->bsize.as<int>(), c->state.as<int>(), c->rankscan.as<int>(), c->labels.as<int>(), t);
     ev_record(c, 6);
     HIP_TRY(hipGetLastError());
