@@ -701,22 +701,28 @@ k_chain_flags(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     }
     chainflag[i] = f;
 }
+// parent[] = chain head for core points (flat forest to start from); chainid[] = the same for
+// core points and -1 for everything else (what the union kernel stages as its payload)
 __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const int* __restrict__ cnt, int minPts,
-                               const int* __restrict__ chainhead, int* __restrict__ parent)
+                               const int* __restrict__ chainhead, int* __restrict__ parent, int* __restrict__ chainid)
 {
     const int M = strip_start[S];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
-    parent[i] = (cnt[i] >= minPts) ? chainhead[i] - 1 : i;
+    const bool core = cnt[i] >= minPts;
+    parent[i] = core ? chainhead[i] - 1 : i;
+    chainid[i] = core ? chainhead[i] - 1 : -1;
 }
 
 // Cross-strip edges: a core i of strip s against the cores of strip s-1 in its window (the
-// pairs with strip s+1 are handled from the other endpoint).  One union per chain segment
-// of strip s-1 suffices: consecutive cores of the window with v-gap <= eps are already in
-// one chain.
+// pairs with strip s+1 are handled from the other endpoint).  Chains, not points, are what
+// has to be united: every lane collects the distinct chains B of strip s-1 it touches, the
+// wave then keeps ONE lane per distinct (own chain A, chain B) pair, and only those lanes run
+// the (latency-bound, global-memory) union-find step -- directly on the chain heads.
+#define UNION_MAXB 4
 __global__ void __launch_bounds__(TPB)
 k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
-              const int* __restrict__ strip_start, const int* __restrict__ cnt, int* parent)
+              const int* __restrict__ strip_start, const int* __restrict__ chainid, int* parent)
 {
     __shared__ int2 lw[T_WIN];
     __shared__ int lx[T_WIN];
@@ -724,26 +730,53 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     __shared__ int l_wcount[TPB / 64];
     const int M = strip_start[g.S];
     Tile t;
-    if (!tile_stage(t, lw, lx, ntiles, M, sv, sa, cnt)) return;
+    if (!tile_stage(t, lw, lx, ntiles, M, sv, sa, chainid)) return;
     const int i0 = t.t0 + threadIdx.x;
-    const int total = block_compact(i0 < M && t.x[i0 < M ? i0 : t.t0] >= g.minPts, l_list, l_wcount);
+    const int total = block_compact(i0 < M && t.x[i0 < M ? i0 : t.t0] >= 0, l_list, l_wcount);
     if ((int)threadIdx.x >= total) return;
     const int i = t.t0 + l_list[threadIdx.x];
     const int2 me = t.w[i];
+    const int A = t.x[i];
     const int s = strip_of(g, me.y);
-    if (s == 0) return;
-    const int tb = strip_start[s - 1], b = strip_start[s];
-    bool linked = false, have_prev = false;
-    int prev_q = 0;
-    tile_visit_segment(t, sv, sa, cnt, tb, b, sat_add(me.x, -g.eps), sat_add(me.x, g.eps),
-                       [&](int j, int qj, int pj, int cj) {
-        if (cj < g.minPts) return;
-        if (have_prev && qj - prev_q > g.eps) linked = false;      // a new chain of strip s-1 starts
-        have_prev = true; prev_q = qj;
-        if (linked) return;
-        const int da = pj - me.y;
-        if ((da < 0 ? -da : da) <= g.eps) { uf_unite(parent, i, j); linked = true; }
-    });
+    int Bs[UNION_MAXB];
+#pragma unroll
+    for (int k = 0; k < UNION_MAXB; ++k) Bs[k] = -1;
+    int nb = 0;
+    if (s > 0) {
+        const int tb = strip_start[s - 1], b = strip_start[s];
+        tile_visit_segment(t, sv, sa, chainid, tb, b, sat_add(me.x, -g.eps), sat_add(me.x, g.eps),
+                           [&](int, int, int pj, int B) {
+            if (B < 0) return;
+            const int da = pj - me.y;
+            if ((da < 0 ? -da : da) > g.eps) return;
+            bool seen = false;
+#pragma unroll
+            for (int k = 0; k < UNION_MAXB; ++k) seen |= (Bs[k] == B);
+            if (seen) return;
+            if (nb < UNION_MAXB) {
+#pragma unroll
+                for (int k = 0; k < UNION_MAXB; ++k) if (k == nb) Bs[k] = B;
+                ++nb;
+            } else {
+                uf_unite(parent, A, B);                    // more chains than slots: unite right away
+            }
+        });
+    }
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < UNION_MAXB; ++k) {
+        const int B = Bs[k];
+        unsigned long long pending = __ballot(B >= 0);
+        bool rep = false;
+        while (pending) {
+            const int leader = __ffsll((long long)pending) - 1;
+            const int LA = __shfl(A, leader), LB = __shfl(B, leader);
+            const unsigned long long m = __ballot(B >= 0 && A == LA && B == LB);
+            if (lane == leader) rep = true;
+            pending &= ~m;
+        }
+        if (rep) uf_unite(parent, A, B);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1880,9 +1913,9 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         hipError_t e = rocprim::inclusive_scan(c->scan_tmp.p, tb, c->chainflag.as<int>(), c->chainhead.as<int>(), (size_t)n,
                                                rocprim::maximum<int>(), c->stream);
         if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan(chain)", hipGetErrorString(e));
-        LAUNCH(k_chain_parent, n, strip, g.S, cnt, g.minPts, c->chainhead.as<int>(), c->parent.as<int>());
+        LAUNCH(k_chain_parent, n, strip, g.S, cnt, g.minPts, c->chainhead.as<int>(), c->parent.as<int>(), c->chainflag.as<int>());
     }
-    hipLaunchKernelGGL(k_union_cores, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, cnt, c->parent.as<int>());
+    hipLaunchKernelGGL(k_union_cores, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->parent.as<int>());
     hipLaunchKernelGGL(k_flatten, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
            c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>());
     ev_record(c, 4);
