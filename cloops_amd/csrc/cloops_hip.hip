@@ -97,7 +97,8 @@ struct GridParams {
     u32 magic;    // strip(a) = a / eps by multiply-shift (Granlund-Montgomery, exact for all u32)
     int sh1, sh2;
     int qbits;    // sort key = strip << (qbits+rbits) | q << rbits | (p mod eps): both coordinates ride
-    int rbits;    //   in the key, so the sorted (q,p) arrays are DECODED, not gathered through row ids
+    int rbits;    //   in the key, so the sorted (q,p) arrays are DECODED, not gathered through row ids;
+                  //   the radix sort skips the low rbits (they are payload, not order)
 };
 
 __device__ __forceinline__ int sat_add(int a, int b)
@@ -1081,14 +1082,15 @@ __global__ void k_rank_flags(GridParams g, const int* __restrict__ strip_start, 
     flag[compkey[i]] = 1;
 }
 
-struct Table { int* count; int* minx; int* maxx; int* miny; int* maxy; };
+struct Table { cl_box* row; };      // one cl_box per cluster id (AoS: a single D2H copy returns the table)
 
 __global__ void k_init_table(Table t, const int* __restrict__ rankscan, int n)
 {
     const int K = rankscan[n];      // total number of ids handed out
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
-    t.count[k] = 0; t.minx[k] = INT_MAX; t.maxx[k] = INT_MIN; t.miny[k] = INT_MAX; t.maxy[k] = INT_MIN;
+    cl_box b; b.count = 0; b.min_x = INT_MAX; b.max_x = INT_MIN; b.min_y = INT_MAX; b.max_y = INT_MIN;
+    t.row[k] = b;
 }
 
 __device__ __forceinline__ int je_minus(const int* __restrict__ cstart, int j) { return cstart[j + 1] - cstart[j]; }
@@ -1128,18 +1130,18 @@ __device__ __forceinline__ void table_accumulate(const Table& t, TableLds& h, in
                 atomicMin(&h.mny[sl], mny); atomicMax(&h.mxy[sl], mxy);
             }
         } else if (mine) {
-            atomicAdd(&t.count[L], 1);
-            atomicMin(&t.minx[L], x); atomicMax(&t.maxx[L], x);
-            atomicMin(&t.miny[L], y); atomicMax(&t.maxy[L], y);
+            atomicAdd(&t.row[L].count, 1);
+            atomicMin(&t.row[L].min_x, x); atomicMax(&t.row[L].max_x, x);
+            atomicMin(&t.row[L].min_y, y); atomicMax(&t.row[L].max_y, y);
         }
         pending &= ~m;
     }
     __syncthreads();
     if (threadIdx.x < AGG_H && h.key[threadIdx.x] >= 0) {
         const int k = threadIdx.x, L = h.key[k];
-        atomicAdd(&t.count[L], h.cnt[k]);
-        atomicMin(&t.minx[L], h.mnx[k]); atomicMax(&t.maxx[L], h.mxx[k]);
-        atomicMin(&t.miny[L], h.mny[k]); atomicMax(&t.maxy[L], h.mxy[k]);
+        atomicAdd(&t.row[L].count, h.cnt[k]);
+        atomicMin(&t.row[L].min_x, h.mnx[k]); atomicMax(&t.row[L].max_x, h.mxx[k]);
+        atomicMin(&t.row[L].min_y, h.mny[k]); atomicMax(&t.row[L].max_y, h.mxy[k]);
     }
 }
 
@@ -1454,6 +1456,8 @@ struct cl_chrom {
     DevBuf sv, sa, strip, cnt, parent, root, head, headidx, cellfirst, compkey, ncore, bsize, owner, state;
     DevBuf flag, rankscan, labels, table, ulist, lo, hi, recs, counters, chainflag, chainhead, usize, b_cstart, b_ckey, b_nb, b_cx, b_cy;
     int* h_pinned = nullptr;          // small pinned staging (counters, K)
+    cl_box* h_boxes = nullptr;        // pinned host copy of the last cluster table
+    size_t h_boxes_cap = 0;
     // last result
     int last_K = 0;                   // ids handed out (max_label + 1 upper bound)
     bool have_result = false;
@@ -1475,6 +1479,7 @@ static void free_chrom(cl_chrom* c)
     for (DevBuf* b : bufs) b->release();
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_boxes) (void)hipHostFree(c->h_boxes);
     if (c->ev_ready) for (auto& e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1556,7 +1561,7 @@ static int ensure_workspace(cl_chrom* c, int S)
     ENS(sv, n * 4); ENS(sa, n * 4); ENS(strip, ((size_t)S + 2) * 4); ENS(cnt, n * 4);
     ENS(parent, n * 4); ENS(root, n * 4); ENS(head, n * 4); ENS(headidx, n * 4); ENS(cellfirst, n * 4);
     ENS(compkey, n * 4); ENS(ncore, n * 4); ENS(bsize, n * 4); ENS(owner, n * 4); ENS(state, n * 4);
-    ENS(flag, (n + 1) * 4); ENS(rankscan, (n + 1) * 4); ENS(labels, n * 4); ENS(table, (n + 1) * 5 * 4);
+    ENS(flag, (n + 1) * 4); ENS(rankscan, (n + 1) * 4); ENS(labels, n * 4); ENS(table, (n + 1) * sizeof(cl_box));
     ENS(ulist, n * 4); ENS(lo, n * 4); ENS(hi, n * 4); ENS(recs, n * sizeof(Rec)); ENS(counters, 256);
     ENS(chainflag, n * 4); ENS(chainhead, n * 4); ENS(usize, n * 4);
 #undef ENS
@@ -1630,7 +1635,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     size_t tmp_bytes = c->sort_tmp.bytes;
     int end_bit = g.qbits + g.rbits + std::max(1, bits_for((unsigned)g.S));
     hipError_t e = rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->keys_in.as<u64>(), c->keys_out.as<u64>(),
-                                             c->vals_in.as<u32>(), c->vals_out.as<u32>(), (size_t)n, 0, end_bit, c->stream);
+                                             c->vals_in.as<u32>(), c->vals_out.as<u32>(), (size_t)n, g.rbits, end_bit, c->stream);
     if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs", hipGetErrorString(e));
     LAUNCH(k_decode_sorted, n, n, g, c->keys_out.as<u64>(), c->sv.as<int>(), c->sa.as<int>());
     LAUNCH(k_strip_table, g.S + 2, c->keys_out.as<u64>(), n, g.S, g.qbits + g.rbits, c->strip.as<int>());
@@ -1711,13 +1716,20 @@ static int finish_run(cl_chrom* c, int n_strips, const int* d_M, const Table& t,
         return fail(CL_ERR_HIP, "internal: release-record overflow (border point with > 4 adjacent components)");
     c->last_K = K;
     c->have_result = true;
+    // the cluster table comes back in one copy (K rows of cl_box) into a pinned host cache;
     // n_clusters / max_label need the per-id counts (variant 1 leaves gaps)
     int nc = 0, ml = -1;
     if (K > 0) {
-        std::vector<int> counts((size_t)K);
-        HIP_TRY(hipMemcpyAsync(counts.data(), t.count, (size_t)K * 4, hipMemcpyDeviceToHost, c->stream));
+        if ((size_t)K > c->h_boxes_cap) {
+            if (c->h_boxes) (void)hipHostFree(c->h_boxes);
+            c->h_boxes = nullptr; c->h_boxes_cap = 0;
+            size_t cap = (size_t)K + (size_t)K / 4 + 1024;
+            HIP_TRY(hipHostMalloc((void**)&c->h_boxes, cap * sizeof(cl_box), hipHostMallocDefault));
+            c->h_boxes_cap = cap;
+        }
+        HIP_TRY(hipMemcpyAsync(c->h_boxes, t.row, (size_t)K * sizeof(cl_box), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        for (int k = 0; k < K; ++k) if (counts[k] > 0) { ++nc; ml = k; }
+        for (int k = 0; k < K; ++k) if (c->h_boxes[k].count > 0) { ++nc; ml = k; }
     }
     if (n_clusters) *n_clusters = nc;
     if (max_label) *max_label = ml;
@@ -1744,9 +1756,7 @@ static int finish_run(cl_chrom* c, int n_strips, const int* d_M, const Table& t,
 static Table make_table(cl_chrom* c)
 {
     Table t;
-    int* base = c->table.as<int>();
-    size_t stride = (size_t)c->n + 1;
-    t.count = base; t.minx = base + stride; t.maxx = base + 2 * stride; t.miny = base + 3 * stride; t.maxy = base + 4 * stride;
+    t.row = c->table.as<cl_box>();
     return t;
 }
 
@@ -1957,16 +1967,8 @@ extern "C" int cl_get_boxes(cl_chrom* c, cl_box* boxes_out)
     const int K = c->last_K;
     if (K <= 0) return CL_OK;
     if (!boxes_out) return fail(CL_ERR_ARG, "boxes_out is null");
-    HIP_TRY(hipSetDevice(c->device));
-    const size_t stride = (size_t)c->n + 1;
-    std::vector<int> h((size_t)K * 5);
-    for (int f = 0; f < 5; ++f)
-        HIP_TRY(hipMemcpyAsync(h.data() + (size_t)f * K, c->table.as<int>() + f * stride, (size_t)K * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
     for (int k = 0; k < K; ++k) {
-        cl_box b;
-        b.count = h[k]; b.min_x = h[(size_t)K + k]; b.max_x = h[(size_t)2 * K + k];
-        b.min_y = h[(size_t)3 * K + k]; b.max_y = h[(size_t)4 * K + k];
+        cl_box b = c->h_boxes[k];
         if (b.count == 0) { b.min_x = b.max_x = b.min_y = b.max_y = 0; }
         boxes_out[k] = b;
     }
