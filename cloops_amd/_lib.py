@@ -26,7 +26,7 @@ VARIANT_BLOCK = 3
 SYMBOLS = [
     "cl_last_error", "cl_device_count", "cl_chrom_create", "cl_chrom_destroy", "cl_chrom_size",
     "cl_cluster", "cl_get_boxes", "cl_neighbor_counts", "cl_labels_device", "cl_set_profiling",
-    "cl_get_timing", "cl_version", "cl_host_alloc", "cl_host_free",
+    "cl_get_timing", "cl_version", "cl_host_alloc", "cl_host_free", "cl_cluster_async", "cl_wait", "cl_boxes_host",
 ]
 
 
@@ -75,6 +75,12 @@ def load():
     lib.cl_chrom_size.argtypes = [vp]
     lib.cl_cluster.restype = ctypes.c_int
     lib.cl_cluster.argtypes = [vp, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, i32p, i32p]
+    lib.cl_cluster_async.restype = ctypes.c_int
+    lib.cl_cluster_async.argtypes = [vp, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
+    lib.cl_wait.restype = ctypes.c_int
+    lib.cl_wait.argtypes = [vp, i32p, i32p]
+    lib.cl_boxes_host.restype = vp
+    lib.cl_boxes_host.argtypes = [vp]
     lib.cl_get_boxes.restype = ctypes.c_int
     lib.cl_get_boxes.argtypes = [vp, vp]
     lib.cl_neighbor_counts.restype = ctypes.c_int

@@ -60,9 +60,16 @@ class Chromosome(object):
             raise ValueError("X and Y differ in length")
         self.n = int(X.shape[0])
         self.device = device
+        self._init_state()
         _lib.check(lib.cl_chrom_create(int(device), ctypes.c_void_p(stream), X.ctypes.data_as(ctypes.c_void_p),
                                        Y.ctypes.data_as(ctypes.c_void_p), self.n, 0, ctypes.byref(self._h)))
+
+    def _init_state(self):
         self._profiling = False
+        self._pinned = [None, None]
+        self._pinned_arr = [None, None]
+        self._inflight = []
+        self._enq = 0
 
     @classmethod
     def from_device_pointers(cls, x_ptr, y_ptr, n, device=0, stream=None, keepalive=None):
@@ -74,7 +81,7 @@ class Chromosome(object):
         self.n = int(n)
         self.device = device
         self._keepalive = keepalive
-        self._profiling = False
+        self._init_state()
         _lib.check(lib.cl_chrom_create(int(device), ctypes.c_void_p(stream), ctypes.c_void_p(x_ptr),
                                        ctypes.c_void_p(y_ptr), self.n, 1, ctypes.byref(self._h)))
         return self
@@ -83,25 +90,26 @@ class Chromosome(object):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.cl_chrom_destroy(self._h)
             self._h = ctypes.c_void_p()
-        if getattr(self, "_pinned", None):
-            self._lib.cl_host_free(ctypes.c_void_p(self._pinned))
-            self._pinned = None
-
-    def _pinned_labels(self):
-        """A page-locked int32[n] result buffer owned by this object, reused by every run."""
-        if not getattr(self, "_pinned", None):
-            p = self._lib.cl_host_alloc(max(4, self.n * 4))
-            if not p:
-                raise MemoryError("cl_host_alloc failed")
-            self._pinned = p
-            self._pinned_arr = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_int32)), shape=(self.n,))
-        return self._pinned_arr
+        for k, p in enumerate(getattr(self, "_pinned", [])):
+            if p:
+                self._lib.cl_host_free(ctypes.c_void_p(p))
+                self._pinned[k] = None
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+    def _pinned_labels(self, which=0):
+        """Page-locked int32[n] result buffers owned by this object (two: one per result slot)."""
+        if self._pinned[which] is None:
+            p = self._lib.cl_host_alloc(max(4, self.n * 4))
+            if not p:
+                raise MemoryError("cl_host_alloc failed")
+            self._pinned[which] = p
+            self._pinned_arr[which] = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_int32)), shape=(self.n,))
+        return self._pinned_arr[which]
 
     def set_profiling(self, on=True):
         self._profiling = bool(on)
@@ -112,12 +120,44 @@ class Chromosome(object):
         _lib.check(self._lib.cl_get_timing(self._h, ctypes.byref(t)))
         return {k: getattr(t, k) for k, _ in _lib.ClTiming._fields_}
 
-    def cluster(self, variant, eps, minPts, cut=0, want_labels=True, want_boxes=True, pinned=False):
-        """`pinned=True` returns labels as a VIEW of a reusable page-locked buffer (valid until
-        the next run on this chromosome) -- the fast path used by the sweep driver and bench."""
+    def _boxes(self, max_label, copy):
+        k = max_label + 1
+        if k <= 0:
+            return np.zeros(0, dtype=BOX_DTYPE)
+        ptr = self._lib.cl_boxes_host(self._h)
+        view = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_int32)), shape=(k * 5,)).view(BOX_DTYPE)
+        return view.copy() if copy else view
+
+    def cluster_async(self, variant, eps, minPts, cut=0):
+        """Enqueue one run without blocking (at most two in flight); pair with wait().
+        Labels land in one of two reusable pinned buffers."""
         v = VARIANTS[variant]
+        labels = self._pinned_labels(self._enq & 1)
+        _lib.check(self._lib.cl_cluster_async(self._h, v, int(eps), int(minPts), int(cut),
+                                              labels.ctypes.data_as(ctypes.c_void_p)))
+        self._inflight.append(labels)
+        self._enq += 1
+
+    def wait(self, copy=False):
+        """Complete the oldest in-flight run -> ClusterResult (labels / boxes are VIEWS of pinned
+        buffers that stay valid until two more runs have been enqueued, unless copy=True)."""
+        labels = self._inflight.pop(0)
+        nc = ctypes.c_int32(0)
+        ml = ctypes.c_int32(-1)
+        _lib.check(self._lib.cl_wait(self._h, ctypes.byref(nc), ctypes.byref(ml)))
+        boxes = self._boxes(ml.value, copy)
+        return ClusterResult(labels.copy() if copy else labels, nc.value, ml.value, boxes,
+                             self.timing() if self._profiling else None)
+
+    def cluster(self, variant, eps, minPts, cut=0, want_labels=True, want_boxes=True, pinned=False):
+        """One synchronous run.  `pinned=True` returns labels and boxes as VIEWS of reusable
+        page-locked buffers (valid until the next run on this chromosome) -- the fast path used
+        by the sweep driver and bench."""
+        v = VARIANTS[variant]
+        if self._inflight:
+            raise RuntimeError("asynchronous runs in flight: call wait() first")
         if want_labels:
-            labels = self._pinned_labels() if pinned else np.empty(self.n, dtype=np.int32)
+            labels = self._pinned_labels(0) if pinned else np.empty(self.n, dtype=np.int32)
         else:
             labels = None
         nc = ctypes.c_int32(0)
@@ -125,11 +165,7 @@ class Chromosome(object):
         lp = labels.ctypes.data_as(ctypes.c_void_p) if want_labels else None
         _lib.check(self._lib.cl_cluster(self._h, v, int(eps), int(minPts), int(cut), lp,
                                         ctypes.byref(nc), ctypes.byref(ml)))
-        boxes = None
-        if want_boxes:
-            boxes = np.zeros(ml.value + 1, dtype=BOX_DTYPE)
-            if ml.value >= 0:
-                _lib.check(self._lib.cl_get_boxes(self._h, boxes.ctypes.data_as(ctypes.c_void_p)))
+        boxes = self._boxes(ml.value, copy=not pinned) if want_boxes else None
         return ClusterResult(labels, nc.value, ml.value, boxes, self.timing() if self._profiling else None)
 
     def neighbor_counts(self, eps, cut=0):

@@ -83,6 +83,9 @@ extern "C" int cl_device_count(void)
 // ------------------------------------------------------------------------------------------
 #define TPB 256
 
+enum { ST_LIVE = 0, ST_DEAD = 1, ST_UNKNOWN = 2 };          // variant-2 release state of a component
+enum { CTR_NU = 0, CTR_NREC = 1, CTR_OVERFLOW = 2 };         // device counters
+
 struct GridParams {
     int eps;      // cell / strip width (cDBSCAN.py:29, cDBSCAN2.py:30: cw = eps)
     int minPts;
@@ -635,6 +638,12 @@ __global__ void k_scatter_counts(const int* __restrict__ strip_start, int S, con
 // ------------------------------------------------------------------------------------------
 // per-run initialisation of the per-point / per-root arrays
 // ------------------------------------------------------------------------------------------
+__global__ void k_init_flags(int n, int* __restrict__ flag, int* __restrict__ counters)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 16) counters[i] = 0;
+    if (i <= n) flag[i] = 0;           // n+1 entries
+}
 __global__ void k_init_arrays(int n, int* __restrict__ parent, int* __restrict__ compkey, int* __restrict__ ncore,
                               int* __restrict__ bsize, int* __restrict__ usize, int* __restrict__ cellfirst,
                               int* __restrict__ flag, int* __restrict__ state, int* __restrict__ counters)
@@ -704,15 +713,21 @@ k_chain_flags(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
 }
 // parent[] = chain head for core points (flat forest to start from); chainid[] = the same for
 // core points and -1 for everything else (what the union kernel stages as its payload)
+// Every component root is a chain head, so the per-root accumulators are reset here, by the chain
+// heads only, instead of memset-ing five N-sized arrays per run.
 __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const int* __restrict__ cnt, int minPts,
-                               const int* __restrict__ chainhead, int* __restrict__ parent, int* __restrict__ chainid)
+                               const int* __restrict__ chainhead, int* __restrict__ parent, int* __restrict__ chainid,
+                               int* __restrict__ compkey, int* __restrict__ ncore, int* __restrict__ bsize,
+                               int* __restrict__ usize, int* __restrict__ state)
 {
     const int M = strip_start[S];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const bool core = cnt[i] >= minPts;
-    parent[i] = core ? chainhead[i] - 1 : i;
-    chainid[i] = core ? chainhead[i] - 1 : -1;
+    const int h = core ? chainhead[i] - 1 : -1;
+    parent[i] = core ? h : i;
+    chainid[i] = h;
+    if (h == i) { compkey[i] = INT_MAX; ncore[i] = 0; bsize[i] = 0; usize[i] = 0; state[i] = ST_LIVE; }
 }
 
 // Cross-strip edges: a core i of strip s against the cores of strip s-1 in its window (the
@@ -929,8 +944,6 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
 // ---- variant 2 release rule (cDBSCAN2.py:180-183) ------------------------------------------
 // A component is surely live if cores + first-come borders >= minPts (its share can only grow
 // when lower components die).  The rest form the small uncertain set U, resolved in key order.
-enum { ST_LIVE = 0, ST_DEAD = 1, ST_UNKNOWN = 2 };
-enum { CTR_NU = 0, CTR_NREC = 1, CTR_OVERFLOW = 2 };
 
 __global__ void k_mark_uncertain(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ root,
                                  const int* __restrict__ ncore, const int* __restrict__ bsize,
@@ -963,10 +976,16 @@ k_emit_records(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
     __shared__ int l_wcount[TPB / 64];
     if (counters[CTR_NU] == 0) return;
     const int M = strip_start[g.S];
+    {
+        // only CONTESTED border points can change hands when a component is released; most tiles
+        // have none and leave before staging anything
+        const int ip = tile_of_block(blockIdx.x) * TPB + threadIdx.x;
+        const int op = ip < M ? owner[ip] : -1;
+        if (!__syncthreads_or(op >= 0 && (op & OWNER_CONTESTED))) return;
+    }
     Tile t;
     if (!tile_stage(t, lw, lx, ntiles, M, sv, sa, root)) return;
     const int i0 = t.t0 + threadIdx.x;
-    // only CONTESTED border points can change hands when a component is released
     const bool act = i0 < M && t.x[i0] < 0 && owner[i0] >= 0 && (owner[i0] & OWNER_CONTESTED);
     const int total = block_compact(act, l_list, l_wcount);
     if ((int)threadIdx.x >= total) return;
@@ -1084,6 +1103,21 @@ __global__ void k_rank_flags(GridParams g, const int* __restrict__ strip_start, 
 
 struct Table { cl_box* row; };      // one cl_box per cluster id (AoS: a single D2H copy returns the table)
 
+// label of every component root (-1 = not kept), so that k_final_labels needs ONE gather per PET
+// instead of the chain owner -> compkey -> rank (+ state / sizes)
+__global__ void k_root_labels(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ root,
+                              const int* __restrict__ compkey, const int* __restrict__ ncore, const int* __restrict__ bsize,
+                              const int* __restrict__ state, const int* __restrict__ rankscan, int* __restrict__ rlabel)
+{
+    const int M = strip_start[g.S];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    if (root[i] != i) return;
+    const bool keep = (g.variant == CL_VARIANT_CDBSCAN2) ? (state[i] != ST_DEAD)
+                                                         : (ncore[i] + bsize[i] >= g.minPts);   // cDBSCAN.py:149-152
+    rlabel[i] = keep ? rankscan[compkey[i]] : -1;
+}
+
 __global__ void k_init_table(Table t, const int* __restrict__ rankscan, int n)
 {
     const int K = rankscan[n];      // total number of ids handed out
@@ -1153,8 +1187,7 @@ __device__ __forceinline__ void table_accumulate(const Table& t, TableLds& h, in
 __global__ void __launch_bounds__(BIGTPB)
 k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ sv,
                const int* __restrict__ sa, const u32* __restrict__ srow, const int* __restrict__ owner,
-               const int* __restrict__ compkey, const int* __restrict__ ncore, const int* __restrict__ bsize,
-               const int* __restrict__ state, const int* __restrict__ rankscan, int* __restrict__ labels, Table t)
+               const int* __restrict__ rlabel, int* __restrict__ labels, Table t)
 {
     __shared__ TableLds h;
     table_lds_init(h);
@@ -1162,12 +1195,8 @@ k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __r
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int lab = -1, x = 0, y = 0;
     if (i < M) {
-        int o = owner_root(owner[i]);
-        if (o >= 0) {
-            bool keep = (g.variant == CL_VARIANT_CDBSCAN2) ? (state[o] != ST_DEAD)
-                                                           : (ncore[o] + bsize[o] >= g.minPts);   // cDBSCAN.py:149-152
-            if (keep) lab = rankscan[compkey[o]];
-        }
+        const int o = owner_root(owner[i]);
+        if (o >= 0) lab = rlabel[o];
         labels[srow[i]] = lab;
         // X = (v - a) / 2, Y = (v + a) / 2 exactly (v and a have equal parity)
         int pp = sa[i] + g.A0, qq = sv[i] + g.V0;
@@ -1454,17 +1483,32 @@ struct cl_chrom {
     // workspace
     DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, scan_tmp;
     DevBuf sv, sa, strip, cnt, parent, root, head, headidx, cellfirst, compkey, ncore, bsize, owner, state;
-    DevBuf flag, rankscan, labels, table, ulist, lo, hi, recs, counters, chainflag, chainhead, usize, b_cstart, b_ckey, b_nb, b_cx, b_cy;
-    int* h_pinned = nullptr;          // small pinned staging (counters, K)
-    cl_box* h_boxes = nullptr;        // pinned host copy of the last cluster table
-    size_t h_boxes_cap = 0;
-    // last result
-    int last_K = 0;                   // ids handed out (max_label + 1 upper bound)
+    DevBuf flag, rankscan, ulist, lo, hi, recs, counters, chainflag, chainhead, usize, b_cstart, b_ckey, b_nb, b_cx, b_cy;
+    int* h_pinned = nullptr;          // small pinned staging (stats, block scalars)
+    // Result slots: two runs may be in flight (cl_cluster_async) -- the labels / table / header of
+    // run k live in slot k & 1, so the D2H copy of run k (copy stream) overlaps the kernels of run k+1.
+    struct Slot {
+        DevBuf labels, table;
+        bool pending = false;
+        int n_strips = 0;
+        hipEvent_t ev_done = nullptr, ev_copied = nullptr;
+        hipEvent_t ev[8]{};           // profiling marks of the run that used this slot
+        int* h_hdr = nullptr;         // pinned: {K, overflow, M}
+        cl_box* h_boxes = nullptr;    // pinned host copy of the cluster table
+        size_t h_boxes_cap = 0;
+        int32_t* labels_out = nullptr;
+    } slot[2];
+    DevBuf hdr;                       // device result headers, 16 ints per slot
+    hipStream_t copy_stream = nullptr, aux_stream = nullptr;
+    int enq = 0, deq = 0;             // runs enqueued / completed
+    int cur = 0;                      // slot of the run being enqueued
+    // last completed result
+    int last_slot = -1;
+    int last_K = 0;                   // max_label + 1
     bool have_result = false;
     // profiling
     bool profiling = false;
     cl_timing timing{};
-    hipEvent_t ev[10]{};
     bool ev_ready = false;
 };
 
@@ -1474,13 +1518,20 @@ static void free_chrom(cl_chrom* c)
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
-                      &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->labels, &c->table,
+                      &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->hdr,
                       &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy};
     for (DevBuf* b : bufs) b->release();
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-    if (c->h_boxes) (void)hipHostFree(c->h_boxes);
-    if (c->ev_ready) for (auto& e : c->ev) (void)hipEventDestroy(e);
+    for (auto& sl : c->slot) {
+        if (sl.h_boxes) (void)hipHostFree(sl.h_boxes);
+        if (sl.h_hdr) (void)hipHostFree(sl.h_hdr);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+        if (sl.ev_copied) (void)hipEventDestroy(sl.ev_copied);
+        if (c->ev_ready) for (auto& e : sl.ev) (void)hipEventDestroy(e);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1494,7 +1545,10 @@ extern "C" int cl_get_timing(const cl_chrom* c, cl_timing* out)
     *out = c->timing;
     return CL_OK;
 }
-extern "C" const int32_t* cl_labels_device(const cl_chrom* c) { return c ? (const int32_t*)c->labels.p : nullptr; }
+extern "C" const int32_t* cl_labels_device(const cl_chrom* c)
+{
+    return (c && c->last_slot >= 0) ? (const int32_t*)c->slot[c->last_slot].labels.p : nullptr;
+}
 
 static inline int nblocks(long long n, int tpb = TPB) { return (int)((n + tpb - 1) / tpb); }
 
@@ -1520,6 +1574,15 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
             c->own_stream = true;
         }
         if (hipHostMalloc((void**)&c->h_pinned, 4096, hipHostMallocDefault) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipHostMalloc"); break; }
+        if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipStreamCreate(copy)"); break; }
+        bool okslots = true;
+        for (auto& sl : c->slot) {
+            okslots = okslots && hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) == hipSuccess;
+            okslots = okslots && hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming) == hipSuccess;
+            okslots = okslots && hipHostMalloc((void**)&sl.h_hdr, 64, hipHostMallocDefault) == hipSuccess;
+        }
+        if (!okslots) { rc = fail(CL_ERR_HIP, "result slot setup"); break; }
         if (on_device) { c->d_x = (int*)x; c->d_y = (int*)y; }
         else if (n > 0) {
             c->own_xy = true;
@@ -1561,7 +1624,8 @@ static int ensure_workspace(cl_chrom* c, int S)
     ENS(sv, n * 4); ENS(sa, n * 4); ENS(strip, ((size_t)S + 2) * 4); ENS(cnt, n * 4);
     ENS(parent, n * 4); ENS(root, n * 4); ENS(head, n * 4); ENS(headidx, n * 4); ENS(cellfirst, n * 4);
     ENS(compkey, n * 4); ENS(ncore, n * 4); ENS(bsize, n * 4); ENS(owner, n * 4); ENS(state, n * 4);
-    ENS(flag, (n + 1) * 4); ENS(rankscan, (n + 1) * 4); ENS(labels, n * 4); ENS(table, (n + 1) * sizeof(cl_box));
+    ENS(flag, (n + 1) * 4); ENS(rankscan, (n + 1) * 4); ENS(hdr, 256);
+    ENS(slot[c->cur].labels, n * 4); ENS(slot[c->cur].table, (n + 1) * sizeof(cl_box));
     ENS(ulist, n * 4); ENS(lo, n * 4); ENS(hi, n * 4); ENS(recs, n * sizeof(Rec)); ENS(counters, 256);
     ENS(chainflag, n * 4); ENS(chainhead, n * 4); ENS(usize, n * 4);
 #undef ENS
@@ -1622,7 +1686,7 @@ static int make_grid(cl_chrom* c, int variant, int eps, int minPts, int cut, Gri
 
 static void ev_record(cl_chrom* c, int k)
 {
-    if (c->profiling) (void)hipEventRecord(c->ev[k], c->stream);
+    if (c->profiling) (void)hipEventRecord(c->slot[c->cur].ev[k], c->stream);
 }
 
 // K0 + K1 + K2: keys, sort, strip table, neighbour counts.  Leaves sorted arrays in the workspace.
@@ -1654,7 +1718,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
 static int ensure_events(cl_chrom* c)
 {
     if (c->profiling && !c->ev_ready) {
-        for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+        for (auto& sl : c->slot) for (auto& e : sl.ev) HIP_TRY(hipEventCreate(&e));
         c->ev_ready = true;
     }
     return CL_OK;
@@ -1683,72 +1747,105 @@ extern "C" int cl_neighbor_counts(cl_chrom* c, int32_t eps, int32_t cut, int32_t
     if ((rc = ensure_events(c))) return rc;
     if ((rc = run_sort_and_count(c, g, true))) return rc;
     const int n = (int)c->n;
-    HIP_TRY(hipMemsetAsync(c->labels.p, 0xFF, (size_t)n * 4, c->stream));
-    LAUNCH(k_scatter_counts, n, c->strip.as<int>(), g.S, c->vals_out.as<u32>(), c->cnt.as<int>(), c->labels.as<int>());
-    HIP_TRY(hipMemcpyAsync(counts_out, c->labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
+    LAUNCH(k_scatter_counts, n, c->strip.as<int>(), g.S, c->vals_out.as<u32>(), c->cnt.as<int>(), c->slot[c->cur].labels.as<int>());
+    HIP_TRY(hipMemcpyAsync(counts_out, c->slot[c->cur].labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->profiling) {
         memset(&c->timing, 0, sizeof(c->timing));
-        (void)hipEventElapsedTime(&c->timing.ms_keys, c->ev[0], c->ev[1]);
-        (void)hipEventElapsedTime(&c->timing.ms_sort, c->ev[1], c->ev[2]);
-        (void)hipEventElapsedTime(&c->timing.ms_region, c->ev[2], c->ev[3]);
+        hipEvent_t* ev = c->slot[c->cur].ev;
+        (void)hipEventElapsedTime(&c->timing.ms_keys, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&c->timing.ms_sort, ev[1], ev[2]);
+        (void)hipEventElapsedTime(&c->timing.ms_region, ev[2], ev[3]);
         c->timing.n_strips = g.S + 2;
     }
     c->have_result = false;
     return CL_OK;
 }
 
-// Shared tail of every variant: ids handed out (K), labels + per-id counts to the host.
-static int finish_run(cl_chrom* c, int n_strips, const int* d_M, const Table& t, int32_t* labels_out,
-                      int32_t* n_clusters, int32_t* max_label)
+// Shared tail of every variant.  finish_enqueue(): pack {K, overflow, M} into the slot's device
+// header, then (copy stream, behind an event) header + labels to the host.  Nothing blocks the
+// host; the compute stream is free for the next run.  finish_wait(): complete the oldest run.
+__global__ void k_pack_header(int* __restrict__ hdr, const int* __restrict__ rankscan_total, const int* __restrict__ counters,
+                              const int* __restrict__ d_M)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        hdr[0] = rankscan_total[0];
+        hdr[1] = counters[CTR_OVERFLOW];
+        hdr[2] = d_M[0];
+    }
+}
+
+static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* labels_out)
 {
     const int n = (int)c->n;
-    int* counters = c->counters.as<int>();
-    int* hp = c->h_pinned;
-    HIP_TRY(hipMemcpyAsync(hp, c->rankscan.as<int>() + n, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(hp + 1, counters, 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(hp + 8, d_M, 4, hipMemcpyDeviceToHost, c->stream));
-    if (labels_out) HIP_TRY(hipMemcpyAsync(labels_out, c->labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    ev_record(c, 7);
-    const int K = hp[0];
-    if (hp[1 + CTR_OVERFLOW] != 0)
+    cl_chrom::Slot& sl = c->slot[c->cur];
+    int* dh = c->hdr.as<int>() + 16 * c->cur;
+    hipLaunchKernelGGL(k_pack_header, dim3(1), dim3(64), 0, c->stream, dh, c->rankscan.as<int>() + n, c->counters.as<int>(), d_M);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sl.ev_done, c->stream));
+    ev_record(c, 6);
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, sl.ev_done, 0));
+    HIP_TRY(hipMemcpyAsync(sl.h_hdr, dh, 16, hipMemcpyDeviceToHost, c->copy_stream));
+    if (labels_out) HIP_TRY(hipMemcpyAsync(labels_out, sl.labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->copy_stream));
+    if (c->profiling) (void)hipEventRecord(sl.ev[7], c->copy_stream);
+    HIP_TRY(hipEventRecord(sl.ev_copied, c->copy_stream));
+    sl.pending = true;
+    sl.n_strips = n_strips;
+    sl.labels_out = labels_out;
+    c->enq++;
+    c->cur ^= 1;
+    return CL_OK;
+}
+
+static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
+{
+    if (c->deq == c->enq) return fail(CL_ERR_ARG, "cl_wait: no run in flight");
+    const int w = c->deq & 1;
+    cl_chrom::Slot& sl = c->slot[w];
+    HIP_TRY(hipEventSynchronize(sl.ev_copied));
+    sl.pending = false;
+    c->deq++;
+    const int K = sl.h_hdr[0];
+    if (sl.h_hdr[1] != 0)
         return fail(CL_ERR_HIP, "internal: release-record overflow (border point with > 4 adjacent components)");
-    c->last_K = K;
-    c->have_result = true;
-    // the cluster table comes back in one copy (K rows of cl_box) into a pinned host cache;
+    // the cluster table comes back in one copy (K rows of cl_box) into the slot's pinned cache;
     // n_clusters / max_label need the per-id counts (variant 1 leaves gaps)
     int nc = 0, ml = -1;
     if (K > 0) {
-        if ((size_t)K > c->h_boxes_cap) {
-            if (c->h_boxes) (void)hipHostFree(c->h_boxes);
-            c->h_boxes = nullptr; c->h_boxes_cap = 0;
+        if ((size_t)K > sl.h_boxes_cap) {
+            if (sl.h_boxes) (void)hipHostFree(sl.h_boxes);
+            sl.h_boxes = nullptr; sl.h_boxes_cap = 0;
             size_t cap = (size_t)K + (size_t)K / 4 + 1024;
-            HIP_TRY(hipHostMalloc((void**)&c->h_boxes, cap * sizeof(cl_box), hipHostMallocDefault));
-            c->h_boxes_cap = cap;
+            HIP_TRY(hipHostMalloc((void**)&sl.h_boxes, cap * sizeof(cl_box), hipHostMallocDefault));
+            sl.h_boxes_cap = cap;
         }
-        HIP_TRY(hipMemcpyAsync(c->h_boxes, t.row, (size_t)K * sizeof(cl_box), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        for (int k = 0; k < K; ++k) if (c->h_boxes[k].count > 0) { ++nc; ml = k; }
+        HIP_TRY(hipMemcpyAsync(sl.h_boxes, sl.table.p, (size_t)K * sizeof(cl_box), hipMemcpyDeviceToHost, c->aux_stream));
+        HIP_TRY(hipStreamSynchronize(c->aux_stream));
+        for (int k = 0; k < K; ++k) {
+            cl_box& b = sl.h_boxes[k];
+            if (b.count > 0) { ++nc; ml = k; } else { b.min_x = b.max_x = b.min_y = b.max_y = 0; }
+        }
     }
     if (n_clusters) *n_clusters = nc;
     if (max_label) *max_label = ml;
     c->last_K = ml + 1;
+    c->last_slot = w;
+    c->have_result = true;
     if (c->profiling) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipEventSynchronize(c->ev[7]));
         cl_timing& tm = c->timing;
         memset(&tm, 0, sizeof(tm));
-        (void)hipEventElapsedTime(&tm.ms_keys, c->ev[0], c->ev[1]);
-        (void)hipEventElapsedTime(&tm.ms_sort, c->ev[1], c->ev[2]);
-        (void)hipEventElapsedTime(&tm.ms_region, c->ev[2], c->ev[3]);
-        (void)hipEventElapsedTime(&tm.ms_union, c->ev[3], c->ev[4]);
-        (void)hipEventElapsedTime(&tm.ms_border, c->ev[4], c->ev[5]);
-        (void)hipEventElapsedTime(&tm.ms_table, c->ev[5], c->ev[6]);
-        (void)hipEventElapsedTime(&tm.ms_d2h, c->ev[6], c->ev[7]);
-        (void)hipEventElapsedTime(&tm.ms_total, c->ev[0], c->ev[7]);
-        tm.n_in = hp[8];
-        tm.n_strips = n_strips;
+        hipEvent_t* ev = sl.ev;
+        (void)hipEventElapsedTime(&tm.ms_keys, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&tm.ms_sort, ev[1], ev[2]);
+        (void)hipEventElapsedTime(&tm.ms_region, ev[2], ev[3]);
+        (void)hipEventElapsedTime(&tm.ms_union, ev[3], ev[4]);
+        (void)hipEventElapsedTime(&tm.ms_border, ev[4], ev[5]);
+        (void)hipEventElapsedTime(&tm.ms_table, ev[5], ev[6]);
+        (void)hipEventElapsedTime(&tm.ms_d2h, ev[6], ev[7]);
+        (void)hipEventElapsedTime(&tm.ms_total, ev[0], ev[7]);
+        tm.n_in = sl.h_hdr[2];
+        tm.n_strips = sl.n_strips;
     }
     return CL_OK;
 }
@@ -1756,16 +1853,14 @@ static int finish_run(cl_chrom* c, int n_strips, const int* d_M, const Table& t,
 static Table make_table(cl_chrom* c)
 {
     Table t;
-    t.row = c->table.as<cl_box>();
+    t.row = c->slot[c->cur].table.as<cl_box>();
     return t;
 }
 
-static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, int32_t* labels_out,
-                       int32_t* n_clusters, int32_t* max_label);
+static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, int32_t* labels_out);
 
 // ---- variant 3 host driver -----------------------------------------------------------------
-static int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_out,
-                     int32_t* n_clusters, int32_t* max_label)
+static int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_out)
 {
     int rc;
     const int n = (int)c->n;
@@ -1782,7 +1877,7 @@ static int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_
     BlkScalars* sc = (BlkScalars*)(counters + 32);
     LAUNCH(k_init_arrays, n + 1, n, c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
            c->usize.as<int>(), c->cellfirst.as<int>(), c->flag.as<int>(), c->state.as<int>(), counters);
-    HIP_TRY(hipMemsetAsync(c->labels.p, 0xFF, (size_t)n * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
     BlkScalars* hsc = (BlkScalars*)(c->h_pinned + 64);
     hsc->minx = INT_MAX; hsc->miny = INT_MAX; hsc->M = 0; hsc->C = 0;
     HIP_TRY(hipMemcpyAsync(sc, hsc, sizeof(BlkScalars), hipMemcpyHostToDevice, c->stream));
@@ -1842,16 +1937,39 @@ static int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_
     LAUNCH(k_init_table, n + 1, t, c->rankscan.as<int>(), n);
     int* clab = c->cnt.as<int>();
     LAUNCH(k_blk_cell_labels, n, sc, nb, linkbits, alive, c->root.as<int>(), c->compkey.as<int>(), c->rankscan.as<int>(), clab);
-    hipLaunchKernelGGL(k_blk_point_labels, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, p, sc, cidp1, clab, srow, sx, sy, c->labels.as<int>(), t);
-    ev_record(c, 6);
+    hipLaunchKernelGGL(k_blk_point_labels, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, p, sc, cidp1, clab, srow, sx, sy, c->slot[c->cur].labels.as<int>(), t);
     HIP_TRY(hipGetLastError());
-    rc = finish_run(c, p.R + 1, &sc->M, t, labels_out, n_clusters, max_label);
-    if (rc) return rc;
     // blockDBSCAN.py:74: an empty (fully filtered) mat raises only when the class is called
     // on it; pipe.py:64-65 returns before that, so cut > 0 with no survivors is just empty.
-    return CL_OK;
+    return finish_enqueue(c, p.R + 1, &sc->M, labels_out);
 }
 
+
+extern "C" int cl_cluster_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut, int32_t* labels_out)
+{
+    int rc = check_args(c, eps, min_pts, cut);
+    if (rc) return rc;
+    if (variant != CL_VARIANT_CDBSCAN1 && variant != CL_VARIANT_CDBSCAN2 && variant != CL_VARIANT_BLOCK)
+        return fail(CL_ERR_ARG, "unknown variant");
+    if (c->enq - c->deq >= 2) return fail(CL_ERR_ARG, "cl_cluster_async: two runs already in flight, call cl_wait first");
+    if (c->n == 0) {
+        // cDBSCAN.py:77 / blockDBSCAN.py:74: mat[0] on an empty mat raises; cDBSCAN2 returns {}
+        if (variant != CL_VARIANT_CDBSCAN2 && cut <= 0) return fail(CL_ERR_EMPTY, "empty input (reference raises IndexError)");
+        return fail(CL_ERR_ARG, "cl_cluster_async: empty chromosome (use cl_cluster)");
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    if (variant == CL_VARIANT_BLOCK) return run_block(c, eps, min_pts, cut, labels_out);
+    return run_rotated(c, variant, eps, min_pts, cut, labels_out);
+}
+
+extern "C" int cl_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
+{
+    if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
+    if (n_clusters) *n_clusters = 0;
+    if (max_label) *max_label = -1;
+    HIP_TRY(hipSetDevice(c->device));
+    return finish_wait(c, n_clusters, max_label);
+}
 
 extern "C" int cl_cluster(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut,
                           int32_t* labels_out, int32_t* n_clusters, int32_t* max_label)
@@ -1860,23 +1978,23 @@ extern "C" int cl_cluster(cl_chrom* c, int variant, int32_t eps, int32_t min_pts
     if (rc) return rc;
     if (n_clusters) *n_clusters = 0;
     if (max_label) *max_label = -1;
-    c->have_result = false;
-    c->last_K = 0;
-    if (variant != CL_VARIANT_CDBSCAN1 && variant != CL_VARIANT_CDBSCAN2 && variant != CL_VARIANT_BLOCK)
-        return fail(CL_ERR_ARG, "unknown variant");
+    if (c->enq != c->deq) return fail(CL_ERR_ARG, "cl_cluster: asynchronous runs still in flight, call cl_wait first");
     if (c->n == 0) {
+        if (variant != CL_VARIANT_CDBSCAN1 && variant != CL_VARIANT_CDBSCAN2 && variant != CL_VARIANT_BLOCK)
+            return fail(CL_ERR_ARG, "unknown variant");
         // cDBSCAN.py:77 / blockDBSCAN.py:74: mat[0] on an empty mat raises; cDBSCAN2 returns {}
         if (variant != CL_VARIANT_CDBSCAN2 && cut <= 0) return fail(CL_ERR_EMPTY, "empty input (reference raises IndexError)");
-        c->have_result = true;
+        c->have_result = true; c->last_K = 0; c->last_slot = -1;
         return CL_OK;
     }
-    HIP_TRY(hipSetDevice(c->device));
-    if (variant == CL_VARIANT_BLOCK) return run_block(c, eps, min_pts, cut, labels_out, n_clusters, max_label);
-    return run_rotated(c, variant, eps, min_pts, cut, labels_out, n_clusters, max_label);
+    c->have_result = false;
+    c->last_K = 0;
+    rc = cl_cluster_async(c, variant, eps, min_pts, cut, labels_out);
+    if (rc) return rc;
+    return finish_wait(c, n_clusters, max_label);
 }
 
-static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, int32_t* labels_out,
-                       int32_t* n_clusters, int32_t* max_label)
+static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, int32_t* labels_out)
 {
     int rc;
     GridParams g;
@@ -1893,9 +2011,8 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     const int ntiles = nblocks(n);
     const int tgrid = tile_grid(ntiles);
 
-    LAUNCH(k_init_arrays, n + 1, n, c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
-           c->usize.as<int>(), c->cellfirst.as<int>(), c->flag.as<int>(), c->state.as<int>(), counters);
-    HIP_TRY(hipMemsetAsync(c->labels.p, 0xFF, (size_t)n * 4, c->stream));
+    LAUNCH(k_init_flags, n + 1, n, c->flag.as<int>(), counters);
+    HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
     if ((rc = run_sort_and_count(c, g, false))) return rc;
 
     // K3
@@ -1923,7 +2040,8 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         hipError_t e = rocprim::inclusive_scan(c->scan_tmp.p, tb, c->chainflag.as<int>(), c->chainhead.as<int>(), (size_t)n,
                                                rocprim::maximum<int>(), c->stream);
         if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan(chain)", hipGetErrorString(e));
-        LAUNCH(k_chain_parent, n, strip, g.S, cnt, g.minPts, c->chainhead.as<int>(), c->parent.as<int>(), c->chainflag.as<int>());
+        LAUNCH(k_chain_parent, n, strip, g.S, cnt, g.minPts, c->chainhead.as<int>(), c->parent.as<int>(), c->chainflag.as<int>(),
+               c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>());
     }
     hipLaunchKernelGGL(k_union_cores, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->parent.as<int>());
     hipLaunchKernelGGL(k_flatten, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
@@ -1953,11 +2071,13 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     }
     Table t = make_table(c);
     LAUNCH(k_init_table, n + 1, t, c->rankscan.as<int>(), n);
-    hipLaunchKernelGGL(k_final_labels, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow, c->owner.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(),
-           c->bsize.as<int>(), c->state.as<int>(), c->rankscan.as<int>(), c->labels.as<int>(), t);
-    ev_record(c, 6);
+    // rlabel reuses the chainhead buffer (free after k_chain_parent)
+    LAUNCH(k_root_labels, n, g, strip, c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
+           c->state.as<int>(), c->rankscan.as<int>(), c->chainhead.as<int>());
+    hipLaunchKernelGGL(k_final_labels, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow, c->owner.as<int>(),
+                       c->chainhead.as<int>(), c->slot[c->cur].labels.as<int>(), t);
     HIP_TRY(hipGetLastError());
-    return finish_run(c, g.S + 2, strip + g.S, t, labels_out, n_clusters, max_label);
+    return finish_enqueue(c, g.S + 2, strip + g.S, labels_out);
 }
 
 extern "C" int cl_get_boxes(cl_chrom* c, cl_box* boxes_out)
@@ -1967,10 +2087,12 @@ extern "C" int cl_get_boxes(cl_chrom* c, cl_box* boxes_out)
     const int K = c->last_K;
     if (K <= 0) return CL_OK;
     if (!boxes_out) return fail(CL_ERR_ARG, "boxes_out is null");
-    for (int k = 0; k < K; ++k) {
-        cl_box b = c->h_boxes[k];
-        if (b.count == 0) { b.min_x = b.max_x = b.min_y = b.max_y = 0; }
-        boxes_out[k] = b;
-    }
+    memcpy(boxes_out, c->slot[c->last_slot].h_boxes, (size_t)K * sizeof(cl_box));
     return CL_OK;
+}
+
+extern "C" const cl_box* cl_boxes_host(const cl_chrom* c)
+{
+    if (!c || !c->have_result || c->last_slot < 0 || c->last_K <= 0) return nullptr;
+    return c->slot[c->last_slot].h_boxes;
 }

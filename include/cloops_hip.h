@@ -105,11 +105,28 @@ int cl_cluster(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t c
                int32_t* labels_out, int32_t* n_clusters, int32_t* max_label);
 
 /*
+ * Asynchronous form for sweeps with a fixed cut (every (eps, minPts) step of the same
+ * chromosome is independent there): cl_cluster_async() enqueues one run and returns without
+ * blocking; cl_wait() completes the OLDEST outstanding run and reports its cluster count.
+ * At most two runs may be in flight; the D2H copy of run k then overlaps the kernels of run
+ * k+1.  `labels_out` must stay valid (and should be pinned, cl_host_alloc) until the matching
+ * cl_wait() returns; use a different buffer for the second in-flight run.
+ * cl_cluster() == cl_cluster_async() + cl_wait().
+ */
+int cl_cluster_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut,
+                     int32_t* labels_out);
+int cl_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label);
+
+/*
  * Cluster table of the last run, indexed by cluster id 0..max_label (count == 0 for the
  * id gaps of variant 1): bounding box + size per label, the inputs of cLoops/pipe.py:83-102.
  * `boxes_out`: (max_label+1) rows of host memory.
  */
 int cl_get_boxes(cl_chrom* c, cl_box* boxes_out);
+/* Zero-copy view of the same table: (max_label+1) rows in pinned host memory owned by the
+ * handle, valid until the next cl_wait()/cl_cluster() that lands in the same result slot
+ * (i.e. for at least one more run).  NULL if there is no result or no cluster. */
+const cl_box* cl_boxes_host(const cl_chrom* c);
 
 /*
  * Region query alone (kernel K2): neighbour counts |{q : |Xp-Xq|+|Yp-Yq| <= eps}|, self

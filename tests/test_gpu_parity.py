@@ -98,3 +98,27 @@ def test_cut_filter_matches_oracle(variant):
         res = gpu_labels(variant, X, Y, eps, minPts, cut)
         want = oracle.single_dbscan(variant, X, Y, eps, minPts, cut)["labels"]
         assert np.array_equal(res.labels, want), (variant, eps, cut)
+
+
+def test_async_two_in_flight_matches_sync():
+    """cl_cluster_async / cl_wait with two runs in flight give the synchronous results."""
+    X, Y = G.chr21_xy()
+    ch = api.Chromosome(X, Y)
+    try:
+        params = [("v2", 500, 5, 0), ("v1", 2000, 5, 0), ("block", 1000, 5, 0), ("v2", 1000, 5, 4601), ("v2", 5000, 20, 0)]
+        sync = [ch.cluster(v, e, m, c) for v, e, m, c in params]
+        got = []
+        ch.cluster_async(*params[0])
+        for k in range(len(params)):
+            if k + 1 < len(params):
+                ch.cluster_async(*params[k + 1])
+            got.append(ch.wait(copy=True))
+        for a, b in zip(sync, got):
+            assert np.array_equal(a.labels, b.labels)
+            assert a.n_clusters == b.n_clusters and a.max_label == b.max_label
+            assert np.array_equal(a.boxes, b.boxes)
+        with pytest.raises(Exception):
+            ch.cluster_async("v2", 500, 5); ch.cluster_async("v2", 500, 5); ch.cluster_async("v2", 500, 5)
+        ch.wait(); ch.wait()
+    finally:
+        ch.close()
