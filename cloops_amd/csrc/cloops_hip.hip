@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <climits>
+#include <ctime>
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -1574,8 +1575,13 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
             c->own_stream = true;
         }
         if (hipHostMalloc((void**)&c->h_pinned, 4096, hipHostMallocDefault) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipHostMalloc"); break; }
-        if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipStreamCreate(copy)"); break; }
+        {
+            // copies must not queue up behind the next run's kernels: give their streams the highest priority
+            int prio_lo = 0, prio_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+            if (hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+                hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipStreamCreate(copy)"); break; }
+        }
         bool okslots = true;
         for (auto& sl : c->slot) {
             okslots = okslots && hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) == hipSuccess;
@@ -1770,10 +1776,34 @@ __global__ void k_pack_header(int* __restrict__ hdr, const int* __restrict__ ran
                               const int* __restrict__ d_M)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        hdr[0] = rankscan_total[0];
+        hdr[0] = rankscan_total[0];          // K  = ids handed out
         hdr[1] = counters[CTR_OVERFLOW];
-        hdr[2] = d_M[0];
+        hdr[2] = d_M[0];                     // M  = PETs that entered DBSCAN
+        hdr[3] = 0;                          // n_clusters (filled by k_export_table)
+        hdr[4] = -1;                         // max_label
+        hdr[5] = 0;                          // 1 = table truncated (host buffer too small)
     }
+}
+
+// The cluster table goes to the host from INSIDE the compute stream: the kernel knows K (the host
+// does not, without a round trip) and stores the K rows straight into pinned host memory, counting
+// the non-empty ids on the way.  cl_wait() then needs no GPU work at all -- a copy issued there
+// would queue behind the kernels of the next run that is already executing.
+__global__ void k_export_table(int* __restrict__ hdr, const cl_box* __restrict__ rows, cl_box* __restrict__ host_rows, int cap)
+{
+    const int K = hdr[0];
+    int nc = 0, ml = -1;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K && k < cap; k += gridDim.x * blockDim.x) {
+        cl_box b = rows[k];
+        if (b.count > 0) { ++nc; ml = k; } else { b.min_x = b.max_x = b.min_y = b.max_y = 0; }
+        host_rows[k] = b;
+    }
+    for (int o = 32; o > 0; o >>= 1) { nc += __shfl_down(nc, o); ml = max(ml, __shfl_down(ml, o)); }
+    if ((threadIdx.x & 63) == 0) {
+        if (nc) atomicAdd(&hdr[3], nc);
+        if (ml >= 0) atomicMax(&hdr[4], ml);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && K > cap) hdr[5] = 1;
 }
 
 static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* labels_out)
@@ -1781,12 +1811,18 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
     const int n = (int)c->n;
     cl_chrom::Slot& sl = c->slot[c->cur];
     int* dh = c->hdr.as<int>() + 16 * c->cur;
+    if (sl.h_boxes_cap == 0) {
+        const size_t cap = (size_t)n / 16 + 65536;
+        HIP_TRY(hipHostMalloc((void**)&sl.h_boxes, cap * sizeof(cl_box), hipHostMallocDefault));
+        sl.h_boxes_cap = cap;
+    }
     hipLaunchKernelGGL(k_pack_header, dim3(1), dim3(64), 0, c->stream, dh, c->rankscan.as<int>() + n, c->counters.as<int>(), d_M);
+    hipLaunchKernelGGL(k_export_table, dim3(256), dim3(TPB), 0, c->stream, dh, sl.table.as<cl_box>(), sl.h_boxes, (int)std::min<size_t>(sl.h_boxes_cap, 0x7fffffff));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sl.ev_done, c->stream));
     ev_record(c, 6);
     HIP_TRY(hipStreamWaitEvent(c->copy_stream, sl.ev_done, 0));
-    HIP_TRY(hipMemcpyAsync(sl.h_hdr, dh, 16, hipMemcpyDeviceToHost, c->copy_stream));
+    HIP_TRY(hipMemcpyAsync(sl.h_hdr, dh, 32, hipMemcpyDeviceToHost, c->copy_stream));
     if (labels_out) HIP_TRY(hipMemcpyAsync(labels_out, sl.labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->copy_stream));
     if (c->profiling) (void)hipEventRecord(sl.ev[7], c->copy_stream);
     HIP_TRY(hipEventRecord(sl.ev_copied, c->copy_stream));
@@ -1803,25 +1839,37 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
     if (c->deq == c->enq) return fail(CL_ERR_ARG, "cl_wait: no run in flight");
     const int w = c->deq & 1;
     cl_chrom::Slot& sl = c->slot[w];
+    static const bool dbg_wait = getenv("CLOOPS_DBG_WAIT") != nullptr;
+    timespec ts0{}, ts1{};
+    if (dbg_wait) {
+        clock_gettime(CLOCK_MONOTONIC, &ts0);
+        hipError_t q1 = hipEventQuery(sl.ev_done), q2 = hipEventQuery(sl.ev_copied);
+        fprintf(stderr, "[wait] run %d slot %d: compute_done=%d copied=%d next_done=%d\n", c->deq, w, q1 == hipSuccess, q2 == hipSuccess,
+                (int)(hipEventQuery(c->slot[w ^ 1].ev_done) == hipSuccess));
+    }
     HIP_TRY(hipEventSynchronize(sl.ev_copied));
+    if (dbg_wait) {
+        clock_gettime(CLOCK_MONOTONIC, &ts1);
+        fprintf(stderr, "[wait]   ev_copied after %.0f us; next_done=%d\n", (ts1.tv_sec - ts0.tv_sec) * 1e6 + (ts1.tv_nsec - ts0.tv_nsec) / 1e3,
+                (int)(hipEventQuery(c->slot[w ^ 1].ev_done) == hipSuccess));
+    }
     sl.pending = false;
     c->deq++;
     const int K = sl.h_hdr[0];
     if (sl.h_hdr[1] != 0)
         return fail(CL_ERR_HIP, "internal: release-record overflow (border point with > 4 adjacent components)");
-    // the cluster table comes back in one copy (K rows of cl_box) into the slot's pinned cache;
-    // n_clusters / max_label need the per-id counts (variant 1 leaves gaps)
-    int nc = 0, ml = -1;
-    if (K > 0) {
-        if ((size_t)K > sl.h_boxes_cap) {
-            if (sl.h_boxes) (void)hipHostFree(sl.h_boxes);
-            sl.h_boxes = nullptr; sl.h_boxes_cap = 0;
-            size_t cap = (size_t)K + (size_t)K / 4 + 1024;
-            HIP_TRY(hipHostMalloc((void**)&sl.h_boxes, cap * sizeof(cl_box), hipHostMallocDefault));
-            sl.h_boxes_cap = cap;
-        }
+    // the table rows are already in the slot's pinned cache (k_export_table); only if that cache was
+    // too small (K > capacity, reported in the header) grow it and fetch the rows with a copy
+    int nc = sl.h_hdr[3], ml = sl.h_hdr[4];
+    if (sl.h_hdr[5] != 0) {
+        if (sl.h_boxes) (void)hipHostFree(sl.h_boxes);
+        sl.h_boxes = nullptr; sl.h_boxes_cap = 0;
+        size_t cap = (size_t)K + (size_t)K / 4 + 1024;
+        HIP_TRY(hipHostMalloc((void**)&sl.h_boxes, cap * sizeof(cl_box), hipHostMallocDefault));
+        sl.h_boxes_cap = cap;
         HIP_TRY(hipMemcpyAsync(sl.h_boxes, sl.table.p, (size_t)K * sizeof(cl_box), hipMemcpyDeviceToHost, c->aux_stream));
         HIP_TRY(hipStreamSynchronize(c->aux_stream));
+        nc = 0; ml = -1;
         for (int k = 0; k < K; ++k) {
             cl_box& b = sl.h_boxes[k];
             if (b.count > 0) { ++nc; ml = k; } else { b.min_x = b.max_x = b.min_y = b.max_y = 0; }
