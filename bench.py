@@ -151,20 +151,47 @@ def main():
         dist.destroy_process_group()
 
 
+def _cpu_worker(seed):
+    """one host process = one chromosome, like a joblib worker of cLoops/pipe.py:117"""
+    import numpy as np
+    import oracle
+    from cloops_amd.synth import synth_chrom
+    X, Y = synth_chrom(N_PETS, CHROM_LEN, seed)
+    t0 = time.perf_counter()
+    lab = oracle.labels(VARIANT, X, Y, EPS, MINPTS)
+    return time.perf_counter() - t0, int((lab >= 0).sum())
+
+
 def cpu_baseline(X, Y, res):
-    """The CPU oracle (single-threaded C port of cLoops/cDBSCAN2.py) on the SAME 5 M PETs;
-    doubles as a full-size parity check of the GPU labels."""
+    """The CPU oracle (C port of cLoops/cDBSCAN2.py) on this box's host cores.
+
+    (1) the benchmark chromosome itself, single thread -- doubles as a full-size parity check
+        of the GPU labels;  (2) the reference's own parallel shape (cLoops/pipe.py:117: one
+        worker process per chromosome): W processes, each clustering its own 5 M-PET chromosome,
+        aggregate PETs/s.  The reported `value` is (2)."""
+    import multiprocessing as mp
     import numpy as np
     import oracle
     oracle.build()
     t0 = time.perf_counter()
     want = oracle.labels(VARIANT, X, Y, EPS, MINPTS)
-    dt = time.perf_counter() - t0
+    dt1 = time.perf_counter() - t0
     same = bool(np.array_equal(want, res.labels))
-    return {"value": len(X) / dt, "unit": "PETs/s", "cores": 1, "kind": "port",
-            "sample": "the full workload once: %d PETs, cDBSCAN2 eps=%d minPts=%d, C oracle, 1 thread, %.1f s" % (len(X), EPS, MINPTS, dt),
+    workers = max(1, min(os.cpu_count() or 1, 16))
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(workers) as pool:
+        per = pool.map(_cpu_worker, [9000 + k for k in range(workers)])
+    wall = time.perf_counter() - t0
+    cpu_s = sum(p[0] for p in per)
+    # wall includes the (untimed-for-GPU) synthetic generation; use the slowest worker's clustering time
+    par_wall = max(p[0] for p in per)
+    return {"value": workers * N_PETS / par_wall, "unit": "PETs/s", "cores": workers, "kind": "port",
+            "sample": "%d worker processes x one 5 M-PET chromosome each (cDBSCAN2 eps=%d minPts=%d, C oracle): "
+                      "%.1f s of CPU work, slowest worker %.2f s" % (workers, EPS, MINPTS, cpu_s + dt1, par_wall),
+            "single_thread_pets_per_s": len(X) / dt1,
             "labels_match_gpu": same,
-            "note": "the Python reference itself runs ~1e5 PETs/s/core (BASELINE.md section 2); the C port is far faster than the reference"}
+            "note": "the Python reference itself runs ~1e5 PETs/s/core (BASELINE.md section 2); the C port is ~20x faster than the reference"}
 
 
 if __name__ == "__main__":
