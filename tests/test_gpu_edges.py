@@ -1,0 +1,132 @@
+"""GPU edge cases against the CPU oracle (bit-exact): pile-ups larger than the LDS window,
+degenerate grids, extreme minPts, tiny inputs, everything filtered, negative coordinates (v1)."""
+import numpy as np
+import pytest
+
+import oracle
+from cloops_amd import api, _lib
+
+pytestmark = pytest.mark.gpu
+ALL = ["v2", "v1", "block"]
+
+
+def run_all(X, Y, eps, minPts, cut=0, variants=ALL):
+    ch = api.Chromosome(X, Y)
+    try:
+        for v in variants:
+            got = ch.cluster(v, eps, minPts, cut)
+            want = oracle.single_dbscan(v, X, Y, eps, minPts, cut)["labels"]
+            assert np.array_equal(got.labels, want), (v, eps, minPts, cut, int((got.labels != want).sum()))
+            assert got.n_clusters == len(np.unique(want[want >= 0]))
+    finally:
+        ch.close()
+
+
+def test_pileups_exceed_lds_window():
+    """thousands of PETs inside one eps window: the staged halo (128) and span (120) overflow"""
+    rng = np.random.default_rng(1)
+    parts = []
+    for c, m in ((50000, 3000), (52000, 700), (300000, 1500)):
+        parts.append(np.stack([c + rng.integers(-40, 41, m), c + 9000 + rng.integers(-40, 41, m)], 1))
+    bg = rng.integers(0, 600000, 4000)
+    parts.append(np.stack([bg, bg + rng.integers(0, 50000, 4000)], 1))
+    P = np.concatenate(parts)
+    P = P[rng.permutation(len(P))]
+    for eps, minPts in ((100, 5), (30, 20), (2000, 50)):
+        run_all(P[:, 0], P[:, 1], eps, minPts)
+
+
+def test_exact_duplicates_heavy():
+    rng = np.random.default_rng(2)
+    base = rng.integers(1000, 200000, 300)
+    reps = rng.integers(1, 40, 300)
+    X = np.repeat(base, reps)
+    Y = X + np.repeat(rng.integers(0, 5000, 300), reps)
+    p = rng.permutation(len(X))
+    run_all(X[p], Y[p], 50, 5)
+    run_all(X[p], Y[p], 1, 3)
+
+
+@pytest.mark.parametrize("eps", [1, 3, 10 ** 6, 2 * 10 ** 8])
+def test_degenerate_grid_sizes(eps):
+    """eps = 1 (maximal strip table for this extent) .. eps larger than the whole extent (one strip)"""
+    rng = np.random.default_rng(eps % 97)
+    n = 4000
+    X = rng.integers(0, 200000, n)
+    Y = X + rng.integers(0, 100000, n)
+    run_all(X, Y, eps, 4)
+
+
+@pytest.mark.parametrize("minPts", [1, 2, 1000, 10 ** 6])
+def test_extreme_minpts(minPts):
+    rng = np.random.default_rng(7)
+    n = 5000
+    X = rng.integers(0, 100000, n)
+    Y = X + rng.integers(0, 3000, n)
+    run_all(X, Y, 500, minPts)
+
+
+def test_tiny_inputs():
+    for n in (1, 2, 3, 7):
+        X = np.arange(n) * 3 + 100
+        Y = X + 10
+        run_all(X, Y, 5, 1)
+        run_all(X, Y, 5, 2)
+        run_all(X, Y, 100, 3)
+
+
+def test_all_identical_points():
+    X = np.full(2000, 12345)
+    Y = np.full(2000, 54321)
+    run_all(X, Y, 10, 5)
+    run_all(X, Y, 10, 5000)
+
+
+def test_cut_filters_everything_and_almost_everything():
+    rng = np.random.default_rng(9)
+    X = rng.integers(0, 100000, 3000)
+    Y = X + rng.integers(0, 2000, 3000)
+    run_all(X, Y, 300, 4, cut=10 ** 7)          # nothing survives: pipe.py:64-65
+    run_all(X, Y, 300, 4, cut=1990)             # a handful survive
+    run_all(X, Y, 300, 4, cut=1)                # only d == 0 rows are dropped
+
+
+def test_negative_and_reversed_coordinates_v1_block():
+    """cDBSCAN (v1) and blockDBSCAN accept any integers; cDBSCAN2 needs 0 <= X <= Y."""
+    rng = np.random.default_rng(11)
+    n = 6000
+    X = rng.integers(-50000, 50000, n)
+    Y = rng.integers(-50000, 50000, n)
+    run_all(X, Y, 700, 4, variants=["v1", "block"])
+    ch = api.Chromosome(X, Y)
+    with pytest.raises(_lib.CloopsHipError) as ei:
+        ch.cluster("v2", 700, 4)
+    assert ei.value.code == _lib.CL_ERR_DOMAIN
+    ch.close()
+
+
+def test_coordinate_domain_limit():
+    with pytest.raises(_lib.CloopsHipError) as ei:
+        api.Chromosome(np.array([0, 1 << 29]), np.array([5, (1 << 29) + 5]))
+    assert ei.value.code == _lib.CL_ERR_DOMAIN
+
+
+def test_large_eps_giant_component_16M():
+    """mode-3/4 regime: eps 5000, minPts 20 on 16 M PETs -- the self-ligation diagonal is one
+    component of millions of PETs (two-level reductions, chain scans)."""
+    from cloops_amd.synth import synth_chrom
+    X, Y = synth_chrom(16000000, 248956422, 4242)
+    ch = api.Chromosome(X, Y)
+    try:
+        got = ch.cluster("v2", 5000, 20, pinned=True)
+        want = oracle.labels("v2", X, Y, 5000, 20)
+        assert np.array_equal(got.labels, want)
+        # cluster table against a host recomputation for the biggest clusters
+        big = np.argsort(-got.boxes["count"])[:5]
+        for c in big:
+            sel = want == c
+            b = got.boxes[c]
+            assert (int(b["count"]), int(b["min_x"]), int(b["max_x"]), int(b["min_y"]), int(b["max_y"])) == (
+                int(sel.sum()), int(X[sel].min()), int(X[sel].max()), int(Y[sel].min()), int(Y[sel].max()))
+    finally:
+        ch.close()
