@@ -27,6 +27,7 @@ SYMBOLS = [
     "cl_last_error", "cl_device_count", "cl_chrom_create", "cl_chrom_destroy", "cl_chrom_size",
     "cl_cluster", "cl_get_boxes", "cl_neighbor_counts", "cl_labels_device", "cl_set_profiling",
     "cl_get_timing", "cl_version", "cl_host_alloc", "cl_host_free", "cl_cluster_async", "cl_wait", "cl_boxes_host",
+    "cl_dist_stats", "cl_dist_sqdev", "cl_dist_hist",
 ]
 
 
@@ -40,6 +41,10 @@ class ClTiming(ctypes.Structure):
                 ("ms_union", ctypes.c_float), ("ms_border", ctypes.c_float), ("ms_table", ctypes.c_float),
                 ("ms_d2h", ctypes.c_float), ("ms_total", ctypes.c_float), ("n_in", ctypes.c_int64),
                 ("n_strips", ctypes.c_int64)]
+
+
+class ClDstats(ctypes.Structure):
+    _fields_ = [("n_all", ctypes.c_int64 * 2), ("n_pos", ctypes.c_int64 * 2), ("sumlog", ctypes.c_double * 2)]
 
 
 class CloopsHipError(RuntimeError):
@@ -81,6 +86,12 @@ def load():
     lib.cl_wait.argtypes = [vp, i32p, i32p]
     lib.cl_boxes_host.restype = vp
     lib.cl_boxes_host.argtypes = [vp]
+    lib.cl_dist_stats.restype = ctypes.c_int
+    lib.cl_dist_stats.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(ClDstats)]
+    lib.cl_dist_sqdev.restype = ctypes.c_int
+    lib.cl_dist_sqdev.argtypes = [vp, ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+    lib.cl_dist_hist.restype = ctypes.c_int
+    lib.cl_dist_hist.argtypes = [vp, ctypes.c_int32, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
     lib.cl_get_boxes.restype = ctypes.c_int
     lib.cl_get_boxes.argtypes = [vp, vp]
     lib.cl_neighbor_counts.restype = ctypes.c_int

@@ -168,6 +168,25 @@ class Chromosome(object):
         boxes = self._boxes(ml.value, copy=not pinned) if want_boxes else None
         return ClusterResult(labels, nc.value, ml.value, boxes, self.timing() if self._profiling else None)
 
+    # ---- distance statistics of the last completed run (K7; inputs of ests.estIntSelCutFrag) ----
+    def dist_stats(self, cut=0):
+        """-> dict(n_all=[inter, self], n_pos=[...], sumlog=[...]) (cl_dist_stats)."""
+        st = _lib.ClDstats()
+        _lib.check(self._lib.cl_dist_stats(self._h, int(cut), ctypes.byref(st)))
+        return {"n_all": [int(st.n_all[0]), int(st.n_all[1])], "n_pos": [int(st.n_pos[0]), int(st.n_pos[1])],
+                "sumlog": [float(st.sumlog[0]), float(st.sumlog[1])]}
+
+    def dist_sqdev(self, cut, mean_inter, mean_self):
+        out = (ctypes.c_double * 2)()
+        _lib.check(self._lib.cl_dist_sqdev(self._h, int(cut), float(mean_inter), float(mean_self), out))
+        return [float(out[0]), float(out[1])]
+
+    def dist_hist(self, cut, group, prefix, shift):
+        out = np.zeros(256, dtype=np.uint64)
+        _lib.check(self._lib.cl_dist_hist(self._h, int(cut), int(group), int(prefix), int(shift),
+                                          out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+        return out
+
     def neighbor_counts(self, eps, cut=0):
         out = np.full(self.n, -1, dtype=np.int32)
         _lib.check(self._lib.cl_neighbor_counts(self._h, int(eps), int(cut), out.ctypes.data_as(ctypes.c_void_p)))

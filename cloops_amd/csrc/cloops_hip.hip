@@ -1461,6 +1461,130 @@ k_blk_point_labels(BlkParams p, const BlkScalars* __restrict__ sc, const int* __
     table_accumulate(t, h, lab, x, y);
 }
 
+// ==========================================================================================
+// K7: distance statistics of one step (the inputs of cLoops/ests.py:36-61, estIntSelCutFrag)
+// ==========================================================================================
+// pipe.py:106-109 collects `dis` = Y-X of the PETs in inter-ligation clusters and `dss` = Y-X of
+// the PETs in self-ligation clusters plus the PETs dropped by the cut (pipe.py:63); ests.py then
+// needs counts, mean / std of log2(|d|) over d > 0 for both groups and the median of the self
+// group.  At tens of millions of PETs per step the host-side masks, log2 and np.median cost
+// ~20x the clustering itself, so the sums are reduced here (fixed order: deterministic) and the
+// median comes from an exact 4-pass radix select on the integer distances.
+// group 0 = inter, group 1 = self (+ short), -1 = in no group
+__global__ void k7_classify(const int* __restrict__ hdr, const cl_box* __restrict__ rows, signed char* __restrict__ cls)
+{
+    const int K = hdr[0];
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const cl_box b = rows[k];
+    signed char c = -1;
+    if (b.count > 0 && b.min_x != b.max_x && b.min_y != b.max_y)           // pipe.py:83-85
+        c = (b.max_x < b.min_y) ? 0 : 1;                                    // pipe.py:97
+    cls[k] = c;
+}
+
+__device__ __forceinline__ int k7_group(int r, const int* __restrict__ X, const int* __restrict__ Y,
+                                        const int* __restrict__ labels, const signed char* __restrict__ cls, int cut, int* ad)
+{
+    const int d = Y[r] - X[r];
+    *ad = d < 0 ? -d : d;                         // ests.py:42-43 np.abs
+    if (cut > 0 && d < cut) return 1;             // pipe.py:63: short PETs go to dss
+    const int lab = labels[r];
+    return lab >= 0 ? (int)cls[lab] : -1;
+}
+
+struct K7Part { double sumlog[2]; long long n_all[2]; long long n_pos[2]; };
+
+// pass 1: counts and sum of log2 per group; one partial per workgroup (fixed row ranges)
+__global__ void __launch_bounds__(TPB)
+k7_pass1(int n, int cut, const int* __restrict__ X, const int* __restrict__ Y, const int* __restrict__ labels,
+         const signed char* __restrict__ cls, K7Part* __restrict__ parts)
+{
+    double sl[2] = {0.0, 0.0};
+    long long na[2] = {0, 0}, np_[2] = {0, 0};
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
+    for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+        int ad;
+        const int g = k7_group(r, X, Y, labels, cls, cut, &ad);
+        if (g < 0) continue;
+        na[g]++;
+        if (ad > 0) { np_[g]++; sl[g] += log2((double)ad); }
+    }
+    __shared__ double s_sl[2][TPB / 64];
+    __shared__ long long s_n[4][TPB / 64];
+    for (int g = 0; g < 2; ++g) {
+        for (int o = 32; o > 0; o >>= 1) {
+            sl[g] += __shfl_down(sl[g], o);
+            na[g] += __shfl_down(na[g], o);
+            np_[g] += __shfl_down(np_[g], o);
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { s_sl[0][wv] = sl[0]; s_sl[1][wv] = sl[1]; s_n[0][wv] = na[0]; s_n[1][wv] = na[1]; s_n[2][wv] = np_[0]; s_n[3][wv] = np_[1]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        K7Part p;
+        for (int g = 0; g < 2; ++g) {
+            double a = 0; long long b = 0, c = 0;
+            for (int w = 0; w < TPB / 64; ++w) { a += s_sl[g][w]; b += s_n[g][w]; c += s_n[2 + g][w]; }
+            p.sumlog[g] = a; p.n_all[g] = b; p.n_pos[g] = c;
+        }
+        parts[blockIdx.x] = p;
+    }
+}
+
+// pass 2: sum of squared deviations of log2(|d|) from the given (global) means
+__global__ void __launch_bounds__(TPB)
+k7_pass2(int n, int cut, const int* __restrict__ X, const int* __restrict__ Y, const int* __restrict__ labels,
+         const signed char* __restrict__ cls, double mean0, double mean1, double* __restrict__ parts /* 2 per block */)
+{
+    double sq[2] = {0.0, 0.0};
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
+    for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+        int ad;
+        const int g = k7_group(r, X, Y, labels, cls, cut, &ad);
+        if (g < 0 || ad <= 0) continue;
+        const double x = log2((double)ad) - (g == 0 ? mean0 : mean1);
+        sq[g] += x * x;
+    }
+    __shared__ double s_sq[2][TPB / 64];
+    for (int g = 0; g < 2; ++g)
+        for (int o = 32; o > 0; o >>= 1) sq[g] += __shfl_down(sq[g], o);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { s_sq[0][wv] = sq[0]; s_sq[1][wv] = sq[1]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int g = 0; g < 2; ++g) {
+            double a = 0;
+            for (int w = 0; w < TPB / 64; ++w) a += s_sq[g][w];
+            parts[2 * blockIdx.x + g] = a;
+        }
+    }
+}
+
+// one radix-select pass: histogram of the byte (|d| >> shift) & 255 over the positive distances of
+// `group` whose higher bits equal `prefix` (top pass: shift = 24, everything matches)
+__global__ void __launch_bounds__(TPB)
+k7_hist(int n, int cut, const int* __restrict__ X, const int* __restrict__ Y, const int* __restrict__ labels,
+        const signed char* __restrict__ cls, int group, unsigned prefix, int shift, unsigned long long* __restrict__ hist)
+{
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0;                               // TPB == 256
+    __syncthreads();
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        int ad;
+        const int g = k7_group(r, X, Y, labels, cls, cut, &ad);
+        if (g != group || ad <= 0) continue;
+        const unsigned u = (unsigned)ad;
+        if (shift < 24 && (u >> (shift + 8)) != prefix) continue;
+        atomicAdd(&h[(u >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1507,6 +1631,8 @@ struct cl_chrom {
         int32_t* labels_out = nullptr;
     } slot[2];
     DevBuf hdr;                       // device result headers, 16 ints per slot
+    DevBuf k7_cls, k7_parts;          // K7: class per cluster id, per-workgroup partials
+    bool k7_classified = false;       // k7_cls matches the last completed run
     hipStream_t copy_stream = nullptr, aux_stream = nullptr;
     int enq = 0, deq = 0;             // runs enqueued / completed
     int cur = 0;                      // slot of the run being enqueued
@@ -1526,7 +1652,7 @@ static void free_chrom(cl_chrom* c)
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
-                      &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->hdr,
+                      &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->hdr, &c->k7_cls, &c->k7_parts,
                       &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy};
     for (DevBuf* b : bufs) b->release();
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
@@ -1887,6 +2013,7 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
     c->last_K = ml + 1;
     c->last_slot = w;
     c->have_result = true;
+    c->k7_classified = false;
     if (c->profiling) {
         cl_timing& tm = c->timing;
         memset(&tm, 0, sizeof(tm));
@@ -2133,6 +2260,86 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
                        c->chainhead.as<int>(), c->slot[c->cur].labels.as<int>(), t);
     HIP_TRY(hipGetLastError());
     return finish_enqueue(c, g.S + 2, strip + g.S, labels_out);
+}
+
+
+// ---- K7 host entry points --------------------------------------------------------------------
+#define K7_BLOCKS 512
+static int k7_prepare(cl_chrom* c)
+{
+    if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
+    if (!c->have_result || c->last_slot < 0) return fail(CL_ERR_ARG, "distance statistics need a completed clustering run");
+    if (c->enq != c->deq) return fail(CL_ERR_ARG, "distance statistics: asynchronous runs still in flight");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->k7_cls.ensure((size_t)c->n + 16))) return rc;
+    if ((rc = c->k7_parts.ensure(K7_BLOCKS * sizeof(K7Part) + 4096))) return rc;
+    if (!c->k7_classified) {
+        cl_chrom::Slot& sl = c->slot[c->last_slot];
+        int* dh = c->hdr.as<int>() + 16 * c->last_slot;
+        LAUNCH(k7_classify, c->n + 1, dh, sl.table.as<cl_box>(), c->k7_cls.as<signed char>());
+        c->k7_classified = true;
+    }
+    return CL_OK;
+}
+
+extern "C" int cl_dist_stats(cl_chrom* c, int32_t cut, cl_dstats* out)
+{
+    if (!out) return fail(CL_ERR_ARG, "cl_dist_stats: out is null");
+    memset(out, 0, sizeof(*out));
+    if (c && c->n == 0) return CL_OK;
+    int rc = k7_prepare(c);
+    if (rc) return rc;
+    cl_chrom::Slot& sl = c->slot[c->last_slot];
+    const int n = (int)c->n;
+    hipLaunchKernelGGL(k7_pass1, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, n, cut, c->d_x, c->d_y, sl.labels.as<int>(),
+                       c->k7_cls.as<signed char>(), c->k7_parts.as<K7Part>());
+    std::vector<K7Part> h(K7_BLOCKS);
+    HIP_TRY(hipMemcpyAsync(h.data(), c->k7_parts.p, K7_BLOCKS * sizeof(K7Part), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int g = 0; g < 2; ++g) {
+        double a = 0; long long b = 0, d = 0;
+        for (int k = 0; k < K7_BLOCKS; ++k) { a += h[k].sumlog[g]; b += h[k].n_all[g]; d += h[k].n_pos[g]; }
+        out->sumlog[g] = a; out->n_all[g] = b; out->n_pos[g] = d;
+    }
+    return CL_OK;
+}
+
+extern "C" int cl_dist_sqdev(cl_chrom* c, int32_t cut, double mean_inter, double mean_self, double* out2)
+{
+    if (!out2) return fail(CL_ERR_ARG, "cl_dist_sqdev: out is null");
+    out2[0] = out2[1] = 0.0;
+    if (c && c->n == 0) return CL_OK;
+    int rc = k7_prepare(c);
+    if (rc) return rc;
+    cl_chrom::Slot& sl = c->slot[c->last_slot];
+    const int n = (int)c->n;
+    hipLaunchKernelGGL(k7_pass2, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, n, cut, c->d_x, c->d_y, sl.labels.as<int>(),
+                       c->k7_cls.as<signed char>(), mean_inter, mean_self, c->k7_parts.as<double>());
+    std::vector<double> h(2 * K7_BLOCKS);
+    HIP_TRY(hipMemcpyAsync(h.data(), c->k7_parts.p, 2 * K7_BLOCKS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < K7_BLOCKS; ++k) { out2[0] += h[2 * k]; out2[1] += h[2 * k + 1]; }
+    return CL_OK;
+}
+
+extern "C" int cl_dist_hist(cl_chrom* c, int32_t cut, int group, uint32_t prefix, int shift, uint64_t* hist256)
+{
+    if (!hist256) return fail(CL_ERR_ARG, "cl_dist_hist: out is null");
+    memset(hist256, 0, 256 * sizeof(uint64_t));
+    if (group < 0 || group > 1 || shift < 0 || shift > 24 || (shift & 7)) return fail(CL_ERR_ARG, "cl_dist_hist: bad group / shift");
+    if (c && c->n == 0) return CL_OK;
+    int rc = k7_prepare(c);
+    if (rc) return rc;
+    cl_chrom::Slot& sl = c->slot[c->last_slot];
+    const int n = (int)c->n;
+    unsigned long long* dh = (unsigned long long*)c->k7_parts.p;
+    HIP_TRY(hipMemsetAsync(dh, 0, 256 * 8, c->stream));
+    hipLaunchKernelGGL(k7_hist, dim3(std::min(nblocks(n), 2048)), dim3(TPB), 0, c->stream, n, cut, c->d_x, c->d_y, sl.labels.as<int>(),
+                       c->k7_cls.as<signed char>(), group, (unsigned)prefix, shift, dh);
+    HIP_TRY(hipMemcpyAsync(hist256, dh, 256 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CL_OK;
 }
 
 extern "C" int cl_get_boxes(cl_chrom* c, cl_box* boxes_out)

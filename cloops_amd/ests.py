@@ -27,3 +27,26 @@ def estIntSelCutFrag(di, ds, log=1):
     frags = np.median(ds)
     rfrags = int(2 ** frags)
     return rcut, rfrags
+
+
+def estIntSelCutFrag_from_stats(n_pos, sumlog, sqdev, median_pair):
+    """The same estimator from pre-reduced statistics (cl_dist_stats / cl_dist_sqdev / radix select
+    of the GPU library) instead of the raw distance lists:
+      n_pos      [inter, self]  number of non-zero distances
+      sumlog     [inter, self]  sum of log2|d|
+      sqdev      [inter, self]  sum of (log2|d| - mean)^2
+      median_pair (lo, hi)      the two middle order statistics of the self-group |d| (equal for odd n)
+    Same formulas, same order of operations as ests.py:49-60; only the summation order inside
+    mean / std differs from numpy's pairwise sums (the result is truncated to int)."""
+    di_mean = sumlog[0] / n_pos[0]
+    ds_mean = sumlog[1] / n_pos[1]
+    di_std = np.sqrt(sqdev[0] / n_pos[0])
+    ds_std = np.sqrt(sqdev[1] / n_pos[1])
+    lo, hi = median_pair
+    ds_median = (np.log2(np.float64(lo)) + np.log2(np.float64(hi))) / 2 if lo != hi else np.log2(np.float64(lo))
+    cut1 = ds_median + 3 * ds_std
+    cut2 = (ds_mean * ds_std + di_mean * di_std) / (ds_std + di_std)
+    cut = min([cut1, cut2])
+    rcut = int(2 ** cut)
+    rfrags = int(2 ** ds_median)
+    return rcut, rfrags

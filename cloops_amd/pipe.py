@@ -23,7 +23,7 @@ import numpy as np
 from . import api
 from .cDBSCAN2 import cDBSCAN as DBSCAN          # pipe.py:42  (production variant)
 from .dist import lpt_assign
-from .ests import estIntSelCutFrag
+from .ests import estIntSelCutFrag, estIntSelCutFrag_from_stats
 
 #: clustering variant used by singleDBSCAN; "block" mirrors the alternative import at pipe.py:43
 DBSCAN_VARIANT = "v2"
@@ -58,7 +58,30 @@ class ChromCache(object):
         self._lock = threading.Lock()
         self.max_items = max_items
 
+    def put_arrays(self, name, X, Y, device=0, ids=None):
+        """Register an in-memory chromosome under the pseudo path 'mem://<chrA>-<chrB>' (no .jd
+        file, no disk): what a direct BEDPE -> HBM loader hands to the sweep."""
+        f = "mem://" + name
+        r = _Resident()
+        r.key = tuple(name.split("-")) if "-" in name else (name, name)
+        r.stamp, r.device = ("mem", len(X)), device
+        r.lock = threading.Lock()
+        r.X = np.ascontiguousarray(X)
+        r.Y = np.ascontiguousarray(Y)
+        r.ids = np.arange(len(r.X), dtype=np.int64) if ids is None else np.asarray(ids)
+        r.d = r.Y.astype(np.int64) - r.X.astype(np.int64)
+        r.chrom = api.Chromosome(r.X, r.Y, device=device)
+        with self._lock:
+            old = self._items.pop(f, None)
+            self._items[f] = r
+        if old is not None:
+            old.chrom.close()
+        return f
+
     def get(self, f, device=0):
+        if f.startswith("mem://"):
+            with self._lock:
+                return self._items[f]
         st = os.stat(f)
         stamp = (st.st_mtime_ns, st.st_size)
         with self._lock:
@@ -177,7 +200,7 @@ def _run_many(fs, eps, minPts, cut, fn):
     devs = _devices()
     if len(devs) <= 1 or len(fs) <= 1:
         return [fn(f, eps, minPts, cut, devs[0]) for f in fs]
-    sizes = [os.path.getsize(f) for f in fs]
+    sizes = [len(CACHE.get(f).d) if f.startswith("mem://") else os.path.getsize(f) for f in fs]
     parts = lpt_assign(sizes, len(devs))
     out = [None] * len(fs)
 
@@ -243,9 +266,131 @@ def _single_arrays(f, eps, minPts, cut, device):
     r = CACHE.get(f, device)
     if len(r.d) == 0:
         e4 = np.zeros((0, 4), np.int64)
-        return r.key, f, e4, e4, np.zeros(0), np.zeros(0)
+        return r.key, f, e4, e4, np.zeros(0), np.zeros(0), 0
     dataI, dataS, dis, dss, nI, nS, n_in = _cluster_arrays(r, eps, minPts, cut)
-    return r.key, f, dataI, dataS, dis, dss
+    return r.key, f, dataI, dataS, dis, dss, n_in
+
+
+def _boxes_classified(r, res):
+    """host part of pipe.py:78-102 on the K-row cluster table: (dataI boxes, dataS boxes) as
+    int64 [k,4] arrays (minX, maxX, minY, maxY) in ascending cluster id"""
+    b = res.boxes
+    K = len(b)
+    empty4 = np.zeros((0, 4), np.int64)
+    if K == 0:
+        return empty4, empty4
+    ok = (b["count"] > 0) & (b["min_x"] != b["max_x"]) & (b["min_y"] != b["max_y"])   # pipe.py:83-85
+    inter = ok & (b["max_x"] < b["min_y"])                                             # pipe.py:97
+    box = np.stack([b["min_x"], b["max_x"], b["min_y"], b["max_y"]], 1).astype(np.int64)
+    return box[inter], box[ok & ~inter]
+
+
+def _select_kth(chroms, cut, group, ranks):
+    """Exact order statistics (0-based `ranks`, ascending) of the |d| of `group` over the union of
+    the chromosomes: 4-pass radix select; every pass sums one 256-bin histogram per chromosome."""
+    out = []
+    cache = {}
+    for rank in ranks:
+        prefix, rem = 0, rank
+        for shift in (24, 16, 8, 0):
+            key = (prefix, shift)
+            if key not in cache:
+                h = np.zeros(256, dtype=np.uint64)
+                for r in chroms:
+                    h += r.chrom.dist_hist(cut, group, prefix, shift)
+                cache[key] = h
+            c = np.cumsum(cache[key].astype(np.int64))
+            digit = int(np.searchsorted(c, rem, side="right"))
+            rem -= int(c[digit - 1]) if digit > 0 else 0
+            prefix = (prefix << 8) | digit
+        out.append(prefix)
+    return out
+
+
+def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None):
+    """runSweep with the per-step statistics reduced on the GPUs: neither labels nor distance
+    lists come back to the host -- per chromosome only the K-row cluster table, a few sums, and
+    the 256-bin histograms of an exact radix select for the median (all additive over chromosomes
+    and over GPUs).  Same chain, same cuts, same candidate boxes as runSweep / the reference's
+    pipe.py:241-281; candidate boxes stay numpy arrays:
+
+    returns (dataI {key: {"f": f, "boxes": int64[k,4]}}, cut, cuts, steps)."""
+    variant = variant or DBSCAN_VARIANT
+    devs = _devices()
+    dataI = {}
+    cuts = [cut]
+    steps = []
+    res_list = [CACHE.get(f, devs[0]) for f in fs] if len(devs) == 1 else None
+    for ep in eps:
+        for m in minPts:
+            step_I = {}
+            used = []
+            nS = n_in = 0
+            for k, f in enumerate(fs):
+                r = res_list[k] if res_list is not None else CACHE.get(f, devs[k % len(devs)])
+                if len(r.d) == 0:
+                    continue
+                with r.lock:
+                    res = r.chrom.cluster(variant, ep, m, cut, want_labels=False, pinned=True)
+                    dI, dS = _boxes_classified(r, res)
+                nS += len(dS)
+                n_in += int((r.d >= cut).sum()) if cut > 0 else len(r.d)
+                if len(dI) == 0:                          # runDBSCAN skips such chromosomes entirely (pipe.py:121-122)
+                    continue
+                step_I[r.key] = {"f": f, "boxes": dI}
+                used.append(r)
+            st = {"eps": ep, "minPts": m, "cut_in": int(cut), "n_inter": sum(len(v["boxes"]) for v in step_I.values()),
+                  "n_self": nS, "n_in": n_in}
+            steps.append(st)
+            if len(step_I) == 0:                          # pipe.py:251-255
+                if log:
+                    log("ERROR: no inter-ligation PETs detected for eps %s minPts %s,can't model the distance cutoff,continue anyway" % (ep, m))
+                continue
+            tot = {"n_all": [0, 0], "n_pos": [0, 0], "sumlog": [0.0, 0.0]}
+            for r in used:
+                s1 = r.chrom.dist_stats(cut)
+                for g in (0, 1):
+                    tot["n_all"][g] += s1["n_all"][g]
+                    tot["n_pos"][g] += s1["n_pos"][g]
+                    tot["sumlog"][g] += s1["sumlog"][g]
+            if tot["n_all"][0] > 0 and tot["n_all"][1] > 0:      # pipe.py:256-259
+                if tot["n_pos"][0] == 0 or tot["n_pos"][1] == 0:
+                    raise ValueError("cannot convert float NaN to integer")      # what int(2 ** nan) raises in ests.py:57
+                mi, ms = tot["sumlog"][0] / tot["n_pos"][0], tot["sumlog"][1] / tot["n_pos"][1]
+                sq = [0.0, 0.0]
+                for r in used:
+                    q = r.chrom.dist_sqdev(cut, mi, ms)
+                    sq[0] += q[0]
+                    sq[1] += q[1]
+                n1 = tot["n_pos"][1]
+                med = _select_kth(used, cut, 1, sorted({(n1 - 1) // 2, n1 // 2}))
+                cut_2, frags = estIntSelCutFrag_from_stats(tot["n_pos"], tot["sumlog"], sq, (med[0], med[-1]))
+                if log:
+                    log("Estimated inter-ligation and self-ligation distance cutoff as %s for eps=%s,minPts=%s" % (cut_2, ep, m))
+                st["cut_out"] = int(cut_2)
+                st["frags"] = int(frags)
+                cuts.append(cut_2)
+                cut = cut_2                               # pipe.py:274
+            # combineTwice (pipe.py:155-174) on arrays: append the boxes not seen before, in order
+            for key, v in step_I.items():
+                if key not in dataI:
+                    dataI[key] = {"f": v["f"], "boxes": v["boxes"]}
+                else:
+                    old = dataI[key]["boxes"]
+                    seen = set(map(tuple, old.tolist()))
+                    add = [b for b in v["boxes"].tolist() if tuple(b) not in seen]
+                    if add:
+                        dataI[key]["boxes"] = np.concatenate([old, np.asarray(add, dtype=np.int64)])
+    pos = [c for c in cuts if c > 0]
+    if pos:
+        cut = int(np.max(pos)) if max_cut else int(np.min(pos))     # pipe.py:276-280
+    else:
+        raise ValueError("zero-size array to reduction operation minimum which has no identity")
+    for key in dataI:                                     # filterClusterByDis (pipe.py:130-143), floor division
+        b = dataI[key]["boxes"]
+        dmid = (b[:, 2] + b[:, 3]) // 2 - (b[:, 0] + b[:, 1]) // 2
+        dataI[key]["boxes"] = b[dmid >= cut]
+    return dataI, cut, cuts, steps
 
 
 def runSweep(fs, eps, minPts, cut=0, cpu=1, max_cut=False, log=None):
@@ -262,8 +407,9 @@ def runSweep(fs, eps, minPts, cut=0, cpu=1, max_cut=False, log=None):
     for ep in eps:
         for m in minPts:
             rs = _run_many(fs, ep, m, cut, _single_arrays)
-            dataI_2, dis_2, dss_2, nS = {}, [], [], 0
-            for key, f, dI, dS, dis, dss in rs:          # runDBSCAN merge, pipe.py:119-127
+            dataI_2, dis_2, dss_2, nS, n_in = {}, [], [], 0, 0
+            for key, f, dI, dS, dis, dss, nin in rs:     # runDBSCAN merge, pipe.py:119-127
+                n_in += nin
                 if len(dI) == 0:
                     continue
                 dataI_2[key] = {"f": f, "records": _records(key, dI)}
@@ -271,7 +417,7 @@ def runSweep(fs, eps, minPts, cut=0, cpu=1, max_cut=False, log=None):
                 dis_2.append(dis)
                 dss_2.append(dss)
             st = {"eps": ep, "minPts": m, "cut_in": int(cut), "n_inter": sum(len(v["records"]) for v in dataI_2.values()),
-                  "n_self": nS}
+                  "n_self": nS, "n_in": n_in}
             steps.append(st)
             if len(dataI_2) == 0:                         # pipe.py:251-255
                 if log:

@@ -137,6 +137,27 @@ const cl_box* cl_boxes_host(const cl_chrom* c);
  */
 int cl_neighbor_counts(cl_chrom* c, int32_t eps, int32_t cut, int32_t* counts_out);
 
+/*
+ * Distance statistics of the last completed run -- the inputs of cLoops/ests.py:36-61
+ * (estIntSelCutFrag), reduced on the GPU instead of materialising the reference's `dis` / `dss`
+ * lists (cLoops/pipe.py:63,106-109).  Group 0 = PETs of inter-ligation clusters, group 1 = PETs of
+ * self-ligation clusters plus the PETs removed by `cut` (pass the SAME cut as to cl_cluster).
+ *   cl_dist_stats : n_all  = len(dis) / len(dss);  n_pos, sumlog = count and sum of log2|d| over d != 0
+ *   cl_dist_sqdev : sum of (log2|d| - mean)^2 over d != 0 for the given (genome-wide) means
+ *   cl_dist_hist  : one pass of an exact radix select for the median: histogram of the byte
+ *                   (|d| >> shift) & 255 over the |d| of `group` whose higher bits equal `prefix`
+ *                   (shift = 24, 16, 8, 0; prefix ignored at shift 24)
+ * All three are additive over chromosomes (and over GPUs), which is what the sweep driver uses.
+ */
+typedef struct {
+    int64_t n_all[2];
+    int64_t n_pos[2];
+    double sumlog[2];
+} cl_dstats;
+int cl_dist_stats(cl_chrom* c, int32_t cut, cl_dstats* out);
+int cl_dist_sqdev(cl_chrom* c, int32_t cut, double mean_inter, double mean_self, double* out2);
+int cl_dist_hist(cl_chrom* c, int32_t cut, int group, uint32_t prefix, int shift, uint64_t* hist256);
+
 /* Device pointer to the labels of the last run (n int32, row aligned) -- lets the caller
  * keep results on the GPU (e.g. to hand them to RCCL) without a host round trip. */
 const int32_t* cl_labels_device(const cl_chrom* c);

@@ -59,3 +59,16 @@ def check_sweep(pipe, f, variant="v2"):
     assert len(dataI[("chr21", "chr21")]["records"]) == m["n_filtered"]
     dataI2, cut2, _, _ = pipe.runSweep([f], [500, 1000, 2000], [5], cut=0, max_cut=True)
     assert cut2 == m["max_cut"]
+
+
+def check_sweep_fast(pipe, f, variant="v2"):
+    """runSweepFast (GPU-side statistics, array candidates) == the reference's chain."""
+    z, meta = pipe_golden()
+    m = meta[variant]
+    dataI, cut, cuts, steps = pipe.runSweepFast([f], [500, 1000, 2000], [5], cut=0)
+    assert cut == m["final_cut"]
+    assert [s.get("cut_out") for s in steps] == [s.get("cut_out") for s in m["steps"]]
+    assert [s.get("frags") for s in steps] == [s.get("frags") for s in m["steps"]]
+    assert np.array_equal(dataI[("chr21", "chr21")]["boxes"], z[variant + "_filtered"])
+    _, cut2, _, _ = pipe.runSweepFast([f], [500, 1000, 2000], [5], cut=0, max_cut=True)
+    assert cut2 == m["max_cut"]

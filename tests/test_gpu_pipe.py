@@ -30,6 +30,40 @@ def test_sweep_gpu(jd):
     pipe_checks.check_sweep(pipe, jd)
 
 
+def test_sweep_fast_gpu_statistics(jd):
+    pipe_checks.check_sweep_fast(pipe, jd)
+
+
+def test_dist_stats_match_numpy(jd):
+    """K7 reductions against numpy on the lists the reference would build (pipe.py:63,106-109)."""
+    import oracle
+    import golden_util as G
+    from cloops_amd import api
+    X, Y = G.chr21_xy()
+    ch = api.Chromosome(X, Y)
+    for eps, minPts, cut in ((500, 5, 0), (1000, 5, 4601)):
+        ch.cluster("v2", eps, minPts, cut, want_labels=False)
+        ref = oracle.single_dbscan("v2", X, Y, eps, minPts, cut)
+        st = ch.dist_stats(cut)
+        assert st["n_all"] == [len(ref["dis"]), len(ref["dss"])]
+        for g, arr in ((0, ref["dis"]), (1, ref["dss"])):
+            a = np.abs(arr)
+            a = a[a > 0]
+            assert st["n_pos"][g] == len(a)
+            assert abs(st["sumlog"][g] - np.log2(a).sum()) < 1e-6 * max(1.0, np.log2(a).sum())
+        mi, ms = st["sumlog"][0] / st["n_pos"][0], st["sumlog"][1] / st["n_pos"][1]
+        sq = ch.dist_sqdev(cut, mi, ms)
+        a = np.abs(ref["dss"]); a = a[a > 0]
+        assert abs(np.sqrt(sq[1] / len(a)) - np.log2(a).std()) < 1e-9
+        srt = np.sort(a).astype(np.int64)
+        n1 = len(srt)
+        class R(object):
+            chrom = ch
+        got = pipe._select_kth([R], cut, 1, sorted({(n1 - 1) // 2, n1 // 2}))
+        assert got[0] == srt[(n1 - 1) // 2] and got[-1] == srt[n1 // 2]
+    ch.close()
+
+
 @pytest.mark.parametrize("variant", ["v1", "v2", "block"])
 def test_class_labels_dict(variant):
     """`DBSCAN(mat, eps, minPts).labels` == the reference's dict (non-contiguous ids)."""

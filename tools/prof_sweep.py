@@ -1,0 +1,13 @@
+import os, sys, time, cProfile, pstats
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from cloops_amd import pipe
+from cloops_amd.synth import synth_genome
+fs=[]
+for name, X, Y in synth_genome(20000000, cfg=3):
+    fs.append(pipe.CACHE.put_arrays("%s-%s" % (name, name), X, Y))
+pipe.runSweep(fs, [5000], [50], cut=0)
+pr=cProfile.Profile(); pr.enable()
+pipe.runSweep(fs, [5000, 7500], [50, 40], cut=0)
+pr.disable()
+pstats.Stats(pr).sort_stats('cumulative').print_stats(22)
