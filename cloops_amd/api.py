@@ -128,13 +128,13 @@ class Chromosome(object):
         view = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_int32)), shape=(k * 5,)).view(BOX_DTYPE)
         return view.copy() if copy else view
 
-    def cluster_async(self, variant, eps, minPts, cut=0):
+    def cluster_async(self, variant, eps, minPts, cut=0, want_labels=True):
         """Enqueue one run without blocking (at most two in flight); pair with wait().
-        Labels land in one of two reusable pinned buffers."""
+        Labels land in one of two reusable pinned buffers (or stay on the device)."""
         v = VARIANTS[variant]
-        labels = self._pinned_labels(self._enq & 1)
+        labels = self._pinned_labels(self._enq & 1) if want_labels else None
         _lib.check(self._lib.cl_cluster_async(self._h, v, int(eps), int(minPts), int(cut),
-                                              labels.ctypes.data_as(ctypes.c_void_p)))
+                                              labels.ctypes.data_as(ctypes.c_void_p) if want_labels else None))
         self._inflight.append(labels)
         self._enq += 1
 
@@ -146,8 +146,9 @@ class Chromosome(object):
         ml = ctypes.c_int32(-1)
         _lib.check(self._lib.cl_wait(self._h, ctypes.byref(nc), ctypes.byref(ml)))
         boxes = self._boxes(ml.value, copy)
-        return ClusterResult(labels.copy() if copy else labels, nc.value, ml.value, boxes,
-                             self.timing() if self._profiling else None)
+        if labels is not None and copy:
+            labels = labels.copy()
+        return ClusterResult(labels, nc.value, ml.value, boxes, self.timing() if self._profiling else None)
 
     def cluster(self, variant, eps, minPts, cut=0, want_labels=True, want_boxes=True, pinned=False):
         """One synchronous run.  `pinned=True` returns labels and boxes as VIEWS of reusable
@@ -167,6 +168,10 @@ class Chromosome(object):
                                         ctypes.byref(nc), ctypes.byref(ml)))
         boxes = self._boxes(ml.value, copy=not pinned) if want_boxes else None
         return ClusterResult(labels, nc.value, ml.value, boxes, self.timing() if self._profiling else None)
+
+    def last_n_in(self):
+        """PETs of the last completed run that entered DBSCAN (after the cut filter)."""
+        return int(self._lib.cl_last_n_in(self._h))
 
     # ---- distance statistics of the last completed run (K7; inputs of ests.estIntSelCutFrag) ----
     def dist_stats(self, cut=0):

@@ -2353,6 +2353,12 @@ extern "C" int cl_get_boxes(cl_chrom* c, cl_box* boxes_out)
     return CL_OK;
 }
 
+extern "C" int64_t cl_last_n_in(const cl_chrom* c)
+{
+    if (!c || !c->have_result || c->last_slot < 0) return 0;
+    return c->slot[c->last_slot].h_hdr[2];
+}
+
 extern "C" const cl_box* cl_boxes_host(const cl_chrom* c)
 {
     if (!c || !c->have_result || c->last_slot < 0 || c->last_K <= 0) return nullptr;

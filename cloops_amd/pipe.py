@@ -285,6 +285,29 @@ def _boxes_classified(r, res):
     return box[inter], box[ok & ~inter]
 
 
+def _combine_steps(step_boxes):
+    """combineTwice (pipe.py:155-174) applied over all steps at once, on arrays: a box is kept
+    in the step where it FIRST appears (duplicates inside one step are all kept, like the
+    reference, whose `ds` set is built before the loop).  step_boxes: list of int64[k,4]."""
+    step_boxes = [b for b in step_boxes if len(b)]
+    if not step_boxes:
+        return np.zeros((0, 4), np.int64)
+    if len(step_boxes) == 1:
+        return step_boxes[0]
+    rows = np.concatenate(step_boxes)
+    step = np.concatenate([np.full(len(b), k, np.int64) for k, b in enumerate(step_boxes)])
+    u = rows.astype(np.uint64)
+    h = (u[:, 0] * np.uint64(0x9E3779B97F4A7C15)) ^ (u[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F)) \
+        ^ (u[:, 2] * np.uint64(0x165667B19E3779F9)) ^ (u[:, 3] * np.uint64(0xD6E8FEB86659FD93))
+    uh, first, inv = np.unique(h, return_index=True, return_inverse=True)
+    if not np.array_equal(rows[first[inv]], rows):            # a 64-bit hash collision: do it exactly
+        uh, first, inv = np.unique(rows, axis=0, return_index=True, return_inverse=True)
+        inv = inv.ravel()
+    first_step = np.full(len(first), np.iinfo(np.int64).max, np.int64)
+    np.minimum.at(first_step, inv, step)
+    return rows[step == first_step[inv]]
+
+
 def _select_kth(chroms, cut, group, ranks):
     """Exact order statistics (0-based `ranks`, ascending) of the |d| of `group` over the union of
     the chromosomes: 4-pass radix select; every pass sums one 256-bin histogram per chromosome."""
@@ -317,7 +340,7 @@ def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None):
     returns (dataI {key: {"f": f, "boxes": int64[k,4]}}, cut, cuts, steps)."""
     variant = variant or DBSCAN_VARIANT
     devs = _devices()
-    dataI = {}
+    acc = {}
     cuts = [cut]
     steps = []
     res_list = [CACHE.get(f, devs[0]) for f in fs] if len(devs) == 1 else None
@@ -326,19 +349,29 @@ def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None):
             step_I = {}
             used = []
             nS = n_in = 0
+            # chromosomes are independent inside a step: enqueue them all (each handle has its own
+            # streams), then collect -- the small kernels of different chromosomes overlap on the GPU
+            active = []
             for k, f in enumerate(fs):
                 r = res_list[k] if res_list is not None else CACHE.get(f, devs[k % len(devs)])
                 if len(r.d) == 0:
                     continue
-                with r.lock:
-                    res = r.chrom.cluster(variant, ep, m, cut, want_labels=False, pinned=True)
+                r.lock.acquire()
+                r.chrom.cluster_async(variant, ep, m, cut, want_labels=False)
+                active.append((f, r))
+            for f, r in active:
+                try:
+                    res = r.chrom.wait()
                     dI, dS = _boxes_classified(r, res)
+                finally:
+                    r.lock.release()
                 nS += len(dS)
-                n_in += int((r.d >= cut).sum()) if cut > 0 else len(r.d)
+                n_in += r.chrom.last_n_in()
                 if len(dI) == 0:                          # runDBSCAN skips such chromosomes entirely (pipe.py:121-122)
                     continue
                 step_I[r.key] = {"f": f, "boxes": dI}
                 used.append(r)
+                acc.setdefault(r.key, {"f": f, "steps": []})["steps"].append(dI)
             st = {"eps": ep, "minPts": m, "cut_in": int(cut), "n_inter": sum(len(v["boxes"]) for v in step_I.values()),
                   "n_self": nS, "n_in": n_in}
             steps.append(st)
@@ -371,22 +404,14 @@ def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None):
                 st["frags"] = int(frags)
                 cuts.append(cut_2)
                 cut = cut_2                               # pipe.py:274
-            # combineTwice (pipe.py:155-174) on arrays: append the boxes not seen before, in order
-            for key, v in step_I.items():
-                if key not in dataI:
-                    dataI[key] = {"f": v["f"], "boxes": v["boxes"]}
-                else:
-                    old = dataI[key]["boxes"]
-                    seen = set(map(tuple, old.tolist()))
-                    add = [b for b in v["boxes"].tolist() if tuple(b) not in seen]
-                    if add:
-                        dataI[key]["boxes"] = np.concatenate([old, np.asarray(add, dtype=np.int64)])
     pos = [c for c in cuts if c > 0]
     if pos:
         cut = int(np.max(pos)) if max_cut else int(np.min(pos))     # pipe.py:276-280
     else:
         raise ValueError("zero-size array to reduction operation minimum which has no identity")
-    for key in dataI:                                     # filterClusterByDis (pipe.py:130-143), floor division
+    # combineTwice over all steps (pipe.py:257,275), then filterClusterByDis (pipe.py:130-143, floor division)
+    dataI = {key: {"f": v["f"], "boxes": _combine_steps(v["steps"])} for key, v in acc.items()}
+    for key in dataI:
         b = dataI[key]["boxes"]
         dmid = (b[:, 2] + b[:, 3]) // 2 - (b[:, 0] + b[:, 1]) // 2
         dataI[key]["boxes"] = b[dmid >= cut]

@@ -127,6 +127,9 @@ int cl_get_boxes(cl_chrom* c, cl_box* boxes_out);
  * handle, valid until the next cl_wait()/cl_cluster() that lands in the same result slot
  * (i.e. for at least one more run).  NULL if there is no result or no cluster. */
 const cl_box* cl_boxes_host(const cl_chrom* c);
+/* Number of PETs of the last completed run that passed the cut filter and entered DBSCAN
+ * (`len(mat)` after cLoops/pipe.py:59-62). */
+int64_t cl_last_n_in(const cl_chrom* c);
 
 /*
  * Region query alone (kernel K2): neighbour counts |{q : |Xp-Xq|+|Yp-Yq| <= eps}|, self

@@ -54,3 +54,25 @@ def test_ests_matches_reference_function():
         di = np.exp(rng.normal(10, 1.5, 3000)).astype(np.int64).astype(float)
         ds = np.exp(rng.normal(6, 1.0, 5000)).astype(np.int64).astype(float)
         assert estIntSelCutFrag(di, ds) == ref(di, ds)
+
+
+def test_combine_steps_equals_sequential_combine_twice():
+    """the array form used by runSweepFast == repeated combineTwice (pipe.py:155-174), order included"""
+    rng = np.random.default_rng(4)
+    pool = rng.integers(0, 50, (60, 4)).astype(np.int64)
+    steps = []
+    for k in range(6):
+        idx = rng.integers(0, len(pool), int(rng.integers(0, 30)))
+        b = pool[idx]
+        if k == 2 and len(b) > 3:
+            b = np.concatenate([b, b[:2]])               # duplicates inside one step are all kept
+        steps.append(b)
+    got = pipe._combine_steps(steps)
+    dataI = {}
+    for b in steps:
+        if len(b) == 0:
+            continue
+        d2 = {("c", "c"): {"f": "x", "records": [["c", int(r[0]), int(r[1]), "c", int(r[2]), int(r[3])] for r in b]}}
+        dataI = pipe.combineTwice(dataI, d2)
+    want = np.asarray([[r[1], r[2], r[4], r[5]] for r in dataI[("c", "c")]["records"]], dtype=np.int64)
+    assert np.array_equal(got, want)

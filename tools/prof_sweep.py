@@ -6,8 +6,8 @@ from cloops_amd.synth import synth_genome
 fs=[]
 for name, X, Y in synth_genome(20000000, cfg=3):
     fs.append(pipe.CACHE.put_arrays("%s-%s" % (name, name), X, Y))
-pipe.runSweep(fs, [5000], [50], cut=0)
+pipe.runSweepFast(fs, [5000], [50], cut=0)
 pr=cProfile.Profile(); pr.enable()
-pipe.runSweep(fs, [5000, 7500], [50, 40], cut=0)
+pipe.runSweepFast(fs, [5000, 7500, 10000], [50, 40, 30, 20], cut=0)
 pr.disable()
 pstats.Stats(pr).sort_stats('cumulative').print_stats(22)
