@@ -98,10 +98,15 @@ def main():
     t0 = time.perf_counter()
     k2_ms = []
     res = run(args.steps, k2_ms)
+    t_run = time.perf_counter() - t0
     if use_dist:
         tables = gather_final(res)
+    t_gather = time.perf_counter() - t0 - t_run
     sync_all()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("CLOOPS_BENCH_DEBUG"):
+        sys.stderr.write("[bench rank %d] run %.3f ms, gather %.3f ms, final sync %.3f ms\n" % (
+            rank, t_run * 1e3, t_gather * 1e3, (elapsed - t_run - t_gather) * 1e3))
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
