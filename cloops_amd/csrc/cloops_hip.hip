@@ -422,8 +422,26 @@ __device__ __forceinline__ int k2_count_glb(const int* __restrict__ pq, const in
     return c;
 }
 
+// Workgroup compaction: slot list of the threads with `active`; returns their number.  Whole
+// waves fall out of the expensive phase instead of running it at partial lane occupancy.
+template <int NT = TPB>
+__device__ __forceinline__ int block_compact(bool active, short* l_list, int* l_wcount)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(active);
+    if (lane == 0) l_wcount[wv] = __popcll(bal);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) { const int c = l_wcount[k]; off += (k < wv) ? c : 0; total += c; }
+    if (active) l_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (short)threadIdx.x;
+    __syncthreads();
+    return total;
+}
+
+#define K2_TPB 512
 #define K2_HALO 128
-#define K2_WIN (TPB + 2 * K2_HALO)
+#define K2_WIN (K2_TPB + 2 * K2_HALO)
 #define K2_SPAN 120      // own-strip window searched branch-free within +-K2_SPAN positions
 #define K2_RUN 8         // consecutive tiles given to one XCD (halo reuse in that XCD's L2)
 
@@ -442,21 +460,20 @@ __device__ __forceinline__ int k2_count_glb(const int* __restrict__ pq, const in
 // Workgroup b runs on XCD b % 8 (observed placement, used for speed only): each XCD is handed
 // runs of K2_RUN consecutive tiles so that halos are re-read from its own L2.
 template <bool EXACT>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(K2_TPB)
 k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
                const int* __restrict__ strip_start, int* __restrict__ cnt)
 {
     __shared__ int2 lw[K2_WIN];
-    __shared__ int l_c[TPB];
-    __shared__ short l_list[TPB];
-    __shared__ int l_wcount[TPB / 64];
+    __shared__ short l_list[K2_TPB];
+    __shared__ int l_wcount[K2_TPB / 64];
     const int M = strip_start[g.S];
     const int xcd = blockIdx.x & 7, kseq = blockIdx.x >> 3;
     const int tile = ((kseq / K2_RUN) * 8 + xcd) * K2_RUN + (kseq % K2_RUN);
-    const int t0 = tile * TPB;
+    const int t0 = tile * K2_TPB;
     if (tile >= ntiles || t0 >= M) return;
     const int base = t0 - K2_HALO;                 // global index of lw[0]
-    for (int k = threadIdx.x; k < K2_WIN; k += TPB) {
+    for (int k = threadIdx.x; k < K2_WIN; k += K2_TPB) {
         const int gi = base + k;
         const bool in = gi >= 0 && gi < M;
         lw[k] = in ? make_int2(sv[gi], sa[gi]) : make_int2(0, 0);
@@ -466,62 +483,62 @@ k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
     const int wbeg = max(base, 0), wend = min(base + K2_WIN, M);
     const int i = t0 + threadIdx.x;
     const bool valid = i < M;
-    bool needy = false;
+    // ---- phase 0: one-read core test ----------------------------------------------------------
+    // If the minPts-1 next (or previous) PETs of the own strip are within eps in q, the point is
+    // core: interiors of clusters are settled by one or two LDS reads, without any search.
+    bool hard = false;
     if (valid) {
-        const int2 me = w[i];
-        const int qi = me.x, pi = me.y;
-        const int s = strip_of(g, pi);
-        const int qlo = sat_add(qi, -g.eps), qhi = sat_add(qi, g.eps);
-        const int b = strip_start[s], e = strip_start[s + 1];
-        const int L = max(max(b, wbeg), i - K2_SPAN);
-        int lo = lds_lower_bound8(w, L, i + 1, qlo);
-        if (lo == L && L > b) lo = lower_bound_4(sv, b, L, qlo);           // window leaves the staged span
-        const int R = min(min(e, wend), i + 1 + K2_SPAN);
-        int hi = lds_upper_bound8(w, i + 1, R, qhi);
-        if (hi == R && R < e) hi = lower_bound_4(sv, R, e, sat_add(qhi, 1));
-        const int c = hi - lo;
-        needy = EXACT || c < g.minPts;
-        if (needy) l_c[threadIdx.x] = c; else cnt[i] = c;
+        bool done = false;
+        if (!EXACT && g.minPts >= 1 && g.minPts - 1 <= K2_SPAN) {
+            const int2 me = w[i];
+            const int s = strip_of(g, me.y);
+            const int b = strip_start[s], e = strip_start[s + 1];
+            const int m1 = g.minPts - 1;
+            const int jr = i + m1, jl = i - m1;
+            if (jr < e && jr < wend && w[jr].x - me.x <= g.eps) done = true;
+            else if (jl >= b && jl >= wbeg && me.x - w[jl].x <= g.eps) done = true;
+        }
+        if (done) cnt[i] = g.minPts; else hard = true;
     }
-    // ---- workgroup compaction of the points that still need their neighbour strips ------------
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const unsigned long long bal = __ballot(needy);
-    if (lane == 0) l_wcount[wv] = __popcll(bal);
-    __syncthreads();
-    int off = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < TPB / 64; ++k) { const int t = l_wcount[k]; off += (k < wv) ? t : 0; total += t; }
-    if (needy) l_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (short)threadIdx.x;
-    __syncthreads();
+    // ---- workgroup compaction: whole waves drop out of the search phases ------------------------
+    const int total = block_compact<K2_TPB>(hard, l_list, l_wcount);
     if ((int)threadIdx.x >= total) return;
-    // ---- phase 2: neighbour strips ------------------------------------------------------------
     {
-        const int tix = l_list[threadIdx.x];
-        const int ii = t0 + tix;
+        const int ii = t0 + l_list[threadIdx.x];
         const int2 me = w[ii];
         const int qi = me.x, pi = me.y;
         const int s = strip_of(g, pi);
         const int qlo = sat_add(qi, -g.eps), qhi = sat_add(qi, g.eps);
         const int b = strip_start[s], e = strip_start[s + 1];
-        const int tb = s > 0 ? strip_start[s - 1] : b;
-        const int te = s + 1 < g.S ? strip_start[s + 2] : e;
-        int c = l_c[tix];
-        if (tb < b) {                                                      // strip s-1 = [tb, b)
-            if (tb >= wbeg && b - tb <= 255) {
-                const int j = lds_lower_bound8(w, tb, b, qlo);
-                c = k2_count_lds<EXACT, 4>(w, j, b, qhi, pi, g.eps, g.minPts, c);
-            } else {
-                const int j = lower_bound_4(sv, tb, b, qlo);
-                c = k2_count_glb<EXACT, 8>(sv, sa, j, b, qhi, pi, g.eps, g.minPts, c);
+        // ---- phase 1: own strip, index difference of two branch-free searches -------------------
+        const int L = max(max(b, wbeg), ii - K2_SPAN);
+        int lo = lds_lower_bound8(w, L, ii + 1, qlo);
+        if (lo == L && L > b) lo = lower_bound_4(sv, b, L, qlo);           // window leaves the staged span
+        const int R = min(min(e, wend), ii + 1 + K2_SPAN);
+        int hi = lds_upper_bound8(w, ii + 1, R, qhi);
+        if (hi == R && R < e) hi = lower_bound_4(sv, R, e, sat_add(qhi, 1));
+        int c = hi - lo;
+        // ---- phase 2: neighbour strips, only while not known to be core -------------------------
+        if (EXACT || c < g.minPts) {
+            const int tb = s > 0 ? strip_start[s - 1] : b;
+            const int te = s + 1 < g.S ? strip_start[s + 2] : e;
+            if (tb < b) {                                                      // strip s-1 = [tb, b)
+                if (tb >= wbeg && b - tb <= 255) {
+                    const int j = lds_lower_bound8(w, tb, b, qlo);
+                    c = k2_count_lds<EXACT, 4>(w, j, b, qhi, pi, g.eps, g.minPts, c);
+                } else {
+                    const int j = lower_bound_4(sv, tb, b, qlo);
+                    c = k2_count_glb<EXACT, 8>(sv, sa, j, b, qhi, pi, g.eps, g.minPts, c);
+                }
             }
-        }
-        if ((EXACT || c < g.minPts) && e < te) {                           // strip s+1 = [e, te)
-            if (te <= wend && te - e <= 255) {
-                const int j = lds_lower_bound8(w, e, te, qlo);
-                c = k2_count_lds<EXACT, 4>(w, j, te, qhi, pi, g.eps, g.minPts, c);
-            } else {
-                const int j = lower_bound_4(sv, e, te, qlo);
-                c = k2_count_glb<EXACT, 8>(sv, sa, j, te, qhi, pi, g.eps, g.minPts, c);
+            if ((EXACT || c < g.minPts) && e < te) {                           // strip s+1 = [e, te)
+                if (te <= wend && te - e <= 255) {
+                    const int j = lds_lower_bound8(w, e, te, qlo);
+                    c = k2_count_lds<EXACT, 4>(w, j, te, qhi, pi, g.eps, g.minPts, c);
+                } else {
+                    const int j = lower_bound_4(sv, e, te, qlo);
+                    c = k2_count_glb<EXACT, 8>(sv, sa, j, te, qhi, pi, g.eps, g.minPts, c);
+                }
             }
         }
         cnt[ii] = c;
@@ -570,22 +587,6 @@ __device__ __forceinline__ bool tile_stage(Tile& t, int2* lw, int* lx, int ntile
     t.w.a = lw; t.w.base = base; t.x.a = lx; t.x.base = base;
     t.wbeg = max(base, 0); t.wend = min(base + T_WIN, M);
     return true;
-}
-
-// Workgroup compaction: slot list of the threads with `active`; returns their number.  Whole
-// waves fall out of the expensive phase instead of running it at partial lane occupancy.
-__device__ __forceinline__ int block_compact(bool active, short* l_list, int* l_wcount)
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const unsigned long long bal = __ballot(active);
-    if (lane == 0) l_wcount[wv] = __popcll(bal);
-    __syncthreads();
-    int off = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < TPB / 64; ++k) { const int c = l_wcount[k]; off += (k < wv) ? c : 0; total += c; }
-    if (active) l_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (short)threadIdx.x;
-    __syncthreads();
-    return total;
 }
 
 // visit, in ascending order, every j of the strip segment [sb,se) with q_j in [qlo,qhi]:
@@ -1844,10 +1845,10 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     LAUNCH(k_strip_table, g.S + 2, c->keys_out.as<u64>(), n, g.S, g.qbits + g.rbits, c->strip.as<int>());
     ev_record(c, 2);
     {
-        const int ntiles = nblocks(n);
+        const int ntiles = nblocks(n, K2_TPB);
         const int grid = ((ntiles + 8 * K2_RUN - 1) / (8 * K2_RUN)) * (8 * K2_RUN);
-        if (exact) hipLaunchKernelGGL(k_region_count<true>, dim3(grid), dim3(TPB), 0, c->stream, g, ntiles, c->sv.as<int>(), c->sa.as<int>(), c->strip.as<int>(), c->cnt.as<int>());
-        else hipLaunchKernelGGL(k_region_count<false>, dim3(grid), dim3(TPB), 0, c->stream, g, ntiles, c->sv.as<int>(), c->sa.as<int>(), c->strip.as<int>(), c->cnt.as<int>());
+        if (exact) hipLaunchKernelGGL(k_region_count<true>, dim3(grid), dim3(K2_TPB), 0, c->stream, g, ntiles, c->sv.as<int>(), c->sa.as<int>(), c->strip.as<int>(), c->cnt.as<int>());
+        else hipLaunchKernelGGL(k_region_count<false>, dim3(grid), dim3(K2_TPB), 0, c->stream, g, ntiles, c->sv.as<int>(), c->sa.as<int>(), c->strip.as<int>(), c->cnt.as<int>());
     }
     ev_record(c, 3);
     HIP_TRY(hipGetLastError());
