@@ -44,3 +44,26 @@ def gather_tables(table, device=None, group=None):
     dist.all_gather_into_tensor(out, pad, group=group)
     out = out.cpu().numpy().reshape(world, kmax, c)
     return [out[r, : ks[r]].copy() for r in range(world)]
+
+
+def make_allsum(device=None, group=None):
+    """-> allsum(np.ndarray) = element-wise sum over all ranks (int64 or float64, any small shape):
+    the only per-step exchange of the chained sweep (cloops_amd.pipe.runSweepFast)."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cpu") if device is None else device
+
+    def allsum(a):
+        a = np.ascontiguousarray(a)
+        t = torch.from_numpy(a.copy()).to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t.cpu().numpy()
+    return allsum
+
+
+def shard_chromosomes(sizes, rank=None, world=None):
+    """indices of the chromosomes this rank owns (LPT by PET count)."""
+    import torch.distributed as dist
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    return sorted(lpt_assign(list(sizes), world)[rank])

@@ -308,9 +308,10 @@ def _combine_steps(step_boxes):
     return rows[step == first_step[inv]]
 
 
-def _select_kth(chroms, cut, group, ranks):
+def _select_kth(chroms, cut, group, ranks, allsum=None):
     """Exact order statistics (0-based `ranks`, ascending) of the |d| of `group` over the union of
-    the chromosomes: 4-pass radix select; every pass sums one 256-bin histogram per chromosome."""
+    the chromosomes (of all ranks): 4-pass radix select; every pass sums one 256-bin histogram per
+    chromosome (and, with `allsum`, over the ranks)."""
     out = []
     cache = {}
     for rank in ranks:
@@ -321,6 +322,8 @@ def _select_kth(chroms, cut, group, ranks):
                 h = np.zeros(256, dtype=np.uint64)
                 for r in chroms:
                     h += r.chrom.dist_hist(cut, group, prefix, shift)
+                if allsum is not None:
+                    h = allsum(h.astype(np.int64)).astype(np.uint64)
                 cache[key] = h
             c = np.cumsum(cache[key].astype(np.int64))
             digit = int(np.searchsorted(c, rem, side="right"))
@@ -330,15 +333,21 @@ def _select_kth(chroms, cut, group, ranks):
     return out
 
 
-def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None):
+def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, allsum=None):
     """runSweep with the per-step statistics reduced on the GPUs: neither labels nor distance
     lists come back to the host -- per chromosome only the K-row cluster table, a few sums, and
     the 256-bin histograms of an exact radix select for the median (all additive over chromosomes
     and over GPUs).  Same chain, same cuts, same candidate boxes as runSweep / the reference's
     pipe.py:241-281; candidate boxes stay numpy arrays:
 
-    returns (dataI {key: {"f": f, "boxes": int64[k,4]}}, cut, cuts, steps)."""
+    `allsum` (optional): element-wise global sum of a small numpy array over all ranks
+    (cloops_amd.dist.make_allsum) -- with it every rank passes ITS chromosomes as `fs` and the
+    chained cut is estimated from the genome-wide statistics; the per-step exchange is a few
+    hundred bytes (6 sums, 2 squared deviations, 4-8 histograms of 256 bins).
+
+    returns (dataI {key: {"f": f, "boxes": int64[k,4]}} of the local chromosomes, cut, cuts, steps)."""
     variant = variant or DBSCAN_VARIANT
+    gsum = allsum if allsum is not None else (lambda a: a)
     devs = _devices()
     acc = {}
     cuts = [cut]
@@ -372,20 +381,23 @@ def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None):
                 step_I[r.key] = {"f": f, "boxes": dI}
                 used.append(r)
                 acc.setdefault(r.key, {"f": f, "steps": []})["steps"].append(dI)
-            st = {"eps": ep, "minPts": m, "cut_in": int(cut), "n_inter": sum(len(v["boxes"]) for v in step_I.values()),
-                  "n_self": nS, "n_in": n_in}
+            g = gsum(np.asarray([sum(len(v["boxes"]) for v in step_I.values()), nS, n_in, len(step_I)], dtype=np.int64))
+            st = {"eps": ep, "minPts": m, "cut_in": int(cut), "n_inter": int(g[0]), "n_self": int(g[1]), "n_in": int(g[2])}
             steps.append(st)
-            if len(step_I) == 0:                          # pipe.py:251-255
+            if int(g[3]) == 0:                            # pipe.py:251-255
                 if log:
                     log("ERROR: no inter-ligation PETs detected for eps %s minPts %s,can't model the distance cutoff,continue anyway" % (ep, m))
                 continue
             tot = {"n_all": [0, 0], "n_pos": [0, 0], "sumlog": [0.0, 0.0]}
             for r in used:
                 s1 = r.chrom.dist_stats(cut)
-                for g in (0, 1):
-                    tot["n_all"][g] += s1["n_all"][g]
-                    tot["n_pos"][g] += s1["n_pos"][g]
-                    tot["sumlog"][g] += s1["sumlog"][g]
+                for gg in (0, 1):
+                    tot["n_all"][gg] += s1["n_all"][gg]
+                    tot["n_pos"][gg] += s1["n_pos"][gg]
+                    tot["sumlog"][gg] += s1["sumlog"][gg]
+            gi = gsum(np.asarray(tot["n_all"] + tot["n_pos"], dtype=np.int64))
+            gf = gsum(np.asarray(tot["sumlog"], dtype=np.float64))
+            tot = {"n_all": [int(gi[0]), int(gi[1])], "n_pos": [int(gi[2]), int(gi[3])], "sumlog": [float(gf[0]), float(gf[1])]}
             if tot["n_all"][0] > 0 and tot["n_all"][1] > 0:      # pipe.py:256-259
                 if tot["n_pos"][0] == 0 or tot["n_pos"][1] == 0:
                     raise ValueError("cannot convert float NaN to integer")      # what int(2 ** nan) raises in ests.py:57
@@ -395,8 +407,9 @@ def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None):
                     q = r.chrom.dist_sqdev(cut, mi, ms)
                     sq[0] += q[0]
                     sq[1] += q[1]
+                sq = [float(v) for v in gsum(np.asarray(sq, dtype=np.float64))]
                 n1 = tot["n_pos"][1]
-                med = _select_kth(used, cut, 1, sorted({(n1 - 1) // 2, n1 // 2}))
+                med = _select_kth(used, cut, 1, sorted({(n1 - 1) // 2, n1 // 2}), allsum)
                 cut_2, frags = estIntSelCutFrag_from_stats(tot["n_pos"], tot["sumlog"], sq, (med[0], med[-1]))
                 if log:
                     log("Estimated inter-ligation and self-ligation distance cutoff as %s for eps=%s,minPts=%s" % (cut_2, ep, m))

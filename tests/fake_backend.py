@@ -29,3 +29,62 @@ class FakeChromosome(object):
             m = lab == c
             boxes[c] = (self.X[m].min(), self.X[m].max(), self.Y[m].min(), self.Y[m].max(), m.sum())
         return api.ClusterResult(lab, int(len(np.unique(lab[lab >= 0]))), ml, boxes, None)
+
+    # ---- the asynchronous / statistics surface used by pipe.runSweepFast -------------------------
+    def cluster_async(self, variant, eps, minPts, cut=0, want_labels=True):
+        self._pending = getattr(self, "_pending", [])
+        self._pending.append((variant, eps, minPts, cut))
+
+    def wait(self, copy=False):
+        variant, eps, minPts, cut = self._pending.pop(0)
+        res = self.cluster(variant, eps, minPts, cut)
+        self._last = (res, cut)
+        return res
+
+    def last_n_in(self):
+        res, cut = self._last
+        d = self.Y - self.X
+        return int((d >= cut).sum()) if cut > 0 else self.n
+
+    def _groups(self, cut):
+        res, _ = self._last
+        lab = res.labels
+        b = res.boxes
+        K = len(b)
+        cls = np.full(K + 1, -1, np.int64)
+        if K:
+            ok = (b["count"] > 0) & (b["min_x"] != b["max_x"]) & (b["min_y"] != b["max_y"])
+            inter = ok & (b["max_x"] < b["min_y"])
+            cls[:K][inter] = 0
+            cls[:K][ok & ~inter] = 1
+        d = self.Y - self.X
+        g = cls[np.where(lab >= 0, lab, K)]
+        if cut > 0:
+            g = np.where(d < cut, 1, g)
+        return g, np.abs(d)
+
+    def dist_stats(self, cut=0):
+        g, ad = self._groups(cut)
+        out = {"n_all": [], "n_pos": [], "sumlog": []}
+        for k in (0, 1):
+            a = ad[g == k]
+            out["n_all"].append(int(len(a)))
+            a = a[a > 0]
+            out["n_pos"].append(int(len(a)))
+            out["sumlog"].append(float(np.log2(a.astype(np.float64)).sum()) if len(a) else 0.0)
+        return out
+
+    def dist_sqdev(self, cut, mean_inter, mean_self):
+        g, ad = self._groups(cut)
+        out = []
+        for k, m in ((0, mean_inter), (1, mean_self)):
+            a = ad[(g == k) & (ad > 0)].astype(np.float64)
+            out.append(float(((np.log2(a) - m) ** 2).sum()) if len(a) else 0.0)
+        return out
+
+    def dist_hist(self, cut, group, prefix, shift):
+        g, ad = self._groups(cut)
+        a = ad[(g == group) & (ad > 0)].astype(np.uint64)
+        if shift < 24:
+            a = a[(a >> np.uint64(shift + 8)) == np.uint64(prefix)]
+        return np.bincount(((a >> np.uint64(shift)) & np.uint64(255)).astype(np.int64), minlength=256).astype(np.uint64)

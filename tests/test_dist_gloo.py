@@ -60,3 +60,65 @@ def test_lpt_assign_balances_hg38():
         parts = lpt_assign(sizes, g)
         assert sorted(i for p in parts for i in p) == list(range(23))
         assert max(sum(sizes[i] for i in p) for p in parts) / sum(sizes) <= bound
+
+
+def _sweep_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import fake_backend
+    from cloops_amd import api, pipe
+    from cloops_amd.dist import make_allsum, shard_chromosomes, gather_tables
+    from cloops_amd.synth import synth_chrom
+    api.Chromosome = fake_backend.FakeChromosome
+    api.device_count = lambda: 1
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    names = ["chrA", "chrB", "chrC"]
+    data = {n: synth_chrom(12000 + 3000 * k, 3000000, 50 + k) for k, n in enumerate(names)}
+    mine = shard_chromosomes([len(data[n][0]) for n in names])
+    fs = [pipe.CACHE.put_arrays("%s-%s" % (names[i], names[i]), *data[names[i]]) for i in mine]
+    dataI, cut, cuts, steps = pipe.runSweepFast(fs, [1000, 2000], [6, 4], cut=0, allsum=make_allsum())
+    tabs = gather_tables(np.concatenate([v["boxes"] for v in dataI.values()]).astype(np.int32).reshape(-1, 4)
+                         if dataI else np.zeros((0, 4), np.int32))
+    q.put((rank, cut, [s.get("cut_out") for s in steps], [s["n_in"] for s in steps],
+           {k[0]: v["boxes"].tolist() for k, v in dataI.items()}, sum(len(t) for t in tabs)))
+    dist.destroy_process_group()
+
+
+def test_distributed_chained_sweep_equals_single_process():
+    """2 ranks (gloo), chromosomes sharded by LPT, cut chained through all-reduced statistics ==
+    one process over all chromosomes (CPU oracle backend for both)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fake_backend
+    from cloops_amd import api, pipe
+    from cloops_amd.synth import synth_chrom
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sweep_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs])
+    for p in procs:
+        p.join(60)
+    # single-process reference with the same backend
+    old = api.Chromosome, api.device_count
+    api.Chromosome, api.device_count = fake_backend.FakeChromosome, (lambda: 1)
+    try:
+        pipe.CACHE.clear()
+        names = ["chrA", "chrB", "chrC"]
+        fs = [pipe.CACHE.put_arrays("%s-%s" % (n, n), *synth_chrom(12000 + 3000 * k, 3000000, 50 + k)) for k, n in enumerate(names)]
+        dataI, cut, cuts, steps = pipe.runSweepFast(fs, [1000, 2000], [6, 4], cut=0)
+    finally:
+        api.Chromosome, api.device_count = old
+        pipe.CACHE.clear()
+    want_boxes = {k[0]: v["boxes"].tolist() for k, v in dataI.items()}
+    got_boxes = {}
+    for r in res:
+        assert r[1] == cut and r[2] == [s.get("cut_out") for s in steps] and r[3] == [s["n_in"] for s in steps]
+        got_boxes.update(r[4])
+        assert r[5] == sum(len(v) for v in want_boxes.values())      # the final gather sees every candidate
+    assert got_boxes == want_boxes
+    assert any(c is not None for c in res[0][2])

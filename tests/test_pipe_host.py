@@ -76,3 +76,9 @@ def test_combine_steps_equals_sequential_combine_twice():
         dataI = pipe.combineTwice(dataI, d2)
     want = np.asarray([[r[1], r[2], r[4], r[5]] for r in dataI[("c", "c")]["records"]], dtype=np.int64)
     assert np.array_equal(got, want)
+
+
+def test_sweep_fast_host_logic(cpu_pipe):
+    """runSweepFast (statistics instead of lists) against the reference-made chain, CPU backend"""
+    p, f = cpu_pipe
+    pipe_checks.check_sweep_fast(p, f)
