@@ -113,3 +113,37 @@ def ref_pipe_namespace(variant="v2"):
     exec(compile(mod, "pipe.py:dispatch", "exec"), ns)
     _cache[key] = ns
     return ns
+
+
+def ref_cmodel_namespace():
+    """The reference's significance module (cLoops/cModel.py) exec'd in memory with the mechanical
+    py2 -> py3 patches the survey lists (section 8f-3): xrange -> range, dict.keys() indexing ->
+    list, floor `/` on ints in getNearbyPairRegions (cModel.py:89-93); its io imports (parseJd,
+    parseIv) are sliced out of the py2-only cLoops/io.py.  Used to MAKE golden vectors only."""
+    import gc
+    import joblib
+    import numpy as np
+    import pandas as pd
+    if "cmodel" in _cache:
+        return _cache["cmodel"]
+    with open(os.path.join(REF_ROOT, "cLoops", "io.py")) as fh:
+        lines = fh.read().split("\n")
+
+    def block(start_pat):
+        s = [i for i, l in enumerate(lines) if l.startswith(start_pat)][0]
+        e = [i for i, l in enumerate(lines) if i > s and (l.startswith("def ") or l.startswith("class "))]
+        return "\n".join(lines[s:(e[0] if e else len(lines))])
+    ns = {"np": np, "pd": pd, "os": os, "joblib": joblib, "gc": gc, "cFlush": lambda *a: None}
+    exec(compile(block("def parseJd") + "\n" + block("def parseIv"), "io.py:slice", "exec"), ns)
+    with open(os.path.join(REF_ROOT, "cLoops", "cModel.py")) as fh:
+        src = fh.read()
+    src = src.replace("from cLoops.io import parseJd, parseIv", "").replace("from cLoops.utils import cFlush", "")
+    src = src.replace("xrange", "range")
+    src = src.replace("keys = ds.keys()", "keys = list(ds.keys())")
+    # Python-2 integer division in getNearbyPairRegions (cModel.py:89-93)
+    src = src.replace("ca = sum(iva) / 2", "ca = sum(iva) // 2").replace("cb = sum(ivb) / 2", "cb = sum(ivb) // 2")
+    src = src.replace("sa = (iva[1] - iva[0]) / 2", "sa = (iva[1] - iva[0]) // 2").replace("sb = (ivb[1] - ivb[0]) / 2", "sb = (ivb[1] - ivb[0]) // 2")
+    src = src.replace("step = (sa + sb) / 2", "step = (sa + sb) // 2")
+    exec(compile(src, "cModel.py:py3", "exec"), ns)
+    _cache["cmodel"] = ns
+    return ns
