@@ -482,3 +482,79 @@ def runSweep(fs, eps, minPts, cut=0, cpu=1, max_cut=False, log=None):
         raise ValueError("zero-size array to reduction operation minimum which has no identity")
     dataI = filterClusterByDis(dataI, cut)
     return dataI, cut, cuts, steps
+
+
+# ---------------------------------------------------------------------------------------
+# the whole flow of cLoops/pipe.py:206-295 (minus the viewer converters and plots, SURVEY 2 #9,#11)
+# ---------------------------------------------------------------------------------------
+MODES = {1: ([500, 1000, 2000], [5], 0), 2: ([1000, 2000, 5000], [5], 0),
+         3: ([5000, 7500, 10000], [50, 40, 30, 20], 1), 4: ([2500, 5000, 7500, 10000], [30, 20], 1)}   # pipe.py:329-344
+
+
+def pipe(fs, fout, eps, minPts, chroms="", cpu=1, tmp=0, hic=0, washU=0, juice=0, cut=0, plot=0, max_cut=False,
+         log=None):
+    """cLoops/pipe.py:206-295: BEDPE -> per-chromosome PETs -> (eps, minPts) sweep with the chained
+    distance cutoff on the GPU(s) -> candidate loops -> significance -> `<fout>.loop`.
+
+    Differences to the reference, all outside the hot path: no washU / juicebox conversion and no
+    plots (`washU`, `juice`, `plot` are accepted and ignored), `eps == 0` (auto-eps from the strand
+    distances, io.py:62-129) is not supported."""
+    import shutil
+    from . import io as cio
+    from . import cModel
+    if chroms == "":
+        chroms = []
+    else:
+        chroms = set(chroms.split(","))
+    if os.path.isdir(fout):                                   # pipe.py:225-228
+        if log:
+            log("working directory %s exists, return." % fout)
+        return
+    if eps == 0 or eps == [0]:
+        raise NotImplementedError("eps = 0 (auto-estimated eps, cLoops/io.py:62-129) is outside the ported path")
+    os.mkdir(fout)
+    cfs = [cio.txt2jd(f) for f in cio.parseRawBedpe2(fs, fout, chroms, cut)]
+    dataI, cut, cuts, steps = runSweepFast(cfs, eps, minPts, cut=cut, max_cut=max_cut, log=log)
+    records = {key: {"f": v["f"], "records": _records(key, v["boxes"])} for key, v in dataI.items()}
+    e = cModel.runStat(records, minPts, 0, cpu, fout, hic)    # pipe.py:284 passes cut = 0
+    if e:
+        shutil.rmtree(fout)
+        return
+    if tmp == False:                                          # noqa: E712  (pipe.py:294)
+        shutil.rmtree(fout)
+    return steps
+
+
+def main(argv=None):
+    """`python -m cloops_amd -f a.bedpe.gz -o out -m 1` -- the flags of cLoops/utils.py:73-204 that
+    drive the hot path (same names; -w / -j / -plot are accepted and ignored)."""
+    import argparse
+    ap = argparse.ArgumentParser(prog="cloops_amd")
+    ap.add_argument("-f", dest="fnIn", required=True)
+    ap.add_argument("-o", dest="fnOut", required=True)
+    ap.add_argument("-m", dest="mode", type=int, default=0, choices=[0, 1, 2, 3, 4])
+    ap.add_argument("-eps", dest="eps", default="0")
+    ap.add_argument("-minPts", dest="minPts", default="0")
+    ap.add_argument("-p", dest="cpu", type=int, default=1)
+    ap.add_argument("-c", dest="chroms", default="")
+    ap.add_argument("-w", dest="washU", action="store_true")
+    ap.add_argument("-j", dest="juice", action="store_true")
+    ap.add_argument("-s", dest="tmp", action="store_true")
+    ap.add_argument("-hic", dest="hic", action="store_true")
+    ap.add_argument("-cut", dest="cut", type=int, default=0)
+    ap.add_argument("-plot", dest="plot", action="store_true")
+    ap.add_argument("-max_cut", dest="max_cut", action="store_true")
+    op = ap.parse_args(argv)
+    if op.mode == 0:                                          # pipe.py:306-327
+        eps = sorted(int(x) for x in str(op.eps).split(","))
+        minPts = sorted((int(x) for x in str(op.minPts).split(",")), reverse=True)
+        if minPts == [0]:
+            sys.stderr.write("minPts not assigned!\n")
+            return 1
+        hic = int(op.hic)
+    else:
+        eps, minPts, hic = MODES[op.mode]
+    sys.stderr.write("mode:%s\t eps:%s\t minPts:%s\t hic:%s\t\n" % (op.mode, eps, minPts, hic))
+    pipe(op.fnIn.split(","), op.fnOut, eps, minPts, op.chroms, op.cpu, op.tmp, hic, op.washU, op.juice, op.cut,
+         op.plot, op.max_cut, log=lambda m: sys.stderr.write(m + "\n"))
+    return 0

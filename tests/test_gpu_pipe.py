@@ -97,3 +97,23 @@ def test_lists_and_mutation_semantics():
     db = cDBSCAN2(rows, 10, 3)
     assert rows == keep
     assert db.labels == {7: 0, 9: 0, 11: 0}
+
+
+def test_end_to_end_bedpe_to_loop_file(tmp_path):
+    """config 1 end to end on the GPU: BEDPE text -> .jd -> chained sweep -> significance -> `.loop`,
+    text-identical to the golden table of the (converted) reference pipeline."""
+    import gzip
+    import os
+    X, Y = G.chr21_xy()
+    bed = os.path.join(str(tmp_path), "in.bedpe.gz")
+    with gzip.open(bed, "wt") as fh:                       # a BEDPE whose mid-points are exactly (X, Y)
+        for x, y in zip(X.tolist(), Y.tolist()):
+            fh.write("chr21\t%d\t%d\tchr21\t%d\t%d\tid\t1\t+\t-\n" % (x, x, y, y))
+    fout = os.path.join(str(tmp_path), "run")
+    pipe.CACHE.clear()
+    steps = pipe.pipe([bed], fout, [500, 1000, 2000], [5], tmp=0, hic=0)
+    assert [s.get("cut_out") for s in steps] == [4601, 13532, 11103]
+    got = open(fout + ".loop").read()
+    want = open(os.path.join(G.GOLD, "chr21_v2.loop")).read()
+    assert got == want
+    assert not os.path.isdir(fout)                         # pipe.py:294-295 removes the working directory
