@@ -27,7 +27,7 @@ SYMBOLS = [
     "cl_last_error", "cl_device_count", "cl_chrom_create", "cl_chrom_destroy", "cl_chrom_size",
     "cl_cluster", "cl_get_boxes", "cl_neighbor_counts", "cl_labels_device", "cl_set_profiling",
     "cl_get_timing", "cl_version", "cl_host_alloc", "cl_host_free", "cl_cluster_async", "cl_wait", "cl_boxes_host",
-    "cl_dist_stats", "cl_dist_sqdev", "cl_dist_hist", "cl_last_n_in",
+    "cl_dist_stats", "cl_dist_sqdev", "cl_dist_hist", "cl_last_n_in", "cl_sig_counts",
 ]
 
 
@@ -92,6 +92,8 @@ def load():
     lib.cl_dist_sqdev.argtypes = [vp, ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
     lib.cl_dist_hist.restype = ctypes.c_int
     lib.cl_dist_hist.argtypes = [vp, ctypes.c_int32, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    lib.cl_sig_counts.restype = ctypes.c_int
+    lib.cl_sig_counts.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp, vp, ctypes.POINTER(ctypes.c_int64)]
     lib.cl_last_n_in.restype = ctypes.c_int64
     lib.cl_last_n_in.argtypes = [vp]
     lib.cl_get_boxes.restype = ctypes.c_int

@@ -192,6 +192,16 @@ class Chromosome(object):
                                           out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
         return out
 
+    def sig_counts(self, windows, cut=0):
+        """K8: interval counts for the significance test.  windows: int32 [R, 44] (lo[22], hi[22];
+        A0..A10 then B0..B10) -> (int32 [R, 144] counts, N)  (cl_sig_counts of include/cloops_hip.h)."""
+        w = np.ascontiguousarray(windows, dtype=np.int32).reshape(-1, 44)
+        out = np.zeros((len(w), 144), dtype=np.int32)
+        npets = ctypes.c_int64(0)
+        _lib.check(self._lib.cl_sig_counts(self._h, int(cut), len(w), w.ctypes.data_as(ctypes.c_void_p),
+                                           out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(npets)))
+        return out, int(npets.value)
+
     def neighbor_counts(self, eps, cut=0):
         out = np.full(self.n, -1, dtype=np.int32)
         _lib.check(self._lib.cl_neighbor_counts(self._h, int(eps), int(cut), out.ctypes.data_as(ctypes.c_void_p)))

@@ -221,17 +221,157 @@ def getIntSigFromMat(mat, records, minPts, discut, name=""):
     return ds
 
 
+def _windows(records):
+    """iva, ivb, distance and the 22 windows of every record (cModel.py:276-279 + getNearbyPairRegions
+    :83-105 with Python-2 integer arithmetic), vectorised: -> (iva int64[R,2], ivb, distance float64[R],
+    windows int32[R,44] = lo[22] then hi[22], A0..A10 then B0..B10)."""
+    r = np.asarray([[x[1], x[2], x[4], x[5]] for x in records], dtype=np.int64).reshape(-1, 4)
+    iva = np.stack([np.maximum(0, r[:, 0]), r[:, 1]], 1)
+    ivb = np.stack([np.maximum(0, r[:, 2]), r[:, 3]], 1)
+    distance = np.abs(ivb.sum(1) / 2.0 - iva.sum(1) / 2.0)
+    ca, cb = iva.sum(1) // 2, ivb.sum(1) // 2
+    sa, sb = (iva[:, 1] - iva[:, 0]) // 2, (ivb[:, 1] - ivb[:, 0]) // 2
+    step = (sa + sb) // 2
+    lo = np.zeros((len(r), 22), np.int64)
+    hi = np.zeros((len(r), 22), np.int64)
+    lo[:, 0], hi[:, 0], lo[:, 11], hi[:, 11] = iva[:, 0], iva[:, 1], ivb[:, 0], ivb[:, 1]
+    k = 1
+    for i in range(-5, 6):
+        if i == 0:
+            continue
+        lo[:, k] = np.maximum(0, ca + i * step - sa)
+        hi[:, k] = np.maximum(0, ca + i * step + sa)
+        lo[:, 11 + k] = np.maximum(0, cb + i * step - sb)
+        hi[:, 11 + k] = np.maximum(0, cb + i * step + sb)
+        k += 1
+    return iva, ivb, distance, np.concatenate([lo, hi], 1).astype(np.int32)
+
+
+def _remove_dup_fast(ds, bpcut=1e-5):
+    """removeDup (cModel.py:198-259) with the inner overlap scan vectorised; same visiting order,
+    same `rekeys` bookkeeping, same result."""
+    keys = list(ds.keys())
+    L = len(keys)
+    if L == 0:
+        return {}
+    iv = np.asarray([parseIv(ds[k]["iva"])[1:] + parseIv(ds[k]["ivb"])[1:] for k in keys], dtype=np.int64)
+    chrom = np.asarray([ds[k]["iva"].split(":")[0] + "|" + ds[k]["ivb"].split(":")[0] for k in keys])
+    removed = np.zeros(L, bool)
+    uniqueds, reds = {}, {}
+
+    def one_end(xa, xb, ya, yb):           # checkOneEndOverlap, cModel.py:174-182
+        t1 = ((ya <= xa) & (xa <= yb)) | ((ya <= xb) & (xb <= yb)) | ((ya <= xa) & (xa <= xb) & (xb <= yb))
+        t2 = ((xa <= ya) & (ya <= xb)) | ((xa <= yb) & (yb <= xb)) | ((xa <= ya) & (ya <= yb) & (yb <= xb))
+        return t1 | t2
+    for i in range(L - 1):
+        if removed[i]:
+            continue
+        js = np.arange(i + 1, L)
+        js = js[~removed[i + 1:]]
+        hit = np.zeros(0, np.int64)
+        if len(js):
+            ok = (chrom[js] == chrom[i]) & one_end(iv[i, 0], iv[i, 1], iv[js, 0], iv[js, 1]) & \
+                one_end(iv[i, 2], iv[i, 3], iv[js, 2], iv[js, 3])
+            hit = js[ok]
+        if len(hit):
+            reds[keys[i]] = [keys[i]] + [keys[j] for j in hit.tolist()]
+            removed[i] = True
+            removed[hit] = True
+        else:
+            uniqueds[keys[i]] = ds[keys[i]]
+    for key in reds.keys():
+        ts = {}
+        for t in reds[key]:
+            if ds[t]["binomial_p-value"] > bpcut:
+                continue
+            ts[t] = float(ds[t]["rab"]) / ds[t]["ra"] / ds[t]["rb"]
+        if len(ts) == 0:
+            continue
+        ts = pd.Series(ts)
+        ts.sort_values(inplace=True, ascending=False)
+        uniqueds[ts.index[0]] = ds[ts.index[0]]
+    return uniqueds
+
+
+def getIntSigFromCounts(records, counts, N, minPts, discut):
+    """getIntSig (cModel.py:262-331) fed with the interval counts of kernel K8 (cl_sig_counts) instead of
+    Python sets: the set sizes are the SAME integers, every float is produced by the same numpy /
+    scipy call on the same operands in the same order, so the rows are bit-identical."""
+    if N < 2:
+        return None
+    iva, ivb, distance, _ = _windows(records)
+    kept = []
+    i = 0
+    for n, r in enumerate(records):
+        if distance[n] < discut:
+            continue
+        if counts[n, 22] < max(minPts):
+            continue
+        kept.append((n, "%s-%s-%s" % (r[0], r[3], i)))
+        i += 1
+    if not kept:
+        return None
+    idx = np.asarray([n for n, _ in kept])
+    c = counts[idx].astype(np.int64)
+    ra, rb, rab = c[:, 0], c[:, 11], c[:, 22]
+    es_l, fdr_l, lam_l, bp_l = [], [], [], []
+    for q in range(len(idx)):
+        nra = c[q, 1:11].astype(np.float64)                  # nralen = float(len(nra))
+        nrb = c[q, 12:22]                                    # nrblen = len(nrb)  (int)
+        cab = c[q, 23:].reshape(11, 11)[1:, 1:].astype(np.float64)
+        rabs, nbps = [], []
+        for k in range(10):
+            for l in range(10):
+                nrab = float(cab[k, l])
+                if nrab > 0:
+                    rabs.append(nrab)
+                    nbps.append(nrab / (nra[k] * nrb[l]))
+                else:
+                    nbps.append(0.0)
+                    rabs.append(0.0)
+        rabs = np.array(rabs)
+        fdr = len(rabs[rabs > rab[q]]) / float(len(rabs))
+        mrabs = float(np.mean(rabs))
+        es = rab[q] / np.mean(rabs[rabs > 0]) if mrabs > 0 else np.inf
+        es_l.append(es)
+        fdr_l.append(fdr)
+        lam_l.append(mrabs)
+        bp_l.append(np.mean(nbps) * ra[q] * rb[q] / N)
+    hyp = np.maximum(1e-300, hypergeom.sf(rab - 1.0, N, ra, rb))
+    pop = np.maximum(1e-300, poisson.sf(rab - 1.0, np.asarray(lam_l)))
+    nbp = np.maximum(1e-300, binom.sf(rab - 1.0, N - rab, np.asarray(bp_l)))
+    ds = {}
+    for q, (n, key) in enumerate(kept):
+        chrom = records[n][0]
+        ds[key] = {
+            "distance": float(distance[n]), "ra": int(ra[q]), "rb": int(rb[q]), "rab": int(rab[q]), "ES": es_l[q], "FDR": fdr_l[q],
+            "hypergeometric_p-value": float(hyp[q]), "poisson_p-value": float(pop[q]), "binomial_p-value": float(nbp[q]),
+            "iva": "%s:%s-%s" % (chrom, iva[n, 0], iva[n, 1]), "ivb": "%s:%s-%s" % (chrom, ivb[n, 0], ivb[n, 1]),
+        }
+    ds = _remove_dup_fast(ds)
+    if len(ds.keys()) == 0:
+        return None
+    ds = _remove_dup_fast(ds)
+    if len(ds.keys()) == 0:
+        return None
+    ds = pd.DataFrame(ds).T
+    ds["poisson_p-value_corrected"] = getBonPvalues(ds["poisson_p-value"])
+    ds["binomial_p-value_corrected"] = getBonPvalues(ds["binomial_p-value"])
+    ds["hypergeometric_p-value_corrected"] = getBonPvalues(ds["hypergeometric_p-value"])
+    return ds
+
+
 def getIntSig(f, records, minPts, discut):
-    """cModel.py:262-331; `f` is a .jd path (or a 'mem://' chromosome of cloops_amd.pipe.CACHE)."""
-    if f.startswith("mem://"):
-        from .pipe import CACHE
-        r = CACHE.get(f)
-        mat = np.stack([r.ids, r.X, r.Y], 1).astype(np.int64)
-        if discut > 0:
-            mat = mat[(mat[:, 2] - mat[:, 1]) >= discut]
-    else:
-        key, mat = parseJd(f, discut)
-    return getIntSigFromMat(mat, records, minPts, discut, name=f)
+    """cModel.py:262-331; `f` is a .jd path or a 'mem://' chromosome of cloops_amd.pipe.CACHE.  The
+    interval counting runs on the GPU (kernel K8) on the chromosome resident in HBM."""
+    from .pipe import CACHE
+    if len(records) == 0:
+        return None
+    r = CACHE.get(f)
+    _, _, _, wins = _windows(records)
+    with r.lock:
+        counts, N = r.chrom.sig_counts(wins, discut)
+    return getIntSigFromCounts(records, counts, N, minPts, discut)
 
 
 def markIntSig(ds, escut=2.0, fdrcut=1e-2, bpcut=1e-3, ppcut=1e-5, hypcut=1e-10):

@@ -1586,6 +1586,125 @@ k7_hist(int n, int cut, const int* __restrict__ X, const int* __restrict__ Y, co
     if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
 
+// ==========================================================================================
+// K8: interval counting for the significance test (cLoops/cModel.py:60-80, 108-143)
+// ==========================================================================================
+// For a candidate loop with anchors iva, ivb the reference builds Python sets of the PETs that have
+// an end inside a window, S(W) = {i : X_i in W} | {i : Y_i in W}, for the two anchors and for 10 + 10
+// shifted windows, and needs |S(A_k)|, |S(B_l)|, |S(A_k) & S(B_l)| and rab = |{X in iva} & {Y in ivb}|.
+// One workgroup per candidate: the PETs with an end inside the span of the A windows (resp. B windows)
+// are two contiguous slices of the X-sorted and Y-sorted PET tables; every PET gets an 11-bit
+// membership mask per side and bumps the counters in LDS.  Pure integer work; the p-values stay on
+// the host (scipy), fed with exactly the reference's counts.
+#define SIG_W 11                       // window 0 = the anchor itself, 1..10 = cModel.getNearbyPairRegions
+#define SIG_OUT (2 * SIG_W + 1 + SIG_W * SIG_W)
+
+__global__ void k8_split(const int* __restrict__ X, const int* __restrict__ Y, int n, int cut,
+                         u64* __restrict__ kx, u64* __restrict__ ky)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int x = X[r], y = Y[r];
+    const bool valid = cut <= 0 || (y - x) >= cut;            // parseJd(f, cut), io.py:213-216
+    // sort key = coordinate (biased to be non-negative), payload = the other coordinate
+    kx[r] = valid ? (((u64)(u32)(x + (1 << 30)) << 32) | (u32)(y + (1 << 30))) : ~0ull;
+    ky[r] = valid ? (((u64)(u32)(y + (1 << 30)) << 32) | (u32)(x + (1 << 30))) : ~0ull;
+}
+
+// first index with (key >> 32) >= v   /   > v   in a sorted u64 table of m valid entries
+__device__ __forceinline__ int k8_lb(const u64* __restrict__ t, int m, long long v)
+{
+    const u64 target = v <= -(1ll << 30) ? 0ull : ((u64)(u32)(v + (1 << 30)) << 32);
+    int lo = 0, hi = m;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (t[mid] < target) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__device__ __forceinline__ int k8_ub(const u64* __restrict__ t, int m, long long v)
+{
+    return k8_lb(t, m, v + 1);
+}
+
+struct SigWin { int lo[2 * SIG_W]; int hi[2 * SIG_W]; };      // [0..10] = A windows, [11..21] = B windows
+
+__global__ void __launch_bounds__(TPB)
+k8_counts(const u64* __restrict__ tx, const u64* __restrict__ ty, const int* __restrict__ d_m, int nrec,
+          const SigWin* __restrict__ wins, int* __restrict__ out)
+{
+    __shared__ int wlo[2 * SIG_W], whi[2 * SIG_W];
+    __shared__ int c_a[SIG_W], c_b[SIG_W], c_ab[SIG_W * SIG_W], c_rab;
+    __shared__ int rng[8];
+    const int rec = blockIdx.x;
+    if (rec >= nrec) return;
+    const int m = d_m[0];
+    if (threadIdx.x < 2 * SIG_W) { wlo[threadIdx.x] = wins[rec].lo[threadIdx.x]; whi[threadIdx.x] = wins[rec].hi[threadIdx.x]; }
+    if (threadIdx.x < SIG_W) { c_a[threadIdx.x] = 0; c_b[threadIdx.x] = 0; }
+    for (int k = threadIdx.x; k < SIG_W * SIG_W; k += blockDim.x) c_ab[k] = 0;
+    if (threadIdx.x == 0) c_rab = 0;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        // spans of the A and of the B windows; slices of the X-sorted (0,2) and Y-sorted (1,3) tables
+        const int side = threadIdx.x >> 1, off = side * SIG_W;
+        int lo = wlo[off], hi = whi[off];
+        for (int k = 1; k < SIG_W; ++k) { lo = min(lo, wlo[off + k]); hi = max(hi, whi[off + k]); }
+        const u64* t = (threadIdx.x & 1) ? ty : tx;
+        rng[threadIdx.x * 2] = k8_lb(t, m, lo);
+        rng[threadIdx.x * 2 + 1] = k8_ub(t, m, hi);
+        if ((threadIdx.x & 1) == 0) { /* keep spans for the dedupe test */ }
+    }
+    __syncthreads();
+    int spanlo[2], spanhi[2];
+    for (int side = 0; side < 2; ++side) {
+        int lo = wlo[side * SIG_W], hi = whi[side * SIG_W];
+        for (int k = 1; k < SIG_W; ++k) { lo = min(lo, wlo[side * SIG_W + k]); hi = max(hi, whi[side * SIG_W + k]); }
+        spanlo[side] = lo; spanhi[side] = hi;
+    }
+    for (int side = 0; side < 2; ++side) {
+        for (int tab = 0; tab < 2; ++tab) {
+            const u64* t = tab ? ty : tx;
+            const int b = rng[(side * 2 + tab) * 2], e = rng[(side * 2 + tab) * 2 + 1];
+            for (int j = b + (int)threadIdx.x; j < e; j += blockDim.x) {
+                const u64 kv = t[j];
+                const int first = (int)(u32)(kv >> 32) - (1 << 30), second = (int)(u32)(kv & 0xffffffffu) - (1 << 30);
+                const int x = tab ? second : first, y = tab ? first : second;
+                // a PET with both ends inside the span is in both slices: count it from the X table only
+                if (tab == 1 && x >= spanlo[side] && x <= spanhi[side]) continue;
+                unsigned ma = 0, mb = 0;
+#pragma unroll
+                for (int k = 0; k < SIG_W; ++k) {
+                    ma |= (unsigned)(((x >= wlo[k]) & (x <= whi[k])) | ((y >= wlo[k]) & (y <= whi[k]))) << k;
+                    mb |= (unsigned)(((x >= wlo[SIG_W + k]) & (x <= whi[SIG_W + k])) | ((y >= wlo[SIG_W + k]) & (y <= whi[SIG_W + k]))) << k;
+                }
+                if (side == 0) {
+                    for (unsigned a = ma; a; a &= a - 1) {
+                        const int k = __ffs(a) - 1;
+                        atomicAdd(&c_a[k], 1);
+                        for (unsigned bb = mb; bb; bb &= bb - 1) atomicAdd(&c_ab[k * SIG_W + (__ffs(bb) - 1)], 1);
+                    }
+                    // rab = |{X in iva} & {Y in ivb}|  (cModel.py:79): needs x in A_0, found in the X table
+                    if (tab == 0 && x >= wlo[0] && x <= whi[0] && y >= wlo[SIG_W] && y <= whi[SIG_W]) atomicAdd(&c_rab, 1);
+                } else {
+                    for (unsigned bb = mb; bb; bb &= bb - 1) atomicAdd(&c_b[__ffs(bb) - 1], 1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    int* o = out + (size_t)rec * SIG_OUT;
+    if (threadIdx.x < SIG_W) { o[threadIdx.x] = c_a[threadIdx.x]; o[SIG_W + threadIdx.x] = c_b[threadIdx.x]; }
+    if (threadIdx.x == 0) o[2 * SIG_W] = c_rab;
+    for (int k = threadIdx.x; k < SIG_W * SIG_W; k += blockDim.x) o[2 * SIG_W + 1 + k] = c_ab[k];
+}
+
+__global__ void k8_count_valid(const u64* __restrict__ t, int n, int* __restrict__ d_m)
+{
+    // number of valid (non-sentinel) entries of the sorted table = lower bound of the sentinel
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int lo = 0, hi = n;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (t[mid] != ~0ull) lo = mid + 1; else hi = mid; }
+        d_m[0] = lo;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1633,6 +1752,8 @@ struct cl_chrom {
     } slot[2];
     DevBuf hdr;                       // device result headers, 16 ints per slot
     DevBuf k7_cls, k7_parts;          // K7: class per cluster id, per-workgroup partials
+    DevBuf sig_tx, sig_ty, sig_tmp, sig_sorttmp, sig_m, sig_win, sig_out;   // K8: sorted PET tables, windows, counts
+    bool sig_ready = false; int sig_cut = 0;
     bool k7_classified = false;       // k7_cls matches the last completed run
     hipStream_t copy_stream = nullptr, aux_stream = nullptr;
     int enq = 0, deq = 0;             // runs enqueued / completed
@@ -1653,7 +1774,7 @@ static void free_chrom(cl_chrom* c)
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
-                      &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->hdr, &c->k7_cls, &c->k7_parts,
+                      &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
                       &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy};
     for (DevBuf* b : bufs) b->release();
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
@@ -2340,6 +2461,52 @@ extern "C" int cl_dist_hist(cl_chrom* c, int32_t cut, int group, uint32_t prefix
                        c->k7_cls.as<signed char>(), group, (unsigned)prefix, shift, dh);
     HIP_TRY(hipMemcpyAsync(hist256, dh, 256 * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return CL_OK;
+}
+
+// ---- K8 host entry point ------------------------------------------------------------------------
+extern "C" int cl_sig_counts(cl_chrom* c, int32_t cut, int32_t n_records, const int32_t* windows, int32_t* out,
+                             int64_t* n_pets)
+{
+    if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
+    if (n_pets) *n_pets = 0;
+    if (n_records < 0 || (n_records > 0 && (!windows || !out))) return fail(CL_ERR_ARG, "cl_sig_counts: bad arguments");
+    if (c->enq != c->deq) return fail(CL_ERR_ARG, "cl_sig_counts: asynchronous runs still in flight");
+    if (c->n == 0) { if (n_records) memset(out, 0, (size_t)n_records * SIG_OUT * 4); return CL_OK; }
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = (int)c->n;
+    int rc;
+    if (!c->sig_ready || c->sig_cut != cut) {
+        // X-sorted and Y-sorted tables of the PETs that pass parseJd(f, cut); built once per (chromosome, cut)
+        if ((rc = c->sig_tx.ensure((size_t)n * 8)) || (rc = c->sig_ty.ensure((size_t)n * 8)) ||
+            (rc = c->sig_tmp.ensure((size_t)n * 8)) || (rc = c->sig_m.ensure(64))) return rc;
+        LAUNCH(k8_split, n, c->d_x, c->d_y, n, cut, c->sig_tmp.as<u64>(), c->sig_ty.as<u64>());
+        size_t bytes = 0;
+        hipError_t e = rocprim::radix_sort_keys(nullptr, bytes, (u64*)nullptr, (u64*)nullptr, (size_t)n, 0, 64, c->stream);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_keys size query", hipGetErrorString(e));
+        if ((rc = c->sig_sorttmp.ensure(std::max<size_t>(bytes, 16)))) return rc;
+        bytes = c->sig_sorttmp.bytes;
+        e = rocprim::radix_sort_keys(c->sig_sorttmp.p, bytes, c->sig_tmp.as<u64>(), c->sig_tx.as<u64>(), (size_t)n, 0, 64, c->stream);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_keys(X)", hipGetErrorString(e));
+        HIP_TRY(hipMemcpyAsync(c->sig_tmp.p, c->sig_ty.p, (size_t)n * 8, hipMemcpyDeviceToDevice, c->stream));
+        bytes = c->sig_sorttmp.bytes;
+        e = rocprim::radix_sort_keys(c->sig_sorttmp.p, bytes, c->sig_tmp.as<u64>(), c->sig_ty.as<u64>(), (size_t)n, 0, 64, c->stream);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_keys(Y)", hipGetErrorString(e));
+        hipLaunchKernelGGL(k8_count_valid, dim3(1), dim3(64), 0, c->stream, c->sig_tx.as<u64>(), n, c->sig_m.as<int>());
+        c->sig_ready = true; c->sig_cut = cut;
+    }
+    int hm = 0;
+    HIP_TRY(hipMemcpyAsync(&hm, c->sig_m.p, 4, hipMemcpyDeviceToHost, c->stream));
+    if (n_records > 0) {
+        if ((rc = c->sig_win.ensure((size_t)n_records * sizeof(SigWin))) || (rc = c->sig_out.ensure((size_t)n_records * SIG_OUT * 4))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->sig_win.p, windows, (size_t)n_records * sizeof(SigWin), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k8_counts, dim3(n_records), dim3(TPB), 0, c->stream, c->sig_tx.as<u64>(), c->sig_ty.as<u64>(), c->sig_m.as<int>(),
+                           n_records, c->sig_win.as<SigWin>(), c->sig_out.as<int>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out, c->sig_out.p, (size_t)n_records * SIG_OUT * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n_pets) *n_pets = hm;
     return CL_OK;
 }
 

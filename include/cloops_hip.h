@@ -161,6 +161,20 @@ int cl_dist_stats(cl_chrom* c, int32_t cut, cl_dstats* out);
 int cl_dist_sqdev(cl_chrom* c, int32_t cut, double mean_inter, double mean_self, double* out2);
 int cl_dist_hist(cl_chrom* c, int32_t cut, int group, uint32_t prefix, int shift, uint64_t* hist256);
 
+/*
+ * Interval counting for the significance test of candidate loops (cLoops/cModel.py:60-80,108-143):
+ * for every record, 11 A windows (the anchor iva + the 10 shifted windows of getNearbyPairRegions,
+ * cModel.py:83-105) and 11 B windows, each [lo, hi] inclusive.  `windows`: n_records x 44 int32 laid
+ * out as lo[22] (A0..A10, B0..B10) then hi[22].  `out`: n_records x 144 int32:
+ *   [0..10]   |S(A_k)|   with S(W) = {PETs with X in W} | {PETs with Y in W}     (ra = [0])
+ *   [11..21]  |S(B_l)|                                                            (rb = [11])
+ *   [22]      rab = |{X in A_0} & {Y in B_0}|                                     (cModel.py:79)
+ *   [23 + 11*k + l]  |S(A_k) & S(B_l)|
+ * `cut` > 0 restricts the PETs to Y-X >= cut like parseJd(f, cut) (cLoops/io.py:213-216);
+ * *n_pets = number of PETs in the model (N of cModel.py:270).
+ */
+int cl_sig_counts(cl_chrom* c, int32_t cut, int32_t n_records, const int32_t* windows, int32_t* out, int64_t* n_pets);
+
 /* Device pointer to the labels of the last run (n int32, row aligned) -- lets the caller
  * keep results on the GPU (e.g. to hand them to RCCL) without a host round trip. */
 const int32_t* cl_labels_device(const cl_chrom* c);

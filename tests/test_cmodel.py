@@ -12,6 +12,30 @@ import pipe_checks
 from cloops_amd import cModel
 
 
+@pytest.fixture(autouse=True)
+def cpu_backend(monkeypatch):
+    """host logic on CPU: the GPU counting kernel is replaced by its numpy stand-in"""
+    import fake_backend
+    from cloops_amd import api, pipe
+    monkeypatch.setattr(api, "Chromosome", fake_backend.FakeChromosome)
+    monkeypatch.setattr(api, "device_count", lambda: 1)
+    pipe.CACHE.clear()
+    yield
+    pipe.CACHE.clear()
+
+
+def test_set_based_restatement_identical(tmp_path):
+    """the literal set-based restatement (getIntSigFromMat) also reproduces the golden table"""
+    z, meta = pipe_checks.pipe_golden()
+    X, Y = G.chr21_xy()
+    mat = np.stack([np.arange(len(X)), X, Y], 1).astype(np.int64)
+    recs = [["chr21", int(a), int(b), "chr21", int(c), int(d)] for a, b, c, d in z["v2_filtered"]]
+    ds = cModel.markIntSig(cModel.getIntSigFromMat(mat, recs, [5], 0))
+    out = os.path.join(str(tmp_path), "x.loop")
+    ds.to_csv(out, sep="\t", index_label="loopId")
+    assert open(out).read() == open(os.path.join(G.GOLD, "chr21_v2.loop")).read()
+
+
 @pytest.mark.parametrize("variant", ["v2", "v1"])
 @pytest.mark.parametrize("hic", [0, 1])
 def test_loop_file_identical(variant, hic, tmp_path):

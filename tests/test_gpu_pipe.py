@@ -117,3 +117,21 @@ def test_end_to_end_bedpe_to_loop_file(tmp_path):
     want = open(os.path.join(G.GOLD, "chr21_v2.loop")).read()
     assert got == want
     assert not os.path.isdir(fout)                         # pipe.py:294-295 removes the working directory
+
+
+def test_sig_counts_kernel_vs_sets():
+    """K8 interval counts == the set-based host restatement (cModel.CoverageModel), incl. a cut filter"""
+    import fake_backend
+    import pipe_checks
+    from cloops_amd import api, cModel
+    X, Y = G.chr21_xy()
+    z, meta = pipe_checks.pipe_golden()
+    recs = [["chr21", int(a), int(b), "chr21", int(c), int(d)] for a, b, c, d in z["v2_filtered"][:200]]
+    _, _, _, wins = cModel._windows(recs)
+    ch = api.Chromosome(X, Y)
+    for cut in (0, 4601):
+        got, n = ch.sig_counts(wins, cut)
+        want, n2 = fake_backend.FakeChromosome(X, Y).sig_counts(wins, cut)
+        assert n == n2
+        assert np.array_equal(got, want)
+    ch.close()
