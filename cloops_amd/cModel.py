@@ -314,29 +314,22 @@ def getIntSigFromCounts(records, counts, N, minPts, discut):
     idx = np.asarray([n for n, _ in kept])
     c = counts[idx].astype(np.int64)
     ra, rb, rab = c[:, 0], c[:, 11], c[:, 22]
-    es_l, fdr_l, lam_l, bp_l = [], [], [], []
-    for q in range(len(idx)):
-        nra = c[q, 1:11].astype(np.float64)                  # nralen = float(len(nra))
-        nrb = c[q, 12:22]                                    # nrblen = len(nrb)  (int)
-        cab = c[q, 23:].reshape(11, 11)[1:, 1:].astype(np.float64)
-        rabs, nbps = [], []
-        for k in range(10):
-            for l in range(10):
-                nrab = float(cab[k, l])
-                if nrab > 0:
-                    rabs.append(nrab)
-                    nbps.append(nrab / (nra[k] * nrb[l]))
-                else:
-                    nbps.append(0.0)
-                    rabs.append(0.0)
-        rabs = np.array(rabs)
-        fdr = len(rabs[rabs > rab[q]]) / float(len(rabs))
-        mrabs = float(np.mean(rabs))
-        es = rab[q] / np.mean(rabs[rabs > 0]) if mrabs > 0 else np.inf
-        es_l.append(es)
-        fdr_l.append(fdr)
-        lam_l.append(mrabs)
-        bp_l.append(np.mean(nbps) * ra[q] * rb[q] / N)
+    # the 10 x 10 permuted background of every record at once (cModel.py:121-158).  rabs are integer
+    # counts, so their sums are exact in any order; nbps (non-integers) are reduced along the last axis,
+    # which numpy sums exactly like the reference's 1-D np.mean of the same 100 values in the same order.
+    nra = c[:, 1:11].astype(np.float64)                      # nralen = float(len(nra))
+    nrb = c[:, 12:22]                                        # nrblen = len(nrb)  (int)
+    cab = c[:, 23:].reshape(-1, 11, 11)[:, 1:, 1:].astype(np.float64)
+    rabs = cab.reshape(len(idx), 100)
+    den = nra[:, :, None] * nrb[:, None, :]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        nbps = np.where(cab > 0, cab / den, 0.0).reshape(len(idx), 100)
+    fdr_l = (rabs > rab[:, None]).sum(1) / float(100)
+    lam_l = rabs.mean(axis=1)
+    npos = (rabs > 0).sum(1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        es_l = np.where(lam_l > 0, rab / (rabs.sum(1) / np.maximum(npos, 1)), np.inf)
+    bp_l = nbps.mean(axis=1) * ra * rb / N
     hyp = np.maximum(1e-300, hypergeom.sf(rab - 1.0, N, ra, rb))
     pop = np.maximum(1e-300, poisson.sf(rab - 1.0, np.asarray(lam_l)))
     nbp = np.maximum(1e-300, binom.sf(rab - 1.0, N - rab, np.asarray(bp_l)))
@@ -344,7 +337,7 @@ def getIntSigFromCounts(records, counts, N, minPts, discut):
     for q, (n, key) in enumerate(kept):
         chrom = records[n][0]
         ds[key] = {
-            "distance": float(distance[n]), "ra": int(ra[q]), "rb": int(rb[q]), "rab": int(rab[q]), "ES": es_l[q], "FDR": fdr_l[q],
+            "distance": float(distance[n]), "ra": int(ra[q]), "rb": int(rb[q]), "rab": int(rab[q]), "ES": float(es_l[q]), "FDR": float(fdr_l[q]),
             "hypergeometric_p-value": float(hyp[q]), "poisson_p-value": float(pop[q]), "binomial_p-value": float(nbp[q]),
             "iva": "%s:%s-%s" % (chrom, iva[n, 0], iva[n, 1]), "ivb": "%s:%s-%s" % (chrom, ivb[n, 0], ivb[n, 1]),
         }
