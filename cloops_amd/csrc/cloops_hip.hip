@@ -351,12 +351,12 @@ struct LdsInts {
 // (a wave pays the LONGEST trip count of its lanes, so data-dependent loops cost far more
 // instructions than the average lane needs).  Valid for hi - lo <= 255.
 // first idx in [lo,hi) with w[idx].x >= val (or hi)
-template <typename W>
+template <int STEPS = 8, typename W>
 __device__ __forceinline__ int lds_lower_bound8(const W& w, int lo, int hi, int val)
 {
     int pos = lo;
 #pragma unroll
-    for (int step = 128; step >= 1; step >>= 1) {
+    for (int step = 1 << (STEPS - 1); step >= 1; step >>= 1) {
         const int idx = pos + step - 1;
         const int v = w[min(idx, hi - 1)].x;
         pos = (idx < hi && v < val) ? pos + step : pos;
@@ -364,12 +364,12 @@ __device__ __forceinline__ int lds_lower_bound8(const W& w, int lo, int hi, int 
     return pos;
 }
 // first idx in [lo,hi) with w[idx].x > val (or hi)
-template <typename W>
+template <int STEPS = 8, typename W>
 __device__ __forceinline__ int lds_upper_bound8(const W& w, int lo, int hi, int val)
 {
     int pos = lo;
 #pragma unroll
-    for (int step = 128; step >= 1; step >>= 1) {
+    for (int step = 1 << (STEPS - 1); step >= 1; step >>= 1) {
         const int idx = pos + step - 1;
         const int v = w[min(idx, hi - 1)].x;
         pos = (idx < hi && v <= val) ? pos + step : pos;
@@ -465,6 +465,7 @@ k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
                const int* __restrict__ strip_start, int* __restrict__ cnt)
 {
     __shared__ int2 lw[K2_WIN];
+    __shared__ int4 l_sb[K2_TPB];
     __shared__ short l_list[K2_TPB];
     __shared__ int l_wcount[K2_TPB / 64];
     const int M = strip_start[g.S];
@@ -483,16 +484,23 @@ k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
     const int wbeg = max(base, 0), wend = min(base + K2_WIN, M);
     const int i = t0 + threadIdx.x;
     const bool valid = i < M;
+    if (g.dbg & 32) { if (valid) cnt[i] = w[i].x + w[i].y; return; }        // developer knob: staging only
     // ---- phase 0: one-read core test ----------------------------------------------------------
     // If the minPts-1 next (or previous) PETs of the own strip are within eps in q, the point is
     // core: interiors of clusters are settled by one or two LDS reads, without any search.
+    // The four strip bounds of every PET are fetched here, once, all loads in flight together, and kept
+    // in LDS for the later phases (after the compaction a thread works on another PET, and a second
+    // round of dependent global loads would sit on the critical path of the few remaining waves).
     bool hard = false;
     if (valid) {
         bool done = false;
+        const int2 me = w[i];
+        const int s = strip_of(g, me.y);
+        const int b = strip_start[s], e = strip_start[s + 1];
+        const int tb = s > 0 ? strip_start[s - 1] : b;
+        const int te = s + 1 < g.S ? strip_start[s + 2] : e;
+        l_sb[threadIdx.x] = make_int4(tb, b, e, te);
         if (!EXACT && g.minPts >= 1 && g.minPts - 1 <= K2_SPAN) {
-            const int2 me = w[i];
-            const int s = strip_of(g, me.y);
-            const int b = strip_start[s], e = strip_start[s + 1];
             const int m1 = g.minPts - 1;
             const int jr = i + m1, jl = i - m1;
             if (jr < e && jr < wend && w[jr].x - me.x <= g.eps) done = true;
@@ -500,31 +508,41 @@ k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
         }
         if (done) cnt[i] = g.minPts; else hard = true;
     }
+    if (g.dbg & 64) { if (valid && hard) cnt[i] = 0; return; }              // developer knob: phase 0 only
     // ---- workgroup compaction: whole waves drop out of the search phases ------------------------
     const int total = block_compact<K2_TPB>(hard, l_list, l_wcount);
     if ((int)threadIdx.x >= total) return;
     {
-        const int ii = t0 + l_list[threadIdx.x];
+        const int tix = l_list[threadIdx.x];
+        const int ii = t0 + tix;
         const int2 me = w[ii];
         const int qi = me.x, pi = me.y;
-        const int s = strip_of(g, pi);
         const int qlo = sat_add(qi, -g.eps), qhi = sat_add(qi, g.eps);
-        const int b = strip_start[s], e = strip_start[s + 1];
+        const int4 sb4 = l_sb[tix];
+        const int tb = sb4.x, b = sb4.y, e = sb4.z, te = sb4.w;
         // ---- phase 1: own strip, index difference of two branch-free searches -------------------
-        const int L = max(max(b, wbeg), ii - K2_SPAN);
-        int lo = lds_lower_bound8(w, L, ii + 1, qlo);
-        if (lo == L && L > b) lo = lower_bound_4(sv, b, L, qlo);           // window leaves the staged span
-        const int R = min(min(e, wend), ii + 1 + K2_SPAN);
-        int hi = lds_upper_bound8(w, ii + 1, R, qhi);
-        if (hi == R && R < e) hi = lower_bound_4(sv, R, e, sat_add(qhi, 1));
+        // most windows hold < 31 PETs per side: 5 steps; a window that reaches the 31st position is
+        // searched again with 8 steps, one that leaves the staged span continues in global memory
+        const int Ls = max(max(b, wbeg), ii - 31);
+        int lo = lds_lower_bound8<5>(w, Ls, ii + 1, qlo);
+        if (lo == Ls && Ls > b) {
+            const int L = max(max(b, wbeg), ii - K2_SPAN);
+            lo = lds_lower_bound8<8>(w, L, Ls + 1, qlo);
+            if (lo == L && L > b) lo = lower_bound_4(sv, b, L, qlo);
+        }
+        const int Rs = min(min(e, wend), ii + 32);
+        int hi = lds_upper_bound8<5>(w, ii + 1, Rs, qhi);
+        if (hi == Rs && Rs < e) {
+            const int R = min(min(e, wend), ii + 1 + K2_SPAN);
+            hi = lds_upper_bound8<8>(w, Rs, R, qhi);
+            if (hi == R && R < e) hi = lower_bound_4(sv, R, e, sat_add(qhi, 1));
+        }
         int c = hi - lo;
         // ---- phase 2: neighbour strips, only while not known to be core -------------------------
         if (EXACT || c < g.minPts) {
-            const int tb = s > 0 ? strip_start[s - 1] : b;
-            const int te = s + 1 < g.S ? strip_start[s + 2] : e;
             if (tb < b) {                                                      // strip s-1 = [tb, b)
                 if (tb >= wbeg && b - tb <= 255) {
-                    const int j = lds_lower_bound8(w, tb, b, qlo);
+                    const int j = (b - tb <= 63) ? lds_lower_bound8<6>(w, tb, b, qlo) : lds_lower_bound8<8>(w, tb, b, qlo);
                     c = k2_count_lds<EXACT, 4>(w, j, b, qhi, pi, g.eps, g.minPts, c);
                 } else {
                     const int j = lower_bound_4(sv, tb, b, qlo);
@@ -533,7 +551,7 @@ k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
             }
             if ((EXACT || c < g.minPts) && e < te) {                           // strip s+1 = [e, te)
                 if (te <= wend && te - e <= 255) {
-                    const int j = lds_lower_bound8(w, e, te, qlo);
+                    const int j = (te - e <= 63) ? lds_lower_bound8<6>(w, e, te, qlo) : lds_lower_bound8<8>(w, e, te, qlo);
                     c = k2_count_lds<EXACT, 4>(w, j, te, qhi, pi, g.eps, g.minPts, c);
                 } else {
                     const int j = lower_bound_4(sv, e, te, qlo);
