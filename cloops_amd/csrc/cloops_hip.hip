@@ -195,14 +195,25 @@ __device__ __forceinline__ void for_each_neighbor(const GridParams& g, const int
     }
 }
 
-// ---- lock-free union-find (roots = smallest sorted index of the component) ---------------
-// Invariant: parent[x] <= x, so the forest is acyclic whatever the interleaving.  parent[]
-// is read with PLAIN (L1-cacheable) loads: a stale value is always an earlier parent of the
-// same node, i.e. still an ancestor, so a find that stops early merely returns a non-root
-// ancestor.  Only the hook is an atomic: atomicCAS succeeds only on a true root, and when it
-// fails it returns the true parent, which is strictly smaller -- every retry makes
-// progress.  (Agent-scope atomic loads here serialise millions of lanes on the one L2
-// channel holding a giant component's root: 77 ms vs 1 ms on a 16 M-PET chromosome.)
+// ---- lock-free union-find with randomised linking ------------------------------------------
+// Every node has a fixed pseudo-random priority (a bijective hash of its index); a root is only
+// ever hooked under a root of HIGHER priority, so the forest is acyclic whatever the interleaving
+// and its expected depth is logarithmic even for a component that is a 50 000-strip long path
+// (the self-ligation diagonal at large eps: linking by smaller index made that a 50 000-deep list
+// whose first traversal alone cost 8 ms).  Which member ends up as the root is irrelevant -- ids,
+// keys and sizes are all reduced over the members.
+// parent[] is read with PLAIN (L1-cacheable) loads: a stale value is always an earlier parent of
+// the same node, i.e. still an ancestor, so a find that stops early merely returns a non-root
+// ancestor.  Only the hook is an atomic: atomicCAS succeeds only on a true root, and when it fails it
+// returns the true parent, whose priority is strictly higher -- every retry makes progress.
+// (Agent-scope atomic loads here serialise millions of lanes on the one L2 channel holding a giant
+// component's root: 77 ms vs 1 ms on a 16 M-PET chromosome.)
+__device__ __forceinline__ unsigned uf_prio(int x)
+{
+    unsigned h = (unsigned)x;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;      // bijective
+    return h;
+}
 __device__ __forceinline__ int uf_find(int* parent, int x)
 {
     for (;;) {
@@ -220,8 +231,8 @@ __device__ __forceinline__ void uf_unite(int* parent, int a, int b)
         a = uf_find(parent, a);
         b = uf_find(parent, b);
         if (a == b) return;
-        if (a < b) { int t = a; a = b; b = t; }
-        int old = atomicCAS(parent + a, a, b);      // hook the larger root under the smaller
+        if (uf_prio(a) > uf_prio(b)) { int t = a; a = b; b = t; }      // a = lower priority: it goes under b
+        int old = atomicCAS(parent + a, a, b);
         if (old == a) return;
         a = old;                                    // not a root any more: continue from its true parent
     }
@@ -622,11 +633,21 @@ __device__ __forceinline__ void tile_visit_segment(const Tile& t, const int* __r
             f(j, c.x, c.y, t.x[j]);
         }
     } else {
+        // the segment is not staged (a strip longer than the window: dense data at large eps): global
+        // memory, with the loads of 4 candidates in flight before the first of them is looked at
         int j = lower_bound_4(gq, sb, se, qlo);
-        for (; j < se; ++j) {
-            const int q = gq[j];
-            if (q > qhi) break;
-            f(j, q, gp[j], gx[j]);
+        while (j < se) {
+            int q[4], p[4], x[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int idx = min(j + k, se - 1); q[k] = gq[idx]; p[k] = gp[idx]; x[k] = gx[idx]; }
+            bool out = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (out || j + k >= se || q[k] > qhi) { out = true; continue; }
+                f(j + k, q[k], p[k], x[k]);
+            }
+            if (out) break;
+            j += 4;
         }
     }
 }
@@ -835,11 +856,12 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
 __device__ __forceinline__ int agg_slot(int* keys, int key)
 {
     unsigned h = ((unsigned)key * 2654435761u) >> 23;            // 9 bits
-    for (;;) {
+    for (int probe = 0; probe < 24; ++probe) {
         const int old = atomicCAS(&keys[h], -1, key);
         if (old == -1 || old == key) return (int)h;
         h = (h + 1) & (AGG_H - 1);
     }
+    return -1;                                                    // table crowded: caller goes to global memory
 }
 
 // K3b: root per core point, component keys and core counts.
@@ -879,7 +901,8 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
             for (int o = 32; o > 0; o >>= 1) mk = min(mk, __shfl_xor(mk, o));
             if (lane == leader) {
                 const int sl = agg_slot(hkey, R);
-                atomicMin(&hmin[sl], mk); atomicAdd(&hcnt[sl], cm);
+                if (sl >= 0) { atomicMin(&hmin[sl], mk); atomicAdd(&hcnt[sl], cm); }
+                else { atomicMin(&compkey[R], mk); atomicAdd(&ncore[R], cm); }
             }
         } else if (mine) {
             atomicMin(&compkey[R], key);
@@ -908,7 +931,8 @@ __device__ __forceinline__ int owner_root(int o) { return o < 0 ? -1 : (o & (OWN
 __global__ void __launch_bounds__(TPB)
 k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
          const int* __restrict__ strip_start, const int* __restrict__ root, const int* __restrict__ compkey,
-         const u32* __restrict__ srow, int* __restrict__ owner, int* __restrict__ bsize, int* __restrict__ usize)
+         const int* __restrict__ ncore, const u32* __restrict__ srow, int* __restrict__ owner, int* __restrict__ bsize,
+         int* __restrict__ usize)
 {
     __shared__ int2 lw[T_WIN];
     __shared__ int lx[T_WIN];
@@ -950,15 +974,18 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
         const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.eps) see(j, r); });
     const int o = (v1 && tbest >= 0) ? tbest : best;
     owner[i] = o < 0 ? -1 : (contested ? (o | OWNER_CONTESTED) : o);
-    // counts per owning component, reduced over the lanes of the wave that share the owner
+    // counts per owning component, reduced over the lanes of the wave that share the owner.  Only
+    // components that are not already >= minPts on their cores need them (release rule of variant 2,
+    // drop rule of variant 1) -- a giant component never sees one of these atomics.
     {
         const int lane = threadIdx.x & 63;
-        unsigned long long pending = __ballot(o >= 0);
+        const bool cnt_me = o >= 0 && ncore[o] < g.minPts;
+        unsigned long long pending = __ballot(cnt_me);
         while (pending) {
             const int leader = __ffsll((long long)pending) - 1;
             const int O = __shfl(o, leader);
-            const unsigned long long m = __ballot(o == O);
-            const unsigned long long mu = __ballot(o == O && !contested);
+            const unsigned long long m = __ballot(cnt_me && o == O);
+            const unsigned long long mu = __ballot(cnt_me && o == O && !contested);
             if (lane == leader) {
                 atomicAdd(&bsize[O], __popcll(m));
                 if (mu) atomicAdd(&usize[O], __popcll(mu));
@@ -1128,7 +1155,17 @@ __global__ void k_rank_flags(GridParams g, const int* __restrict__ strip_start, 
     flag[compkey[i]] = 1;
 }
 
-struct Table { cl_box* row; };      // one cl_box per cluster id (AoS: a single D2H copy returns the table)
+// Device cluster table, struct-of-arrays: the five accumulators of one id live in five different cache
+// lines, so the atomics of a hot id (a giant component) spread over five L2 channels instead of
+// queueing on one line (AoS measured 3x slower on the 16 M-PET giant-component case).
+struct Table {
+    int* count; int* minx; int* maxx; int* miny; int* maxy;
+    __device__ __forceinline__ cl_box get(int k) const
+    {
+        cl_box b; b.min_x = minx[k]; b.max_x = maxx[k]; b.min_y = miny[k]; b.max_y = maxy[k]; b.count = count[k];
+        return b;
+    }
+};
 
 // label of every component root (-1 = not kept), so that k_final_labels needs ONE gather per PET
 // instead of the chain owner -> compkey -> rank (+ state / sizes)
@@ -1150,8 +1187,7 @@ __global__ void k_init_table(Table t, const int* __restrict__ rankscan, int n)
     const int K = rankscan[n];      // total number of ids handed out
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
-    cl_box b; b.count = 0; b.min_x = INT_MAX; b.max_x = INT_MIN; b.min_y = INT_MAX; b.max_y = INT_MIN;
-    t.row[k] = b;
+    t.count[k] = 0; t.minx[k] = INT_MAX; t.maxx[k] = INT_MIN; t.miny[k] = INT_MAX; t.maxy[k] = INT_MIN;
 }
 
 __device__ __forceinline__ int je_minus(const int* __restrict__ cstart, int j) { return cstart[j + 1] - cstart[j]; }
@@ -1161,16 +1197,27 @@ __device__ __forceinline__ int wave_max_i(int v) { for (int o = 32; o > 0; o >>=
 // Cluster table (pipe.py:78-102) by the two-level reduce-by-key above; called by all threads
 // of a BIGTPB workgroup (sorted order keeps a cluster's PETs in neighbouring lanes, so a wave
 // usually carries a handful of labels).
-struct TableLds { int key[AGG_H], cnt[AGG_H], mnx[AGG_H], mxx[AGG_H], mny[AGG_H], mxy[AGG_H]; };
+#define TAB_H 2048
+struct TableLds { int key[TAB_H], cnt[TAB_H], mnx[TAB_H], mxx[TAB_H], mny[TAB_H], mxy[TAB_H]; };
 
 __device__ __forceinline__ void table_lds_init(TableLds& h)
 {
-    if (threadIdx.x < AGG_H) {
-        const int k = threadIdx.x;
+    for (int k = threadIdx.x; k < TAB_H; k += blockDim.x) {
         h.key[k] = -1; h.cnt[k] = 0; h.mnx[k] = INT_MAX; h.mxx[k] = INT_MIN; h.mny[k] = INT_MAX; h.mxy[k] = INT_MIN;
     }
     __syncthreads();
 }
+__device__ __forceinline__ int tab_slot(int* keys, int key)
+{
+    unsigned h = ((unsigned)key * 2654435761u) >> 21;            // 11 bits
+    for (int probe = 0; probe < 16; ++probe) {
+        const int old = atomicCAS(&keys[h], -1, key);
+        if (old == -1 || old == key) return (int)h;
+        h = (h + 1) & (TAB_H - 1);
+    }
+    return -1;
+}
+// level 1 + insertion into the workgroup's LDS table (no barrier inside: may be called repeatedly)
 __device__ __forceinline__ void table_accumulate(const Table& t, TableLds& h, int lab, int x, int y)
 {
     const int lane = threadIdx.x & 63;
@@ -1185,24 +1232,35 @@ __device__ __forceinline__ void table_accumulate(const Table& t, TableLds& h, in
             int mnx = wave_min_i(mine ? x : INT_MAX), mxx = wave_max_i(mine ? x : INT_MIN);
             int mny = wave_min_i(mine ? y : INT_MAX), mxy = wave_max_i(mine ? y : INT_MIN);
             if (lane == leader) {
-                const int sl = agg_slot(h.key, L);
-                atomicAdd(&h.cnt[sl], cm);
-                atomicMin(&h.mnx[sl], mnx); atomicMax(&h.mxx[sl], mxx);
-                atomicMin(&h.mny[sl], mny); atomicMax(&h.mxy[sl], mxy);
+                const int sl = tab_slot(h.key, L);
+                if (sl >= 0) {
+                    atomicAdd(&h.cnt[sl], cm);
+                    atomicMin(&h.mnx[sl], mnx); atomicMax(&h.mxx[sl], mxx);
+                    atomicMin(&h.mny[sl], mny); atomicMax(&h.mxy[sl], mxy);
+                } else {
+                    atomicAdd(&t.count[L], cm);
+                    atomicMin(&t.minx[L], mnx); atomicMax(&t.maxx[L], mxx);
+                    atomicMin(&t.miny[L], mny); atomicMax(&t.maxy[L], mxy);
+                }
             }
         } else if (mine) {
-            atomicAdd(&t.row[L].count, 1);
-            atomicMin(&t.row[L].min_x, x); atomicMax(&t.row[L].max_x, x);
-            atomicMin(&t.row[L].min_y, y); atomicMax(&t.row[L].max_y, y);
+            atomicAdd(&t.count[L], 1);
+            atomicMin(&t.minx[L], x); atomicMax(&t.maxx[L], x);
+            atomicMin(&t.miny[L], y); atomicMax(&t.maxy[L], y);
         }
         pending &= ~m;
     }
+}
+// level 2 -> global: one set of atomics per key of the workgroup
+__device__ __forceinline__ void table_flush(const Table& t, TableLds& h)
+{
     __syncthreads();
-    if (threadIdx.x < AGG_H && h.key[threadIdx.x] >= 0) {
-        const int k = threadIdx.x, L = h.key[k];
-        atomicAdd(&t.row[L].count, h.cnt[k]);
-        atomicMin(&t.row[L].min_x, h.mnx[k]); atomicMax(&t.row[L].max_x, h.mxx[k]);
-        atomicMin(&t.row[L].min_y, h.mny[k]); atomicMax(&t.row[L].max_y, h.mxy[k]);
+    for (int k = threadIdx.x; k < TAB_H; k += blockDim.x) {
+        if (h.key[k] < 0) continue;
+        const int L = h.key[k];
+        atomicAdd(&t.count[L], h.cnt[k]);
+        atomicMin(&t.minx[L], h.mnx[k]); atomicMax(&t.maxx[L], h.mxx[k]);
+        atomicMin(&t.miny[L], h.mny[k]); atomicMax(&t.maxy[L], h.mxy[k]);
     }
 }
 
@@ -1211,6 +1269,7 @@ __device__ __forceinline__ void table_accumulate(const Table& t, TableLds& h, in
 // per wave first: sorted order keeps a cluster's PETs in neighbouring lanes, so a wave
 // usually carries a handful of labels and a giant cluster costs 5 atomics per wave, not
 // 5 per PET.
+#define FINAL_CHUNKS 4          // PETs per workgroup = FINAL_CHUNKS * BIGTPB: one LDS table, one flush
 __global__ void __launch_bounds__(BIGTPB)
 k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ sv,
                const int* __restrict__ sa, const u32* __restrict__ srow, const int* __restrict__ owner,
@@ -1219,18 +1278,21 @@ k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __r
     __shared__ TableLds h;
     table_lds_init(h);
     const int M = strip_start[g.S];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int lab = -1, x = 0, y = 0;
-    if (i < M) {
-        const int o = owner_root(owner[i]);
-        if (o >= 0) lab = rlabel[o];
-        labels[srow[i]] = lab;
-        // X = (v - a) / 2, Y = (v + a) / 2 exactly (v and a have equal parity)
-        int pp = sa[i] + g.A0, qq = sv[i] + g.V0;
-        int a = g.swap ? qq : pp, v = g.swap ? pp : qq;
-        x = (v - a) / 2; y = (v + a) / 2;
+    for (int ch = 0; ch < FINAL_CHUNKS; ++ch) {
+        const int i = (blockIdx.x * FINAL_CHUNKS + ch) * BIGTPB + threadIdx.x;
+        int lab = -1, x = 0, y = 0;
+        if (i < M) {
+            const int o = owner_root(owner[i]);
+            if (o >= 0) lab = rlabel[o];
+            labels[srow[i]] = lab;
+            // X = (v - a) / 2, Y = (v + a) / 2 exactly (v and a have equal parity)
+            int pp = sa[i] + g.A0, qq = sv[i] + g.V0;
+            int a = g.swap ? qq : pp, v = g.swap ? pp : qq;
+            x = (v - a) / 2; y = (v + a) / 2;
+        }
+        table_accumulate(t, h, lab, x, y);
     }
-    table_accumulate(t, h, lab, x, y);
+    table_flush(t, h);
 }
 
 
@@ -1478,6 +1540,7 @@ k_blk_point_labels(BlkParams p, const BlkScalars* __restrict__ sc, const int* __
         x = sx[i]; y = sy[i];
     }
     table_accumulate(t, h, lab, x, y);
+    table_flush(t, h);
 }
 
 // ==========================================================================================
@@ -1490,12 +1553,12 @@ k_blk_point_labels(BlkParams p, const BlkScalars* __restrict__ sc, const int* __
 // ~20x the clustering itself, so the sums are reduced here (fixed order: deterministic) and the
 // median comes from an exact 4-pass radix select on the integer distances.
 // group 0 = inter, group 1 = self (+ short), -1 = in no group
-__global__ void k7_classify(const int* __restrict__ hdr, const cl_box* __restrict__ rows, signed char* __restrict__ cls)
+__global__ void k7_classify(const int* __restrict__ hdr, Table t, signed char* __restrict__ cls)
 {
     const int K = hdr[0];
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
-    const cl_box b = rows[k];
+    const cl_box b = t.get(k);
     signed char c = -1;
     if (b.count > 0 && b.min_x != b.max_x && b.min_y != b.max_y)           // pipe.py:83-85
         c = (b.max_x < b.min_y) ? 0 : 1;                                    // pipe.py:97
@@ -2062,12 +2125,12 @@ __global__ void k_pack_header(int* __restrict__ hdr, const int* __restrict__ ran
 // does not, without a round trip) and stores the K rows straight into pinned host memory, counting
 // the non-empty ids on the way.  cl_wait() then needs no GPU work at all -- a copy issued there
 // would queue behind the kernels of the next run that is already executing.
-__global__ void k_export_table(int* __restrict__ hdr, const cl_box* __restrict__ rows, cl_box* __restrict__ host_rows, int cap)
+__global__ void k_export_table(int* __restrict__ hdr, Table t, cl_box* __restrict__ host_rows, int cap)
 {
     const int K = hdr[0];
     int nc = 0, ml = -1;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K && k < cap; k += gridDim.x * blockDim.x) {
-        cl_box b = rows[k];
+        cl_box b = t.get(k);
         if (b.count > 0) { ++nc; ml = k; } else { b.min_x = b.max_x = b.min_y = b.max_y = 0; }
         host_rows[k] = b;
     }
@@ -2078,6 +2141,16 @@ __global__ void k_export_table(int* __restrict__ hdr, const cl_box* __restrict__
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && K > cap) hdr[5] = 1;
 }
+
+static Table make_table_slot(cl_chrom* c, int slot)
+{
+    Table t;
+    int* base = c->slot[slot].table.as<int>();
+    const size_t stride = (size_t)c->n + 1;
+    t.count = base; t.minx = base + stride; t.maxx = base + 2 * stride; t.miny = base + 3 * stride; t.maxy = base + 4 * stride;
+    return t;
+}
+static Table make_table(cl_chrom* c) { return make_table_slot(c, c->cur); }
 
 static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* labels_out)
 {
@@ -2090,7 +2163,7 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
         sl.h_boxes_cap = cap;
     }
     hipLaunchKernelGGL(k_pack_header, dim3(1), dim3(64), 0, c->stream, dh, c->rankscan.as<int>() + n, c->counters.as<int>(), d_M);
-    hipLaunchKernelGGL(k_export_table, dim3(256), dim3(TPB), 0, c->stream, dh, sl.table.as<cl_box>(), sl.h_boxes, (int)std::min<size_t>(sl.h_boxes_cap, 0x7fffffff));
+    hipLaunchKernelGGL(k_export_table, dim3(256), dim3(TPB), 0, c->stream, dh, make_table(c), sl.h_boxes, (int)std::min<size_t>(sl.h_boxes_cap, 0x7fffffff));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sl.ev_done, c->stream));
     ev_record(c, 6);
@@ -2140,13 +2213,14 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
         size_t cap = (size_t)K + (size_t)K / 4 + 1024;
         HIP_TRY(hipHostMalloc((void**)&sl.h_boxes, cap * sizeof(cl_box), hipHostMallocDefault));
         sl.h_boxes_cap = cap;
-        HIP_TRY(hipMemcpyAsync(sl.h_boxes, sl.table.p, (size_t)K * sizeof(cl_box), hipMemcpyDeviceToHost, c->aux_stream));
+        // slow path (first run with very many clusters): export again into the larger buffer
+        int* dh = c->hdr.as<int>() + 16 * w;
+        int reset[3] = {0, -1, 0};
+        HIP_TRY(hipMemcpyAsync(dh + 3, reset, 12, hipMemcpyHostToDevice, c->aux_stream));
+        hipLaunchKernelGGL(k_export_table, dim3(256), dim3(TPB), 0, c->aux_stream, dh, make_table_slot(c, w), sl.h_boxes, (int)std::min<size_t>(cap, 0x7fffffff));
+        HIP_TRY(hipMemcpyAsync(sl.h_hdr, dh, 32, hipMemcpyDeviceToHost, c->aux_stream));
         HIP_TRY(hipStreamSynchronize(c->aux_stream));
-        nc = 0; ml = -1;
-        for (int k = 0; k < K; ++k) {
-            cl_box& b = sl.h_boxes[k];
-            if (b.count > 0) { ++nc; ml = k; } else { b.min_x = b.max_x = b.min_y = b.max_y = 0; }
-        }
+        nc = sl.h_hdr[3]; ml = sl.h_hdr[4];
     }
     if (n_clusters) *n_clusters = nc;
     if (max_label) *max_label = ml;
@@ -2172,12 +2246,6 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
     return CL_OK;
 }
 
-static Table make_table(cl_chrom* c)
-{
-    Table t;
-    t.row = c->slot[c->cur].table.as<cl_box>();
-    return t;
-}
 
 static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, int32_t* labels_out);
 
@@ -2371,7 +2439,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     ev_record(c, 4);
     // K4
     hipLaunchKernelGGL(k_border, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(),
-                       srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>());
+                       c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>());
     if (variant == CL_VARIANT_CDBSCAN2) {
         const int rec_cap = n;
         LAUNCH(k_mark_uncertain, n, g, strip, c->root.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->state.as<int>(),
@@ -2396,7 +2464,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     // rlabel reuses the chainhead buffer (free after k_chain_parent)
     LAUNCH(k_root_labels, n, g, strip, c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
            c->state.as<int>(), c->rankscan.as<int>(), c->chainhead.as<int>());
-    hipLaunchKernelGGL(k_final_labels, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow, c->owner.as<int>(),
+    hipLaunchKernelGGL(k_final_labels, dim3(nblocks(n, BIGTPB * FINAL_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow, c->owner.as<int>(),
                        c->chainhead.as<int>(), c->slot[c->cur].labels.as<int>(), t);
     HIP_TRY(hipGetLastError());
     return finish_enqueue(c, g.S + 2, strip + g.S, labels_out);
@@ -2417,7 +2485,7 @@ static int k7_prepare(cl_chrom* c)
     if (!c->k7_classified) {
         cl_chrom::Slot& sl = c->slot[c->last_slot];
         int* dh = c->hdr.as<int>() + 16 * c->last_slot;
-        LAUNCH(k7_classify, c->n + 1, dh, sl.table.as<cl_box>(), c->k7_cls.as<signed char>());
+        LAUNCH(k7_classify, c->n + 1, dh, make_table_slot(c, c->last_slot), c->k7_cls.as<signed char>());
         c->k7_classified = true;
     }
     return CL_OK;
