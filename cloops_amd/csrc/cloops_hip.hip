@@ -740,7 +740,8 @@ __global__ void k_cell_heads(int n, const int* __restrict__ sv, const int* __res
 // (self-ligation PETs) become one chain per strip.
 __global__ void __launch_bounds__(TPB)
 k_chain_flags(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
-              const int* __restrict__ strip_start, const int* __restrict__ cnt, int* __restrict__ chainflag)
+              const int* __restrict__ strip_start, const int* __restrict__ cnt, int* __restrict__ chainflag,
+              int* __restrict__ chainlast)
 {
     __shared__ int2 lw[T_WIN];
     __shared__ int lx[T_WIN];
@@ -749,15 +750,20 @@ k_chain_flags(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     if (!tile_stage(t, lw, lx, ntiles, M, sv, sa, cnt)) return;
     const int i = t.t0 + threadIdx.x;
     if (i >= M) return;
-    int f = 0;
+    int f = 0, last = 0;
     if (t.x[i] >= g.minPts) {
         const int2 me = t.w[i];
-        const int b = strip_start[strip_of(g, me.y)];
+        const int s = strip_of(g, me.y);
+        const int b = strip_start[s], e = strip_start[s + 1];
         f = i + 1;
-        tile_visit_own(t, sv, cnt, i, b, 0, sat_add(me.x, -g.eps), 0, 1,
+        last = 1;
+        tile_visit_own(t, sv, cnt, i, b, e, sat_add(me.x, -g.eps), sat_add(me.x, g.eps), 1,
                        [&](int, int cj) { if (cj >= g.minPts) { f = 0; return true; } return false; });
+        tile_visit_own(t, sv, cnt, i, b, e, sat_add(me.x, -g.eps), sat_add(me.x, g.eps), 2,
+                       [&](int, int cj) { if (cj >= g.minPts) { last = 0; return true; } return false; });
     }
     chainflag[i] = f;
+    chainlast[i] = last;        // 1 = last core of its chain: its q is the chain's upper end
 }
 // parent[] = chain head for core points (flat forest to start from); chainid[] = the same for
 // core points and -1 for everything else (what the union kernel stages as its payload)
@@ -766,7 +772,8 @@ k_chain_flags(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
 __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const int* __restrict__ cnt, int minPts,
                                const int* __restrict__ chainhead, int* __restrict__ parent, int* __restrict__ chainid,
                                int* __restrict__ compkey, int* __restrict__ ncore, int* __restrict__ bsize,
-                               int* __restrict__ usize, int* __restrict__ state)
+                               int* __restrict__ usize, int* __restrict__ state, const int* __restrict__ chainlast,
+                               const int* __restrict__ sv, int* __restrict__ chain_qend)
 {
     const int M = strip_start[S];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -776,6 +783,7 @@ __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const
     parent[i] = core ? h : i;
     chainid[i] = h;
     if (h == i) { compkey[i] = INT_MAX; ncore[i] = 0; bsize[i] = 0; usize[i] = 0; state[i] = ST_LIVE; }
+    if (core && chainlast[i]) chain_qend[h] = sv[i];        // indexed by chain head
 }
 
 // Cross-strip edges: a core i of strip s against the cores of strip s-1 in its window (the
@@ -786,7 +794,8 @@ __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const
 #define UNION_MAXB 4
 __global__ void __launch_bounds__(TPB)
 k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
-              const int* __restrict__ strip_start, const int* __restrict__ chainid, int* parent)
+              const int* __restrict__ strip_start, const int* __restrict__ chainid, const int* __restrict__ chain_qend,
+              int* parent)
 {
     __shared__ int2 lw[T_WIN];
     __shared__ int lx[T_WIN];
@@ -808,11 +817,8 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     int nb = 0;
     if (s > 0) {
         const int tb = strip_start[s - 1], b = strip_start[s];
-        tile_visit_segment(t, sv, sa, chainid, tb, b, sat_add(me.x, -g.eps), sat_add(me.x, g.eps),
-                           [&](int, int, int pj, int B) {
-            if (B < 0) return;
-            const int da = pj - me.y;
-            if ((da < 0 ? -da : da) > g.eps) return;
+        const int qlo = sat_add(me.x, -g.eps), qhi = sat_add(me.x, g.eps);
+        auto touch = [&](int B) {
             bool seen = false;
 #pragma unroll
             for (int k = 0; k < UNION_MAXB; ++k) seen |= (Bs[k] == B);
@@ -824,7 +830,36 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
             } else {
                 uf_unite(parent, A, B);                    // more chains than slots: unite right away
             }
-        });
+        };
+        if (tb >= t.wbeg && b - tb <= 255) {
+            // short strips: the whole neighbour strip is staged
+            tile_visit_segment(t, sv, sa, chainid, tb, b, qlo, qhi, [&](int, int, int pj, int B) {
+                if (B < 0) return;
+                const int da = pj - me.y;
+                if ((da < 0 ? -da : da) <= g.eps) touch(B);
+            });
+        } else {
+            // long strips (dense data at large eps: hundreds of candidates per window, nearly all of them in
+            // ONE chain): once a chain has been touched the scan jumps past its last core, whose q is
+            // chain_qend[chain] -- a window that is one chain costs two searches instead of a full scan
+            int k = lower_bound_4(sv, tb, b, qlo);
+            while (k < b) {
+                const int qk = sv[k];
+                if (qk > qhi) break;
+                const int B = chainid[k];
+                if (B >= 0) {
+                    const int da = sa[k] - me.y;
+                    if ((da < 0 ? -da : da) <= g.eps) {
+                        touch(B);
+                        const int qe = chain_qend[B];
+                        if (qe >= qhi) break;
+                        k = lower_bound_4(sv, k + 1, b, qe + 1);
+                        continue;
+                    }
+                }
+                ++k;
+            }
+        }
     }
     const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -2425,15 +2460,18 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         // own-strip chains by scan (headidx / head buffers are free again here for variant 2:
         // k_cell_first has consumed them into cellfirst... they are still needed by k_flatten,
         // so the chain scan uses its own pair of buffers)
-        hipLaunchKernelGGL(k_chain_flags, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, cnt, c->chainflag.as<int>());
+        hipLaunchKernelGGL(k_chain_flags, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, cnt, c->chainflag.as<int>(),
+                           c->headidx.as<int>());          // headidx is free again after the cell-head scan
         size_t tb = c->scan_tmp.bytes;
         hipError_t e = rocprim::inclusive_scan(c->scan_tmp.p, tb, c->chainflag.as<int>(), c->chainhead.as<int>(), (size_t)n,
                                                rocprim::maximum<int>(), c->stream);
         if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan(chain)", hipGetErrorString(e));
         LAUNCH(k_chain_parent, n, strip, g.S, cnt, g.minPts, c->chainhead.as<int>(), c->parent.as<int>(), c->chainflag.as<int>(),
-               c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>());
+               c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
+               c->headidx.as<int>(), sv, c->lo.as<int>());   // chain ends live in `lo` until the release fix-up reuses it
     }
-    hipLaunchKernelGGL(k_union_cores, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->parent.as<int>());
+    hipLaunchKernelGGL(k_union_cores, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
+                       c->parent.as<int>());
     hipLaunchKernelGGL(k_flatten, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
            c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>());
     ev_record(c, 4);

@@ -130,3 +130,15 @@ def test_large_eps_giant_component_16M():
                 int(sel.sum()), int(X[sel].min()), int(X[sel].max()), int(Y[sel].min()), int(Y[sel].max()))
     finally:
         ch.close()
+
+
+@pytest.mark.parametrize("n,L,eps,minPts", [(300000, 3000000, 20000, 30), (300000, 3000000, 20000, 5),
+                                            (600000, 3000000, 50000, 100), (200000, 1000000, 3000, 8)])
+def test_strips_longer_than_the_lds_window(n, L, eps, minPts):
+    """dense data at large eps: a strip holds ~1000 PETs, tiles lie inside one strip and the neighbour
+    strips are staged as separate (capped) far windows -- every source of a window is exercised:
+    main LDS window, far window, capped far window + global continuation, plain global"""
+    from cloops_amd.synth import synth_chrom
+    X, Y = synth_chrom(n, L, 99)
+    run_all(X, Y, eps, minPts)
+    run_all(X, Y, eps, minPts, cut=eps // 2, variants=["v2"])
