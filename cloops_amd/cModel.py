@@ -247,32 +247,47 @@ def _windows(records):
     return iva, ivb, distance, np.concatenate([lo, hi], 1).astype(np.int32)
 
 
+def _overlap_lists(iv, chrom, chunk=256):
+    """for every loop i the ascending array of j > i whose two anchors both overlap i's
+    (checkOverlap, cModel.py:174-195), from chunked broadcast comparisons"""
+    L = len(iv)
+
+    def one_end(xa, xb, ya, yb):           # checkOneEndOverlap, cModel.py:174-182 (xa,xb: column vectors)
+        t1 = ((ya <= xa) & (xa <= yb)) | ((ya <= xb) & (xb <= yb)) | ((ya <= xa) & (xa <= xb) & (xb <= yb))
+        t2 = ((xa <= ya) & (ya <= xb)) | ((xa <= yb) & (yb <= xb)) | ((xa <= ya) & (ya <= yb) & (yb <= xb))
+        return t1 | t2
+    _, cid = np.unique(chrom, return_inverse=True)
+    adj = [None] * L
+    for r0 in range(0, L, chunk):
+        r1 = min(L, r0 + chunk)
+        a = iv[r0:r1]
+        ok = (cid[r0:r1, None] == cid[None, :])
+        ok &= one_end(a[:, 0:1], a[:, 1:2], iv[None, :, 0], iv[None, :, 1])
+        ok &= one_end(a[:, 2:3], a[:, 3:4], iv[None, :, 2], iv[None, :, 3])
+        for i in range(r0, r1):
+            js = np.nonzero(ok[i - r0, i + 1:])[0]
+            adj[i] = js + (i + 1)
+    return adj
+
+
 def _remove_dup_fast(ds, bpcut=1e-5):
-    """removeDup (cModel.py:198-259) with the inner overlap scan vectorised; same visiting order,
-    same `rekeys` bookkeeping, same result."""
+    """removeDup (cModel.py:198-259) with the overlap tests vectorised; same visiting order, same
+    `rekeys` bookkeeping, same result."""
     keys = list(ds.keys())
     L = len(keys)
     if L == 0:
         return {}
     iv = np.asarray([parseIv(ds[k]["iva"])[1:] + parseIv(ds[k]["ivb"])[1:] for k in keys], dtype=np.int64)
     chrom = np.asarray([ds[k]["iva"].split(":")[0] + "|" + ds[k]["ivb"].split(":")[0] for k in keys])
+    adj = _overlap_lists(iv, chrom)
     removed = np.zeros(L, bool)
     uniqueds, reds = {}, {}
-
-    def one_end(xa, xb, ya, yb):           # checkOneEndOverlap, cModel.py:174-182
-        t1 = ((ya <= xa) & (xa <= yb)) | ((ya <= xb) & (xb <= yb)) | ((ya <= xa) & (xa <= xb) & (xb <= yb))
-        t2 = ((xa <= ya) & (ya <= xb)) | ((xa <= yb) & (yb <= xb)) | ((xa <= ya) & (ya <= yb) & (yb <= xb))
-        return t1 | t2
     for i in range(L - 1):
         if removed[i]:
             continue
-        js = np.arange(i + 1, L)
-        js = js[~removed[i + 1:]]
-        hit = np.zeros(0, np.int64)
-        if len(js):
-            ok = (chrom[js] == chrom[i]) & one_end(iv[i, 0], iv[i, 1], iv[js, 0], iv[js, 1]) & \
-                one_end(iv[i, 2], iv[i, 3], iv[js, 2], iv[js, 3])
-            hit = js[ok]
+        hit = adj[i]
+        if len(hit):
+            hit = hit[~removed[hit]]
         if len(hit):
             reds[keys[i]] = [keys[i]] + [keys[j] for j in hit.tolist()]
             removed[i] = True

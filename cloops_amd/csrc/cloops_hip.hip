@@ -262,18 +262,26 @@ __global__ void k_stats(const int* __restrict__ X, const int* __restrict__ Y, lo
         int vi = (int)max(min(v, (long long)INT_MAX), (long long)INT_MIN);
         amin = min(amin, ai); amax = max(amax, ai); vmin = min(vmin, vi); vmax = max(vmax, vi);
     }
-    // wave reduction, then one atomic per wave
+    // wave reduction, workgroup reduction in LDS, then one set of atomics per workgroup
     for (int off = 32; off > 0; off >>= 1) {
         amin = min(amin, __shfl_down(amin, off)); amax = max(amax, __shfl_down(amax, off));
         vmin = min(vmin, __shfl_down(vmin, off)); vmax = max(vmax, __shfl_down(vmax, off));
         xmin = min(xmin, __shfl_down(xmin, off)); xmax = max(xmax, __shfl_down(xmax, off));
         ymin = min(ymin, __shfl_down(ymin, off)); ymax = max(ymax, __shfl_down(ymax, off));
     }
+    __shared__ int red[TPB / 64][8];
+    const int wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        atomicMin(&out->amin, amin); atomicMax(&out->amax, amax);
-        atomicMin(&out->vmin, vmin); atomicMax(&out->vmax, vmax);
-        atomicMin(&out->xmin, xmin); atomicMax(&out->xmax, xmax);
-        atomicMin(&out->ymin, ymin); atomicMax(&out->ymax, ymax);
+        red[wv][0] = amin; red[wv][1] = amax; red[wv][2] = vmin; red[wv][3] = vmax;
+        red[wv][4] = xmin; red[wv][5] = xmax; red[wv][6] = ymin; red[wv][7] = ymax;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const bool is_min = (threadIdx.x & 1) == 0;
+        int v = red[0][threadIdx.x];
+        for (int w = 1; w < TPB / 64; ++w) v = is_min ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
+        int* dst = &out->amin + threadIdx.x;          // Stats is 8 consecutive ints in this order
+        if (is_min) atomicMin(dst, v); else atomicMax(dst, v);
     }
 }
 
@@ -1973,7 +1981,7 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
             Stats* hs = (Stats*)c->h_pinned;
             *hs = init;
             if (hipMemcpyAsync(c->counters.p, hs, sizeof(Stats), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(CL_ERR_HIP, "stats init"); break; }
-            int grid = std::min(nblocks(n), 2048);
+            int grid = std::min(nblocks(n), 512);
             hipLaunchKernelGGL(k_stats, dim3(grid), dim3(TPB), 0, c->stream, c->d_x, c->d_y, (long long)n, (Stats*)c->counters.p);
             if (hipMemcpyAsync(hs, c->counters.p, sizeof(Stats), hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(CL_ERR_HIP, "stats readback"); break; }
             hipError_t e = hipStreamSynchronize(c->stream);
