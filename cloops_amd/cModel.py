@@ -247,27 +247,50 @@ def _windows(records):
     return iva, ivb, distance, np.concatenate([lo, hi], 1).astype(np.int32)
 
 
-def _overlap_lists(iv, chrom, chunk=256):
+def _overlap_lists(iv, chrom):
     """for every loop i the ascending array of j > i whose two anchors both overlap i's
-    (checkOverlap, cModel.py:174-195), from chunked broadcast comparisons"""
+    (checkOverlap, cModel.py:174-195).  Candidate pairs come from a sorted sweep over the left anchors
+    (two well-formed intervals can only satisfy checkOneEndOverlap if they intersect); the reference's
+    exact predicate is then evaluated on the candidates, vectorised."""
     L = len(iv)
 
-    def one_end(xa, xb, ya, yb):           # checkOneEndOverlap, cModel.py:174-182 (xa,xb: column vectors)
+    def one_end(xa, xb, ya, yb):           # checkOneEndOverlap, cModel.py:174-182
         t1 = ((ya <= xa) & (xa <= yb)) | ((ya <= xb) & (xb <= yb)) | ((ya <= xa) & (xa <= xb) & (xb <= yb))
         t2 = ((xa <= ya) & (ya <= xb)) | ((xa <= yb) & (yb <= xb)) | ((xa <= ya) & (ya <= yb) & (yb <= xb))
         return t1 | t2
     _, cid = np.unique(chrom, return_inverse=True)
-    adj = [None] * L
-    for r0 in range(0, L, chunk):
-        r1 = min(L, r0 + chunk)
-        a = iv[r0:r1]
-        ok = (cid[r0:r1, None] == cid[None, :])
-        ok &= one_end(a[:, 0:1], a[:, 1:2], iv[None, :, 0], iv[None, :, 1])
-        ok &= one_end(a[:, 2:3], a[:, 3:4], iv[None, :, 2], iv[None, :, 3])
-        for i in range(r0, r1):
-            js = np.nonzero(ok[i - r0, i + 1:])[0]
-            adj[i] = js + (i + 1)
-    return adj
+    a0, a1 = iv[:, 0], iv[:, 1]
+    length = a1 - a0
+    # a few very long anchors would blow up the sweep window: they are paired with everything instead
+    lim = max(1, int(np.percentile(length, 99)) * 4) if L else 1
+    long_idx = np.nonzero(length > lim)[0]
+    short = length <= lim
+    order = np.argsort(a0, kind="stable")
+    S = a0[order]
+    lo = np.searchsorted(S, a0 - lim, side="left")      # sorted positions whose start could still reach a0
+    hi = np.searchsorted(S, a1, side="right")           # ... and do not start after a1
+    cnt = np.maximum(hi - lo, 0)
+    ii = np.repeat(np.arange(L), cnt)
+    off = np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    jj = order[np.repeat(lo, cnt) + off]
+    keep = short[jj]                                    # long partners are added below
+    ii, jj = ii[keep], jj[keep]
+    if len(long_idx):
+        ii = np.concatenate([ii, np.repeat(np.arange(L), len(long_idx))])
+        jj = np.concatenate([jj, np.tile(long_idx, L)])
+    m = jj > ii
+    ii, jj = ii[m], jj[m]
+    ok = (cid[ii] == cid[jj]) & one_end(iv[ii, 0], iv[ii, 1], iv[jj, 0], iv[jj, 1]) & \
+        one_end(iv[ii, 2], iv[ii, 3], iv[jj, 2], iv[jj, 3])
+    ii, jj = ii[ok], jj[ok]
+    o2 = np.lexsort((jj, ii))
+    ii, jj = ii[o2], jj[o2]
+    if len(ii):                                         # a long anchor can be produced by both routes
+        uniq = np.ones(len(ii), bool)
+        uniq[1:] = (ii[1:] != ii[:-1]) | (jj[1:] != jj[:-1])
+        ii, jj = ii[uniq], jj[uniq]
+    bounds = np.searchsorted(ii, np.arange(L + 1))
+    return [jj[bounds[i]:bounds[i + 1]] for i in range(L)]
 
 
 def _remove_dup_fast(ds, bpcut=1e-5):

@@ -69,3 +69,24 @@ def test_counts_are_inclusive_and_use_row_positions():
     assert m.side([100, 150], 1).tolist() == [1, 2]          # Y in [100,150]
     assert m.region([100, 150]).tolist() == [0, 1, 2, 3]
     assert cModel.getPETsforRegions([100, 150], [500, 900], m) == (4, 2, 2)
+
+
+def test_overlap_lists_match_reference_predicate():
+    """the sweep-based candidate enumeration of removeDup == brute-force checkOverlap (cModel.py:174-195)"""
+    rng = np.random.default_rng(0)
+    for t in range(12):
+        L = int(rng.integers(1, 300))
+        a0 = rng.integers(0, 20000, L)
+        a1 = a0 + rng.integers(0, 300, L)
+        b0 = a0 + rng.integers(0, 5000, L)
+        b1 = b0 + rng.integers(0, 300, L)
+        if t % 3 == 0 and L >= 3:
+            a1[:3] = a0[:3] + rng.integers(5000, 30000, 3)          # a few very long anchors
+        iv = np.stack([a0, a1, b0, b1], 1).astype(np.int64)
+        chrom = np.asarray(["c1|c1" if x else "c2|c2" for x in rng.random(L) < 0.8])
+        adj = cModel._overlap_lists(iv, chrom)
+        for i in range(L):
+            want = [j for j in range(i + 1, L)
+                    if cModel.checkOverlap([chrom[i], iv[i, 0], iv[i, 1]], [chrom[i], iv[i, 2], iv[i, 3]],
+                                           [chrom[j], iv[j, 0], iv[j, 1]], [chrom[j], iv[j, 2], iv[j, 3]])]
+            assert adj[i].tolist() == want
