@@ -2529,7 +2529,6 @@ static int k7_prepare(cl_chrom* c)
     if ((rc = c->k7_cls.ensure((size_t)c->n + 16))) return rc;
     if ((rc = c->k7_parts.ensure(K7_BLOCKS * sizeof(K7Part) + 4096))) return rc;
     if (!c->k7_classified) {
-        cl_chrom::Slot& sl = c->slot[c->last_slot];
         int* dh = c->hdr.as<int>() + 16 * c->last_slot;
         LAUNCH(k7_classify, c->n + 1, dh, make_table_slot(c, c->last_slot), c->k7_cls.as<signed char>());
         c->k7_classified = true;
