@@ -1354,19 +1354,32 @@ struct BlkParams {
     int eps, minPts, cut;
     int R;            // rows of the cell-row table; key row R marks filtered PETs
     int n;
+    int nyb, rb;      // sort key = ((nx << nyb | ny) << 2*rb) | rx << rb | ry ; only the cell bits are sorted
+    u32 magic; int sh1, sh2;      // v / eps by multiply-shift (same constants as GridParams)
 };
+__device__ __forceinline__ u32 blk_div(const BlkParams& p, u32 n)
+{
+    const u32 t1 = __umulhi(p.magic, n);
+    return (t1 + ((n - t1) >> p.sh1)) >> p.sh2;
+}
 struct BlkScalars { int minx, miny, M, C; };
 
 __global__ void k_blk_minmax(const int* __restrict__ X, const int* __restrict__ Y, int n, int cut, BlkScalars* sc)
 {
+    __shared__ int red[2][TPB / 64];
     int mx = INT_MAX, my = INT_MAX;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int x = X[i], y = Y[i];
-        if (cut > 0 && y - x < cut) continue;
+        if (y - x < cut) continue;
         mx = min(mx, x); my = min(my, y);
     }
     for (int o = 32; o > 0; o >>= 1) { mx = min(mx, __shfl_down(mx, o)); my = min(my, __shfl_down(my, o)); }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&sc->minx, mx); atomicMin(&sc->miny, my); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = mx; red[1][threadIdx.x >> 6] = my; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TPB / 64; ++w) { mx = min(mx, red[0][w]); my = min(my, red[1][w]); }
+        if (mx != INT_MAX) { atomicMin(&sc->minx, mx); atomicMin(&sc->miny, my); }
+    }
 }
 
 __global__ void k_blk_keys(const int* __restrict__ X, const int* __restrict__ Y, BlkParams p, const BlkScalars* __restrict__ sc,
@@ -1377,25 +1390,34 @@ __global__ void k_blk_keys(const int* __restrict__ X, const int* __restrict__ Y,
     int x = X[r], y = Y[r];
     bool valid = (p.cut <= 0) || (y - x >= p.cut);
     // nx = int((X - minX) / cw) + 1 (:81-82); the +1 is dropped (cells are only compared)
-    u32 nx = valid ? (u32)((x - sc->minx) / p.eps) : (u32)p.R;
-    u32 ny = valid ? (u32)((y - sc->miny) / p.eps) : 0u;
-    keys[r] = ((u64)nx << 32) | ny;
+    u64 key = (u64)(u32)p.R << (p.nyb + 2 * p.rb);
+    if (valid) {
+        const u32 ux = (u32)(x - sc->minx), uy = (u32)(y - sc->miny);
+        const u32 nx = blk_div(p, ux), ny = blk_div(p, uy);
+        const u32 rx = ux - nx * (u32)p.eps, ry = uy - ny * (u32)p.eps;
+        key = ((((u64)nx << p.nyb) | ny) << (2 * p.rb)) | ((u64)rx << p.rb) | ry;
+    }
+    keys[r] = key;
     vals[r] = (u32)r;
 }
 
-__global__ void k_blk_gather(const int* __restrict__ X, const int* __restrict__ Y, BlkParams p,
-                             const u64* __restrict__ skeys, const u32* __restrict__ srow,
+// decode the sorted keys back into coordinates (no gather), mark cell heads
+__global__ void k_blk_gather(BlkParams p, const u64* __restrict__ skeys,
                              int* __restrict__ sx, int* __restrict__ sy, int* __restrict__ headflag, BlkScalars* sc)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n) return;
-    u64 k = skeys[i];
-    bool valid = (u32)(k >> 32) < (u32)p.R;
-    u32 r = srow[i];
-    sx[i] = X[r]; sy[i] = Y[r];
-    bool head = valid && (i == 0 || skeys[i - 1] != k);
-    headflag[i] = head ? 1 : 0;
-    if (!valid && (i == 0 || (u32)(skeys[i - 1] >> 32) < (u32)p.R)) sc->M = i;   // first filtered row
+    const int cb = 2 * p.rb;
+    const u64 k = skeys[i];
+    const u64 cell = k >> cb;
+    const u32 nx = (u32)(cell >> p.nyb), ny = (u32)(cell & ((1ull << p.nyb) - 1));
+    const bool valid = nx < (u32)p.R;
+    const u32 rmask = (1u << p.rb) - 1;
+    sx[i] = sc->minx + (int)(nx * (u32)p.eps + ((u32)(k >> p.rb) & rmask));
+    sy[i] = sc->miny + (int)(ny * (u32)p.eps + ((u32)k & rmask));
+    const u64 prev = i ? (skeys[i - 1] >> cb) : ~0ull;
+    headflag[i] = (valid && prev != cell) ? 1 : 0;
+    if (!valid && (i == 0 || (u32)(prev >> p.nyb) < (u32)p.R)) sc->M = i;   // first filtered row
     if (valid && i == p.n - 1) sc->M = p.n;
 }
 
@@ -1410,7 +1432,7 @@ __global__ void k_blk_cells(BlkParams p, const u64* __restrict__ skeys, const in
     if (headflag[i]) {
         int c = cidp1[i] - 1;
         cstart[c] = i;
-        ckey[c] = skeys[i];
+        ckey[c] = skeys[i] >> (2 * p.rb);
         cfirst[c] = (int)srow[i];       // stable sort: first of the run = smallest input row
     }
     if (i == M - 1) { int C = cidp1[i]; sc->C = C; cstart[C] = M; }
@@ -1423,51 +1445,69 @@ __global__ void k_blk_rowtable(BlkParams p, const BlkScalars* __restrict__ sc, c
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r > p.R) return;
     const int C = sc->C;
-    u64 target = (u64)(u32)r << 32;
+    u64 target = (u64)(u32)r << p.nyb;
     int lo = 0, hi = C;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (ckey[mid] < target) lo = mid + 1; else hi = mid; }
     rowcell[r] = lo;
 }
 
-__device__ __forceinline__ int blk_find_cell(const u64* __restrict__ ckey, const int* __restrict__ rowcell, int R,
-                                             long long nx, long long ny)
-{
-    if (nx < 0 || nx >= R || ny < 0) return -1;
-    u64 target = ((u64)(u32)nx << 32) | (u32)ny;
-    int lo = rowcell[nx], hi = rowcell[nx + 1];
-    while (lo < hi) { int mid = (lo + hi) >> 1; if (ckey[mid] < target) lo = mid + 1; else hi = mid; }
-    return (lo < rowcell[nx + 1] && ckey[lo] == target) ? lo : -1;
-}
-
-// neighbour indices (8 per cell), 9-cell population test, centroids
+// neighbour indices (8 per cell, order (dx,dy) = (-1,-1),(-1,0),(-1,1),(0,-1),(0,1),(1,-1),(1,0),(1,1); the
+// reverse of direction q is 7-q), 9-cell population test, centroids.  Cells of one row are consecutive in
+// the cell table, so each neighbouring row costs ONE binary search (for ny-1) plus a walk over <= 3 cells.
 __global__ void k_blk_neighbors(BlkParams p, const BlkScalars* __restrict__ sc, const u64* __restrict__ ckey,
                                 const int* __restrict__ rowcell, const int* __restrict__ cstart,
                                 const int* __restrict__ sx, const int* __restrict__ sy,
                                 int* __restrict__ nb, int* __restrict__ low, double* __restrict__ cx, double* __restrict__ cy)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= sc->C) return;
-    u64 k = ckey[c];
-    long long nx = (long long)(u32)(k >> 32), ny = (long long)(u32)(k & 0xffffffffu);
-    int tot = cstart[c + 1] - cstart[c];
-    int q = 0;
-    for (int dx = -1; dx <= 1; ++dx)
-        for (int dy = -1; dy <= 1; ++dy) {
-            if (!dx && !dy) continue;
-            int j = blk_find_cell(ckey, rowcell, p.R, nx + dx, ny + dy);
-            nb[(size_t)c * 8 + q++] = j;
-            if (j >= 0) tot += cstart[j + 1] - cstart[j];
+    const int C = sc->C;
+    if (c >= C) return;
+    const u64 k = ckey[c];
+    const long long nx = (long long)(k >> p.nyb), ny = (long long)(k & ((1ull << p.nyb) - 1));
+    const int cb = cstart[c], ce = cstart[c + 1];
+    int tot = ce - cb;
+    int res[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) res[q] = -1;
+    // same row: the neighbours are c-1 / c+1 when their keys are k-1 / k+1 (ny-1 >= 0 checked: k-1 would borrow)
+    if (ny > 0 && c > 0 && ckey[c - 1] == k - 1) res[3] = c - 1;
+    if (c + 1 < C && ckey[c + 1] == k + 1 && ny + 1 < (1ll << p.nyb)) res[4] = c + 1;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const long long rx = nx + (side ? 1 : -1);
+        if (rx < 0 || rx >= p.R) continue;
+        const int rlo = rowcell[rx], rhi = rowcell[rx + 1];
+        const long long y0 = ny > 0 ? ny - 1 : 0;
+        const u64 target = ((u64)rx << p.nyb) | (u64)y0;
+        int lo = rlo, hi = rhi;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (ckey[mid] < target) lo = mid + 1; else hi = mid; }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (lo >= rhi) break;
+            const long long yy = (long long)(ckey[lo] & ((1ull << p.nyb) - 1));
+            const long long d = yy - ny;
+            if (d > 1) break;
+            if (d == -1) res[side * 5 + 0] = lo;       // side 0 -> q 0..2, side 1 -> q 5..7
+            if (d == 0) res[side * 5 + 1] = lo;
+            if (d == 1) res[side * 5 + 2] = lo;
+            ++lo;
         }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (res[q] >= 0) tot += cstart[res[q] + 1] - cstart[res[q]];
+    int4* o = reinterpret_cast<int4*>(nb + (size_t)c * 8);
+    o[0] = make_int4(res[0], res[1], res[2], res[3]);
+    o[1] = make_int4(res[4], res[5], res[6], res[7]);
     low[c] = tot < p.minPts ? 1 : 0;
     long long sumx = 0, sumy = 0;
-    for (int t = cstart[c]; t < cstart[c + 1]; ++t) { sumx += sx[t]; sumy += sy[t]; }
-    double m = (double)(cstart[c + 1] - cstart[c]);
+    for (int t = cb; t < ce; ++t) { sumx += sx[t]; sumy += sy[t]; }
+    double m = (double)(ce - cb);
     cx[c] = (double)sumx / m;          // true division of Python ints (:136-137)
     cy[c] = (double)sumy / m;
 }
 
 __global__ void k_blk_alive(const BlkScalars* __restrict__ sc, const int* __restrict__ nb, const int* __restrict__ low,
-                            int* __restrict__ alive)
+                            int* __restrict__ alive, int* __restrict__ linkbits)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= sc->C) return;
@@ -1477,41 +1517,52 @@ __global__ void k_blk_alive(const BlkScalars* __restrict__ sc, const int* __rest
         for (int q = 0; q < 8; ++q) { int j = nb[(size_t)c * 8 + q]; if (j >= 0 && !low[j]) { a = 1; break; } }
     }
     alive[c] = a;
+    linkbits[c] = 0;
 }
 
-// link bits + population sum + core flag
+// link bits: one thread per (cell, forward direction q = 4..7); the link test is symmetric (same centroid
+// distance, same point pairs), so the thread sets bit q of its cell and bit 7-q of the neighbour.
 __global__ void k_blk_links(BlkParams p, const BlkScalars* __restrict__ sc, const int* __restrict__ nb,
                             const int* __restrict__ alive, const int* __restrict__ cstart,
                             const int* __restrict__ sx, const int* __restrict__ sy,
                             const double* __restrict__ cx, const double* __restrict__ cy,
-                            int* __restrict__ linkbits, int* __restrict__ corec)
+                            int* __restrict__ linkbits)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = t >> 2, q = 4 + (t & 3);
+    if (c >= sc->C) return;
+    const int j = nb[(size_t)c * 8 + q];
+    if (j < 0 || !alive[c] || !alive[j]) return;
+    bool linked = (fabs(cx[c] - cx[j]) + fabs(cy[c] - cy[j])) <= (double)p.eps;        // :232
+    if (!linked) {                                                                     // getGridDist :204-213
+        const int cb = cstart[c], ce = cstart[c + 1];
+        const int jb = cstart[j], je = cstart[j + 1];
+        for (int s = cb; s < ce && !linked; ++s) {
+            const int x = sx[s], y = sy[s];
+            for (int u = jb; u < je; ++u) {
+                int dx = x - sx[u], dy = y - sy[u];
+                if ((dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy) <= p.eps) { linked = true; break; }
+            }
+        }
+    }
+    if (linked) { atomicOr(&linkbits[c], 1 << q); atomicOr(&linkbits[j], 1 << (7 - q)); }
+}
+
+// population over the linked cells + core flag (:236-240)
+__global__ void k_blk_core(BlkParams p, const BlkScalars* __restrict__ sc, const int* __restrict__ nb,
+                           const int* __restrict__ alive, const int* __restrict__ cstart,
+                           const int* __restrict__ linkbits, int* __restrict__ corec)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= sc->C) return;
-    int bits = 0, core = 0;
+    int core = 0;
     if (alive[c]) {
-        const int cb = cstart[c], ce = cstart[c + 1];
-        int psum = ce - cb;
-        const double epsd = (double)p.eps;
-        for (int q = 0; q < 8; ++q) {
-            int j = nb[(size_t)c * 8 + q];
-            if (j < 0 || !alive[j]) continue;
-            bool linked = (fabs(cx[c] - cx[j]) + fabs(cy[c] - cy[j])) <= epsd;        // :232
-            if (!linked) {                                                            // getGridDist :204-213
-                const int jb = cstart[j], je = cstart[j + 1];
-                for (int s = cb; s < ce && !linked; ++s) {
-                    const int x = sx[s], y = sy[s];
-                    for (int t = jb; t < je; ++t) {
-                        int dx = x - sx[t], dy = y - sy[t];
-                        if ((dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy) <= p.eps) { linked = true; break; }
-                    }
-                }
-            }
-            if (linked) { bits |= 1 << q; psum += je_minus(cstart, j); }
-        }
+        const int bits = linkbits[c];
+        int psum = cstart[c + 1] - cstart[c];
+        for (int q = 0; q < 8; ++q)
+            if (bits & (1 << q)) psum += je_minus(cstart, nb[(size_t)c * 8 + q]);
         core = psum >= p.minPts ? 1 : 0;
     }
-    linkbits[c] = bits;
     corec[c] = core;
 }
 
@@ -2306,23 +2357,35 @@ static int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_
     ENSB(b_cx, (size_t)n * 8); ENSB(b_cy, (size_t)n * 8);
 #undef ENSB
     BlkParams p; p.eps = eps; p.minPts = minPts; p.cut = cut; p.R = (int)R; p.n = n;
+    p.nyb = std::max(1, bits_for((unsigned)(((long long)c->st.ymax - c->st.ymin) / eps)));
+    p.rb = bits_for((unsigned)(eps - 1));
+    {
+        const unsigned d = (unsigned)eps;
+        int l = 0; while ((1ull << l) < d) ++l;
+        p.magic = (u32)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+        p.sh1 = l < 1 ? l : 1; p.sh2 = l > 1 ? l - 1 : 0;
+    }
     int* counters = c->counters.as<int>();
     BlkScalars* sc = (BlkScalars*)(counters + 32);
     LAUNCH(k_init_arrays, n + 1, n, c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
            c->usize.as<int>(), c->cellfirst.as<int>(), c->flag.as<int>(), c->state.as<int>(), counters);
     HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
     BlkScalars* hsc = (BlkScalars*)(c->h_pinned + 64);
-    hsc->minx = INT_MAX; hsc->miny = INT_MAX; hsc->M = 0; hsc->C = 0;
+    // minX / minY of the (filtered) mat (blockDBSCAN.py:74-80): known from the upload statistics when
+    // nothing is filtered, one reduction pass otherwise
+    hsc->minx = cut > 0 ? INT_MAX : c->st.xmin; hsc->miny = cut > 0 ? INT_MAX : c->st.ymin; hsc->M = 0; hsc->C = 0;
     HIP_TRY(hipMemcpyAsync(sc, hsc, sizeof(BlkScalars), hipMemcpyHostToDevice, c->stream));
     ev_record(c, 0);
-    hipLaunchKernelGGL(k_blk_minmax, dim3(std::min(nblocks(n), 2048)), dim3(TPB), 0, c->stream, c->d_x, c->d_y, n, cut, sc);
+    if (cut > 0)
+        hipLaunchKernelGGL(k_blk_minmax, dim3(std::min(nblocks(n), 2048)), dim3(TPB), 0, c->stream, c->d_x, c->d_y, n, cut, sc);
     LAUNCH(k_blk_keys, n, c->d_x, c->d_y, p, sc, c->keys_in.as<u64>(), c->vals_in.as<u32>());
     ev_record(c, 1);
     {
         size_t tmp_bytes = c->sort_tmp.bytes;
-        int end_bit = 32 + std::max(1, bits_for((unsigned)p.R));
+        const int begin_bit = 2 * p.rb;
+        const int end_bit = begin_bit + p.nyb + std::max(1, bits_for((unsigned)p.R));
         hipError_t e = rocprim::radix_sort_pairs<SortConfig>(c->sort_tmp.p, tmp_bytes, c->keys_in.as<u64>(), c->keys_out.as<u64>(),
-                                                 c->vals_in.as<u32>(), c->vals_out.as<u32>(), (size_t)n, 0, end_bit, c->stream);
+                                                 c->vals_in.as<u32>(), c->vals_out.as<u32>(), (size_t)n, begin_bit, end_bit, c->stream);
         if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs", hipGetErrorString(e));
     }
     u64* skeys = c->keys_out.as<u64>();
@@ -2331,7 +2394,7 @@ static int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_
     int* sy = c->sa.as<int>();
     int* headflag = c->chainflag.as<int>();
     int* cidp1 = c->chainhead.as<int>();
-    LAUNCH(k_blk_gather, n, c->d_x, c->d_y, p, skeys, srow, sx, sy, headflag, sc);
+    LAUNCH(k_blk_gather, n, p, skeys, sx, sy, headflag, sc);
     {
         size_t tb = c->scan_tmp.bytes;
         hipError_t e = rocprim::inclusive_scan(c->scan_tmp.p, tb, headflag, cidp1, (size_t)n, rocprim::plus<int>(), c->stream);
@@ -2352,8 +2415,10 @@ static int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_
     int* linkbits = c->owner.as<int>();
     int* corec = c->state.as<int>();
     LAUNCH(k_blk_neighbors, n, p, sc, ckey, rowcell, cstart, sx, sy, nb, low, cx, cy);
-    LAUNCH(k_blk_alive, n, sc, nb, low, alive);
-    LAUNCH(k_blk_links, n, p, sc, nb, alive, cstart, sx, sy, cx, cy, linkbits, corec);
+    LAUNCH(k_blk_alive, n, sc, nb, low, alive, linkbits);
+    hipLaunchKernelGGL(k_blk_links, dim3((unsigned)(((size_t)n * 4 + TPB - 1) / TPB)), dim3(TPB), 0, c->stream,
+                       p, sc, nb, alive, cstart, sx, sy, cx, cy, linkbits);
+    LAUNCH(k_blk_core, n, p, sc, nb, alive, cstart, linkbits, corec);
     ev_record(c, 3);
     LAUNCH(k_blk_union, n, sc, nb, linkbits, corec, c->parent.as<int>());
     LAUNCH(k_blk_flatten, n, sc, corec, c->parent.as<int>(), cfirst, c->root.as<int>(), c->compkey.as<int>());
