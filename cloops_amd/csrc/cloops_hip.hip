@@ -1364,6 +1364,11 @@ __device__ __forceinline__ u32 blk_div(const BlkParams& p, u32 n)
 }
 struct BlkScalars { int minx, miny, M, C; };
 
+__global__ void k_blk_init_scalars(BlkScalars* sc, int minx, int miny)
+{
+    sc->minx = minx; sc->miny = miny; sc->M = 0; sc->C = 0;
+}
+
 __global__ void k_blk_minmax(const int* __restrict__ X, const int* __restrict__ Y, int n, int cut, BlkScalars* sc)
 {
     __shared__ int red[2][TPB / 64];
@@ -1506,8 +1511,9 @@ __global__ void k_blk_neighbors(BlkParams p, const BlkScalars* __restrict__ sc, 
     cy[c] = (double)sumy / m;
 }
 
+// alive[c] = population of the cell if it survives the 9-cell test (:215-228), else 0
 __global__ void k_blk_alive(const BlkScalars* __restrict__ sc, const int* __restrict__ nb, const int* __restrict__ low,
-                            int* __restrict__ alive, int* __restrict__ linkbits)
+                            const int* __restrict__ cstart, int* __restrict__ alive, int* __restrict__ linkbits)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= sc->C) return;
@@ -1516,12 +1522,14 @@ __global__ void k_blk_alive(const BlkScalars* __restrict__ sc, const int* __rest
         a = 0;
         for (int q = 0; q < 8; ++q) { int j = nb[(size_t)c * 8 + q]; if (j >= 0 && !low[j]) { a = 1; break; } }
     }
-    alive[c] = a;
+    alive[c] = a ? cstart[c + 1] - cstart[c] : 0;
     linkbits[c] = 0;
 }
 
 // link bits: one thread per (cell, forward direction q = 4..7); the link test is symmetric (same centroid
 // distance, same point pairs), so the thread sets bit q of its cell and bit 7-q of the neighbour.
+// (A work list + 16 lanes per undecided cell pair was measured slower: the list append costs more
+// than the pair loops it spreads.)
 __global__ void k_blk_links(BlkParams p, const BlkScalars* __restrict__ sc, const int* __restrict__ nb,
                             const int* __restrict__ alive, const int* __restrict__ cstart,
                             const int* __restrict__ sx, const int* __restrict__ sy,
@@ -1532,16 +1540,29 @@ __global__ void k_blk_links(BlkParams p, const BlkScalars* __restrict__ sc, cons
     const int c = t >> 2, q = 4 + (t & 3);
     if (c >= sc->C) return;
     const int j = nb[(size_t)c * 8 + q];
-    if (j < 0 || !alive[c] || !alive[j]) return;
+    if (j < 0) return;
+    const int na = alive[c], nbj = alive[j];
+    if (!na || !nbj) return;
     bool linked = (fabs(cx[c] - cx[j]) + fabs(cy[c] - cy[j])) <= (double)p.eps;        // :232
-    if (!linked) {                                                                     // getGridDist :204-213
-        const int cb = cstart[c], ce = cstart[c + 1];
-        const int jb = cstart[j], je = cstart[j + 1];
-        for (int s = cb; s < ce && !linked; ++s) {
+    // two single-PET cells: the centroids ARE the PETs, the pair test below cannot differ
+    if (!linked && (na > 1 || nbj > 1)) {                                              // getGridDist :204-213
+        int ab = cstart[c], ae = ab + na, bb = cstart[j], be = bb + nbj;
+        if (na > nbj) { int x0 = ab, x1 = ae; ab = bb; ae = be; bb = x0; be = x1; }    // walk the larger cell inside
+        for (int s = ab; s < ae && !linked; ++s) {
             const int x = sx[s], y = sy[s];
-            for (int u = jb; u < je; ++u) {
+            int u = bb;
+            for (; u + 4 <= be && !linked; u += 4) {
+                int d[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int dx = x - sx[u + k], dy = y - sy[u + k];
+                    d[k] = (dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy);
+                }
+                linked = min(min(d[0], d[1]), min(d[2], d[3])) <= p.eps;
+            }
+            for (; u < be && !linked; ++u) {
                 int dx = x - sx[u], dy = y - sy[u];
-                if ((dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy) <= p.eps) { linked = true; break; }
+                linked = (dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy) <= p.eps;
             }
         }
     }
@@ -1580,14 +1601,42 @@ __global__ void k_blk_union(const BlkScalars* __restrict__ sc, const int* __rest
     }
 }
 
-__global__ void k_blk_flatten(const BlkScalars* __restrict__ sc, const int* __restrict__ corec, int* parent,
-                              const int* __restrict__ cfirst, int* __restrict__ root, int* __restrict__ compkey)
+// root per core cell + component key = smallest cfirst (two-level reduce-by-key like k_flatten: a giant
+// component would otherwise serialise millions of atomicMin on one address)
+__global__ void __launch_bounds__(BIGTPB)
+k_blk_flatten(const BlkScalars* __restrict__ sc, const int* __restrict__ corec, int* parent,
+              const int* __restrict__ cfirst, int* __restrict__ root, int* __restrict__ compkey)
 {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= sc->C) return;
-    int r = -1;
-    if (corec[c]) { r = uf_find(parent, c); atomicMin(&compkey[r], cfirst[c]); }
-    root[c] = r;
+    __shared__ int hkey[AGG_H], hmin[AGG_H];
+    if (threadIdx.x < AGG_H) { hkey[threadIdx.x] = -1; hmin[threadIdx.x] = INT_MAX; }
+    __syncthreads();
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = -1, key = INT_MAX;
+    if (c < sc->C) {
+        if (corec[c]) { r = uf_find(parent, c); key = cfirst[c]; }
+        root[c] = r;
+    }
+    const int lane = threadIdx.x & 63;
+    unsigned long long pending = __ballot(r >= 0);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int R = __shfl(r, leader);
+        const unsigned long long m = __ballot(r == R);
+        const bool mine = r == R;
+        if (__popcll(m) >= 4) {
+            int mk = mine ? key : INT_MAX;
+            for (int o = 32; o > 0; o >>= 1) mk = min(mk, __shfl_xor(mk, o));
+            if (lane == leader) {
+                const int sl = agg_slot(hkey, R);
+                if (sl >= 0) atomicMin(&hmin[sl], mk); else atomicMin(&compkey[R], mk);
+            }
+        } else if (mine) {
+            atomicMin(&compkey[R], key);
+        }
+        pending &= ~m;
+    }
+    __syncthreads();
+    if (threadIdx.x < AGG_H && hkey[threadIdx.x] >= 0) atomicMin(&compkey[hkey[threadIdx.x]], hmin[threadIdx.x]);
 }
 
 __global__ void k_blk_rank_flags(const BlkScalars* __restrict__ sc, const int* __restrict__ root,
@@ -2370,11 +2419,10 @@ static int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_
     LAUNCH(k_init_arrays, n + 1, n, c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
            c->usize.as<int>(), c->cellfirst.as<int>(), c->flag.as<int>(), c->state.as<int>(), counters);
     HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
-    BlkScalars* hsc = (BlkScalars*)(c->h_pinned + 64);
     // minX / minY of the (filtered) mat (blockDBSCAN.py:74-80): known from the upload statistics when
     // nothing is filtered, one reduction pass otherwise
-    hsc->minx = cut > 0 ? INT_MAX : c->st.xmin; hsc->miny = cut > 0 ? INT_MAX : c->st.ymin; hsc->M = 0; hsc->C = 0;
-    HIP_TRY(hipMemcpyAsync(sc, hsc, sizeof(BlkScalars), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_blk_init_scalars, dim3(1), dim3(1), 0, c->stream, sc, cut > 0 ? INT_MAX : c->st.xmin,
+                       cut > 0 ? INT_MAX : c->st.ymin);
     ev_record(c, 0);
     if (cut > 0)
         hipLaunchKernelGGL(k_blk_minmax, dim3(std::min(nblocks(n), 2048)), dim3(TPB), 0, c->stream, c->d_x, c->d_y, n, cut, sc);
@@ -2415,13 +2463,14 @@ static int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_
     int* linkbits = c->owner.as<int>();
     int* corec = c->state.as<int>();
     LAUNCH(k_blk_neighbors, n, p, sc, ckey, rowcell, cstart, sx, sy, nb, low, cx, cy);
-    LAUNCH(k_blk_alive, n, sc, nb, low, alive, linkbits);
+    LAUNCH(k_blk_alive, n, sc, nb, low, cstart, alive, linkbits);
     hipLaunchKernelGGL(k_blk_links, dim3((unsigned)(((size_t)n * 4 + TPB - 1) / TPB)), dim3(TPB), 0, c->stream,
                        p, sc, nb, alive, cstart, sx, sy, cx, cy, linkbits);
     LAUNCH(k_blk_core, n, p, sc, nb, alive, cstart, linkbits, corec);
     ev_record(c, 3);
     LAUNCH(k_blk_union, n, sc, nb, linkbits, corec, c->parent.as<int>());
-    LAUNCH(k_blk_flatten, n, sc, corec, c->parent.as<int>(), cfirst, c->root.as<int>(), c->compkey.as<int>());
+    hipLaunchKernelGGL(k_blk_flatten, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, sc, corec, c->parent.as<int>(), cfirst,
+                       c->root.as<int>(), c->compkey.as<int>());
     ev_record(c, 4);
     LAUNCH(k_blk_rank_flags, n, sc, c->root.as<int>(), c->compkey.as<int>(), c->flag.as<int>());
     {
