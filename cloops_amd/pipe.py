@@ -273,42 +273,68 @@ def _single_arrays(f, eps, minPts, cut, device):
 
 def _boxes_classified(r, res):
     """host part of pipe.py:78-102 on the K-row cluster table: (dataI boxes, dataS boxes) as
-    int64 [k,4] arrays (minX, maxX, minY, maxY) in ascending cluster id"""
+    int32 [k,4] arrays (minX, maxX, minY, maxY) in ascending cluster id"""
     b = res.boxes
     K = len(b)
-    empty4 = np.zeros((0, 4), np.int64)
+    empty4 = np.zeros((0, 4), np.int32)
     if K == 0:
         return empty4, empty4
-    ok = (b["count"] > 0) & (b["min_x"] != b["max_x"]) & (b["min_y"] != b["max_y"])   # pipe.py:83-85
-    inter = ok & (b["max_x"] < b["min_y"])                                             # pipe.py:97
-    box = np.stack([b["min_x"], b["max_x"], b["min_y"], b["max_y"]], 1).astype(np.int64)
-    return box[inter], box[ok & ~inter]
+    t = b.view(np.int32).reshape(K, 5)                     # rows {minX, maxX, minY, maxY, count}
+    ok = (t[:, 4] > 0) & (t[:, 0] != t[:, 1]) & (t[:, 2] != t[:, 3])      # pipe.py:83-85
+    inter = ok & (t[:, 1] < t[:, 2])                                       # pipe.py:97
+    return t[inter, :4], t[ok & ~inter, :4]              # copies (fancy index): the pinned view may be reused
 
 
 def _combine_steps(step_boxes):
     """combineTwice (pipe.py:155-174) applied over all steps at once, on arrays: a box is kept
     in the step where it FIRST appears (duplicates inside one step are all kept, like the
-    reference, whose `ds` set is built before the loop).  step_boxes: list of int64[k,4]."""
+    reference, whose `ds` set is built before the loop).  step_boxes: list of int64[k,4].
+
+    One value sort of `hash << ibits | position` (numpy's SIMD sort, no argsort): equal boxes become
+    one run whose first element carries the smallest position, i.e. the first step."""
     step_boxes = [b for b in step_boxes if len(b)]
     if not step_boxes:
         return np.zeros((0, 4), np.int64)
     if len(step_boxes) == 1:
         return step_boxes[0]
     rows = np.concatenate(step_boxes)
-    step = np.concatenate([np.full(len(b), k, np.int64) for k, b in enumerate(step_boxes)])
+    n = len(rows)
+    step = np.repeat(np.arange(len(step_boxes), dtype=np.int32), [len(b) for b in step_boxes])
+    ibits = max(1, int(n - 1).bit_length())
     u = rows.astype(np.uint64)
     h = (u[:, 0] * np.uint64(0x9E3779B97F4A7C15)) ^ (u[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F)) \
         ^ (u[:, 2] * np.uint64(0x165667B19E3779F9)) ^ (u[:, 3] * np.uint64(0xD6E8FEB86659FD93))
-    uh, first, inv = np.unique(h, return_index=True, return_inverse=True)
-    if not np.array_equal(rows[first[inv]], rows):            # a 64-bit hash collision: do it exactly
-        uh, first, inv = np.unique(rows, axis=0, return_index=True, return_inverse=True)
+    h ^= h >> np.uint64(29)
+    key = ((h >> np.uint64(ibits)) << np.uint64(ibits)) | np.arange(n, dtype=np.uint64)
+    key.sort()
+    pos = (key & np.uint64((1 << ibits) - 1)).astype(np.int64)          # original positions, grouped by hash
+    hs = key >> np.uint64(ibits)
+    head = np.empty(n, dtype=bool)
+    head[0] = True
+    np.not_equal(hs[1:], hs[:-1], out=head[1:])
+    first_sorted = np.maximum.accumulate(np.where(head, np.arange(n), 0))    # index (in sorted order) of the run head
+    first_pos = pos[first_sorted]                                        # smallest position of the run
+    dup = np.flatnonzero(~head)                                          # only runs longer than 1 need the exact check
+    if len(dup) and not np.array_equal(rows[first_pos[dup]], rows[pos[dup]]):    # a hash collision: do it exactly
+        _, first, inv = np.unique(rows, axis=0, return_index=True, return_inverse=True)
         inv = inv.ravel()
-    first_step = np.full(len(first), np.iinfo(np.int64).max, np.int64)
-    np.minimum.at(first_step, inv, step)
-    return rows[step == first_step[inv]]
+        first_step = np.full(len(first), np.iinfo(np.int32).max, np.int32)
+        np.minimum.at(first_step, inv, step)
+        return rows[step == first_step[inv]]
+    keep = np.ones(n, dtype=bool)
+    keep[pos[dup]] = step[pos[dup]] == step[first_pos[dup]]
+    return rows[keep]
 
 
-def _select_kth(chroms, cut, group, ranks, allsum=None):
+def _pmap(pool, fn, items):
+    """fn over items on the host thread pool (ctypes calls and numpy kernels release the GIL, so the
+    per-chromosome waits / small synchronous statistics calls overlap instead of adding up)."""
+    if pool is None or len(items) <= 1:
+        return [fn(x) for x in items]
+    return list(pool.map(fn, items))
+
+
+def _select_kth(chroms, cut, group, ranks, allsum=None, pool=None):
     """Exact order statistics (0-based `ranks`, ascending) of the |d| of `group` over the union of
     the chromosomes (of all ranks): 4-pass radix select; every pass sums one 256-bin histogram per
     chromosome (and, with `allsum`, over the ranks)."""
@@ -320,8 +346,8 @@ def _select_kth(chroms, cut, group, ranks, allsum=None):
             key = (prefix, shift)
             if key not in cache:
                 h = np.zeros(256, dtype=np.uint64)
-                for r in chroms:
-                    h += r.chrom.dist_hist(cut, group, prefix, shift)
+                for hh in _pmap(pool, lambda r: r.chrom.dist_hist(cut, group, prefix, shift), chroms):
+                    h += hh
                 if allsum is not None:
                     h = allsum(h.astype(np.int64)).astype(np.uint64)
                 cache[key] = h
@@ -331,6 +357,9 @@ def _select_kth(chroms, cut, group, ranks, allsum=None):
             prefix = (prefix << 8) | digit
         out.append(prefix)
     return out
+
+
+SWEEP_THREADS = 8
 
 
 def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, allsum=None):
@@ -352,82 +381,98 @@ def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, 
     acc = {}
     cuts = [cut]
     steps = []
-    res_list = [CACHE.get(f, devs[0]) for f in fs] if len(devs) == 1 else None
-    for ep in eps:
-        for m in minPts:
-            step_I = {}
-            used = []
-            nS = n_in = 0
-            # chromosomes are independent inside a step: enqueue them all (each handle has its own
-            # streams), then collect -- the small kernels of different chromosomes overlap on the GPU
-            active = []
-            for k, f in enumerate(fs):
-                r = res_list[k] if res_list is not None else CACHE.get(f, devs[k % len(devs)])
-                if len(r.d) == 0:
+    res_all = [CACHE.get(f, devs[k % len(devs)]) for k, f in enumerate(fs)]
+    live = [(f, r) for f, r in zip(fs, res_all) if len(r.d)]
+    pool = ThreadPoolExecutor(max_workers=SWEEP_THREADS) if len(live) > 1 else None
+    try:
+        for ep in eps:
+            for m in minPts:
+                step_cut = cut
+
+                # chromosomes are independent inside a step: enqueue them all (each handle has its own
+                # streams), then collect -- the kernels of different chromosomes overlap on the GPU
+                # and the host-side collection runs on the pool
+                for f, r in live:
+                    r.lock.acquire()
+                    try:
+                        r.chrom.cluster_async(variant, ep, m, step_cut, want_labels=False)
+                    except Exception:
+                        r.lock.release()
+                        raise
+
+                def collect(fr):
+                    f, r = fr
+                    try:
+                        res = r.chrom.wait()
+                        dI, dS = _boxes_classified(r, res)
+                        n_in = r.chrom.last_n_in()
+                        s1 = r.chrom.dist_stats(step_cut) if len(dI) else None
+                    finally:
+                        r.lock.release()
+                    return f, r, dI, len(dS), n_in, s1
+
+                step_I = {}
+                used = []
+                nS = n_in = 0
+                tot = {"n_all": [0, 0], "n_pos": [0, 0], "sumlog": [0.0, 0.0]}
+                for f, r, dI, ndS, nin, s1 in _pmap(pool, collect, live):
+                    nS += ndS
+                    n_in += nin
+                    if len(dI) == 0:                          # runDBSCAN skips such chromosomes entirely (pipe.py:121-122)
+                        continue
+                    step_I[r.key] = {"f": f, "boxes": dI}
+                    used.append(r)
+                    acc.setdefault(r.key, {"f": f, "steps": []})["steps"].append(dI)
+                    for gg in (0, 1):
+                        tot["n_all"][gg] += s1["n_all"][gg]
+                        tot["n_pos"][gg] += s1["n_pos"][gg]
+                        tot["sumlog"][gg] += s1["sumlog"][gg]
+                g = gsum(np.asarray([sum(len(v["boxes"]) for v in step_I.values()), nS, n_in, len(step_I)], dtype=np.int64))
+                st = {"eps": ep, "minPts": m, "cut_in": int(cut), "n_inter": int(g[0]), "n_self": int(g[1]), "n_in": int(g[2])}
+                steps.append(st)
+                if int(g[3]) == 0:                            # pipe.py:251-255
+                    if log:
+                        log("ERROR: no inter-ligation PETs detected for eps %s minPts %s,can't model the distance cutoff,continue anyway" % (ep, m))
                     continue
-                r.lock.acquire()
-                r.chrom.cluster_async(variant, ep, m, cut, want_labels=False)
-                active.append((f, r))
-            for f, r in active:
-                try:
-                    res = r.chrom.wait()
-                    dI, dS = _boxes_classified(r, res)
-                finally:
-                    r.lock.release()
-                nS += len(dS)
-                n_in += r.chrom.last_n_in()
-                if len(dI) == 0:                          # runDBSCAN skips such chromosomes entirely (pipe.py:121-122)
-                    continue
-                step_I[r.key] = {"f": f, "boxes": dI}
-                used.append(r)
-                acc.setdefault(r.key, {"f": f, "steps": []})["steps"].append(dI)
-            g = gsum(np.asarray([sum(len(v["boxes"]) for v in step_I.values()), nS, n_in, len(step_I)], dtype=np.int64))
-            st = {"eps": ep, "minPts": m, "cut_in": int(cut), "n_inter": int(g[0]), "n_self": int(g[1]), "n_in": int(g[2])}
-            steps.append(st)
-            if int(g[3]) == 0:                            # pipe.py:251-255
-                if log:
-                    log("ERROR: no inter-ligation PETs detected for eps %s minPts %s,can't model the distance cutoff,continue anyway" % (ep, m))
-                continue
-            tot = {"n_all": [0, 0], "n_pos": [0, 0], "sumlog": [0.0, 0.0]}
-            for r in used:
-                s1 = r.chrom.dist_stats(cut)
-                for gg in (0, 1):
-                    tot["n_all"][gg] += s1["n_all"][gg]
-                    tot["n_pos"][gg] += s1["n_pos"][gg]
-                    tot["sumlog"][gg] += s1["sumlog"][gg]
-            gi = gsum(np.asarray(tot["n_all"] + tot["n_pos"], dtype=np.int64))
-            gf = gsum(np.asarray(tot["sumlog"], dtype=np.float64))
-            tot = {"n_all": [int(gi[0]), int(gi[1])], "n_pos": [int(gi[2]), int(gi[3])], "sumlog": [float(gf[0]), float(gf[1])]}
-            if tot["n_all"][0] > 0 and tot["n_all"][1] > 0:      # pipe.py:256-259
-                if tot["n_pos"][0] == 0 or tot["n_pos"][1] == 0:
-                    raise ValueError("cannot convert float NaN to integer")      # what int(2 ** nan) raises in ests.py:57
-                mi, ms = tot["sumlog"][0] / tot["n_pos"][0], tot["sumlog"][1] / tot["n_pos"][1]
-                sq = [0.0, 0.0]
-                for r in used:
-                    q = r.chrom.dist_sqdev(cut, mi, ms)
-                    sq[0] += q[0]
-                    sq[1] += q[1]
-                sq = [float(v) for v in gsum(np.asarray(sq, dtype=np.float64))]
-                n1 = tot["n_pos"][1]
-                med = _select_kth(used, cut, 1, sorted({(n1 - 1) // 2, n1 // 2}), allsum)
-                cut_2, frags = estIntSelCutFrag_from_stats(tot["n_pos"], tot["sumlog"], sq, (med[0], med[-1]))
-                if log:
-                    log("Estimated inter-ligation and self-ligation distance cutoff as %s for eps=%s,minPts=%s" % (cut_2, ep, m))
-                st["cut_out"] = int(cut_2)
-                st["frags"] = int(frags)
-                cuts.append(cut_2)
-                cut = cut_2                               # pipe.py:274
-    pos = [c for c in cuts if c > 0]
-    if pos:
-        cut = int(np.max(pos)) if max_cut else int(np.min(pos))     # pipe.py:276-280
-    else:
-        raise ValueError("zero-size array to reduction operation minimum which has no identity")
-    # combineTwice over all steps (pipe.py:257,275), then filterClusterByDis (pipe.py:130-143, floor division)
-    dataI = {key: {"f": v["f"], "boxes": _combine_steps(v["steps"])} for key, v in acc.items()}
-    for key in dataI:
-        b = dataI[key]["boxes"]
-        dmid = (b[:, 2] + b[:, 3]) // 2 - (b[:, 0] + b[:, 1]) // 2
-        dataI[key]["boxes"] = b[dmid >= cut]
+                gi = gsum(np.asarray(tot["n_all"] + tot["n_pos"], dtype=np.int64))
+                gf = gsum(np.asarray(tot["sumlog"], dtype=np.float64))
+                tot = {"n_all": [int(gi[0]), int(gi[1])], "n_pos": [int(gi[2]), int(gi[3])], "sumlog": [float(gf[0]), float(gf[1])]}
+                if tot["n_all"][0] > 0 and tot["n_all"][1] > 0:      # pipe.py:256-259
+                    if tot["n_pos"][0] == 0 or tot["n_pos"][1] == 0:
+                        raise ValueError("cannot convert float NaN to integer")      # what int(2 ** nan) raises in ests.py:57
+                    mi, ms = tot["sumlog"][0] / tot["n_pos"][0], tot["sumlog"][1] / tot["n_pos"][1]
+                    sq = [0.0, 0.0]
+                    for q in _pmap(pool, lambda r: r.chrom.dist_sqdev(step_cut, mi, ms), used):
+                        sq[0] += q[0]
+                        sq[1] += q[1]
+                    sq = [float(v) for v in gsum(np.asarray(sq, dtype=np.float64))]
+                    n1 = tot["n_pos"][1]
+                    med = _select_kth(used, cut, 1, sorted({(n1 - 1) // 2, n1 // 2}), allsum, pool)
+                    cut_2, frags = estIntSelCutFrag_from_stats(tot["n_pos"], tot["sumlog"], sq, (med[0], med[-1]))
+                    if log:
+                        log("Estimated inter-ligation and self-ligation distance cutoff as %s for eps=%s,minPts=%s" % (cut_2, ep, m))
+                    st["cut_out"] = int(cut_2)
+                    st["frags"] = int(frags)
+                    cuts.append(cut_2)
+                    cut = cut_2                               # pipe.py:274
+        pos = [c for c in cuts if c > 0]
+        if pos:
+            cut = int(np.max(pos)) if max_cut else int(np.min(pos))     # pipe.py:276-280
+        else:
+            raise ValueError("zero-size array to reduction operation minimum which has no identity")
+        # combineTwice over all steps (pipe.py:257,275), then filterClusterByDis (pipe.py:130-143, floor division)
+        final_cut = cut
+
+        def combine(kv):
+            key, v = kv
+            b = _combine_steps(v["steps"]).astype(np.int64)
+            dmid = (b[:, 2] + b[:, 3]) // 2 - (b[:, 0] + b[:, 1]) // 2
+            return key, {"f": v["f"], "boxes": b[dmid >= final_cut]}
+
+        dataI = dict(_pmap(pool, combine, list(acc.items())))
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True)
     return dataI, cut, cuts, steps
 
 

@@ -4,7 +4,7 @@ import numpy as np
 from cloops_amd import pipe
 from cloops_amd.synth import synth_genome
 fs=[]
-for name, X, Y in synth_genome(20000000, cfg=3):
+for name, X, Y in synth_genome(int(float(sys.argv[1])) if len(sys.argv) > 1 else 20000000, cfg=3):
     fs.append(pipe.CACHE.put_arrays("%s-%s" % (name, name), X, Y))
 pipe.runSweepFast(fs, [5000], [50], cut=0)
 pr=cProfile.Profile(); pr.enable()

@@ -13,7 +13,11 @@ from cloops_amd import pipe
 from cloops_amd.synth import synth_genome
 
 MODES = {1: ([500, 1000, 2000], [5]), 2: ([1000, 2000, 5000], [5]), 3: ([5000, 7500, 10000], [50, 40, 30, 20]),
-         4: ([2500, 5000, 7500, 10000], [30, 20])}          # cLoops/pipe.py:329-344
+         4: ([2500, 5000, 7500, 10000], [30, 20]),          # cLoops/pipe.py:329-344
+         5: (list(range(1000, 10001, 1000)), [50, 30, 20, 10, 5])}      # BASELINE.json configs[4]: dense user sweep
+FAST_ONLY = "--fast-only" in sys.argv
+if FAST_ONLY:
+    sys.argv.remove("--fast-only")
 
 n_total = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20000000
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else 3
@@ -26,7 +30,7 @@ for name, X, Y in synth_genome(n_total, cfg=mode):
     npets += len(X)
 t_up = time.perf_counter() - t0
 print("generated + uploaded %d PETs on %d chromosomes in %.1f s" % (npets, len(fs), t_up))
-for rep in range(3):
+for rep in range(1 if FAST_ONLY else 0, 3):
     fast = rep > 0
     t0 = time.perf_counter()
     dataI, cut, cuts, steps = (pipe.runSweepFast if fast else pipe.runSweep)(fs, eps, minPts, cut=0)
