@@ -285,7 +285,7 @@ def _boxes_classified(r, res):
     return t[inter, :4], t[ok & ~inter, :4]              # copies (fancy index): the pinned view may be reused
 
 
-def _combine_steps(step_boxes):
+def _combine_steps(step_boxes, _hash_bits=None):
     """combineTwice (pipe.py:155-174) applied over all steps at once, on arrays: a box is kept
     in the step where it FIRST appears (duplicates inside one step are all kept, like the
     reference, whose `ds` set is built before the loop).  step_boxes: list of int64[k,4].
@@ -305,6 +305,8 @@ def _combine_steps(step_boxes):
     h = (u[:, 0] * np.uint64(0x9E3779B97F4A7C15)) ^ (u[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F)) \
         ^ (u[:, 2] * np.uint64(0x165667B19E3779F9)) ^ (u[:, 3] * np.uint64(0xD6E8FEB86659FD93))
     h ^= h >> np.uint64(29)
+    if _hash_bits:                                                        # tests: force hash collisions
+        h = (h & np.uint64((1 << _hash_bits) - 1)) << np.uint64(64 - _hash_bits)
     key = ((h >> np.uint64(ibits)) << np.uint64(ibits)) | np.arange(n, dtype=np.uint64)
     key.sort()
     pos = (key & np.uint64((1 << ibits) - 1)).astype(np.int64)          # original positions, grouped by hash
@@ -314,15 +316,22 @@ def _combine_steps(step_boxes):
     np.not_equal(hs[1:], hs[:-1], out=head[1:])
     first_sorted = np.maximum.accumulate(np.where(head, np.arange(n), 0))    # index (in sorted order) of the run head
     first_pos = pos[first_sorted]                                        # smallest position of the run
-    dup = np.flatnonzero(~head)                                          # only runs longer than 1 need the exact check
-    if len(dup) and not np.array_equal(rows[first_pos[dup]], rows[pos[dup]]):    # a hash collision: do it exactly
-        _, first, inv = np.unique(rows, axis=0, return_index=True, return_inverse=True)
-        inv = inv.ravel()
-        first_step = np.full(len(first), np.iinfo(np.int32).max, np.int32)
-        np.minimum.at(first_step, inv, step)
-        return rows[step == first_step[inv]]
+    dup = np.flatnonzero(~head)                                          # elements of runs longer than 1
     keep = np.ones(n, dtype=bool)
+    if len(dup) == 0:
+        return rows
     keep[pos[dup]] = step[pos[dup]] == step[first_pos[dup]]
+    # exact check: an element whose row differs from its run head shares only the (truncated) hash with
+    # it.  Those few runs are redone exactly; everything else is settled.
+    mism = dup[(rows[first_pos[dup]] != rows[pos[dup]]).any(axis=1)]
+    if len(mism):
+        bad = np.flatnonzero(np.isin(first_sorted, np.unique(first_sorted[mism])))
+        bpos = pos[bad]
+        _, inv = np.unique(rows[bpos], axis=0, return_inverse=True)
+        inv = inv.ravel()
+        first_step = np.full(int(inv.max()) + 1, np.iinfo(np.int32).max, np.int32)
+        np.minimum.at(first_step, inv, step[bpos])
+        keep[bpos] = step[bpos] == first_step[inv]
     return rows[keep]
 
 
