@@ -360,6 +360,12 @@ __device__ __forceinline__ int lower_bound_4(const int* pv, int lo, int hi, int 
 struct LdsPairs {       // LDS window of (q = in-strip coord, p = strip coord), addressed by GLOBAL sorted index
     const int2* a; int base;
     __device__ __forceinline__ int2 operator[](int j) const { return a[j - base]; }
+    __device__ __forceinline__ int qat(int j) const { return a[j - base].x; }
+};
+struct LdsSoA {         // same window as two int arrays: the searches only read q, and consecutive
+    const int* q; const int* p; int base;          // dwords spread over all LDS banks (pairs: every other bank)
+    __device__ __forceinline__ int2 operator[](int j) const { return make_int2(q[j - base], p[j - base]); }
+    __device__ __forceinline__ int qat(int j) const { return q[j - base]; }
 };
 struct LdsInts {
     const int* a; int base;
@@ -377,7 +383,7 @@ __device__ __forceinline__ int lds_lower_bound8(const W& w, int lo, int hi, int 
 #pragma unroll
     for (int step = 1 << (STEPS - 1); step >= 1; step >>= 1) {
         const int idx = pos + step - 1;
-        const int v = w[min(idx, hi - 1)].x;
+        const int v = w.qat(min(idx, hi - 1));
         pos = (idx < hi && v < val) ? pos + step : pos;
     }
     return pos;
@@ -390,7 +396,7 @@ __device__ __forceinline__ int lds_upper_bound8(const W& w, int lo, int hi, int 
 #pragma unroll
     for (int step = 1 << (STEPS - 1); step >= 1; step >>= 1) {
         const int idx = pos + step - 1;
-        const int v = w[min(idx, hi - 1)].x;
+        const int v = w.qat(min(idx, hi - 1));
         pos = (idx < hi && v <= val) ? pos + step : pos;
     }
     return pos;
@@ -483,7 +489,7 @@ __global__ void __launch_bounds__(K2_TPB)
 k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
                const int* __restrict__ strip_start, int* __restrict__ cnt)
 {
-    __shared__ int2 lw[K2_WIN];
+    __shared__ int lq[K2_WIN], lp[K2_WIN];
     __shared__ int4 l_sb[K2_TPB];
     __shared__ short l_list[K2_TPB];
     __shared__ int l_wcount[K2_TPB / 64];
@@ -492,14 +498,22 @@ k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
     const int tile = ((kseq / K2_RUN) * 8 + xcd) * K2_RUN + (kseq % K2_RUN);
     const int t0 = tile * K2_TPB;
     if (tile >= ntiles || t0 >= M) return;
-    const int base = t0 - K2_HALO;                 // global index of lw[0]
-    for (int k = threadIdx.x; k < K2_WIN; k += K2_TPB) {
-        const int gi = base + k;
-        const bool in = gi >= 0 && gi < M;
-        lw[k] = in ? make_int2(sv[gi], sa[gi]) : make_int2(0, 0);
+    const int base = t0 - K2_HALO;                 // global index of lq[0] / lp[0]
+    {
+        // all loads of the thread are issued before the first LDS store (a rolled loop waits for
+        // its first round trip before it starts the second)
+        static_assert(K2_WIN <= 2 * K2_TPB, "two staging slots per thread");
+        const int k0 = threadIdx.x, k1 = threadIdx.x + K2_TPB;
+        const int g0 = base + k0, g1 = base + k1;
+        const bool in0 = g0 >= 0 && g0 < M, in1 = k1 < K2_WIN && g1 < M;
+        int q0 = 0, p0v = 0, q1 = 0, p1v = 0;
+        if (in0) { q0 = sv[g0]; p0v = sa[g0]; }
+        if (in1) { q1 = sv[g1]; p1v = sa[g1]; }
+        lq[k0] = q0; lp[k0] = p0v;
+        if (k1 < K2_WIN) { lq[k1] = q1; lp[k1] = p1v; }
     }
     __syncthreads();
-    LdsPairs w; w.a = lw; w.base = base;           // w[global sorted index] = (in-strip coord q, strip coord p)
+    LdsSoA w; w.q = lq; w.p = lp; w.base = base;   // w[global sorted index] = (in-strip coord q, strip coord p)
     const int wbeg = max(base, 0), wend = min(base + K2_WIN, M);
     const int i = t0 + threadIdx.x;
     const bool valid = i < M;
@@ -507,23 +521,26 @@ k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
     // ---- phase 0: one-read core test ----------------------------------------------------------
     // If the minPts-1 next (or previous) PETs of the own strip are within eps in q, the point is
     // core: interiors of clusters are settled by one or two LDS reads, without any search.
-    // The four strip bounds of every PET are fetched here, once, all loads in flight together, and kept
-    // in LDS for the later phases (after the compaction a thread works on another PET, and a second
-    // round of dependent global loads would sit on the critical path of the few remaining waves).
+    // The four strip bounds of every PET are fetched here, once, and kept in LDS for the later phases
+    // (after the compaction a thread works on another PET, and a second round of dependent global loads
+    // would sit on the critical path of the few remaining waves).  Staging a slice of the strip table per
+    // tile instead was measured slower: it puts two more dependent loads in front of the staging barrier.
+    const int m1 = g.minPts - 1;
+    const bool p0 = !EXACT && g.minPts >= 1 && m1 <= K2_SPAN;
     bool hard = false;
     if (valid) {
         bool done = false;
         const int2 me = w[i];
         const int s = strip_of(g, me.y);
+        // the four strip bounds: all loads in flight together (L2 hits: neighbouring PETs share them)
         const int b = strip_start[s], e = strip_start[s + 1];
-        const int tb = s > 0 ? strip_start[s - 1] : b;
+        const int tb = strip_start[max(s - 1, 0)];
         const int te = s + 1 < g.S ? strip_start[s + 2] : e;
         l_sb[threadIdx.x] = make_int4(tb, b, e, te);
-        if (!EXACT && g.minPts >= 1 && g.minPts - 1 <= K2_SPAN) {
-            const int m1 = g.minPts - 1;
+        if (p0) {
             const int jr = i + m1, jl = i - m1;
-            if (jr < e && jr < wend && w[jr].x - me.x <= g.eps) done = true;
-            else if (jl >= b && jl >= wbeg && me.x - w[jl].x <= g.eps) done = true;
+            if (jr < e && jr < wend && w.qat(jr) - me.x <= g.eps) done = true;
+            else if (jl >= b && jl >= wbeg && me.x - w.qat(jl) <= g.eps) done = true;
         }
         if (done) cnt[i] = g.minPts; else hard = true;
     }
@@ -540,41 +557,95 @@ k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
         const int4 sb4 = l_sb[tix];
         const int tb = sb4.x, b = sb4.y, e = sb4.z, te = sb4.w;
         // ---- phase 1: own strip, index difference of two branch-free searches -------------------
-        // most windows hold < 31 PETs per side: 5 steps; a window that reaches the 31st position is
-        // searched again with 8 steps, one that leaves the staged span continues in global memory
-        const int Ls = max(max(b, wbeg), ii - 31);
-        int lo = lds_lower_bound8<5>(w, Ls, ii + 1, qlo);
-        if (lo == Ls && Ls > b) {
-            const int L = max(max(b, wbeg), ii - K2_SPAN);
-            lo = lds_lower_bound8<8>(w, L, Ls + 1, qlo);
-            if (lo == L && L > b) lo = lower_bound_4(sv, b, L, qlo);
-        }
-        const int Rs = min(min(e, wend), ii + 32);
-        int hi = lds_upper_bound8<5>(w, ii + 1, Rs, qhi);
-        if (hi == Rs && Rs < e) {
-            const int R = min(min(e, wend), ii + 1 + K2_SPAN);
-            hi = lds_upper_bound8<8>(w, Rs, R, qhi);
-            if (hi == R && R < e) hi = lower_bound_4(sv, R, e, sat_add(qhi, 1));
+        int lo, hi;
+        if (p0) {
+            // phase 0 failed on both sides, so the window ends before the (minPts-1)-th PET on either
+            // side (or at the strip bounds): the searches run over at most minPts-1 positions and never
+            // leave the staged range
+            const int Ls = max(b, ii - m1 + 1), Rs = min(e, ii + m1);
+            if (m1 <= 7) { lo = lds_lower_bound8<3>(w, Ls, ii + 1, qlo); hi = lds_upper_bound8<3>(w, ii + 1, Rs, qhi); }
+            else if (m1 <= 31) { lo = lds_lower_bound8<5>(w, Ls, ii + 1, qlo); hi = lds_upper_bound8<5>(w, ii + 1, Rs, qhi); }
+            else { lo = lds_lower_bound8<7>(w, Ls, ii + 1, qlo); hi = lds_upper_bound8<7>(w, ii + 1, Rs, qhi); }
+        } else {
+            // exact counts: most windows hold < 31 PETs per side: 5 steps; a window that reaches the 31st
+            // position is searched again with 8 steps, one that leaves the staged span continues in global memory
+            const int Ls = max(max(b, wbeg), ii - 31);
+            lo = lds_lower_bound8<5>(w, Ls, ii + 1, qlo);
+            if (lo == Ls && Ls > b) {
+                const int L = max(max(b, wbeg), ii - K2_SPAN);
+                lo = lds_lower_bound8<8>(w, L, Ls + 1, qlo);
+                if (lo == L && L > b) lo = lower_bound_4(sv, b, L, qlo);
+            }
+            const int Rs = min(min(e, wend), ii + 32);
+            hi = lds_upper_bound8<5>(w, ii + 1, Rs, qhi);
+            if (hi == Rs && Rs < e) {
+                const int R = min(min(e, wend), ii + 1 + K2_SPAN);
+                hi = lds_upper_bound8<8>(w, Rs, R, qhi);
+                if (hi == R && R < e) hi = lower_bound_4(sv, R, e, sat_add(qhi, 1));
+            }
         }
         int c = hi - lo;
+        if (g.dbg & 128) { cnt[ii] = c; return; }                             // developer knob: no neighbour strips
         // ---- phase 2: neighbour strips, only while not known to be core -------------------------
         if (EXACT || c < g.minPts) {
-            if (tb < b) {                                                      // strip s-1 = [tb, b)
-                if (tb >= wbeg && b - tb <= 255) {
-                    const int j = (b - tb <= 63) ? lds_lower_bound8<6>(w, tb, b, qlo) : lds_lower_bound8<8>(w, tb, b, qlo);
-                    c = k2_count_lds<EXACT, 4>(w, j, b, qhi, pi, g.eps, g.minPts, c);
+            const bool ldsA = tb < b && tb >= wbeg && b - tb <= 255;           // strip s-1 = [tb, b) staged
+            const bool ldsB = e < te && te <= wend && te - e <= 255;           // strip s+1 = [e, te) staged
+            if (ldsA && ldsB) {
+                // the usual case: both searches advance together (two independent LDS chains in flight --
+                // after the compaction few waves are left per CU and latency, not issue, is the limit),
+                // then the first candidates of both strips are fetched together
+                int ja = tb, jb = e;
+                if (b - tb <= 31 && te - e <= 31) {
+#pragma unroll
+                    for (int step = 16; step >= 1; step >>= 1) {
+                        const int ia = ja + step - 1, ib = jb + step - 1;
+                        const int va = w.qat(min(ia, b - 1)), vb = w.qat(min(ib, te - 1));
+                        ja = (ia < b && va < qlo) ? ja + step : ja;
+                        jb = (ib < te && vb < qlo) ? jb + step : jb;
+                    }
                 } else {
-                    const int j = lower_bound_4(sv, tb, b, qlo);
-                    c = k2_count_glb<EXACT, 8>(sv, sa, j, b, qhi, pi, g.eps, g.minPts, c);
+#pragma unroll
+                    for (int step = 128; step >= 1; step >>= 1) {
+                        const int ia = ja + step - 1, ib = jb + step - 1;
+                        const int va = w.qat(min(ia, b - 1)), vb = w.qat(min(ib, te - 1));
+                        ja = (ia < b && va < qlo) ? ja + step : ja;
+                        jb = (ib < te && vb < qlo) ? jb + step : jb;
+                    }
                 }
-            }
-            if ((EXACT || c < g.minPts) && e < te) {                           // strip s+1 = [e, te)
-                if (te <= wend && te - e <= 255) {
-                    const int j = (te - e <= 63) ? lds_lower_bound8<6>(w, e, te, qlo) : lds_lower_bound8<8>(w, e, te, qlo);
-                    c = k2_count_lds<EXACT, 4>(w, j, te, qhi, pi, g.eps, g.minPts, c);
-                } else {
-                    const int j = lower_bound_4(sv, e, te, qlo);
-                    c = k2_count_glb<EXACT, 8>(sv, sa, j, te, qhi, pi, g.eps, g.minPts, c);
+                int2 va[2], vb[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { va[k] = w[min(ja + k, b - 1)]; vb[k] = w[min(jb + k, te - 1)]; }
+                bool outA = false, outB = false;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const bool ina = (ja + k < b) && (va[k].x <= qhi), inb = (jb + k < te) && (vb[k].x <= qhi);
+                    outA |= !ina; outB |= !inb;
+                    const int da = va[k].y - pi, db = vb[k].y - pi;
+                    c += (ina && (da < 0 ? -da : da) <= g.eps) ? 1 : 0;
+                    c += (inb && (db < 0 ? -db : db) <= g.eps) ? 1 : 0;
+                }
+                if (EXACT || c < g.minPts) {
+                    if (!outA) c = k2_count_lds<EXACT, 4>(w, ja + 2, b, qhi, pi, g.eps, g.minPts, c);
+                    if (!outB && (EXACT || c < g.minPts)) c = k2_count_lds<EXACT, 4>(w, jb + 2, te, qhi, pi, g.eps, g.minPts, c);
+                }
+            } else {
+                if (tb < b) {
+                    if (ldsA) {
+                        const int j = (b - tb <= 63) ? lds_lower_bound8<6>(w, tb, b, qlo) : lds_lower_bound8<8>(w, tb, b, qlo);
+                        c = k2_count_lds<EXACT, 4>(w, j, b, qhi, pi, g.eps, g.minPts, c);
+                    } else {
+                        const int j = lower_bound_4(sv, tb, b, qlo);
+                        c = k2_count_glb<EXACT, 8>(sv, sa, j, b, qhi, pi, g.eps, g.minPts, c);
+                    }
+                }
+                if ((EXACT || c < g.minPts) && e < te) {
+                    if (ldsB) {
+                        const int j = (te - e <= 63) ? lds_lower_bound8<6>(w, e, te, qlo) : lds_lower_bound8<8>(w, e, te, qlo);
+                        c = k2_count_lds<EXACT, 4>(w, j, te, qhi, pi, g.eps, g.minPts, c);
+                    } else {
+                        const int j = lower_bound_4(sv, e, te, qlo);
+                        c = k2_count_glb<EXACT, 8>(sv, sa, j, te, qhi, pi, g.eps, g.minPts, c);
+                    }
                 }
             }
         }
