@@ -464,7 +464,24 @@ __device__ __forceinline__ int block_compact(bool active, short* l_list, int* l_
     return total;
 }
 
-#define K2_TPB 512
+// same, with `between()` executed by every thread between the two barriers (stores that may complete late)
+template <int NT, typename F>
+__device__ __forceinline__ int block_compact_with(bool active, short* l_list, int* l_wcount, F&& between)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(active);
+    if (lane == 0) l_wcount[wv] = __popcll(bal);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) { const int c = l_wcount[k]; off += (k < wv) ? c : 0; total += c; }
+    if (active) l_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (short)threadIdx.x;
+    between();
+    __syncthreads();
+    return total;
+}
+
+#define K2_TPB 256
 #define K2_HALO 128
 #define K2_WIN (K2_TPB + 2 * K2_HALO)
 #define K2_SPAN 120      // own-strip window searched branch-free within +-K2_SPAN positions
@@ -486,18 +503,21 @@ __device__ __forceinline__ int block_compact(bool active, short* l_list, int* l_
 // runs of K2_RUN consecutive tiles so that halos are re-read from its own L2.
 template <bool EXACT>
 __global__ void __launch_bounds__(K2_TPB)
-k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
+k_region_count(GridParams g, int ntiles, int n, const int* __restrict__ sv, const int* __restrict__ sa,
                const int* __restrict__ strip_start, int* __restrict__ cnt)
 {
     __shared__ int lq[K2_WIN], lp[K2_WIN];
     __shared__ int4 l_sb[K2_TPB];
     __shared__ short l_list[K2_TPB];
     __shared__ int l_wcount[K2_TPB / 64];
-    const int M = strip_start[g.S];
     const int xcd = blockIdx.x & 7, kseq = blockIdx.x >> 3;
     const int tile = ((kseq / K2_RUN) * 8 + xcd) * K2_RUN + (kseq % K2_RUN);
     const int t0 = tile * K2_TPB;
-    if (tile >= ntiles || t0 >= M) return;
+    if (tile >= ntiles) return;
+    // M (PETs that passed the cut filter) lives on the device; the staging loads are predicated on the
+    // host-known n instead (rows M..n-1 exist, they carry the sentinel strip), so that the load of M
+    // overlaps the staging round trip instead of preceding it
+    const int M = strip_start[g.S];
     const int base = t0 - K2_HALO;                 // global index of lq[0] / lp[0]
     {
         // all loads of the thread are issued before the first LDS store (a rolled loop waits for
@@ -505,7 +525,7 @@ k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
         static_assert(K2_WIN <= 2 * K2_TPB, "two staging slots per thread");
         const int k0 = threadIdx.x, k1 = threadIdx.x + K2_TPB;
         const int g0 = base + k0, g1 = base + k1;
-        const bool in0 = g0 >= 0 && g0 < M, in1 = k1 < K2_WIN && g1 < M;
+        const bool in0 = g0 >= 0 && g0 < n, in1 = k1 < K2_WIN && g1 < n;
         int q0 = 0, p0v = 0, q1 = 0, p1v = 0;
         if (in0) { q0 = sv[g0]; p0v = sa[g0]; }
         if (in1) { q1 = sv[g1]; p1v = sa[g1]; }
@@ -513,6 +533,7 @@ k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
         if (k1 < K2_WIN) { lq[k1] = q1; lp[k1] = p1v; }
     }
     __syncthreads();
+    if (t0 >= M) return;
     LdsSoA w; w.q = lq; w.p = lp; w.base = base;   // w[global sorted index] = (in-strip coord q, strip coord p)
     const int wbeg = max(base, 0), wend = min(base + K2_WIN, M);
     const int i = t0 + threadIdx.x;
@@ -520,33 +541,31 @@ k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
     if (g.dbg & 32) { if (valid) cnt[i] = w[i].x + w[i].y; return; }        // developer knob: staging only
     // ---- phase 0: one-read core test ----------------------------------------------------------
     // If the minPts-1 next (or previous) PETs of the own strip are within eps in q, the point is
-    // core: interiors of clusters are settled by one or two LDS reads, without any search.
-    // The four strip bounds of every PET are fetched here, once, and kept in LDS for the later phases
-    // (after the compaction a thread works on another PET, and a second round of dependent global loads
-    // would sit on the critical path of the few remaining waves).  Staging a slice of the strip table per
-    // tile instead was measured slower: it puts two more dependent loads in front of the staging barrier.
+    // core: interiors of clusters are settled by one or two LDS reads, without any search.  "Same
+    // strip" is tested on the staged p values, so phase 0 needs no strip bounds: the four bounds of
+    // every PET are requested here (all loads in flight together, L2 hits) but only land in LDS after
+    // the first compaction barrier -- their round trip overlaps phase 0 instead of preceding it.
     const int m1 = g.minPts - 1;
     const bool p0 = !EXACT && g.minPts >= 1 && m1 <= K2_SPAN;
     bool hard = false;
+    int4 sbv = make_int4(0, 0, 0, 0);
     if (valid) {
         bool done = false;
         const int2 me = w[i];
         const int s = strip_of(g, me.y);
-        // the four strip bounds: all loads in flight together (L2 hits: neighbouring PETs share them)
-        const int b = strip_start[s], e = strip_start[s + 1];
-        const int tb = strip_start[max(s - 1, 0)];
-        const int te = s + 1 < g.S ? strip_start[s + 2] : e;
-        l_sb[threadIdx.x] = make_int4(tb, b, e, te);
+        sbv.y = strip_start[s]; sbv.z = strip_start[s + 1];
+        sbv.x = strip_start[max(s - 1, 0)];
+        sbv.w = strip_start[min(s + 2, g.S)];           // s + 1 == S: strip_start[S] == e
         if (p0) {
             const int jr = i + m1, jl = i - m1;
-            if (jr < e && jr < wend && w.qat(jr) - me.x <= g.eps) done = true;
-            else if (jl >= b && jl >= wbeg && me.x - w.qat(jl) <= g.eps) done = true;
+            if (jr < wend && w.qat(jr) - me.x <= g.eps && strip_of(g, w.p[jr - base]) == s) done = true;
+            else if (jl >= wbeg && me.x - w.qat(jl) <= g.eps && strip_of(g, w.p[jl - base]) == s) done = true;
         }
         if (done) cnt[i] = g.minPts; else hard = true;
     }
     if (g.dbg & 64) { if (valid && hard) cnt[i] = 0; return; }              // developer knob: phase 0 only
     // ---- workgroup compaction: whole waves drop out of the search phases ------------------------
-    const int total = block_compact<K2_TPB>(hard, l_list, l_wcount);
+    const int total = block_compact_with<K2_TPB>(hard, l_list, l_wcount, [&]() { if (hard) l_sb[threadIdx.x] = sbv; });
     if ((int)threadIdx.x >= total) return;
     {
         const int tix = l_list[threadIdx.x];
@@ -588,36 +607,33 @@ k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
         if (g.dbg & 128) { cnt[ii] = c; return; }                             // developer knob: no neighbour strips
         // ---- phase 2: neighbour strips, only while not known to be core -------------------------
         if (EXACT || c < g.minPts) {
-            const bool ldsA = tb < b && tb >= wbeg && b - tb <= 255;           // strip s-1 = [tb, b) staged
-            const bool ldsB = e < te && te <= wend && te - e <= 255;           // strip s+1 = [e, te) staged
+            // strip s-1 = [tb, b), strip s+1 = [e, te); an EMPTY strip counts as staged (the searches
+            // return at once), so that a wave only leaves the common path for unstaged / very long strips
+            const bool ldsA = tb >= wbeg && b - tb <= 255;
+            const bool ldsB = te <= wend && te - e <= 255;
             if (ldsA && ldsB) {
-                // the usual case: both searches advance together (two independent LDS chains in flight --
-                // after the compaction few waves are left per CU and latency, not issue, is the limit),
-                // then the first candidates of both strips are fetched together
+                // both searches advance together (two independent LDS chains in flight); the number of
+                // steps is chosen per WAVE (a per-lane choice makes most waves run every variant)
+                const int longest = max(b - tb, te - e);
                 int ja = tb, jb = e;
-                if (b - tb <= 31 && te - e <= 31) {
-#pragma unroll
-                    for (int step = 16; step >= 1; step >>= 1) {
-                        const int ia = ja + step - 1, ib = jb + step - 1;
-                        const int va = w.qat(min(ia, b - 1)), vb = w.qat(min(ib, te - 1));
-                        ja = (ia < b && va < qlo) ? ja + step : ja;
-                        jb = (ib < te && vb < qlo) ? jb + step : jb;
-                    }
-                } else {
-#pragma unroll
-                    for (int step = 128; step >= 1; step >>= 1) {
-                        const int ia = ja + step - 1, ib = jb + step - 1;
-                        const int va = w.qat(min(ia, b - 1)), vb = w.qat(min(ib, te - 1));
-                        ja = (ia < b && va < qlo) ? ja + step : ja;
-                        jb = (ib < te && vb < qlo) ? jb + step : jb;
-                    }
+#define K2_PAIR_SEARCH(TOP)                                                                          \
+                _Pragma("unroll") for (int step = TOP; step >= 1; step >>= 1) {                      \
+                    const int ia = ja + step - 1, ib = jb + step - 1;                                \
+                    const int va = w.qat(max(min(ia, b - 1), wbeg)), vb = w.qat(min(ib, te - 1));    \
+                    ja = (ia < b && va < qlo) ? ja + step : ja;                                      \
+                    jb = (ib < te && vb < qlo) ? jb + step : jb;                                     \
                 }
-                int2 va[2], vb[2];
+                if (!__any(longest > 31)) { K2_PAIR_SEARCH(16) }
+                else if (!__any(longest > 63)) { K2_PAIR_SEARCH(32) }
+                else { K2_PAIR_SEARCH(128) }
+#undef K2_PAIR_SEARCH
+                // first four candidates of both strips, all loads in flight before the first compare
+                int2 va[4], vb[4];
 #pragma unroll
-                for (int k = 0; k < 2; ++k) { va[k] = w[min(ja + k, b - 1)]; vb[k] = w[min(jb + k, te - 1)]; }
+                for (int k = 0; k < 4; ++k) { va[k] = w[max(min(ja + k, b - 1), wbeg)]; vb[k] = w[min(jb + k, te - 1)]; }
                 bool outA = false, outB = false;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < 4; ++k) {
                     const bool ina = (ja + k < b) && (va[k].x <= qhi), inb = (jb + k < te) && (vb[k].x <= qhi);
                     outA |= !ina; outB |= !inb;
                     const int da = va[k].y - pi, db = vb[k].y - pi;
@@ -625,8 +641,8 @@ k_region_count(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
                     c += (inb && (db < 0 ? -db : db) <= g.eps) ? 1 : 0;
                 }
                 if (EXACT || c < g.minPts) {
-                    if (!outA) c = k2_count_lds<EXACT, 4>(w, ja + 2, b, qhi, pi, g.eps, g.minPts, c);
-                    if (!outB && (EXACT || c < g.minPts)) c = k2_count_lds<EXACT, 4>(w, jb + 2, te, qhi, pi, g.eps, g.minPts, c);
+                    if (!outA) c = k2_count_lds<EXACT, 4>(w, ja + 4, b, qhi, pi, g.eps, g.minPts, c);
+                    if (!outB && (EXACT || c < g.minPts)) c = k2_count_lds<EXACT, 4>(w, jb + 4, te, qhi, pi, g.eps, g.minPts, c);
                 }
             } else {
                 if (tb < b) {
@@ -2263,8 +2279,8 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     {
         const int ntiles = nblocks(n, K2_TPB);
         const int grid = ((ntiles + 8 * K2_RUN - 1) / (8 * K2_RUN)) * (8 * K2_RUN);
-        if (exact) hipLaunchKernelGGL(k_region_count<true>, dim3(grid), dim3(K2_TPB), 0, c->stream, g, ntiles, c->sv.as<int>(), c->sa.as<int>(), c->strip.as<int>(), c->cnt.as<int>());
-        else hipLaunchKernelGGL(k_region_count<false>, dim3(grid), dim3(K2_TPB), 0, c->stream, g, ntiles, c->sv.as<int>(), c->sa.as<int>(), c->strip.as<int>(), c->cnt.as<int>());
+        if (exact) hipLaunchKernelGGL(k_region_count<true>, dim3(grid), dim3(K2_TPB), 0, c->stream, g, ntiles, n, c->sv.as<int>(), c->sa.as<int>(), c->strip.as<int>(), c->cnt.as<int>());
+        else hipLaunchKernelGGL(k_region_count<false>, dim3(grid), dim3(K2_TPB), 0, c->stream, g, ntiles, n, c->sv.as<int>(), c->sa.as<int>(), c->strip.as<int>(), c->cnt.as<int>());
     }
     ev_record(c, 3);
     HIP_TRY(hipGetLastError());
