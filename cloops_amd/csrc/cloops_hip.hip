@@ -481,6 +481,7 @@ __device__ __forceinline__ int block_compact_with(bool active, short* l_list, in
     return total;
 }
 
+#define UNION_CH 8       // candidates fetched per round trip in the long-strip scan of k_union_cores
 #define K2_TPB 256
 #define K2_HALO 128
 #define K2_WIN (K2_TPB + 2 * K2_HALO)
@@ -887,10 +888,21 @@ __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const
 // wave then keeps ONE lane per distinct (own chain A, chain B) pair, and only those lanes run
 // the (latency-bound, global-memory) union-find step -- directly on the chain heads.
 #define UNION_MAXB 4
+
+// pmax32[k] = max strip coordinate p over the CORE PETs of sorted positions [32k, 32k+32) (INT_MIN if none).
+// k_union_cores skips 32 candidates of a long strip with one load when none of them can be within eps in p.
+__global__ void k_block_pmax(int n, const int* __restrict__ chainid, const int* __restrict__ sa, int* __restrict__ pmax32)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int v = (i < n && chainid[i] >= 0) ? sa[i] : INT_MIN;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 31) == 0 && i < n) pmax32[i >> 5] = v;
+}
 __global__ void __launch_bounds__(TPB)
 k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
               const int* __restrict__ strip_start, const int* __restrict__ chainid, const int* __restrict__ chain_qend,
-              int* parent)
+              const int* __restrict__ pmax32, int* parent)
 {
     __shared__ int2 lw[T_WIN];
     __shared__ int lx[T_WIN];
@@ -927,32 +939,73 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
             }
         };
         if (tb >= t.wbeg && b - tb <= 255) {
-            // short strips: the whole neighbour strip is staged
-            tile_visit_segment(t, sv, sa, chainid, tb, b, qlo, qhi, [&](int, int, int pj, int B) {
-                if (B < 0) return;
-                const int da = pj - me.y;
-                if ((da < 0 ? -da : da) <= g.eps) touch(B);
-            });
+            // short strips: the whole neighbour strip is staged.  Every candidate lies one strip below, so
+            // "within eps in p" is p_j >= p_i - eps.  In a well-filled strip the walk jumps past a chain once
+            // it has been touched (its last core has q = chain_qend[chain]): a window covered by one chain
+            // costs one candidate instead of a hundred.
+            const int T = me.y - g.eps;
+            const bool dense = b - tb > 48;
+            int j = lds_lower_bound8(t.w, tb, b, qlo);
+            while (j < b) {
+                const int2 cnd = t.w[j];
+                if (cnd.x > qhi) break;
+                const int B = t.x[j];
+                if (B >= 0 && cnd.y >= T) {
+                    touch(B);
+                    if (dense) {
+                        const int qe = chain_qend[B];
+                        if (qe >= qhi) break;
+                        j = lds_upper_bound8(t.w, j + 1, b, qe);
+                        continue;
+                    }
+                }
+                ++j;
+            }
         } else {
             // long strips (dense data at large eps: hundreds of candidates per window, nearly all of them in
             // ONE chain): once a chain has been touched the scan jumps past its last core, whose q is
             // chain_qend[chain] -- a window that is one chain costs two searches instead of a full scan
+            // Every candidate j lies one strip below, so p_j < p_i and "within eps in p" is p_j >= p_i - eps.
+            // A PET near the top of its strip is within eps in p of few PETs of the strip below and used to
+            // walk through most of its window, one round trip per candidate: the tail of the kernel.  Now
+            //  * the window end k1 is found up front (no q loads in the walk),
+            //  * whole 32-PET blocks are skipped on their summary pmax32 (8 summaries per round trip),
+            //  * inside a block the candidates are fetched UNION_CH at a time.
+            const int T = me.y - g.eps;
             int k = lower_bound_4(sv, tb, b, qlo);
-            while (k < b) {
-                const int qk = sv[k];
-                if (qk > qhi) break;
-                const int B = chainid[k];
-                if (B >= 0) {
-                    const int da = sa[k] - me.y;
-                    if ((da < 0 ? -da : da) <= g.eps) {
-                        touch(B);
-                        const int qe = chain_qend[B];
-                        if (qe >= qhi) break;
-                        k = lower_bound_4(sv, k + 1, b, qe + 1);
-                        continue;
+            const int k1 = lower_bound_4(sv, k, b, sat_add(qhi, 1));
+            while (k < k1) {
+                if (pmax32 && (k & 31) == 0 && k + 32 <= k1) {
+                    const int blk = k >> 5, nblk = min(8, (k1 - k) >> 5);
+                    int m[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) m[u] = pmax32[blk + min(u, nblk - 1)];
+                    int hit = nblk;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (hit == nblk && u < nblk && m[u] >= T) hit = u;
+                    k += hit * 32;
+                    if (hit == nblk) continue;
+                }
+                const int lim = pmax32 ? min(k1, (k | 31) + 1) : k1;
+                int cv[UNION_CH], pv[UNION_CH];
+#pragma unroll
+                for (int u = 0; u < UNION_CH; ++u) {
+                    const int idx = min(k + u, lim - 1);
+                    cv[u] = chainid[idx]; pv[u] = sa[idx];
+                }
+                int next = min(k + UNION_CH, lim);
+                bool found = false;
+#pragma unroll
+                for (int u = 0; u < UNION_CH; ++u) {
+                    if (found || k + u >= lim) continue;
+                    if (cv[u] >= 0 && pv[u] >= T) {
+                        touch(cv[u]);
+                        const int qe = chain_qend[cv[u]];
+                        found = true;
+                        next = (qe >= qhi) ? k1 : lower_bound_4(sv, k + u + 1, k1, qe + 1);
                     }
                 }
-                ++k;
+                k = next;
             }
         }
     }
@@ -2679,8 +2732,14 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
                c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                c->headidx.as<int>(), sv, c->lo.as<int>());   // chain ends live in `lo` until the release fix-up reuses it
     }
+    // long strips (dense data at large eps): 32-PET block summaries for the union scan (`hi` is free until K4)
+    int* pmax32 = nullptr;
+    if ((long long)n > 64LL * g.S) {
+        pmax32 = c->hi.as<int>();
+        LAUNCH(k_block_pmax, n, n, c->chainflag.as<int>(), sa, pmax32);
+    }
     hipLaunchKernelGGL(k_union_cores, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
-                       c->parent.as<int>());
+                       pmax32, c->parent.as<int>());
     hipLaunchKernelGGL(k_flatten, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
            c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>());
     ev_record(c, 4);
