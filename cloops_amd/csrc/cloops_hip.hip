@@ -338,6 +338,81 @@ __global__ void k_strip_table(const u64* __restrict__ skeys, int n, int S, int s
 }
 
 // ------------------------------------------------------------------------------------------
+// K1 (hybrid): when every strip is short, only the STRIP bits are radix-sorted (2 passes instead of 5 on
+// the bench workload) and the order inside a strip is finished here: a PET's place in its strip is the
+// number of PETs of the strip with a smaller q (ties: the one that comes first, i.e. the smaller input
+// row -- the passes are stable), counted on an LDS window.  The kernel also decodes (q, p) and moves
+// the row ids, so it replaces k_decode_sorted as well.  "Every strip is short" is a property of the
+// chromosome and eps, measured once per (layout, eps) over ALL rows (a cut only removes rows) and kept in
+// the handle (strip_maxlen below) -- results are never cached, only this choice of algorithm.
+// ------------------------------------------------------------------------------------------
+#define HS_TPB 256
+#define HS_HALO 256
+#define HS_WIN (HS_TPB + 2 * HS_HALO)
+#define HS_LMAX 256          // longest strip the in-strip ranking accepts (must be <= HS_HALO)
+enum { CTR_MAXLEN = 48 };
+
+__global__ void k_strip_hist(const int* __restrict__ X, const int* __restrict__ Y, int n, GridParams g, int* __restrict__ hist)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int x = X[r], y = Y[r];
+    const int prel = (g.swap ? x + y : y - x) - g.A0;
+    atomicAdd(&hist[div_eps(g, prel) - g.s0], 1);
+}
+__global__ void k_max_int(const int* __restrict__ v, int n, int* __restrict__ out)
+{
+    __shared__ int red[TPB / 64];
+    int m = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = max(m, v[i]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_down(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TPB / 64; ++w) m = max(m, red[w]);
+        atomicMax(out, m);
+    }
+}
+
+__global__ void __launch_bounds__(HS_TPB)
+k_strip_sort(int n, GridParams g, const u64* __restrict__ keys, const u32* __restrict__ rows,
+             const int* __restrict__ strip_start, int* __restrict__ sv, int* __restrict__ sa, u32* __restrict__ srow,
+             int* __restrict__ counters)
+{
+    __shared__ u32 lq[HS_WIN];
+    const int t0 = blockIdx.x * HS_TPB, base = t0 - HS_HALO;
+    const u64 qmask = (1ull << g.qbits) - 1ull;
+    u64 kk[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int gi = base + (int)threadIdx.x + u * HS_TPB;
+        kk[u] = (gi >= 0 && gi < n) ? keys[gi] : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) lq[threadIdx.x + u * HS_TPB] = (u32)((kk[u] >> g.rbits) & qmask);
+    const int i = t0 + threadIdx.x;
+    const u32 row = i < n ? rows[i] : 0u;
+    __syncthreads();
+    if (i >= n) return;
+    const u64 k = kk[1];                                   // slot 1 of the thread is its own PET (HS_HALO == HS_TPB)
+    static_assert(HS_HALO == HS_TPB, "own PET = staging slot 1");
+    const int strip = (int)(k >> (g.qbits + g.rbits));
+    if (strip >= g.S) { sv[i] = INT_MAX; sa[i] = 0; srow[i] = row; return; }      // filtered rows keep their places
+    const int b = strip_start[strip], e = strip_start[strip + 1];
+    if (e - b > HS_LMAX) { counters[CTR_OVERFLOW] = 4; return; }                  // cannot happen (strip_maxlen)
+    const u32 qi = lq[i - base];
+    int rank = 0;
+    for (int j = b; j < e; ++j) {
+        const u32 qj = lq[j - base];
+        rank += (qj < qi || (qj == qi && j < i)) ? 1 : 0;
+    }
+    const int dst = b + rank;
+    sv[dst] = (int)qi;
+    sa[dst] = (strip + g.s0) * g.eps + (int)(k & ((1ull << g.rbits) - 1ull));
+    srow[dst] = row;
+}
+
+// ------------------------------------------------------------------------------------------
 // K2: region query  (cDBSCAN.py:186-205 regionQuery / cDBSCAN2.py:304-334 neighbour count)
 // ------------------------------------------------------------------------------------------
 // 4-way lower bound: three independent probes per step -- half the dependent memory round
@@ -2101,6 +2176,9 @@ struct cl_chrom {
     DevBuf sv, sa, strip, cnt, parent, root, head, headidx, cellfirst, compkey, ncore, bsize, owner, state;
     DevBuf flag, rankscan, ulist, lo, hi, recs, counters, chainflag, chainhead, usize, b_cstart, b_ckey, b_nb, b_cx, b_cy;
     int* h_pinned = nullptr;          // small pinned staging (stats, block scalars)
+    struct StripPlan { int layout, eps, maxlen; };
+    std::vector<StripPlan> plans;     // longest strip over all rows per (layout, eps): picks the sort path
+    u32* srow = nullptr;              // sorted position -> input row of the run being enqueued
     // Result slots: two runs may be in flight (cl_cluster_async) -- the labels / table / header of
     // run k live in slot k & 1, so the D2H copy of run k (copy stream) overlaps the kernels of run k+1.
     struct Slot {
@@ -2314,20 +2392,58 @@ static void ev_record(cl_chrom* c, int k)
     if (c->profiling) (void)hipEventRecord(c->slot[c->cur].ev[k], c->stream);
 }
 
+// Longest strip over ALL rows of the chromosome for this layout and eps (an upper bound for every cut):
+// measured on first use (one histogram pass + a blocking read-back, once per (layout, eps) and handle).
+static int strip_maxlen(cl_chrom* c, const GridParams& g, int* out)
+{
+    const int layout = (g.variant == CL_VARIANT_CDBSCAN2 ? 2 : 0) | (g.swap ? 1 : 0);
+    for (const auto& pl : c->plans)
+        if (pl.layout == layout && pl.eps == g.eps) { *out = pl.maxlen; return CL_OK; }
+    const int n = (int)c->n;
+    int* hist = c->strip.as<int>();
+    int* dmax = c->counters.as<int>() + CTR_MAXLEN;
+    HIP_TRY(hipMemsetAsync(hist, 0, ((size_t)g.S + 2) * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(dmax, 0, 4, c->stream));
+    LAUNCH(k_strip_hist, n, c->d_x, c->d_y, n, g, hist);
+    hipLaunchKernelGGL(k_max_int, dim3(std::min(nblocks(g.S), 1024)), dim3(TPB), 0, c->stream, hist, g.S, dmax);
+    int* h = c->h_pinned + 128;
+    HIP_TRY(hipMemcpyAsync(h, dmax, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->plans.size() >= 64) c->plans.erase(c->plans.begin());
+    c->plans.push_back({layout, g.eps, *h});
+    *out = *h;
+    return CL_OK;
+}
+
 // K0 + K1 + K2: keys, sort, strip table, neighbour counts.  Leaves sorted arrays in the workspace.
 static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
 {
     const int n = (int)c->n;
+    const int sh = g.qbits + g.rbits, strip_bits = std::max(1, bits_for((unsigned)g.S));
+    // hybrid sort: worth it when it saves at least two radix passes (9-bit digits) and every strip is short
+    bool hybrid = false;
+    if (!(g.dbg & 256) && (g.qbits + strip_bits + 8) / 9 - (strip_bits + 8) / 9 >= 2) {
+        int maxlen = 0, rc;
+        if ((rc = strip_maxlen(c, g, &maxlen))) return rc;
+        hybrid = maxlen <= HS_LMAX;
+    }
     ev_record(c, 0);
     LAUNCH(k_make_keys, n, c->d_x, c->d_y, n, g, c->keys_in.as<u64>(), c->vals_in.as<u32>());
     ev_record(c, 1);
     size_t tmp_bytes = c->sort_tmp.bytes;
-    int end_bit = g.qbits + g.rbits + std::max(1, bits_for((unsigned)g.S));
+    const int end_bit = sh + strip_bits;
     hipError_t e = rocprim::radix_sort_pairs<SortConfig>(c->sort_tmp.p, tmp_bytes, c->keys_in.as<u64>(), c->keys_out.as<u64>(),
-                                             c->vals_in.as<u32>(), c->vals_out.as<u32>(), (size_t)n, g.rbits, end_bit, c->stream);
+                                             c->vals_in.as<u32>(), c->vals_out.as<u32>(), (size_t)n, hybrid ? sh : g.rbits, end_bit, c->stream);
     if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs", hipGetErrorString(e));
-    LAUNCH(k_decode_sorted, n, n, g, c->keys_out.as<u64>(), c->sv.as<int>(), c->sa.as<int>());
-    LAUNCH(k_strip_table, g.S + 2, c->keys_out.as<u64>(), n, g.S, g.qbits + g.rbits, c->strip.as<int>());
+    LAUNCH(k_strip_table, g.S + 2, c->keys_out.as<u64>(), n, g.S, sh, c->strip.as<int>());
+    if (hybrid) {
+        c->srow = c->vals_in.as<u32>();                  // the unsorted row ids are dead after the sort
+        hipLaunchKernelGGL(k_strip_sort, dim3(nblocks(n, HS_TPB)), dim3(HS_TPB), 0, c->stream, n, g, c->keys_out.as<u64>(),
+                           c->vals_out.as<u32>(), c->strip.as<int>(), c->sv.as<int>(), c->sa.as<int>(), c->srow, c->counters.as<int>());
+    } else {
+        c->srow = c->vals_out.as<u32>();
+        LAUNCH(k_decode_sorted, n, n, g, c->keys_out.as<u64>(), c->sv.as<int>(), c->sa.as<int>());
+    }
     ev_record(c, 2);
     {
         const int ntiles = nblocks(n, K2_TPB);
@@ -2373,7 +2489,7 @@ extern "C" int cl_neighbor_counts(cl_chrom* c, int32_t eps, int32_t cut, int32_t
     if ((rc = run_sort_and_count(c, g, true))) return rc;
     const int n = (int)c->n;
     HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
-    LAUNCH(k_scatter_counts, n, c->strip.as<int>(), g.S, c->vals_out.as<u32>(), c->cnt.as<int>(), c->slot[c->cur].labels.as<int>());
+    LAUNCH(k_scatter_counts, n, c->strip.as<int>(), g.S, c->srow, c->cnt.as<int>(), c->slot[c->cur].labels.as<int>());
     HIP_TRY(hipMemcpyAsync(counts_out, c->slot[c->cur].labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->profiling) {
@@ -2486,7 +2602,8 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
     c->deq++;
     const int K = sl.h_hdr[0];
     if (sl.h_hdr[1] != 0)
-        return fail(CL_ERR_HIP, "internal: release-record overflow (border point with > 4 adjacent components)");
+        return fail(CL_ERR_HIP, sl.h_hdr[1] == 4 ? "internal: strip longer than the hybrid sort accepts"
+                                                 : "internal: release-record overflow (border point with > 4 adjacent components)");
     // the table rows are already in the slot's pinned cache (k_export_table); only if that cache was
     // too small (K > capacity, reported in the header) grow it and fetch the rows with a copy
     int nc = sl.h_hdr[3], ml = sl.h_hdr[4];
@@ -2693,7 +2810,6 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     int* sv = c->sv.as<int>();
     int* sa = c->sa.as<int>();
     int* cnt = c->cnt.as<int>();
-    u32* srow = c->vals_out.as<u32>();
     int* counters = c->counters.as<int>();
     const int ntiles = nblocks(n);
     const int tgrid = tile_grid(ntiles);
@@ -2701,6 +2817,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     LAUNCH(k_init_flags, n + 1, n, c->flag.as<int>(), counters);
     HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
     if ((rc = run_sort_and_count(c, g, false))) return rc;
+    const u32* srow = c->srow;
 
     // K3
     if (variant == CL_VARIANT_CDBSCAN2) {

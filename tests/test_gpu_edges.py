@@ -142,3 +142,33 @@ def test_strips_longer_than_the_lds_window(n, L, eps, minPts):
     X, Y = synth_chrom(n, L, 99)
     run_all(X, Y, eps, minPts)
     run_all(X, Y, eps, minPts, cut=eps // 2, variants=["v2"])
+
+
+@pytest.mark.parametrize("variant", ["v2", "v1"])
+def test_hybrid_sort_equals_full_radix_sort(variant, monkeypatch):
+    """short strips everywhere -> the strip-level radix sort + in-strip ranking path; CLOOPS_DBG=256
+    forces the full radix sort: same labels, same table, and both equal the oracle.  A second
+    chromosome with a pile-up (a strip of thousands of PETs) must pick the full sort by itself."""
+    from cloops_amd.synth import synth_chrom
+    X, Y = synth_chrom(400000, 20000000, 77)
+    want = oracle.labels(variant, X, Y, 2000, 5)
+    for dbg in ("0", "256"):
+        monkeypatch.setenv("CLOOPS_DBG", dbg)
+        ch = api.Chromosome(X, Y)                       # fresh handle: the sort plan is per handle
+        try:
+            for cut in (0, 3000, 0):
+                got = ch.cluster(variant, 2000, 5, cut)
+                if cut == 0:
+                    assert np.array_equal(got.labels, want), (variant, dbg)
+                else:
+                    keep = Y.astype(np.int64) - X >= cut
+                    w2 = np.full(len(X), -1, np.int32)
+                    w2[keep] = oracle.labels(variant, X[keep], Y[keep], 2000, 5)
+                    assert np.array_equal(got.labels, w2), (variant, dbg, cut)
+        finally:
+            ch.close()
+    monkeypatch.setenv("CLOOPS_DBG", "0")
+    rng = np.random.default_rng(5)
+    Xp = np.concatenate([X, 5000000 + rng.integers(-300, 301, 5000).astype(np.int32)])
+    Yp = np.concatenate([Y, 5600000 + rng.integers(-300, 301, 5000).astype(np.int32)])
+    run_all(Xp, Yp, 2000, 5, variants=[variant])
