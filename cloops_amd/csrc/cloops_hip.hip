@@ -1502,9 +1502,19 @@ __device__ __forceinline__ void table_accumulate(const Table& t, TableLds& h, in
                 }
             }
         } else if (mine) {
-            atomicAdd(&t.count[L], 1);
-            atomicMin(&t.minx[L], x); atomicMax(&t.maxx[L], x);
-            atomicMin(&t.miny[L], y); atomicMax(&t.maxy[L], y);
+            // a handful of lanes share the label: straight into the LDS table (five LDS atomics instead of five
+            // global ones -- clusters are spread over several strips, so most PETs of a wave are in such
+            // small groups and their global atomics used to dominate the kernel)
+            const int sl = tab_slot(h.key, L);
+            if (sl >= 0) {
+                atomicAdd(&h.cnt[sl], 1);
+                atomicMin(&h.mnx[sl], x); atomicMax(&h.mxx[sl], x);
+                atomicMin(&h.mny[sl], y); atomicMax(&h.mxy[sl], y);
+            } else {
+                atomicAdd(&t.count[L], 1);
+                atomicMin(&t.minx[L], x); atomicMax(&t.maxx[L], x);
+                atomicMin(&t.miny[L], y); atomicMax(&t.maxy[L], y);
+            }
         }
         pending &= ~m;
     }
