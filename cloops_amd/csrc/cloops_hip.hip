@@ -1020,21 +1020,32 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
             // costs one candidate instead of a hundred.
             const int T = me.y - g.eps;
             const bool dense = b - tb > 48;
-            int j = lds_lower_bound8(t.w, tb, b, qlo);
+            // search depth chosen per wave (a per-lane choice would make most waves run every variant)
+            int j;
+            if (!__any(b - tb > 31)) j = lds_lower_bound8<5>(t.w, tb, b, qlo);
+            else if (!__any(b - tb > 63)) j = lds_lower_bound8<6>(t.w, tb, b, qlo);
+            else j = lds_lower_bound8<8>(t.w, tb, b, qlo);
             while (j < b) {
-                const int2 cnd = t.w[j];
-                if (cnd.x > qhi) break;
-                const int B = t.x[j];
-                if (B >= 0 && cnd.y >= T) {
-                    touch(B);
-                    if (dense) {
-                        const int qe = chain_qend[B];
-                        if (qe >= qhi) break;
-                        j = lds_upper_bound8(t.w, j + 1, b, qe);
-                        continue;
+                // four candidates per round, all LDS reads in flight before the first compare
+                int2 cv[4]; int bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int idx = min(j + u, b - 1); cv[u] = t.w[idx]; bv[u] = t.x[idx]; }
+                int next = j + 4;
+                bool stop = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (stop || j + u >= b) continue;
+                    if (cv[u].x > qhi) { stop = true; next = b; continue; }
+                    if (bv[u] >= 0 && cv[u].y >= T) {
+                        touch(bv[u]);
+                        if (dense) {
+                            const int qe = chain_qend[bv[u]];
+                            stop = true;
+                            next = (qe >= qhi) ? b : lds_upper_bound8(t.w, j + u + 1, b, qe);
+                        }
                     }
                 }
-                ++j;
+                j = next;
             }
         } else {
             // long strips (dense data at large eps: hundreds of candidates per window, nearly all of them in
