@@ -27,7 +27,7 @@ SYMBOLS = [
     "cl_last_error", "cl_device_count", "cl_chrom_create", "cl_chrom_destroy", "cl_chrom_size",
     "cl_cluster", "cl_get_boxes", "cl_neighbor_counts", "cl_labels_device", "cl_set_profiling",
     "cl_get_timing", "cl_version", "cl_host_alloc", "cl_host_free", "cl_cluster_async", "cl_wait", "cl_boxes_host",
-    "cl_dist_stats", "cl_dist_sqdev", "cl_dist_hist", "cl_last_n_in", "cl_sig_counts",
+    "cl_dist_stats", "cl_dist_sqdev", "cl_dist_hist", "cl_last_n_in", "cl_sig_counts", "cl_cluster_weighted",
 ]
 
 
@@ -80,6 +80,8 @@ def load():
     lib.cl_chrom_size.argtypes = [vp]
     lib.cl_cluster.restype = ctypes.c_int
     lib.cl_cluster.argtypes = [vp, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, i32p, i32p]
+    lib.cl_cluster_weighted.restype = ctypes.c_int
+    lib.cl_cluster_weighted.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, i32p, i32p]
     lib.cl_cluster_async.restype = ctypes.c_int
     lib.cl_cluster_async.argtypes = [vp, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     lib.cl_wait.restype = ctypes.c_int

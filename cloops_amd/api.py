@@ -169,6 +169,19 @@ class Chromosome(object):
         boxes = self._boxes(ml.value, copy=not pinned) if want_boxes else None
         return ClusterResult(labels, nc.value, ml.value, boxes, self.timing() if self._profiling else None)
 
+    def cluster_weighted(self, eps, minPts, wx=1, wy=1):
+        """Variant 1 under the metric wx*|dX| + wy*|dY| <= eps: the labels of
+        `cDBSCAN(mat * [1, wx, wy], eps, minPts)` (scripts/callStripes:37-52); boxes in unscaled
+        coordinates (cl_cluster_weighted of include/cloops_hip.h)."""
+        if self._inflight:
+            raise RuntimeError("asynchronous runs in flight: call wait() first")
+        labels = np.empty(self.n, dtype=np.int32)
+        nc = ctypes.c_int32(0)
+        ml = ctypes.c_int32(-1)
+        _lib.check(self._lib.cl_cluster_weighted(self._h, int(eps), int(minPts), int(wx), int(wy),
+                                                 labels.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nc), ctypes.byref(ml)))
+        return ClusterResult(labels, nc.value, ml.value, self._boxes(ml.value, copy=True), self.timing() if self._profiling else None)
+
     def last_n_in(self):
         """PETs of the last completed run that entered DBSCAN (after the cut filter)."""
         return int(self._lib.cl_last_n_in(self._h))

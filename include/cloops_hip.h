@@ -105,6 +105,19 @@ int cl_cluster(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t c
                int32_t* labels_out, int32_t* n_clusters, int32_t* max_label);
 
 /*
+ * Variant 1 under an axis-weighted city-block metric: the result of
+ *     cDBSCAN(mat * [1, wx, wy], eps, minPts)            (cLoops/cDBSCAN.py:12)
+ * i.e. of scripts/callStripes:37-52 (singleStripDBSCAN), which multiplies the X or the Y column by
+ * `ext` (50) before clustering to find stripes: two PETs are neighbours iff wx*|dX| + wy*|dY| <= eps.
+ * The scaled coordinates (up to 1.25e10) never exist as int32: the kernels work on 64-bit rotated
+ * coordinates.  labels_out / n_clusters / max_label as for cl_cluster (ids of variant 1, gaps kept);
+ * cl_get_boxes() afterwards returns the boxes in UNSCALED coordinates (callStripes:59-66 divides the
+ * scaled extrema by ext again).  1 <= wx, wy <= 4096.  Synchronous; no cut (callStripes uses none).
+ */
+int cl_cluster_weighted(cl_chrom* c, int32_t eps, int32_t min_pts, int32_t wx, int32_t wy,
+                        int32_t* labels_out, int32_t* n_clusters, int32_t* max_label);
+
+/*
  * Asynchronous form for sweeps with a fixed cut (every (eps, minPts) step of the same
  * chromosome is independent there): cl_cluster_async() enqueues one run and returns without
  * blocking; cl_wait() completes the OLDEST outstanding run and reports its cluster count.

@@ -58,3 +58,25 @@ def test_closed_forms_on_chr21():
     assert np.array_equal(M.labels_v2(X, Y, 2000, 5, st), G.chr21_labels("v2", 2000, 5))
     st1 = {}
     assert np.array_equal(M.labels_v1(X, Y, 2000, 5, st1), G.chr21_labels("v1", 2000, 5))
+
+
+def test_v1_closed_form_on_scaled_coordinates_vs_the_real_class():
+    """the axis-stretched use of variant 1 (scripts/callStripes:44-46: X * ext, coordinates beyond int32):
+    closed form R1 on int64 coordinates == the real cLoops.cDBSCAN on the scaled matrix (runs where
+    /root/reference exists); it is the checker of tests/test_gpu_weighted.py"""
+    import refload
+    if not refload.available():
+        pytest.skip("reference checkout not present")
+    rng = np.random.default_rng(3)
+    for k in range(8):
+        n = int(rng.integers(200, 1500))
+        X = rng.integers(10 ** 8, 10 ** 8 + 40000, n).astype(np.int64)
+        Y = X + rng.integers(0, 400000, n)
+        if k % 2:
+            X[: n // 3] = X[0] + rng.integers(-3, 4, n // 3)      # a vertical stripe
+        ids = np.arange(n, dtype=np.int64)
+        for wx, wy in ((50, 1), (1, 50)):
+            mat = np.stack([ids, X * wx, Y * wy], 1)
+            want = refload.labels_dict_to_array(refload.ref_labels("v1", mat, 20000, 5), ids)
+            assert int(mat[:, 1:].max()) > 2 ** 31
+            assert np.array_equal(M.labels_v1(X * wx, Y * wy, 20000, 5), want), (k, wx, wy)

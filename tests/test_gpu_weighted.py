@@ -1,0 +1,93 @@
+"""GPU: variant 1 under the axis-weighted metric (cl_cluster_weighted; scripts/callStripes:37-72) against
+(a) golden labels made with the REAL reference class on the explicitly scaled chr21 matrix
+(tests/golden/make_golden_stripes.py), (b) the closed form R1 (tests/closed_form_model.py, itself checked against
+the real class on scaled matrices in tests/test_closed_form_model.py) on scaled int64 coordinates, (c) the
+unweighted path (wx = wy = 1)."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as G
+import closed_form_model as M
+from cloops_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+def scaled_labels_model(X, Y, eps, minPts, wx, wy):
+    return M.labels_v1(np.asarray(X, np.int64) * wx, np.asarray(Y, np.int64) * wy, eps, minPts)
+
+
+def run(X, Y, eps, minPts, wx, wy):
+    ch = api.Chromosome(np.ascontiguousarray(X, np.int32), np.ascontiguousarray(Y, np.int32))
+    try:
+        return ch.cluster_weighted(eps, minPts, wx, wy)
+    finally:
+        ch.close()
+
+
+@pytest.mark.parametrize("wx,wy", [(50, 1), (1, 50), (7, 3)])
+def test_random_cases_vs_closed_form(wx, wy):
+    rng = np.random.default_rng(wx * 100 + wy)
+    for k in range(25):
+        n = int(rng.integers(40, 700))
+        eps = int(rng.choice([60, 400, 2500]))
+        minPts = int(rng.choice([3, 5, 8]))
+        span = int(rng.integers(5, 60)) * eps
+        x0 = 10 ** 8 if k % 2 else 1000                  # scaled coordinates beyond int32 in every other case
+        X = rng.integers(x0, x0 + max(2, span // max(wx, 1)) + 1, n)
+        Y = X + rng.integers(0, max(2, span // max(wy, 1)) + 1, n)
+        if k % 3 == 0:                                   # line-like pile-ups: what the stretch is for
+            m = n // 3
+            X[:m] = X[0] + rng.integers(-2, 3, m)
+        got = run(X, Y, eps, minPts, wx, wy)
+        want = scaled_labels_model(X, Y, eps, minPts, wx, wy)
+        assert np.array_equal(got.labels, want), (k, n, eps, minPts)
+        lab = got.labels
+        for c in np.unique(lab[lab >= 0])[:20]:          # boxes are UNSCALED
+            sel = lab == c
+            b = got.boxes[c]
+            assert (b["min_x"], b["max_x"], b["min_y"], b["max_y"], b["count"]) == (X[sel].min(), X[sel].max(), Y[sel].min(), Y[sel].max(), sel.sum())
+
+
+def test_unit_weights_equal_variant1():
+    X, Y = G.chr21_xy()
+    ch = api.Chromosome(X, Y)
+    try:
+        a = ch.cluster("v1", 2000, 5).labels.copy()
+        b = ch.cluster_weighted(2000, 5, 1, 1).labels
+        assert np.array_equal(a, b)
+    finally:
+        ch.close()
+
+
+def test_chr21_stripes_golden():
+    """callStripes defaults: eps 20000, minPts 5, ext 50 on either axis; coordinates reach 2.3e9 * ... > int32"""
+    z = np.load(os.path.join(G.GOLD, "chr21_stripes_labels.npz"))
+    X, Y = G.chr21_xy()
+    for name, wx, wy in (("x50", 50, 1), ("y50", 1, 50)):
+        got = run(X, Y, 20000, 5, wx, wy)
+        assert np.array_equal(got.labels, z[name]), name
+
+
+def test_single_strip_dbscan_records():
+    """cloops_amd.stripes.singleStripDBSCAN == scripts/callStripes:37-72 on the chr21 example: one record
+    [chrA, minX, maxX, chrB, minY, maxY, nPETs] per cluster id of the golden labels, unscaled coordinates."""
+    from cloops_amd import pipe, stripes
+    z = np.load(os.path.join(G.GOLD, "chr21_stripes_labels.npz"))
+    X, Y = G.chr21_xy()
+    f = pipe.CACHE.put_arrays("chr21-chr21", X, Y)
+    try:
+        for name, ex, ey in (("x50", 50, 1), ("y50", 1, 50)):
+            key, dataI = stripes.singleStripDBSCAN(f, 20000, 5, extx=ex, exty=ey)
+            lab = z[name]
+            want = []
+            for c in np.unique(lab[lab >= 0]):
+                sel = lab == c
+                want.append(["chr21", int(X[sel].min()), int(X[sel].max()), "chr21", int(Y[sel].min()), int(Y[sel].max()), int(sel.sum())])
+            assert key == ("chr21", "chr21") and dataI == want
+        rs = stripes.filterCandidateStripes({key: dataI}, pets=20, lengthFoldDiff=5)
+        assert all(r[6] >= 20 for r in rs[key]) and len(rs[key]) <= len(dataI)
+    finally:
+        pipe.CACHE.clear()

@@ -84,3 +84,16 @@ def test_sweep_fast_host_logic(cpu_pipe):
     """runSweepFast (statistics instead of lists) against the reference-made chain, CPU backend"""
     p, f = cpu_pipe
     pipe_checks.check_sweep_fast(p, f)
+
+
+def test_filter_candidate_stripes_semantics():
+    """scripts/callStripes:75-86: keep records with >= pets PETs whose side lengths differ by more than
+    lengthFoldDiff (py2 integer division)"""
+    from cloops_amd import stripes
+    rs = {("c", "c"): [["c", 0, 1000, "c", 0, 10, 300],       # 100x longer in X: kept
+                       ["c", 0, 10, "c", 0, 1000, 300],       # 100x longer in Y: kept
+                       ["c", 0, 100, "c", 0, 100, 300],       # square: dropped
+                       ["c", 0, 1000, "c", 0, 10, 100],       # too few PETs: dropped
+                       ["c", 0, 209, "c", 0, 10, 300]]}       # 209 // 10 = 20, not > 20: dropped
+    out = stripes.filterCandidateStripes(rs, pets=200, lengthFoldDiff=20)
+    assert out[("c", "c")] == [["c", 0, 1000, "c", 0, 10, 300], ["c", 0, 10, "c", 0, 1000, 300]]
