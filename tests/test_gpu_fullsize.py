@@ -99,3 +99,18 @@ def test_cfg3_dense_regime_40M():
         assert np.array_equal(l1, r2.labels)
     finally:
         ch.close()
+
+
+@pytest.mark.parametrize("wx,wy", [(50, 1), (1, 50)])
+def test_cfg2_weighted_metric_table_and_determinism(cfg2, wx, wy):
+    """callStripes' stretched metric on a whole chromosome: scaled coordinates reach 1.2e10 (64-bit path)"""
+    X, Y = cfg2
+    ch = api.Chromosome(X, Y)
+    try:
+        r1 = ch.cluster_weighted(20000, 5, wx, wy)
+        check_table(X, Y, r1)
+        r2 = ch.cluster_weighted(20000, 5, wx, wy)
+        assert np.array_equal(r1.labels, r2.labels)
+        assert r1.n_clusters > 50000
+    finally:
+        ch.close()
