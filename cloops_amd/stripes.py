@@ -46,3 +46,128 @@ def filterCandidateStripes(rs, pets=200, lengthFoldDiff=20):
                 nds.append(r)
         rs[key] = nds
     return rs
+
+
+# ---- significance of candidate stripes (host side, scipy; scripts/callStripes:89-269) ---------
+def getNearbyStripes(iva, ivb, win=5):
+    """scripts/callStripes:89-120 with Python-2 integer arithmetic: the longer anchor stays, the shorter
+    one slides by its half-length; equal lengths return None (the script then fails unpacking it)."""
+    lena = iva[1] - iva[0]
+    lenb = ivb[1] - ivb[0]
+    ivas, ivbs = [], []
+    ca = sum(iva) // 2
+    cb = sum(ivb) // 2
+    sa = (iva[1] - iva[0]) // 2
+    sb = (ivb[1] - ivb[0]) // 2
+    if lena > lenb:
+        step = sb
+        for i in range(0 - win, win + 1):
+            if i == 0:
+                continue
+            ivas.append(iva)
+            ivbs.append([max([0, cb + i * step - sb]), max([0, cb + i * step + sb])])
+        return ivas, ivbs
+    if lena < lenb:
+        step = sa
+        for i in range(0 - win, win + 1):
+            if i == 0:
+                continue
+            ivas.append([max([0, ca + i * step - sa]), max([0, ca + i * step + sa])])
+            ivbs.append(ivb)
+        return ivas, ivbs
+    return None
+
+
+def getStripePsFdr(iva, ivb, model, N, win=5):
+    """scripts/callStripes:123-185 -> ra, rb, rab, es, es_ra, es_rb, fdr, pop, nbp"""
+    from scipy.stats import binom, poisson
+    from .cModel import getPETsforRegions
+    ra, rb, rab = getPETsforRegions(iva, ivb, model)
+    ivas, ivbs = getNearbyStripes(iva, ivb, win=win)       # TypeError for equal lengths, like the script
+    nras = [model.region(na) for na in ivas]
+    nrbs = [model.region(nb) for nb in ivbs]
+    rabs, nbps = [], []
+    for nra in nras:
+        nralen = float(len(nra))
+        for nrb in nrbs:
+            nrblen = len(nrb)
+            nrab = float(len(np.intersect1d(nra, nrb, assume_unique=True)))
+            if nrab > 0:
+                rabs.append(nrab)
+                nbps.append(nrab / (nralen * nrblen))
+            else:
+                nbps.append(0.0)
+                rabs.append(0.0)
+    rabs = np.array(rabs)
+    fdr = len(rabs[rabs > rab]) / float(len(rabs))
+    mrabs = float(np.mean(rabs))
+    es = rab / np.mean(rabs[rabs > 0]) if mrabs > 0 else np.inf
+    pop = max([1e-300, poisson.sf(rab - 1.0, mrabs)])
+    bp = np.mean(nbps) * ra * rb / N
+    nbp = max([1e-300, binom.sf(rab - 1.0, N - rab, bp)])
+    return ra, rb, rab, es, rab / float(ra), rab / float(rb), fdr, pop, nbp
+
+
+def estStripeSig(f, records, device=0):
+    """scripts/callStripes:188-233: one row per candidate stripe; None without PETs or records"""
+    import pandas as pd
+    from .cModel import CoverageModel
+    r0 = CACHE.get(f, device)
+    N = len(r0.d)
+    if N < 2:                                             # getGenomeCoverage returns (None, 0) (cModel.py:53-54)
+        return None
+    model = CoverageModel(np.stack([np.asarray(r0.ids), np.asarray(r0.X), np.asarray(r0.Y)], 1))
+    ds = {}
+    for i, r in enumerate(records):
+        chrom = r[0]
+        key = "%s-%s-%s" % (r[0], r[3], i)
+        iva = [max(0, r[1]), r[2]]
+        ivb = [max(0, r[4]), r[5]]
+        ra, rb, rab, es, es_ra, es_rb, fdr, pop, nbp = getStripePsFdr(iva, ivb, model, N)
+        ds[key] = {
+            "ra": ra, "rb": rb, "rab": rab, "ES": es, "ES_ra": es_ra, "ES_rb": es_rb, "FDR": fdr,
+            "poisson_p-value": pop, "binomial_p-value": nbp,
+            "iva": "%s:%s-%s" % (chrom, iva[0], iva[1]), "ivb": "%s:%s-%s" % (chrom, ivb[0], ivb[1]),
+        }
+    if len(ds) == 0:
+        return None
+    return pd.DataFrame(ds).T
+
+
+def markStripeSig(ds, escut=2.0, fdrcut=0.1, ppcut=1e-5, es_cut=0.2):
+    """scripts/callStripes:236-269"""
+    import pandas as pd
+    a = ds["ES"]
+    a = a[a >= escut]
+    b = ds.loc[a.index, "FDR"]
+    b = b[b <= fdrcut]
+    c = ds.loc[b.index, "poisson_p-value"]
+    c = c[c <= ppcut]
+    d = ds.loc[c.index, "ES_ra"]
+    d = d[d >= es_cut]
+    e = ds.loc[c.index, "ES_rb"]
+    e = e[e >= es_cut]
+    rs = d.index.union(e.index)
+    ns = pd.Series(data=np.zeros(ds.shape[0]), index=ds.index)
+    ns[rs] = 1.0
+    ds["significant"] = ns
+    return ds
+
+
+def callStripes(fs, fout, eps=20000, minPts=5, pets=100, ext=50, lengthFoldDiff=50):
+    """scripts/callStripes:285-372 for a list of .jd files (or 'mem://' chromosomes of pipe.CACHE): horizontal
+    (X stretched) and vertical (Y stretched) stripes -> `fout_x_horizontal.stripe`, `fout_y_vertical.stripe`.
+    The juicebox converter (`-j`) is a viewer format and not part of this package."""
+    import pandas as pd
+    out = {}
+    for name, kw in (("x_horizontal", {"extx": ext}), ("y_vertical", {"exty": ext})):
+        ds = dict(singleStripDBSCAN(f, eps, minPts, **kw) for f in fs)
+        key2f = {CACHE.get(f).key: f for f in fs}
+        ds = filterCandidateStripes(ds, pets=pets, lengthFoldDiff=lengthFoldDiff)
+        tabs = [estStripeSig(key2f[key], ds[key]) for key in ds.keys()]
+        tabs = [t for t in tabs if t is not None]
+        if len(tabs) > 0:
+            tab = markStripeSig(pd.concat(tabs))
+            tab.to_csv(fout + "_%s.stripe" % name, sep="\t", index_label="stripeId")
+            out[name] = tab
+    return out

@@ -147,3 +147,39 @@ def ref_cmodel_namespace():
     exec(compile(src, "cModel.py:py3", "exec"), ns)
     _cache["cmodel"] = ns
     return ns
+
+
+def ref_stripes_namespace():
+    """The stripe functions of scripts/callStripes (singleStripDBSCAN :37-72, filterCandidateStripes :75-86,
+    getNearbyStripes :89-120, getStripePsFdr :123-185, estStripeSig :188-233, markStripeSig :236-269),
+    extracted from the parsed script (it cannot be imported: py2-only cLoops.io / cLoops.utils) and exec'd in a
+    namespace wired to the real variant-1 class, the real parseJd and the converted reference cModel
+    (ref_cmodel_namespace).  Mechanical py2 -> py3 patches: xrange -> range, integer `/` -> `//` in
+    getNearbyStripes and filterCandidateStripes.  Used to MAKE golden vectors only."""
+    import ast
+    import numpy as np
+    import pandas as pd
+    import gc
+    from scipy.stats import hypergeom, binom, poisson, combine_pvalues
+    if "stripes" in _cache:
+        return _cache["stripes"]
+    cm = ref_cmodel_namespace()
+    ns = {"np": np, "pd": pd, "gc": gc, "os": os, "hypergeom": hypergeom, "binom": binom, "poisson": poisson,
+          "combine_pvalues": combine_pvalues, "DBSCAN": ref_classes()["v1"], "parseJd": cm["parseJd"],
+          "getGenomeCoverage": cm["getGenomeCoverage"], "getPETsforRegions": cm["getPETsforRegions"],
+          "getCounts": cm["getCounts"], "cFlush": lambda *a: None}
+    with open(os.path.join(REF_ROOT, "scripts", "callStripes")) as fh:
+        src = fh.read()
+    src = src.replace("xrange", "range")
+    for a, b in (("ca = sum(iva) / 2", "ca = sum(iva) // 2"), ("cb = sum(ivb) / 2", "cb = sum(ivb) // 2"),
+                 ("sa = (iva[1] - iva[0]) / 2", "sa = (iva[1] - iva[0]) // 2"), ("sb = (ivb[1] - ivb[0]) / 2", "sb = (ivb[1] - ivb[0]) // 2"),
+                 ("if (xlen / ylen > lengthFoldDiff) or (ylen / xlen >", "if (xlen // ylen > lengthFoldDiff) or (ylen // xlen >")):
+        assert a in src, a
+        src = src.replace(a, b)
+    tree = ast.parse(src)
+    want = {"singleStripDBSCAN", "filterCandidateStripes", "getNearbyStripes", "getStripePsFdr", "estStripeSig", "markStripeSig"}
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert len(body) == len(want)
+    exec(compile(ast.Module(body=body, type_ignores=[]), "callStripes:functions", "exec"), ns)
+    _cache["stripes"] = ns
+    return ns

@@ -91,3 +91,22 @@ def test_single_strip_dbscan_records():
         assert all(r[6] >= 20 for r in rs[key]) and len(rs[key]) <= len(dataI)
     finally:
         pipe.CACHE.clear()
+
+
+def test_call_stripes_end_to_end(tmp_path):
+    """scripts/callStripes:285-372 on the chr21 example: GPU clustering under the stretched metric + host
+    significance -> `.stripe` tables text-identical to the reference's own functions"""
+    import json
+    from cloops_amd import pipe, stripes
+    meta = json.load(open(os.path.join(G.GOLD, "chr21_stripes_meta.json")))
+    X, Y = G.chr21_xy()
+    f = pipe.CACHE.put_arrays("chr21-chr21", X, Y)
+    try:
+        fout = os.path.join(str(tmp_path), "s")
+        out = stripes.callStripes([f], fout, eps=meta["eps"], minPts=meta["minPts"], pets=meta["pets"], ext=meta["ext"],
+                                  lengthFoldDiff=meta["lengthFoldDiff"])
+        for name in ("x_horizontal", "y_vertical"):
+            assert open(fout + "_%s.stripe" % name).read() == open(os.path.join(G.GOLD, "chr21_%s.stripe" % name)).read()
+            assert int(out[name]["significant"].sum()) == meta[name + "_significant"]
+    finally:
+        pipe.CACHE.clear()
