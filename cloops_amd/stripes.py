@@ -171,3 +171,35 @@ def callStripes(fs, fout, eps=20000, minPts=5, pets=100, ext=50, lengthFoldDiff=
             tab.to_csv(fout + "_%s.stripe" % name, sep="\t", index_label="stripeId")
             out[name] = tab
     return out
+
+
+def main(argv=None):
+    """`python -m cloops_amd.stripes -d <dir of .jd> -o <prefix>`: the flags of scripts/callStripes:375-459
+    (`-j` accepted and ignored: viewer format; `-p` accepted: parallelism is over GPUs)."""
+    import argparse
+    import os
+    from glob import glob
+    ap = argparse.ArgumentParser(description="Call stripes (scripts/callStripes) on MI355X")
+    ap.add_argument("-d", dest="d", required=True, type=str)
+    ap.add_argument("-o", dest="output", required=True, type=str)
+    ap.add_argument("-eps", dest="eps", default=20000, type=int)
+    ap.add_argument("-minPts", dest="minPts", default=5, type=int)
+    ap.add_argument("-ext", dest="ext", default=50, type=int)
+    ap.add_argument("-pets", dest="pets", default=200, type=int)
+    ap.add_argument("-lenFold", dest="lengthFoldDiff", default=50, type=int)
+    ap.add_argument("-c", dest="chroms", default="", type=str)
+    ap.add_argument("-j", dest="juice", action="store_true")
+    ap.add_argument("-p", dest="cpu", default=1, type=int)
+    op = ap.parse_args(argv)
+    chroms = op.chroms.split(",")
+    fs = []
+    for f in sorted(glob(os.path.join(op.d, "*.jd"))):
+        c = tuple(os.path.splitext(os.path.split(f)[-1])[0].split("-"))
+        if chroms == [""] or (c[0] in chroms and c[1] in chroms):          # scripts/callStripes:300-306
+            fs.append(f)
+    callStripes(fs, op.output, eps=op.eps, minPts=op.minPts, pets=op.pets, ext=op.ext, lengthFoldDiff=op.lengthFoldDiff)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
