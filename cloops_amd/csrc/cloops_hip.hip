@@ -2369,6 +2369,7 @@ struct cl_chrom {
     bool profiling = false;
     cl_timing timing{};
     bool ev_ready = false;
+    float ev_bracket_ms = 0.f;        // event bracket around an empty kernel (calibration, see cl_timing)
 };
 
 static void free_chrom(cl_chrom* c)
@@ -2617,11 +2618,26 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     return CL_OK;
 }
 
+__global__ void k_nop() {}
+
 static int ensure_events(cl_chrom* c)
 {
     if (c->profiling && !c->ev_ready) {
         for (auto& sl : c->slot) for (auto& e : sl.ev) HIP_TRY(hipEventCreate(&e));
         c->ev_ready = true;
+        // calibration of the event bracket itself: an EMPTY kernel between two event records (median of 9).
+        // A bracket around one kernel reads kernel time + this (event packets, dispatch gap).
+        float v[9];
+        hipEvent_t a = c->slot[0].ev[0], b = c->slot[0].ev[1];
+        for (int r = 0; r < 9; ++r) {
+            HIP_TRY(hipEventRecord(a, c->stream));
+            hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, c->stream);
+            HIP_TRY(hipEventRecord(b, c->stream));
+            HIP_TRY(hipEventSynchronize(b));
+            (void)hipEventElapsedTime(&v[r], a, b);
+        }
+        std::sort(v, v + 9);
+        c->ev_bracket_ms = v[4];
     }
     return CL_OK;
 }
@@ -2803,6 +2819,7 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
         (void)hipEventElapsedTime(&tm.ms_total, ev[0], ev[7]);
         tm.n_in = sl.h_hdr[2];
         tm.n_strips = sl.n_strips;
+        tm.ms_bracket = c->ev_bracket_ms;
     }
     return CL_OK;
 }

@@ -65,6 +65,9 @@ typedef struct {
     float ms_total;       /* first kernel -> results on host                             */
     int64_t n_in;         /* PETs that entered DBSCAN (after the cut filter)             */
     int64_t n_strips;     /* rows of the strip table (C+1 term of the algorithmic bytes) */
+    float ms_bracket;     /* calibration: the same event bracket around an EMPTY kernel (event packets +
+                             dispatch gap + ~1 us of empty kernel); a phase that is one kernel (ms_region)
+                             reads kernel time + about this much                                    */
 } cl_timing;
 
 /* Human-readable description of the last error on the calling thread. */
