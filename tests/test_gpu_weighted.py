@@ -110,3 +110,16 @@ def test_call_stripes_end_to_end(tmp_path):
             assert int(out[name]["significant"].sum()) == meta[name + "_significant"]
     finally:
         pipe.CACHE.clear()
+
+
+@pytest.mark.parametrize("wx,wy", [(50, 1), (1, 50)])
+def test_midsize_vs_sequential_oracle(wx, wy):
+    """300 k synthetic PETs on a chr1-sized axis (scaled coordinates up to 1.2e10): GPU == sequential C oracle
+    run on the explicitly scaled 64-bit matrix"""
+    import oracle
+    from cloops_amd.synth import synth_chrom
+    X, Y = synth_chrom(300000, 248956422, 11)
+    want = oracle.labels("v1", X.astype(np.int64) * wx, Y.astype(np.int64) * wy, 20000, 5)
+    got = run(X, Y, 20000, 5, wx, wy)
+    assert np.array_equal(got.labels, want)
+    assert got.n_clusters == len(np.unique(want[want >= 0]))

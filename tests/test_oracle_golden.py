@@ -65,3 +65,15 @@ def test_neighbor_counts_bruteforce():
     c = oracle.neighbor_counts(X, Y, 40)
     d = np.abs(X[:, None] - X[None, :]) + np.abs(Y[:, None] - Y[None, :])
     assert np.array_equal(c, (d <= 40).sum(1))
+
+
+def test_oracle_v1_on_scaled_coordinates_matches_the_real_class():
+    """scripts/callStripes:44-46 stretches one axis by ext = 50 before cDBSCAN (variant 1): the oracle takes
+    64-bit coordinates, and on the x50-scaled chr21 matrix it reproduces the labels of the REAL class
+    (tests/golden/make_golden_stripes.py) -- which makes it the checker of cl_cluster_weighted."""
+    import os
+    X, Y = G.chr21_xy()
+    z = np.load(os.path.join(G.GOLD, "chr21_stripes_labels.npz"))
+    for name, wx, wy in (("x50", 50, 1), ("y50", 1, 50)):
+        lab = oracle.labels("v1", X.astype(np.int64) * wx, Y.astype(np.int64) * wy, 20000, 5)
+        assert np.array_equal(lab, z[name]), name
