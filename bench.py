@@ -17,6 +17,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
   "cpu_baseline"  the CPU oracle (C port of cDBSCAN2) timed on this box's host cores
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -39,6 +40,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line (rank 0): park the real stdout and point fd 1 at stderr until the end
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -77,6 +83,8 @@ def main():
         tab = np.stack([b["min_x"], b["max_x"], b["min_y"], b["max_y"], b["count"]], 1) if len(b) else np.zeros((0, 5), np.int32)
         return gather_tables(tab, device=tdev)
 
+    step_t = [] if os.environ.get("CLOOPS_BENCH_DEBUG") else None
+
     def run(nsteps, k2_ms=None):
         # Steps of a fixed-cut sweep are independent runs: step k+1 is enqueued before step k is
         # completed, so the D2H copy of step k overlaps the kernels of step k+1 (two result slots).
@@ -88,12 +96,23 @@ def main():
             res = chrom.wait()
             if k2_ms is not None:
                 k2_ms.append(res.timing["ms_region"])
+                if step_t is not None:
+                    step_t.append((time.perf_counter(), res.timing["ms_total"], dict(res.timing)))
         return res
 
+    extra_warm = 0
     if args.warmup > 0:
-        res = run(args.warmup)
         if use_dist:
-            gather_final(res)              # untimed: RCCL communicator set-up happens on the first collective
+            # untimed: RCCL communicator set-up happens on the first collective.  It goes FIRST so that the warm-up
+            # ends with GPU work and only the barrier separates it from the timed region.  With torch's HIP runtime
+            # in the process one early device-to-host copy stalls for ~4 ms (seen at the 3rd..5th step after the
+            # first collective, never later): the warm-up is padded to 8 steps so that it cannot land in the timed ones.
+            gather_final(run(1))
+            extra_warm = max(0, 8 - args.warmup)
+            if args.warmup + extra_warm > 1:
+                run(args.warmup + extra_warm - 1)
+        else:
+            run(args.warmup)
     sync_all()
     t0 = time.perf_counter()
     k2_ms = []
@@ -107,6 +126,11 @@ def main():
     if os.environ.get("CLOOPS_BENCH_DEBUG"):
         sys.stderr.write("[bench rank %d] run %.3f ms, gather %.3f ms, final sync %.3f ms\n" % (
             rank, t_run * 1e3, t_gather * 1e3, (elapsed - t_run - t_gather) * 1e3))
+        sys.stderr.write("[bench rank %d] per-step wall (ms): %s\n" % (rank, " ".join(
+            "%.2f" % ((b[0] - a[0]) * 1e3) for a, b in zip([(t0, 0)] + step_t[:-1], step_t))))
+        sys.stderr.write("[bench rank %d] per-step GPU total (ms): %s\n" % (rank, " ".join("%.2f" % s[1] for s in step_t)))
+        worst = max(step_t, key=lambda s: s[1])
+        sys.stderr.write("[bench rank %d] slowest step phases: %s\n" % (rank, {k[3:]: round(v, 3) for k, v in worst[2].items() if k.startswith("ms_")}))
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -117,6 +141,7 @@ def main():
     total_pets = n_in * args.steps * world
     value = total_pets / elapsed
 
+    line = None
     if rank == 0:
         # K2 is the only kernel between its two events; the bracket around an EMPTY kernel (event packets +
         # dispatch gap, calibrated by the library when profiling is switched on) is reported next to the raw
@@ -151,7 +176,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "synthetic-5M-chr1-eps2000-minPts5 (BASELINE.json configs[1])",
                        "variant": "cDBSCAN2", "pets_per_gpu": n_in, "eps": EPS, "minPts": MINPTS,
-                       "clusters": int(res.n_clusters), "parallelism": "chromosome-per-gpu x%d" % world},
+                       "clusters": int(res.n_clusters), "parallelism": "chromosome-per-gpu x%d" % world,
+                       "extra_untimed_warmup_steps": extra_warm},
             "roofline": {"bound": "hbm", "kernel": "k_region_count", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k2,
@@ -160,11 +186,21 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(X, Y, res)
-        print(json.dumps(line), flush=True)
     chrom.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    # everything written to fd 1 during the run (RCCL's NCCL_DEBUG=VERSION banner comes through C stdio) went to
+    # stderr: give stdout back and print the ONE JSON line
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 def _cpu_worker(seed):
