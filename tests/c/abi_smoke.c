@@ -1,0 +1,60 @@
+/* Plain-C consumer of include/cloops_hip.h (no Python, no C++): what a non-Python host would write.
+ * Clusters a small synthetic chromosome with every variant through the C ABI and checks the table against
+ * the labels.  Built and run by tests/test_gpu_c_abi.py:  gcc -std=c99 -I include abi_smoke.c -L... -lcloops_hip */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "cloops_hip.h"
+
+#define CHECK(call) do { int rc_ = (call); if (rc_ != CL_OK) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, cl_last_error()); return 1; } } while (0)
+
+int main(void)
+{
+    const int64_t n = 200000;
+    int32_t *x = malloc(n * sizeof *x), *y = malloc(n * sizeof *y), *lab = malloc(n * sizeof *lab);
+    uint64_t s = 88172645463325252ull;
+    for (int64_t i = 0; i < n; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        int32_t a = (int32_t)(s % 40000000u);
+        int32_t anchor = (int32_t)((s >> 32) % 2000u) * 20000;           /* 2000 loop anchors */
+        if (i % 3) { x[i] = anchor + (int32_t)(s % 600u); y[i] = anchor + 150000 + (int32_t)((s >> 20) % 600u); }
+        else { x[i] = a; y[i] = a + (int32_t)((s >> 40) % 500000u); }
+    }
+    if (cl_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
+    cl_chrom* c = NULL;
+    CHECK(cl_chrom_create(0, NULL, x, y, n, 0, &c));
+    if (cl_chrom_size(c) != n) return 3;
+    const int variants[3] = {CL_VARIANT_CDBSCAN2, CL_VARIANT_CDBSCAN1, CL_VARIANT_BLOCK};
+    for (int v = 0; v < 3; ++v) {
+        int32_t nc = 0, ml = -1;
+        CHECK(cl_cluster(c, variants[v], 2000, 5, 0, lab, &nc, &ml));
+        cl_box* boxes = malloc((size_t)(ml + 1) * sizeof *boxes);
+        CHECK(cl_get_boxes(c, boxes));
+        int64_t* cnt = calloc((size_t)(ml + 1), sizeof *cnt);
+        int64_t labelled = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            if (lab[i] < 0) continue;
+            if (lab[i] > ml) { fprintf(stderr, "label beyond max_label\n"); return 4; }
+            ++cnt[lab[i]]; ++labelled;
+            const cl_box* b = &boxes[lab[i]];
+            if (x[i] < b->min_x || x[i] > b->max_x || y[i] < b->min_y || y[i] > b->max_y) { fprintf(stderr, "PET outside its box\n"); return 5; }
+        }
+        int32_t live = 0;
+        for (int32_t k = 0; k <= ml; ++k) {
+            if (cnt[k] != boxes[k].count) { fprintf(stderr, "count mismatch at %d\n", k); return 6; }
+            live += cnt[k] > 0;
+        }
+        if (live != nc || nc < 100) { fprintf(stderr, "cluster count %d vs %d\n", live, nc); return 7; }
+        printf("variant %d: %d clusters, %lld labelled PETs\n", variants[v], nc, (long long)labelled);
+        free(boxes); free(cnt);
+    }
+    int32_t nc = 0, ml = -1;
+    CHECK(cl_cluster_weighted(c, 20000, 5, 50, 1, lab, &nc, &ml));
+    printf("weighted (50,1): %d clusters\n", nc);
+    if (cl_cluster(c, 7, 2000, 5, 0, lab, &nc, &ml) != CL_ERR_ARG) return 8;          /* unknown variant */
+    if (cl_cluster(c, CL_VARIANT_CDBSCAN2, 0, 5, 0, lab, &nc, &ml) != CL_ERR_ARG) return 9;   /* eps = 0 */
+    cl_chrom_destroy(c);
+    free(x); free(y); free(lab);
+    printf("abi smoke ok (library version %d)\n", cl_version());
+    return 0;
+}
