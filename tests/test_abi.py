@@ -48,3 +48,14 @@ def test_missing_library_is_an_import_error(monkeypatch):
     monkeypatch.setattr(_lib, "SO_PATH", "/nonexistent/libcloops_hip.so")
     with pytest.raises(ImportError):
         _lib.load()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/cloops_hip.h is C (not C++): the plain-C consumer of tests/c compiles against it with -Werror"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), "-c",
+                           os.path.join(root, "tests", "c", "abi_smoke.c"), "-o", os.path.join(str(tmp_path), "a.o")])
