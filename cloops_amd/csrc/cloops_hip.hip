@@ -3077,7 +3077,9 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     const int tgrid = tile_grid(ntiles);
 
     LAUNCH(k_init_flags, n + 1, n, c->flag.as<int>(), counters);
-    HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
+    // k_final_labels writes the label (or -1) of every PET that entered DBSCAN; only rows removed by the cut
+    // filter need the -1 fill
+    if (cut > 0) HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
     if ((rc = run_sort_and_count(c, g, false))) return rc;
     const u32* srow = c->srow;
 
