@@ -882,25 +882,6 @@ __global__ void k_init_arrays(int n, int* __restrict__ parent, int* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// v2: cellfirst(cell) = smallest input row of ANY point of the rotated cell
-// (cDBSCAN2.py:69-71,117: start cells are visited in dict insertion order)
-// ------------------------------------------------------------------------------------------
-__global__ void k_cell_heads(int n, const int* __restrict__ sv, const int* __restrict__ sa, const int* __restrict__ strip_start,
-                             GridParams g, int* __restrict__ headidx)
-{
-    const int M = strip_start[g.S];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (i >= M) { headidx[i] = i; return; }           // filtered tail: singleton segments
-    bool head = true;
-    if (i > 0) {
-        // a rotated cell = (strip, q / eps); variant 2 runs with A0 = V0 = 0, so q IS the absolute coordinate
-        head = (div_eps(g, sa[i]) != div_eps(g, sa[i - 1])) || (div_eps(g, sv[i]) != div_eps(g, sv[i - 1]));
-    }
-    headidx[i] = head ? i : 0;
-}
-
-// ------------------------------------------------------------------------------------------
 // K3: union of core points
 // ------------------------------------------------------------------------------------------
 // Inside a strip every pair is within eps in `a`, so core points whose v-gaps are <= eps
@@ -910,20 +891,46 @@ __global__ void k_cell_heads(int n, const int* __restrict__ sv, const int* __res
 // (parent = chain head), so no million-long pointer chains ever exist -- dense diagonals
 // (self-ligation PETs) become one chain per strip.
 __global__ void __launch_bounds__(TPB)
-k_chain_flags(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
+k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const int* __restrict__ sa,
               const int* __restrict__ strip_start, const int* __restrict__ cnt, int* __restrict__ chainflag,
-              int* __restrict__ chainlast)
+              int* __restrict__ chainlast, int* __restrict__ head)
 {
     __shared__ int2 lw[T_WIN];
     __shared__ int lx[T_WIN];
     const int M = strip_start[g.S];
+    if (head) {                                          // filtered tail: singleton cells (keys of the cellfirst scan)
+        const int ig = tile_of_block(blockIdx.x) * TPB + threadIdx.x;
+        if (ig >= M && ig < n) head[ig] = ig;
+    }
     Tile t;
     if (!tile_stage(t, lw, lx, ntiles, M, sv, sa, cnt)) return;
     const int i = t.t0 + threadIdx.x;
     if (i >= M) return;
+    const int2 me = t.w[i];
+    if (head) {
+        // variant 2: head of the PET's rotated cell (strip, q / eps) = first PET of the sorted order that is
+        // neither in an earlier strip nor below the cell's lower q edge -- a bisection on the staged tile
+        // instead of head flags + a max-scan over all PETs (variant 2 runs with A0 = V0 = 0)
+        const int p0 = div_eps(g, me.y) * g.eps, q0 = div_eps(g, me.x) * g.eps;
+        int pos = t.wbeg;
+#pragma unroll
+        for (int step = 256; step >= 1; step >>= 1) {
+            const int idx = pos + step - 1;
+            const int2 c = t.w[min(idx, i)];
+            pos = (idx <= i && (c.y < p0 || c.x < q0)) ? pos + step : pos;
+        }
+        if (pos == t.wbeg && t.wbeg > 0) {               // the cell starts before the staged window (pile-up)
+            int lo = 0, hi = t.wbeg;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (sa[mid] < p0 || sv[mid] < q0) lo = mid + 1; else hi = mid;
+            }
+            pos = lo;
+        }
+        head[i] = pos;
+    }
     int f = 0, last = 0;
     if (t.x[i] >= g.minPts) {
-        const int2 me = t.w[i];
         const int s = strip_of(g, me.y);
         const int b = strip_start[s], e = strip_start[s + 1];
         f = i + 1;
@@ -3084,27 +3091,21 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     const u32* srow = c->srow;
 
     // K3
-    if (variant == CL_VARIANT_CDBSCAN2) {
-        LAUNCH(k_cell_heads, n, n, sv, sa, strip, g, c->headidx.as<int>());
-        size_t tb = c->scan_tmp.bytes;
-        hipError_t e = rocprim::inclusive_scan(c->scan_tmp.p, tb, c->headidx.as<int>(), c->head.as<int>(), (size_t)n,
-                                               rocprim::maximum<int>(), c->stream);
-        if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan", hipGetErrorString(e));
-        // cellfirst: segmented suffix-min of the input rows, keyed by the cell's head index, so that
-        // cellfirst[head] = smallest row of the whole cell (replaces one atomicMin per PET)
-        tb = c->scan_tmp.bytes;
-        e = rocprim::inclusive_scan_by_key(c->scan_tmp.p, tb, rocprim::make_reverse_iterator(c->head.as<int>() + n),
-                                           rocprim::make_reverse_iterator((int*)srow + n),
-                                           rocprim::make_reverse_iterator(c->cellfirst.as<int>() + n), (size_t)n,
-                                           rocprim::minimum<int>(), rocprim::equal_to<int>(), c->stream);
-        if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan_by_key", hipGetErrorString(e));
-    }
     {
-        // own-strip chains by scan (headidx / head buffers are free again here for variant 2:
-        // k_cell_first has consumed them into cellfirst... they are still needed by k_flatten,
-        // so the chain scan uses its own pair of buffers)
-        hipLaunchKernelGGL(k_chain_flags, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, cnt, c->chainflag.as<int>(),
-                           c->headidx.as<int>());          // headidx is free again after the cell-head scan
+        // own-strip chains by scan; variant 2: the same tile kernel also finds every PET's cell head
+        int* head = variant == CL_VARIANT_CDBSCAN2 ? c->head.as<int>() : nullptr;
+        hipLaunchKernelGGL(k_chain_flags, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, n, sv, sa, strip, cnt, c->chainflag.as<int>(),
+                           c->headidx.as<int>(), head);
+        if (head) {
+            // cellfirst: segmented suffix-min of the input rows, keyed by the cell's head index, so that
+            // cellfirst[head] = smallest row of the whole cell (replaces one atomicMin per PET)
+            size_t tb = c->scan_tmp.bytes;
+            hipError_t e = rocprim::inclusive_scan_by_key(c->scan_tmp.p, tb, rocprim::make_reverse_iterator(head + n),
+                                               rocprim::make_reverse_iterator((int*)srow + n),
+                                               rocprim::make_reverse_iterator(c->cellfirst.as<int>() + n), (size_t)n,
+                                               rocprim::minimum<int>(), rocprim::equal_to<int>(), c->stream);
+            if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan_by_key", hipGetErrorString(e));
+        }
         size_t tb = c->scan_tmp.bytes;
         hipError_t e = rocprim::inclusive_scan(c->scan_tmp.p, tb, c->chainflag.as<int>(), c->chainhead.as<int>(), (size_t)n,
                                                rocprim::maximum<int>(), c->stream);
