@@ -1307,16 +1307,20 @@ k_emit_records(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
     if (counters[CTR_NU] == 0) return;
     const int M = strip_start[g.S];
     {
-        // only CONTESTED border points can change hands when a component is released; most tiles
-        // have none and leave before staging anything
+        // Only a CONTESTED border point whose first-come owner (its lowest-key adjacent component) is
+        // UNCERTAIN can change hands: the fix-up walks a record's components in key order and a component
+        // that is surely live ends the walk (k_resolve_release), so a record that starts with a live component
+        // contributes nothing.  Nearly all tiles have no such point and leave before staging anything.
         const int ip = tile_of_block(blockIdx.x) * TPB + threadIdx.x;
         const int op = ip < M ? owner[ip] : -1;
-        if (!__syncthreads_or(op >= 0 && (op & OWNER_CONTESTED))) return;
+        const bool cand = op >= 0 && (op & OWNER_CONTESTED) && state[owner_root(op)] == ST_UNKNOWN;
+        if (!__syncthreads_or(cand)) return;
     }
     Tile t;
     if (!tile_stage(t, lw, lx, ntiles, M, sv, sa, root)) return;
     const int i0 = t.t0 + threadIdx.x;
-    const bool act = i0 < M && t.x[i0] < 0 && owner[i0] >= 0 && (owner[i0] & OWNER_CONTESTED);
+    const bool act = i0 < M && t.x[i0] < 0 && owner[i0] >= 0 && (owner[i0] & OWNER_CONTESTED) &&
+                     state[owner_root(owner[i0])] == ST_UNKNOWN;
     const int total = block_compact(act, l_list, l_wcount);
     if ((int)threadIdx.x >= total) return;
     const int i = t.t0 + l_list[threadIdx.x];
