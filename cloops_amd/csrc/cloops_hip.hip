@@ -2595,7 +2595,9 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     const int sh = g.qbits + g.rbits, strip_bits = std::max(1, bits_for((unsigned)g.S));
     // hybrid sort: worth it when it saves at least two radix passes (9-bit digits) and every strip is short
     bool hybrid = false;
-    if (!(g.dbg & 256) && (g.qbits + strip_bits + 8) / 9 - (strip_bits + 8) / 9 >= 2) {
+    // (a chromosome with more than 64 PETs per strip on average is not measured at all: its longest strip is
+    // practically never <= HS_LMAX, and the histogram pass on such data is slow -- many atomics per strip)
+    if (!(g.dbg & 256) && (g.qbits + strip_bits + 8) / 9 - (strip_bits + 8) / 9 >= 2 && (long long)n <= 64LL * g.S) {
         int maxlen = 0, rc;
         if ((rc = strip_maxlen(c, g, &maxlen))) return rc;
         hybrid = maxlen <= HS_LMAX;
