@@ -405,40 +405,23 @@ def getIntSig(f, records, minPts, discut):
     return getIntSigFromCounts(records, counts, N, minPts, discut)
 
 
-def markIntSig(ds, escut=2.0, fdrcut=1e-2, bpcut=1e-3, ppcut=1e-5, hypcut=1e-10):
-    """cModel.py:334-362"""
-    a = ds["ES"]
-    a = a[a >= escut]
-    b = ds.loc[a.index, "FDR"]
-    b = b[b <= fdrcut]
-    c = ds.loc[b.index, "hypergeometric_p-value"]
-    c = c[c <= hypcut]
-    d = ds.loc[c.index, "poisson_p-value"]
-    d = d[d <= ppcut]
-    e = ds.loc[d.index, "binomial_p-value"]
-    e = e[e <= bpcut]
-    rs = e.index
-    ns = pd.Series(data=np.zeros(ds.shape[0]), index=ds.index)
-    ns[rs] = 1.0
-    ds["significant"] = ns
+def _mark(ds, sig):
+    ds["significant"] = sig.astype(float)                 # 1.0 / 0.0, the column the reference writes
     return ds
+
+
+def markIntSig(ds, escut=2.0, fdrcut=1e-2, bpcut=1e-3, ppcut=1e-5, hypcut=1e-10):
+    """cModel.py:334-362 as one boolean mask: every cut must hold (enrichment, local FDR, the three p-values)"""
+    col = lambda name: ds[name].astype(float)
+    return _mark(ds, (col("ES") >= escut) & (col("FDR") <= fdrcut) & (col("hypergeometric_p-value") <= hypcut)
+                 & (col("poisson_p-value") <= ppcut) & (col("binomial_p-value") <= bpcut))
 
 
 def markIntSigHic(ds, escut=2.0, fdrcut=0.01, bpcut=1e-5, ppcut=1e-5):
-    """cModel.py:365-386"""
-    a = ds["ES"]
-    a = a[a >= escut]
-    b = ds.loc[a.index, "FDR"]
-    b = b[b < fdrcut]
-    c = ds.loc[b.index, "poisson_p-value"]
-    c = c[c <= ppcut]
-    d = ds.loc[b.index, "binomial_p-value"]
-    d = d[d <= bpcut]
-    e = c.index.intersection(d.index)
-    ns = pd.Series(data=np.zeros(ds.shape[0]), index=ds.index)
-    ns[e] = 1.0
-    ds["significant"] = ns
-    return ds
+    """cModel.py:365-386 (Hi-C / HiChIP cuts: strict `<` on the FDR, no hypergeometric cut)"""
+    col = lambda name: ds[name].astype(float)
+    return _mark(ds, (col("ES") >= escut) & (col("FDR") < fdrcut) & (col("poisson_p-value") <= ppcut)
+                 & (col("binomial_p-value") <= bpcut))
 
 
 def runStat(dataI, minPts, cut, cpu, fout, hichip=0):

@@ -135,22 +135,12 @@ def estStripeSig(f, records, device=0):
 
 
 def markStripeSig(ds, escut=2.0, fdrcut=0.1, ppcut=1e-5, es_cut=0.2):
-    """scripts/callStripes:236-269"""
-    import pandas as pd
-    a = ds["ES"]
-    a = a[a >= escut]
-    b = ds.loc[a.index, "FDR"]
-    b = b[b <= fdrcut]
-    c = ds.loc[b.index, "poisson_p-value"]
-    c = c[c <= ppcut]
-    d = ds.loc[c.index, "ES_ra"]
-    d = d[d >= es_cut]
-    e = ds.loc[c.index, "ES_rb"]
-    e = e[e >= es_cut]
-    rs = d.index.union(e.index)
-    ns = pd.Series(data=np.zeros(ds.shape[0]), index=ds.index)
-    ns[rs] = 1.0
-    ds["significant"] = ns
+    """scripts/callStripes:236-269 as one boolean mask: enrichment, local FDR and Poisson cuts, and at least one
+    anchor holding the fraction `es_cut` of its PETs in the stripe; `significant` is 1.0 / 0.0 like the script's."""
+    col = lambda name: ds[name].astype(float)
+    sig = (col("ES") >= escut) & (col("FDR") <= fdrcut) & (col("poisson_p-value") <= ppcut) \
+        & ((col("ES_ra") >= es_cut) | (col("ES_rb") >= es_cut))
+    ds["significant"] = sig.astype(float)
     return ds
 
 
