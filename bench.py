@@ -1,45 +1,81 @@
 #!/usr/bin/env python
-"""bench.py -- PETs clustered / s on MI355X for the cDBSCAN hot path (BASELINE.json metric).
+"""bench.py -- PETs clustered / s and sweep wall-clock on MI355X for the cDBSCAN hot path (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A "step" is one pass of the hot path over one batch: ONE clustering run
-(variant cDBSCAN2 = the production class, cLoops/pipe.py:42) of a 5 M-PET synthetic
-chromosome (BASELINE.json configs[1]: "Synthetic 5 M cis PETs, one chromosome, single
-eps=2000 minPts=5"), timed from "X,Y resident in HBM" to "labels + cluster table on the
-host".  With N > 1 every rank owns its own 5 M-PET chromosome (weak scaling, chromosomes
-are independent units -- cLoops/pipe.py:117): no collective on the data path; the
-candidate-loop tables are all-gathered once over RCCL at the end of the timed job
-(the only exchange of the path, cLoops/pipe.py:119-127).
+Workload (default): BASELINE.json configs[3] -- the synthetic genome of SURVEY.md 8d, 200 M cis PETs over the
+23 hg38 chromosomes, Hi-C mode `-m 3` = eps [5000, 7500, 10000] x minPts [50, 40, 30, 20]
+(cLoops/pipe.py:337-340) with the CHAINED distance cut of cLoops/pipe.py:247-275, variant cDBSCAN2 (the production
+class, cLoops/pipe.py:42), through `cloops_amd.pipe.runSweepFast`.
+
+A "step" is one pass of the hot path over the batch: ONE whole 12-run sweep over all 23 chromosomes, from "X,Y
+resident in HBM" to "deduplicated, distance-filtered candidate-loop table on the host" (cluster tables cross
+PCIe every run; labels stay on the device -- the sweep never needs them).  `value` = PETs that entered DBSCAN,
+summed over the 12 runs and the K timed sweeps, / wall time; `sweep_wall_s` = ms_per_step / 1000 is the second
+half of the metric.  Every sweep redoes everything (keys, sort, region query ... table) for every run; the first
+sweep of the process (allocations) is reported separately as `first_sweep_s`.
+
+With N > 1 (`--gpus N` spawns N ranks through torch.distributed.run when not already launched by it) the 23
+chromosomes are LPT-sharded over the ranks (cloops_amd.dist.shard_chromosomes; chromosomes are independent units,
+cLoops/pipe.py:117), every run exchanges a few hundred bytes of statistics (all-reduce: the chained cut is a
+genome-wide estimate) and the final candidate tables are all-gathered once per sweep over RCCL -- the path's only
+exchanges.  Total work is fixed (the same 200 M PETs): "scaling": "strong".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  "roofline"      K2 region-query kernel: algorithmic bytes / HIP-event measured duration
-  "cpu_baseline"  the CPU oracle (C port of cDBSCAN2) timed on this box's host cores
+  "roofline"      K2 region-query kernel, measured INSIDE the timed sweeps on chr1 (16.4 M PETs) with HIP events:
+                  algorithmic bytes / launch duration, overall and per eps
+  "secondary_5M"  BASELINE.json configs[1] (5 M PETs, one chromosome, eps 2000, minPts 5), the round-1 headline
+  "cpu_baseline"  the CPU oracle (C port of cDBSCAN2) on this box's host cores, one process per chromosome
 """
 import argparse
 import ctypes
+import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_PETS = 5000000
-CHROM_LEN = 248956422          # chr1 (cfg2 = one chromosome, L = chr1)
-EPS, MINPTS = 2000, 5
+N_TOTAL = 200000000
+MODE3 = ([5000, 7500, 10000], [50, 40, 30, 20])        # cLoops/pipe.py:337-340
+CFG = 3                                                 # seed family of cloops_amd.synth.synth_genome
 VARIANT = "v2"
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0                                   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+N_5M, CHR1_LEN, EPS_5M, MINPTS_5M = 5000000, 248956422, 2000, 5
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-total", type=float, default=N_TOTAL, help="PETs of the synthetic genome (tests use less)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU ranks (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not launched by torch.distributed.run: start the N ranks ourselves (one process per GPU)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)]
+        cmd += sys.argv[1:] if argv is None else list(argv)
+        sys.exit(subprocess.call(cmd))
 
     # stdout carries exactly one JSON line (rank 0): park the real stdout and point fd 1 at stderr until the end
     sys.stdout.flush()
@@ -50,148 +86,129 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or os.environ.get("CLOOPS_BENCH_FORCE_DIST") == "1"
+    on_gpu = args.backend == "nccl"
+    if os.environ.get("CLOOPS_BENCH_PRELOAD"):
+        # test hook: a module imported before anything else (the CPU tests install their stand-in GPU backend here)
+        importlib.import_module(os.environ["CLOOPS_BENCH_PRELOAD"])
     import numpy as np
-    torch = None
-    dist = None
+    torch = dist = tdev = None
     if use_dist:
         # torch first: its bundled HIP runtime then also serves libcloops_hip.so (same SONAME)
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from cloops_amd import api
-    from cloops_amd.synth import synth_chrom
-    from cloops_amd.dist import gather_tables
-
-    device = local_rank if use_dist else 0
-    # weak scaling: every rank has its own chromosome (seed differs per rank)
-    X, Y = synth_chrom(N_PETS, CHROM_LEN, 2000 + rank)
-    chrom = api.Chromosome(X, Y, device=device)
-    chrom.set_profiling(True)
-    tdev = torch.device("cuda", local_rank) if use_dist else None
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+            tdev = torch.device("cuda", local_rank)
+            dist.init_process_group("nccl", device_id=tdev)
+        else:
+            dist.init_process_group("gloo")
+    os.environ["CLOOPS_DEVICES"] = str(local_rank if (use_dist and on_gpu) else 0)
+    from cloops_amd import api, pipe
+    from cloops_amd.synth import synth_chrom, chrom_sizes
+    from cloops_amd.dist import gather_tables, make_allsum, lpt_assign
 
     def sync_all():
         if use_dist:
             dist.barrier()
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
 
-    def gather_final(res):
-        """the path's only exchange: the candidate-loop tables of all ranks, gathered ONCE at the end of
-        the job over RCCL (cLoops/pipe.py:119-127 merges its workers' results the same way; the steps
-        themselves need no collective -- chromosomes are independent)"""
-        b = res.boxes
-        tab = np.stack([b["min_x"], b["max_x"], b["min_y"], b["max_y"], b["count"]], 1) if len(b) else np.zeros((0, 5), np.int32)
-        return gather_tables(tab, device=tdev)
+    # ---- the genome, LPT-sharded over the ranks -------------------------------------------------------------
+    n_total = int(args.n_total)
+    sizes = chrom_sizes(n_total)
+    mine = sorted(lpt_assign([n for _, _, n in sizes], world)[rank])
+    device = local_rank if (use_dist and on_gpu) else 0
+    t_gen = time.perf_counter()
+    fs = []
+    for ci in mine:
+        name, length, n = sizes[ci]
+        X, Y = synth_chrom(n, length, 1000 * CFG + ci)
+        fs.append(pipe.CACHE.put_arrays("%s-%s" % (name, name), X, Y, device=device))
+    t_gen = time.perf_counter() - t_gen
+    allsum = make_allsum(device=tdev) if use_dist else None
+    eps_list, minpts_list = MODE3
 
-    step_t = [] if os.environ.get("CLOOPS_BENCH_DEBUG") else None
+    # K2 is timed inside the sweeps on the largest local chromosome (chr1 on rank 0): HIP events on the library's stream
+    probe_f = max(fs, key=lambda f: len(pipe.CACHE.get(f).d)) if fs else None
+    k2_log = []
+    if probe_f is not None and rank == 0:
+        pipe.CACHE.get(probe_f).chrom.set_profiling(True)
 
-    def run(nsteps, k2_ms=None):
-        # Steps of a fixed-cut sweep are independent runs: step k+1 is enqueued before step k is
-        # completed, so the D2H copy of step k overlaps the kernels of step k+1 (two result slots).
-        res = None
-        chrom.cluster_async(VARIANT, EPS, MINPTS, 0)
-        for k in range(nsteps):
-            if k + 1 < nsteps:
-                chrom.cluster_async(VARIANT, EPS, MINPTS, 0)
-            res = chrom.wait()
-            if k2_ms is not None:
-                k2_ms.append(res.timing["ms_region"])
-                if step_t is not None:
-                    step_t.append((time.perf_counter(), res.timing["ms_total"], dict(res.timing)))
-        return res
+    def probe(f, ep, m, cut_in, res):
+        if f == probe_f and res.timing is not None:
+            k2_log.append((ep, m, cut_in, dict(res.timing)))
 
-    extra_warm = 0
-    if args.warmup > 0:
+    def one_sweep(log_k2):
+        dataI, cut, cuts, steps = pipe.runSweepFast(fs, eps_list, minpts_list, cut=0, variant=VARIANT, allsum=allsum,
+                                                    probe=probe if (log_k2 and rank == 0) else None)
+        rows = [v["boxes"] for v in dataI.values() if len(v["boxes"])]
+        tab = np.concatenate(rows).astype(np.int32) if rows else np.zeros((0, 4), np.int32)
         if use_dist:
-            # untimed: RCCL communicator set-up happens on the first collective.  It goes FIRST so that the warm-up
-            # ends with GPU work and only the barrier separates it from the timed region.  With torch's HIP runtime
-            # in the process one early device-to-host copy stalls for ~4 ms (seen at the 3rd..5th step after the
-            # first collective, never later): the warm-up is padded to 8 steps so that it cannot land in the timed ones.
-            gather_final(run(1))
-            extra_warm = max(0, 8 - args.warmup)
-            if args.warmup + extra_warm > 1:
-                run(args.warmup + extra_warm - 1)
+            # the path's final exchange (cLoops/pipe.py:119-127 merges its workers' results): all candidate tables
+            ncand = sum(len(t) for t in gather_tables(tab, device=tdev))
         else:
-            run(args.warmup)
+            ncand = len(tab)
+        return cut, steps, ncand
+
+    first_sweep_s = None
+    for w in range(args.warmup):
+        t0 = time.perf_counter()
+        one_sweep(False)
+        if w == 0:
+            first_sweep_s = time.perf_counter() - t0
     sync_all()
     t0 = time.perf_counter()
-    k2_ms = []
-    res = run(args.steps, k2_ms)
-    t_run = time.perf_counter() - t0
-    if use_dist:
-        tables = gather_final(res)
-    t_gather = time.perf_counter() - t0 - t_run
+    pets = 0
+    for k in range(args.steps):
+        cut, steps, ncand = one_sweep(True)
+        pets += sum(s["n_in"] for s in steps)          # genome-wide (all-reduced inside runSweepFast)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if os.environ.get("CLOOPS_BENCH_DEBUG"):
-        sys.stderr.write("[bench rank %d] run %.3f ms, gather %.3f ms, final sync %.3f ms\n" % (
-            rank, t_run * 1e3, t_gather * 1e3, (elapsed - t_run - t_gather) * 1e3))
-        sys.stderr.write("[bench rank %d] per-step wall (ms): %s\n" % (rank, " ".join(
-            "%.2f" % ((b[0] - a[0]) * 1e3) for a, b in zip([(t0, 0)] + step_t[:-1], step_t))))
-        sys.stderr.write("[bench rank %d] per-step GPU total (ms): %s\n" % (rank, " ".join("%.2f" % s[1] for s in step_t)))
-        worst = max(step_t, key=lambda s: s[1])
-        sys.stderr.write("[bench rank %d] slowest step phases: %s\n" % (rank, {k[3:]: round(v, 3) for k, v in worst[2].items() if k.startswith("ms_")}))
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev if on_gpu else None)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    timing = res.timing
-    n_in = int(timing["n_in"])
-    total_pets = n_in * args.steps * world
-    value = total_pets / elapsed
-
     line = None
     if rank == 0:
-        # K2 is the only kernel between its two events; the bracket around an EMPTY kernel (event packets +
-        # dispatch gap, calibrated by the library when profiling is switched on) is reported next to the raw
-        # bracket and taken out of the launch duration -- rocprofv3's kernel duration has no such term
-        k2_raw = float(np.mean(k2_ms))
-        bracket = float(timing.get("ms_bracket", 0.0))
-        k2 = max(k2_raw - bracket, 1e-6)
-        alg_bytes = n_in * 12 + int(timing["n_strips"]) * 4        # SURVEY.md 8d: N*(8+4) + (C+1)*4
-        achieved = alg_bytes / (k2 * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "k2_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as fh:
-                    tj = json.load(fh)
-                if tj.get("workload") == "synthetic-5M-chr1-eps2000-minPts5":
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         line = {
-            "metric": "PETs clustered/sec (whole node)",
-            "value": value,
+            "metric": "PETs clustered/sec (whole node) + wall-clock for mode-3 eps x minPts sweep",
+            "value": pets / elapsed,
             "unit": "PETs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": elapsed / max(1, args.steps) * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": "synthetic-5M-chr1-eps2000-minPts5 (BASELINE.json configs[1])",
-                       "variant": "cDBSCAN2", "pets_per_gpu": n_in, "eps": EPS, "minPts": MINPTS,
-                       "clusters": int(res.n_clusters), "parallelism": "chromosome-per-gpu x%d" % world,
-                       "extra_untimed_warmup_steps": extra_warm},
-            "roofline": {"bound": "hbm", "kernel": "k_region_count", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k2,
-                         "avg_event_bracket_ms": k2_raw, "empty_kernel_bracket_ms": bracket},
-            "kernel_ms": {k[3:]: round(float(v), 4) for k, v in timing.items() if k.startswith("ms_") and k != "ms_bracket"},
+            "sweep_wall_s": elapsed / max(1, args.steps),
+            "first_sweep_s": first_sweep_s,
+            "config": {"workload": "synthetic-%s-23chr-mode3 (BASELINE.json configs[3])" % _human(n_total),
+                       "variant": "cDBSCAN2", "pets": n_total, "chromosomes": len(sizes), "eps": eps_list, "minPts": minpts_list,
+                       "runs_per_sweep": len(steps), "chained_cut": True, "cuts": [s.get("cut_out") for s in steps],
+                       "final_cut": int(cut), "candidate_loops": int(ncand),
+                       "pets_entering_dbscan_per_sweep": int(pets // max(1, args.steps)),
+                       "parallelism": "23 chromosomes LPT-sharded over %d GPU(s)" % world,
+                       "synthesis_s_rank0": round(t_gen, 2)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(X, Y, res)
-    chrom.close()
+        if k2_log:
+            line["roofline"] = roofline_block(k2_log, len(pipe.CACHE.get(probe_f).d))
+    # the secondary single-eps figure and the CPU baseline: rank 0, single GPU only
+    if rank == 0 and world == 1 and on_gpu:
+        pipe.CACHE.clear()
+        if not args.no_secondary:
+            line["secondary_5M"] = secondary_5m(api, synth_chrom)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(api, sizes, steps)
+    pipe.CACHE.clear()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    # everything written to fd 1 during the run (RCCL's NCCL_DEBUG=VERSION banner comes through C stdio) went to
-    # stderr: give stdout back and print the ONE JSON line
+    # everything written to fd 1 during the run (RCCL's banner comes through C stdio) went to stderr: give stdout
+    # back and print the ONE JSON line
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:
@@ -203,46 +220,135 @@ def main():
         print(json.dumps(line), flush=True)
 
 
-def _cpu_worker(seed):
-    """one host process = one chromosome, like a joblib worker of cLoops/pipe.py:117"""
+def _human(n):
+    return "%dM" % (n // 1000000) if n >= 1000000 else "%dk" % (n // 1000)
+
+
+def k2_bytes(tm):
+    """sorted (q, p) in + count out per PET that entered DBSCAN + the strip offset table"""
+    return int(tm["n_in"]) * 12 + int(tm["n_strips"]) * 4
+
+
+def roofline_block(k2_log, n_probe):
+    """K2 (k_region_count) inside the timed sweeps on the probe chromosome: K2 is the only kernel between its two
+    events; the bracket around an EMPTY kernel (event packets + dispatch gap, calibrated by the library) is taken
+    out of every launch -- rocprofv3's kernel duration has no such term (profiles/README.md)."""
+    def agg(rows):
+        b = sum(k2_bytes(tm) for _, _, _, tm in rows)
+        raw = sum(tm["ms_region"] for _, _, _, tm in rows)
+        net = sum(max(tm["ms_region"] - tm["ms_bracket"], 1e-6) for _, _, _, tm in rows)
+        return b, raw, net
+    b, raw, net = agg(k2_log)
+    ach = b / (net * 1e-3) / 1e9
+    per_eps = {}
+    for ep in sorted({r[0] for r in k2_log}):
+        bb, _, nn = agg([r for r in k2_log if r[0] == ep])
+        per_eps[str(ep)] = {"achieved": bb / (nn * 1e-3) / 1e9, "frac": bb / (nn * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "avg_launch_ms": nn / len([r for r in k2_log if r[0] == ep])}
+    traffic, src = None, None
+    tpath = os.path.join(ROOT, "profiles", "k2_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            traffic, src = tj.get("hbm_bytes_per_launch"), "profiles/k2_traffic.json (%s; %s)" % (tj.get("workload"), tj.get("source"))
+        except Exception:
+            pass
+    return {"bound": "hbm", "kernel": "k_region_count", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+            "launches": len(k2_log), "probe": "chr1 of the genome (%d PETs), every run of the timed sweeps" % n_probe,
+            "algorithmic_bytes_per_launch": b // len(k2_log), "avg_launch_ms": net / len(k2_log),
+            "avg_event_bracket_ms": raw / len(k2_log), "empty_kernel_bracket_ms": float(k2_log[0][3]["ms_bracket"]),
+            "per_eps": per_eps}
+
+
+def secondary_5m(api, synth_chrom, steps=20, warmup=3):
+    """BASELINE.json configs[1]: 5 M PETs on one chromosome, eps 2000, minPts 5 -- one clustering run per step,
+    labels + table to the host, pipelined over the two result slots (the round-1 headline, kept comparable)."""
     import numpy as np
+    X, Y = synth_chrom(N_5M, CHR1_LEN, 2000)
+    ch = api.Chromosome(X, Y, device=0)
+    ch.set_profiling(True)
+
+    def run(nsteps, k2):
+        res = None
+        ch.cluster_async(VARIANT, EPS_5M, MINPTS_5M, 0)
+        for k in range(nsteps):
+            if k + 1 < nsteps:
+                ch.cluster_async(VARIANT, EPS_5M, MINPTS_5M, 0)
+            res = ch.wait()
+            if k2 is not None:
+                k2.append(dict(res.timing))
+        return res
+    run(warmup, None)
+    t0 = time.perf_counter()
+    k2 = []
+    res = run(steps, k2)
+    dt = time.perf_counter() - t0
+    n_in = int(k2[-1]["n_in"])
+    net = float(np.mean([max(t["ms_region"] - t["ms_bracket"], 1e-6) for t in k2]))
+    b = k2_bytes(k2[-1])
+    out = {"workload": "synthetic-5M-chr1-eps2000-minPts5 (BASELINE.json configs[1])", "value": n_in * steps / dt, "unit": "PETs/s",
+           "ms_per_step": dt / steps * 1e3, "clusters": int(res.n_clusters),
+           "k2_avg_launch_ms": net, "k2_achieved_GBs": b / (net * 1e-3) / 1e9, "k2_frac": b / (net * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "k2_algorithmic_bytes": b,
+           "kernel_ms": {k[3:]: round(float(v), 4) for k, v in k2[-1].items() if k.startswith("ms_") and k != "ms_bracket"}}
+    ch.close()
+    return out
+
+
+# ---- CPU baseline: the C oracle, one host process per chromosome (the reference's own shape, cLoops/pipe.py:117) ----
+def _cpu_worker(job):
     import oracle
     from cloops_amd.synth import synth_chrom
-    X, Y = synth_chrom(N_PETS, CHROM_LEN, seed)
-    t0 = time.perf_counter()
-    lab = oracle.labels(VARIANT, X, Y, EPS, MINPTS)
-    return time.perf_counter() - t0, int((lab >= 0).sum())
+    ci, length, n, runs = job
+    X, Y = synth_chrom(n, length, 1000 * CFG + ci)
+    d = Y.astype("int64") - X
+    out = []
+    for eps, m, cut in runs:
+        keep = d >= cut
+        t0 = time.perf_counter()
+        oracle.labels(VARIANT, X[keep], Y[keep], eps, m)
+        out.append((time.perf_counter() - t0, int(keep.sum())))
+    return out
 
 
-def cpu_baseline(X, Y, res):
-    """The CPU oracle (C port of cLoops/cDBSCAN2.py) on this box's host cores.
-
-    (1) the benchmark chromosome itself, single thread -- doubles as a full-size parity check
-        of the GPU labels;  (2) the reference's own parallel shape (cLoops/pipe.py:117: one
-        worker process per chromosome): W processes, each clustering its own 5 M-PET chromosome,
-        aggregate PETs/s.  The reported `value` is (2)."""
+def cpu_baseline(api, sizes, steps):
+    """The CPU oracle (C port of cLoops/cDBSCAN2.py) over the SAME 23 chromosomes, one worker process per chromosome
+    up to os.cpu_count() (cLoops/pipe.py:117), on a bounded sample of the sweep: 2 of its 12 runs -- (eps 5000,
+    minPts 50, cut 0) and (eps 7500, minPts 30, the GPU chain's cut) -- with the same per-run barrier the reference has
+    (runDBSCAN returns when its slowest worker, chr1, is done).  Also a full-size parity check: GPU labels ==
+    oracle labels on chr21 at the second setting."""
     import multiprocessing as mp
     import numpy as np
     import oracle
+    from cloops_amd.synth import synth_chrom
     oracle.build()
-    t0 = time.perf_counter()
-    want = oracle.labels(VARIANT, X, Y, EPS, MINPTS)
-    dt1 = time.perf_counter() - t0
-    same = bool(np.array_equal(want, res.labels))
-    workers = max(1, min(os.cpu_count() or 1, 16))
+    st = {(s["eps"], s["minPts"]): s for s in steps}
+    runs = [(5000, 50, 0), (7500, 30, int(st[(7500, 30)]["cut_in"]))]
+    # parity at full size on one chromosome
+    ci = 20
+    name, length, n = sizes[ci]
+    X, Y = synth_chrom(n, length, 1000 * CFG + ci)
+    ch = api.Chromosome(X, Y, device=0)
+    got = ch.cluster(VARIANT, runs[1][0], runs[1][1], runs[1][2]).labels
+    ch.close()
+    want = oracle.single_dbscan(VARIANT, X, Y, runs[1][0], runs[1][1], runs[1][2])["labels"]
+    same = bool(np.array_equal(got, want))
+    workers = max(1, min(os.cpu_count() or 1, len(sizes)))
+    jobs = [(k, length, n, runs) for k, (_, length, n) in enumerate(sizes)]
     ctx = mp.get_context("fork")
-    t0 = time.perf_counter()
     with ctx.Pool(workers) as pool:
-        per = pool.map(_cpu_worker, [9000 + k for k in range(workers)])
-    wall = time.perf_counter() - t0
-    cpu_s = sum(p[0] for p in per)
-    # wall includes the (untimed-for-GPU) synthetic generation; use the slowest worker's clustering time
-    par_wall = max(p[0] for p in per)
-    return {"value": workers * N_PETS / par_wall, "unit": "PETs/s", "cores": workers, "kind": "port",
-            "sample": "%d worker processes x one 5 M-PET chromosome each (cDBSCAN2 eps=%d minPts=%d, C oracle): "
-                      "%.1f s of CPU work, slowest worker %.2f s" % (workers, EPS, MINPTS, cpu_s + dt1, par_wall),
-            "single_thread_pets_per_s": len(X) / dt1,
-            "labels_match_gpu": same,
+        per = pool.map(_cpu_worker, jobs, chunksize=1)
+    walls = [max(p[r][0] for p in per) for r in range(len(runs))]           # per-run barrier: slowest chromosome
+    n_in = [sum(p[r][1] for p in per) for r in range(len(runs))]
+    cpu_s = sum(p[r][0] for p in per for r in range(len(runs)))
+    return {"value": sum(n_in) / sum(walls), "unit": "PETs/s", "cores": workers, "kind": "port",
+            "sample": "2 of the 12 runs of the same sweep over the same 23 chromosomes, %d worker processes (one chromosome each, "
+                      "%d host cores visible): %s; %.0f s of CPU work, slowest-chromosome wall %.1f s + %.1f s" % (
+                          workers, os.cpu_count() or 1, ", ".join("(eps %d, minPts %d, cut %d)" % r for r in runs), cpu_s, walls[0], walls[1]),
+            "single_thread_pets_per_s": sum(p[r][1] for p in per for r in range(len(runs))) / cpu_s,
+            "labels_match_gpu": same, "labels_checked_on": "%s (%d PETs) at eps %d minPts %d cut %d" % ((name, n) + runs[1]),
             "note": "the Python reference itself runs ~1e5 PETs/s/core (BASELINE.md section 2); the C port is ~20x faster than the reference"}
 
 

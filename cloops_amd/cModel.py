@@ -1,22 +1,25 @@
 """Significance of candidate loops against the local permuted background, and the `.loop` table.
 
-Host-side restatement of cLoops/cModel.py (getGenomeCoverage :45-57, getCounts :60-70,
-getPETsforRegions :73-80, getNearbyPairRegions :83-105, getMultiplePsFdr :108-161, getBonPvalues
-:164-171, checkOneEndOverlap/checkOverlap :174-195, removeDup :198-259, getIntSig :262-331,
-markIntSig :334-362, markIntSigHic :365-386) and of runStat (cLoops/pipe.py:177-203).
+What cLoops/cModel.py computes per candidate loop (getIntSig :262-331 with getPETsforRegions :73-80,
+getNearbyPairRegions :83-105, getMultiplePsFdr :108-161, getBonPvalues :164-171, removeDup :198-259,
+markIntSig :334-362, markIntSigHic :365-386) and runStat (cLoops/pipe.py:177-203), restructured: the
+interval counting (getGenomeCoverage :45-57, getCounts :60-70 and every set union / intersection) is
+kernel K8 on the chromosome resident in HBM (`cl_sig_counts`), the statistics of ALL records of a
+chromosome are evaluated as array expressions on the count table, and the duplicate removal works on a
+sorted sweep instead of the reference's O(L^2) pair loop.  There is no per-record Python path here; the
+cross-check against the reference's own functions lives in tests/ (tests/refload.py).
 
 Semantics pinned: the reference is Python 2 -- `/` on the integer
 interval ends in getNearbyPairRegions is FLOOR division (:89-93) and dicts iterate in insertion
 order under the Python-3 conversion the goldens were made with (removeDup :206-259 depends on
-that order).  The PET index sets of the reference (Python sets of row positions) are sorted
-index arrays here; every float is produced by the same scipy / numpy call on the same operands in
-the same order, so the `.loop` rows are bit-identical to the converted reference.
+that order).  The set sizes of the reference are the integers K8 returns; every float is produced by
+the same scipy / numpy call on the same operands in the same order, so the `.loop` rows are
+bit-identical to the converted reference.
 """
 import numpy as np
 import pandas as pd
 from scipy.stats import hypergeom, binom, poisson
 
-from .pipe import parseJd
 
 
 def parseIv(iv):
@@ -26,199 +29,10 @@ def parseIv(iv):
     return [chrom, int(a), int(b)]
 
 
-class CoverageModel(object):
-    """getGenomeCoverage (cModel.py:45-57): sorted X and Y coordinates with the row positions."""
-
-    def __init__(self, mat):
-        X = np.asarray(mat[:, 1])
-        Y = np.asarray(mat[:, 2])
-        self.N = len(X)
-        self.xo = np.argsort(X, kind="stable")
-        self.yo = np.argsort(Y, kind="stable")
-        self.xs = X[self.xo]
-        self.ys = Y[self.yo]
-
-    def side(self, iv, axis):
-        """getCounts (cModel.py:60-70): row positions of the PETs whose X (axis 0) / Y (axis 1) lies in
-        [iv[0], iv[1]] (both ends inclusive), as a sorted unique array."""
-        keys, order = (self.xs, self.xo) if axis == 0 else (self.ys, self.yo)
-        l = np.searchsorted(keys, iv[0], side="left")
-        r = np.searchsorted(keys, iv[1], side="right")
-        return np.sort(order[l:r])
-
-    def region(self, iv):
-        """S_X(iv) | S_Y(iv)"""
-        return np.union1d(self.side(iv, 0), self.side(iv, 1))
-
-
-def getPETsforRegions(iva, ivb, model):
-    """cModel.py:73-80"""
-    ra = len(model.region(iva))
-    rb = len(model.region(ivb))
-    rab = len(np.intersect1d(model.side(iva, 0), model.side(ivb, 1), assume_unique=True))
-    return ra, rb, rab
-
-
-def getNearbyPairRegions(iva, ivb, win=5):
-    """cModel.py:83-105 with Python-2 integer arithmetic"""
-    ivas, ivbs = [], []
-    ca = sum(iva) // 2
-    cb = sum(ivb) // 2
-    sa = (iva[1] - iva[0]) // 2
-    sb = (ivb[1] - ivb[0]) // 2
-    step = (sa + sb) // 2
-    for i in range(0 - win, win + 1):
-        if i == 0:
-            continue
-        ivas.append([max([0, ca + i * step - sa]), max([0, ca + i * step + sa])])
-        ivbs.append([max([0, cb + i * step - sb]), max([0, cb + i * step + sb])])
-    return ivas, ivbs
-
-
-def getMultiplePsFdr(iva, ivb, model, N, win=5):
-    """cModel.py:108-161 -> ra, rb, rab, es, fdr, hyp, pop, nbp"""
-    ra, rb, rab = getPETsforRegions(iva, ivb, model)
-    hyp = max([1e-300, hypergeom.sf(rab - 1.0, N, ra, rb)])
-    ivas, ivbs = getNearbyPairRegions(iva, ivb, win=win)
-    nras = [model.region(na) for na in ivas]
-    nrbs = [model.region(nb) for nb in ivbs]
-    rabs, nbps = [], []
-    for nra in nras:
-        nralen = float(len(nra))
-        for nrb in nrbs:
-            nrblen = len(nrb)
-            nrab = float(len(np.intersect1d(nra, nrb, assume_unique=True)))
-            if nrab > 0:
-                rabs.append(nrab)
-                nbps.append(nrab / (nralen * nrblen))
-            else:
-                nbps.append(0.0)
-                rabs.append(0.0)
-    if len(rabs) == 0:
-        return ra, rb, rab, np.inf, 0.0, hyp, 0.0, 1e-300, 1e-300,
-    rabs = np.array(rabs)
-    fdr = len(rabs[rabs > rab]) / float(len(rabs))
-    mrabs = float(np.mean(rabs))
-    if mrabs > 0:
-        es = rab / np.mean(rabs[rabs > 0])
-    else:
-        es = np.inf
-    lam = mrabs
-    pop = max([1e-300, poisson.sf(rab - 1.0, lam)])
-    bp = np.mean(nbps) * ra * rb / N
-    nbp = max([1e-300, binom.sf(rab - 1.0, N - rab, bp)])
-    return ra, rb, rab, es, fdr, hyp, pop, nbp
-
-
 def getBonPvalues(ps):
-    """cModel.py:164-171"""
-    ps = np.array(ps)
-    ps = ps * len(ps)
-    ps[ps > 1.0] = 1.0
-    return ps
-
-
-def checkOneEndOverlap(xa, xb, ya, yb):
-    """cModel.py:174-182"""
-    if (ya <= xa <= yb) or (ya <= xb <= yb) or (ya <= xa <= xb <= yb):
-        return True
-    if (xa <= ya <= xb) or (xa <= yb <= xb) or (xa <= ya <= yb <= xb):
-        return True
-    return False
-
-
-def checkOverlap(ivai, ivbi, ivaj, ivbj):
-    """cModel.py:185-195"""
-    if ivai[0] != ivaj[0] or ivbi[0] != ivbj[0]:
-        return
-    if checkOneEndOverlap(ivai[1], ivai[2], ivaj[1], ivaj[2]) and checkOneEndOverlap(ivbi[1], ivbi[2], ivbj[1], ivbj[2]):
-        return True
-    return False
-
-
-def removeDup(ds, bpcut=1e-5):
-    """cModel.py:198-259: overlapped loops -> keep, among those with binomial p <= bpcut, the one with
-    the highest rab / ra / rb; iteration in dict insertion order."""
-    uniqueds = {}
-    reds = {}
-    rekeys = set()
-    keys = list(ds.keys())
-    ivs = {k: (parseIv(ds[k]["iva"]), parseIv(ds[k]["ivb"])) for k in keys}
-    for i in range(len(keys) - 1):
-        keyi = keys[i]
-        if keyi in rekeys:
-            continue
-        ivai, ivbi = ivs[keyi]
-        flag = 1
-        for j in range(i + 1, len(keys)):
-            keyj = keys[j]
-            if keyj in rekeys:
-                continue
-            ivaj, ivbj = ivs[keyj]
-            if checkOverlap(ivai, ivbi, ivaj, ivbj):
-                if keyi not in reds:
-                    reds[keyi] = [keyi]
-                    rekeys.add(keyi)
-                reds[keyi].append(keyj)
-                rekeys.add(keyj)
-                flag = 0
-        if flag:
-            uniqueds[keyi] = ds[keyi]
-    for key in reds.keys():
-        ts = {}
-        for t in reds[key]:
-            if ds[t]["binomial_p-value"] > bpcut:
-                continue
-            ts[t] = float(ds[t]["rab"]) / ds[t]["ra"] / ds[t]["rb"]
-        if len(ts) == 0:
-            continue
-        ts = pd.Series(ts)
-        ts.sort_values(inplace=True, ascending=False)
-        uniqueds[ts.index[0]] = ds[ts.index[0]]
-    return uniqueds
-
-
-def getIntSigFromMat(mat, records, minPts, discut, name=""):
-    """getIntSig (cModel.py:262-331) on an in-memory [n,3] matrix (already cut-filtered by the caller
-    exactly like parseJd(f, discut), io.py:213-216)."""
-    j = mat.shape[0]
-    if j < 2:                                  # getGenomeCoverage :52-54
-        return None
-    model = CoverageModel(mat)
-    N = j
-    ds = {}
-    i = 0
-    for r in records:
-        chrom = r[0]
-        key = "%s-%s-%s" % (r[0], r[3], i)
-        iva = [max(0, r[1]), r[2]]
-        ivb = [max(0, r[4]), r[5]]
-        distance = abs(sum(ivb) / 2.0 - sum(iva) / 2.0)
-        if distance < discut:
-            continue
-        ra, rb, rab = getPETsforRegions(iva, ivb, model)
-        if rab < max(minPts):
-            continue
-        i += 1
-        ra, rb, rab, es, fdr, hyp, pop, nbp = getMultiplePsFdr(iva, ivb, model, N)
-        ds[key] = {
-            "distance": distance, "ra": ra, "rb": rb, "rab": rab, "ES": es, "FDR": fdr,
-            "hypergeometric_p-value": hyp, "poisson_p-value": pop, "binomial_p-value": nbp,
-            "iva": "%s:%s-%s" % (chrom, iva[0], iva[1]), "ivb": "%s:%s-%s" % (chrom, ivb[0], ivb[1]),
-        }
-    if len(ds.keys()) == 0:
-        return None
-    ds = removeDup(ds)
-    if len(ds.keys()) == 0:
-        return None
-    ds = removeDup(ds)
-    if len(ds.keys()) == 0:
-        return None
-    ds = pd.DataFrame(ds).T
-    ds["poisson_p-value_corrected"] = getBonPvalues(ds["poisson_p-value"])
-    ds["binomial_p-value_corrected"] = getBonPvalues(ds["binomial_p-value"])
-    ds["hypergeometric_p-value_corrected"] = getBonPvalues(ds["hypergeometric_p-value"])
-    return ds
+    """Bonferroni correction (cModel.py:164-171): p * number of tests, capped at 1"""
+    ps = np.asarray(ps, dtype=float)
+    return np.minimum(ps * len(ps), 1.0)
 
 
 def _windows(records):
@@ -317,18 +131,22 @@ def _remove_dup_fast(ds, bpcut=1e-5):
             removed[hit] = True
         else:
             uniqueds[keys[i]] = ds[keys[i]]
-    for key in reds.keys():
-        ts = {}
-        for t in reds[key]:
-            if ds[t]["binomial_p-value"] > bpcut:
-                continue
-            ts[t] = float(ds[t]["rab"]) / ds[t]["ra"] / ds[t]["rb"]
-        if len(ts) == 0:
-            continue
-        ts = pd.Series(ts)
-        ts.sort_values(inplace=True, ascending=False)
-        uniqueds[ts.index[0]] = ds[ts.index[0]]
+    for members in reds.values():
+        best = _best_of_group(ds, members, bpcut)
+        if best is not None:
+            uniqueds[best] = ds[best]
     return uniqueds
+
+
+def _best_of_group(ds, members, bpcut):
+    """the survivor of one group of overlapping loops (cModel.py:247-258): among the members whose binomial
+    p-value passes `bpcut`, the one with the largest rab / ra / rb -- picked with the same pandas sort as the
+    reference so that ties resolve identically; None when no member passes"""
+    cand = [t for t in members if not ds[t]["binomial_p-value"] > bpcut]
+    if not cand:
+        return None
+    score = pd.Series({t: float(ds[t]["rab"]) / ds[t]["ra"] / ds[t]["rb"] for t in cand})
+    return score.sort_values(ascending=False).index[0]
 
 
 def getIntSigFromCounts(records, counts, N, minPts, discut):

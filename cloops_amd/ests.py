@@ -29,7 +29,7 @@ def estIntSelCutFrag(di, ds, log=1):
     return rcut, rfrags
 
 
-def estIntSelCutFrag_from_stats(n_pos, sumlog, sqdev, median_pair):
+def estIntSelCutFrag_from_stats(n_pos, sumlog, sqdev, median_pair, with_margin=False):
     """The same estimator from pre-reduced statistics (cl_dist_stats / cl_dist_sqdev / radix select
     of the GPU library) instead of the raw distance lists:
       n_pos      [inter, self]  number of non-zero distances
@@ -49,4 +49,9 @@ def estIntSelCutFrag_from_stats(n_pos, sumlog, sqdev, median_pair):
     cut = min([cut1, cut2])
     rcut = int(2 ** cut)
     rfrags = int(2 ** ds_median)
+    if with_margin:
+        # distance of 2**cut from the nearest integer: the sums behind `cut` are reduced in a different order
+        # than numpy's pairwise sums, so a value this close to an integer could truncate differently
+        raw = float(2 ** cut)
+        return rcut, rfrags, abs(raw - round(raw))
     return rcut, rfrags

@@ -47,16 +47,61 @@ def parseJd(f, cut=0):
 # resident chromosomes
 # ---------------------------------------------------------------------------------------
 class _Resident(object):
-    __slots__ = ("key", "ids", "X", "Y", "d", "chrom", "device", "stamp", "lock")
+    __slots__ = ("key", "ids", "X", "Y", "d", "chrom", "device", "stamp", "lock", "pins")
 
 
 class ChromCache(object):
-    """path -> chromosome resident in HBM (+ host copies of ids and distances)."""
+    """path -> chromosome resident in HBM (+ host copies of ids and distances).
+
+    `max_items` bounds the number of IDLE residents kept around; a resident that is pinned (a sweep holds it,
+    `pinned()`) or whose lock is held is never evicted, so a sweep over any number of chromosomes keeps all of
+    its handles alive (the reference has no such limit: it re-reads every .jd in every step)."""
 
     def __init__(self, max_items=64):
         self._items = OrderedDict()
         self._lock = threading.Lock()
         self.max_items = max_items
+
+    def _evict_idle(self):
+        """called with self._lock held: drop the oldest residents that nobody uses while over the limit"""
+        if len(self._items) <= self.max_items:
+            return []
+        out = []
+        for f in list(self._items.keys()):
+            if len(self._items) - len(out) <= self.max_items:
+                break
+            r = self._items[f]
+            if r.pins > 0 or r.lock.locked():
+                continue
+            out.append(f)
+        return [self._items.pop(f) for f in out]
+
+    def pinned(self, fs, devices=None):
+        """context manager: the residents of `fs` (loaded on demand, file k on devices[k % len]; None = wherever it
+        already is), pinned against eviction until the block ends"""
+        cache = self
+
+        class _Pinned(object):
+            def __enter__(self_inner):
+                self_inner.rs = []
+                try:
+                    for k, f in enumerate(fs):
+                        dev = None if devices is None else devices[k % len(devices)]
+                        self_inner.rs.append(cache.get(f, dev, _pin=True))
+                except Exception:
+                    self_inner.__exit__(None, None, None)
+                    raise
+                return self_inner.rs
+
+            def __exit__(self_inner, *exc):
+                with cache._lock:
+                    for r in self_inner.rs:
+                        r.pins -= 1
+                    victims = cache._evict_idle()
+                for v in victims:
+                    v.chrom.close()
+                return False
+        return _Pinned()
 
     def put_arrays(self, name, X, Y, device=0, ids=None):
         """Register an in-memory chromosome under the pseudo path 'mem://<chrA>-<chrB>' (no .jd
@@ -66,6 +111,7 @@ class ChromCache(object):
         r.key = tuple(name.split("-")) if "-" in name else (name, name)
         r.stamp, r.device = ("mem", len(X)), device
         r.lock = threading.Lock()
+        r.pins = 0
         r.X = np.ascontiguousarray(X)
         r.Y = np.ascontiguousarray(Y)
         r.ids = np.arange(len(r.X), dtype=np.int64) if ids is None else np.asarray(ids)
@@ -78,22 +124,29 @@ class ChromCache(object):
             old.chrom.close()
         return f
 
-    def get(self, f, device=0):
+    def get(self, f, device=None, _pin=False):
+        """the resident of `f`; `device=None` takes it wherever it already lives (GPU 0 if it has to be loaded),
+        an explicit device reloads a chromosome that lives on another GPU"""
         if f.startswith("mem://"):
             with self._lock:
-                return self._items[f]
+                r = self._items[f]
+                r.pins += 1 if _pin else 0
+                return r
         st = os.stat(f)
         stamp = (st.st_mtime_ns, st.st_size)
         with self._lock:
             r = self._items.get(f)
-            if r is not None and r.stamp == stamp and r.device == device:
+            if r is not None and r.stamp == stamp and (device is None or r.device == device):
                 self._items.move_to_end(f)
+                r.pins += 1 if _pin else 0
                 return r
+        device = 0 if device is None else device
         key, mat = parseJd(f, cut=0)
         mat = np.asarray(mat)
         r = _Resident()
         r.key, r.stamp, r.device = key, stamp, device
         r.lock = threading.Lock()
+        r.pins = 1 if _pin else 0
         if len(mat):
             r.ids = mat[:, 0]
             r.X = np.ascontiguousarray(mat[:, 1])
@@ -105,10 +158,10 @@ class ChromCache(object):
         with self._lock:
             old = self._items.pop(f, None)
             self._items[f] = r
-            while len(self._items) > self.max_items:
-                _, ev = self._items.popitem(last=False)
-                ev.chrom.close()
-        if old is not None:
+            victims = self._evict_idle()
+        for v in victims:
+            v.chrom.close()
+        if old is not None and old.pins == 0:
             old.chrom.close()
         return r
 
@@ -167,7 +220,7 @@ def _records(key, boxes):
     return [[key[0], int(x0), int(x1), key[1], int(y0), int(y1)] for x0, x1, y0, y1 in boxes]
 
 
-def singleDBSCAN(f, eps, minPts, cut=0, device=0):
+def singleDBSCAN(f, eps, minPts, cut=0, device=None):
     """Run DBSCAN to detect interactions for one chromosome (cLoops/pipe.py:52-110).
 
     Returns (key, f, dataI, dataS, dis, dss) exactly shaped like the reference: record rows
@@ -228,37 +281,33 @@ def runDBSCAN(fs, eps, minPts, cut=0, cpu=1):
 
 
 def filterClusterByDis(data, cut):
-    """Filter inter-ligation clusters by distances (cLoops/pipe.py:130-143).  The reference
-    is Python 2: `/` on the int mid-points is FLOOR division (pipe.py:138)."""
-    for key in data:
-        nr = []
-        for r in data[key]["records"]:
-            d = (r[4] + r[5]) // 2 - (r[1] + r[2]) // 2
-            if d >= cut:
-                nr.append(r)
-        data[key]["records"] = nr
+    """Filter inter-ligation clusters by distances (cLoops/pipe.py:130-143): keep a record when the distance
+    between its anchor mid-points is >= cut.  The reference is Python 2: `/` on the int mid-points is FLOOR
+    division (pipe.py:138).  Mutates and returns `data` like the reference."""
+    def mid_distance(rec):
+        return (rec[4] + rec[5]) // 2 - (rec[1] + rec[2]) // 2
+    for entry in data.values():
+        entry["records"] = [rec for rec in entry["records"] if mid_distance(rec) >= cut]
     return data
 
 
 def checkSameLoop(ra, rb):
     """check if two anchors are exact same (cLoops/pipe.py:146-152)."""
-    if ra[1] == rb[1] and ra[2] == rb[2] and ra[4] == rb[4] and ra[5] == rb[5]:
-        return True
-    return False
+    return (ra[1], ra[2], ra[4], ra[5]) == (rb[1], rb[2], rb[4], rb[5])
 
 
 def combineTwice(dataI, dataI_2):
-    """Combining multiple clustering result (cLoops/pipe.py:155-174): exact-box dedup."""
-    for key in dataI_2.keys():
-        if key not in dataI:
-            dataI[key] = {"f": dataI_2[key]["f"], "records": dataI_2[key]["records"]}
-        else:
-            ds = set()
-            for r in dataI[key]["records"]:
-                ds.add((r[1], r[2], r[4], r[5]))
-            for r in dataI_2[key]["records"]:
-                if (r[1], r[2], r[4], r[5]) not in ds:
-                    dataI[key]["records"].append(r)
+    """Combining multiple clustering result (cLoops/pipe.py:155-174): records of `dataI_2` whose exact box is not
+    already in `dataI` are appended (the set of known boxes is taken BEFORE appending, so duplicates inside
+    `dataI_2` all come through, like the reference)."""
+    box = lambda rec: (rec[1], rec[2], rec[4], rec[5])
+    for key, new in dataI_2.items():
+        have = dataI.get(key)
+        if have is None:
+            dataI[key] = {"f": new["f"], "records": new["records"]}
+            continue
+        known = {box(rec) for rec in have["records"]}
+        have["records"].extend(rec for rec in new["records"] if box(rec) not in known)
     return dataI
 
 
@@ -369,9 +418,11 @@ def _select_kth(chroms, cut, group, ranks, allsum=None, pool=None):
 
 
 SWEEP_THREADS = 8
+#: |2**cut - nearest integer| below which runSweepFast re-derives the cut from the distance lists (ests.py:57 truncates)
+CUT_RECHECK_MARGIN = 1e-6
 
 
-def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, allsum=None):
+def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, allsum=None, probe=None):
     """runSweep with the per-step statistics reduced on the GPUs: neither labels nor distance
     lists come back to the host -- per chromosome only the K-row cluster table, a few sums, and
     the 256-bin histograms of an exact radix select for the median (all additive over chromosomes
@@ -383,14 +434,21 @@ def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, 
     chained cut is estimated from the genome-wide statistics; the per-step exchange is a few
     hundred bytes (6 sums, 2 squared deviations, 4-8 histograms of 256 bins).
 
+    `probe` (optional): called as probe(f, eps, minPts, cut_in, result) for every completed run (bench.py reads
+    the HIP-event kernel timings of profiled handles through it).
+
     returns (dataI {key: {"f": f, "boxes": int64[k,4]}} of the local chromosomes, cut, cuts, steps)."""
     variant = variant or DBSCAN_VARIANT
     gsum = allsum if allsum is not None else (lambda a: a)
     devs = _devices()
+    with CACHE.pinned(fs, devs) as res_all:
+        return _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gsum, probe)
+
+
+def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gsum, probe=None):
     acc = {}
     cuts = [cut]
     steps = []
-    res_all = [CACHE.get(f, devs[k % len(devs)]) for k, f in enumerate(fs)]
     live = [(f, r) for f, r in zip(fs, res_all) if len(r.d)]
     pool = ThreadPoolExecutor(max_workers=SWEEP_THREADS) if len(live) > 1 else None
     try:
@@ -401,18 +459,32 @@ def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, 
                 # chromosomes are independent inside a step: enqueue them all (each handle has its own
                 # streams), then collect -- the kernels of different chromosomes overlap on the GPU
                 # and the host-side collection runs on the pool
-                for f, r in live:
-                    r.lock.acquire()
-                    try:
-                        r.chrom.cluster_async(variant, ep, m, step_cut, want_labels=False)
-                    except Exception:
+                enqueued = []
+                try:
+                    for f, r in live:
+                        r.lock.acquire()
+                        try:
+                            r.chrom.cluster_async(variant, ep, m, step_cut, want_labels=False)
+                        except Exception:
+                            r.lock.release()
+                            raise
+                        enqueued.append(r)
+                except Exception:
+                    # a failed enqueue must not leave the earlier chromosomes locked with a run in flight
+                    for r in enqueued:
+                        try:
+                            r.chrom.wait()
+                        except Exception:
+                            pass
                         r.lock.release()
-                        raise
+                    raise
 
                 def collect(fr):
                     f, r = fr
                     try:
                         res = r.chrom.wait()
+                        if probe is not None:
+                            probe(f, ep, m, step_cut, res)
                         dI, dS = _boxes_classified(r, res)
                         n_in = r.chrom.last_n_in()
                         s1 = r.chrom.dist_stats(step_cut) if len(dI) else None
@@ -457,7 +529,14 @@ def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, 
                     sq = [float(v) for v in gsum(np.asarray(sq, dtype=np.float64))]
                     n1 = tot["n_pos"][1]
                     med = _select_kth(used, cut, 1, sorted({(n1 - 1) // 2, n1 // 2}), allsum, pool)
-                    cut_2, frags = estIntSelCutFrag_from_stats(tot["n_pos"], tot["sumlog"], sq, (med[0], med[-1]))
+                    cut_2, frags, margin = estIntSelCutFrag_from_stats(tot["n_pos"], tot["sumlog"], sq, (med[0], med[-1]), with_margin=True)
+                    if margin < CUT_RECHECK_MARGIN and allsum is None:
+                        # 2**cut sits on an integer boundary within the rounding noise of the reduction order: settle
+                        # it the reference's way, from the distance lists with numpy's own sums (rare; one extra run
+                        # per chromosome with labels on the host)
+                        parts = [_cluster_arrays(r, ep, m, step_cut, variant) for r in used]
+                        cut_2, frags = estIntSelCutFrag(np.concatenate([p[2] for p in parts]), np.concatenate([p[3] for p in parts]))
+                        st["cut_rechecked"] = True
                     if log:
                         log("Estimated inter-ligation and self-ligation distance cutoff as %s for eps=%s,minPts=%s" % (cut_2, ep, m))
                     st["cut_out"] = int(cut_2)

@@ -12,7 +12,7 @@ from . import api
 from .pipe import CACHE
 
 
-def singleStripDBSCAN(f, eps, minPts, extx=1, exty=1, device=0):
+def singleStripDBSCAN(f, eps, minPts, extx=1, exty=1, device=None):
     """scripts/callStripes:37-72.  Returns (key, dataI) with records
     [chrA, minX, maxX, chrB, minY, maxY, nPETs] in ascending cluster id (the iteration order of
     `set(labels.values)`, as in pipe.singleDBSCAN); coordinates unscaled like callStripes:59-66
@@ -33,105 +33,78 @@ def singleStripDBSCAN(f, eps, minPts, extx=1, exty=1, device=0):
 
 
 def filterCandidateStripes(rs, pets=200, lengthFoldDiff=20):
-    """scripts/callStripes:75-86 (py2 integer `/` on ints is floor division; a zero-length side raises
-    ZeroDivisionError there too)."""
-    for key in list(rs.keys()):
-        nds = []
-        for r in rs[key]:
-            if r[6] < pets:
-                continue
-            xlen = r[2] - r[1]
-            ylen = r[5] - r[4]
-            if (xlen // ylen > lengthFoldDiff) or (ylen // xlen > lengthFoldDiff):
-                nds.append(r)
-        rs[key] = nds
+    """scripts/callStripes:75-86: keep clusters with >= `pets` PETs whose bounding box is line-like -- one side more
+    than `lengthFoldDiff` times the other (Python-2 integer `/` = floor division; a zero-length side raises
+    ZeroDivisionError there too).  Mutates and returns `rs` like the script."""
+    def line_like(rec):
+        w, h = rec[2] - rec[1], rec[5] - rec[4]
+        return max(w // h, h // w) > lengthFoldDiff
+    for key, recs in rs.items():
+        rs[key] = [rec for rec in recs if rec[6] >= pets and line_like(rec)]
     return rs
 
 
-# ---- significance of candidate stripes (host side, scipy; scripts/callStripes:89-269) ---------
-def getNearbyStripes(iva, ivb, win=5):
-    """scripts/callStripes:89-120 with Python-2 integer arithmetic: the longer anchor stays, the shorter
-    one slides by its half-length; equal lengths return None (the script then fails unpacking it)."""
-    lena = iva[1] - iva[0]
-    lenb = ivb[1] - ivb[0]
-    ivas, ivbs = [], []
-    ca = sum(iva) // 2
-    cb = sum(ivb) // 2
-    sa = (iva[1] - iva[0]) // 2
-    sb = (ivb[1] - ivb[0]) // 2
-    if lena > lenb:
-        step = sb
-        for i in range(0 - win, win + 1):
-            if i == 0:
-                continue
-            ivas.append(iva)
-            ivbs.append([max([0, cb + i * step - sb]), max([0, cb + i * step + sb])])
-        return ivas, ivbs
-    if lena < lenb:
-        step = sa
-        for i in range(0 - win, win + 1):
-            if i == 0:
-                continue
-            ivas.append([max([0, ca + i * step - sa]), max([0, ca + i * step + sa])])
-            ivbs.append(ivb)
-        return ivas, ivbs
-    return None
+# ---- significance of candidate stripes (scripts/callStripes:89-233) on the K8 interval counts ---------
+def _stripe_windows(records, win=5):
+    """The 22 count windows of every candidate stripe, vectorised: window 0 of each side is the anchor itself,
+    1..10 its permuted background (scripts/callStripes:89-120 in Python-2 integer arithmetic): the LONGER anchor
+    stays in place, the shorter one slides by multiples of its own half-length.  Equal lengths have no
+    background in the script (`getNearbyStripes` returns None and the caller fails unpacking it): TypeError.
+    -> (iva int64[R,2], ivb int64[R,2], windows int32[R,44] = lo[22] then hi[22]; A0..A10 then B0..B10)"""
+    r = np.asarray([[x[1], x[2], x[4], x[5]] for x in records], dtype=np.int64).reshape(-1, 4)
+    iva = np.stack([np.maximum(0, r[:, 0]), r[:, 1]], 1)
+    ivb = np.stack([np.maximum(0, r[:, 2]), r[:, 3]], 1)
+    lens = np.stack([iva[:, 1] - iva[:, 0], ivb[:, 1] - ivb[:, 0]], 1)
+    if (lens[:, 0] == lens[:, 1]).any():
+        raise TypeError("cannot unpack non-iterable NoneType object")       # scripts/callStripes:135 on equal anchor lengths
+    slide_b = lens[:, 0] > lens[:, 1]                       # anchor a is the longer one: b slides
+    lo = np.empty((len(r), 22), np.int64)
+    hi = np.empty((len(r), 22), np.int64)
+    for side, iv, slides in ((0, iva, ~slide_b), (11, ivb, slide_b)):
+        centre = iv.sum(1) // 2
+        half = (iv[:, 1] - iv[:, 0]) // 2
+        lo[:, side], hi[:, side] = iv[:, 0], iv[:, 1]
+        shifts = [i for i in range(-win, win + 1) if i != 0]
+        for k, i in enumerate(shifts, start=1):
+            lo[:, side + k] = np.where(slides, np.maximum(0, centre + i * half - half), iv[:, 0])
+            hi[:, side + k] = np.where(slides, np.maximum(0, centre + i * half + half), iv[:, 1])
+    return iva, ivb, np.concatenate([lo, hi], 1).astype(np.int32)
 
 
-def getStripePsFdr(iva, ivb, model, N, win=5):
-    """scripts/callStripes:123-185 -> ra, rb, rab, es, es_ra, es_rb, fdr, pop, nbp"""
-    from scipy.stats import binom, poisson
-    from .cModel import getPETsforRegions
-    ra, rb, rab = getPETsforRegions(iva, ivb, model)
-    ivas, ivbs = getNearbyStripes(iva, ivb, win=win)       # TypeError for equal lengths, like the script
-    nras = [model.region(na) for na in ivas]
-    nrbs = [model.region(nb) for nb in ivbs]
-    rabs, nbps = [], []
-    for nra in nras:
-        nralen = float(len(nra))
-        for nrb in nrbs:
-            nrblen = len(nrb)
-            nrab = float(len(np.intersect1d(nra, nrb, assume_unique=True)))
-            if nrab > 0:
-                rabs.append(nrab)
-                nbps.append(nrab / (nralen * nrblen))
-            else:
-                nbps.append(0.0)
-                rabs.append(0.0)
-    rabs = np.array(rabs)
-    fdr = len(rabs[rabs > rab]) / float(len(rabs))
-    mrabs = float(np.mean(rabs))
-    es = rab / np.mean(rabs[rabs > 0]) if mrabs > 0 else np.inf
-    pop = max([1e-300, poisson.sf(rab - 1.0, mrabs)])
-    bp = np.mean(nbps) * ra * rb / N
-    nbp = max([1e-300, binom.sf(rab - 1.0, N - rab, bp)])
-    return ra, rb, rab, es, rab / float(ra), rab / float(rb), fdr, pop, nbp
-
-
-def estStripeSig(f, records, device=0):
-    """scripts/callStripes:188-233: one row per candidate stripe; None without PETs or records"""
+def estStripeSig(f, records, device=None):
+    """scripts/callStripes:123-233: one row per candidate stripe; None without PETs or records.  The interval
+    counting is kernel K8 on the resident chromosome (`cl_sig_counts`: |region(A_k)|, |region(B_l)|, the
+    direct X-in-A / Y-in-B count and all |region(A_k) & region(B_l)|); the statistics of all stripes are array
+    expressions on that table -- same integers, same numpy / scipy calls on the same operands as the script."""
     import pandas as pd
-    from .cModel import CoverageModel
+    from scipy.stats import binom, poisson
     r0 = CACHE.get(f, device)
-    N = len(r0.d)
-    if N < 2:                                             # getGenomeCoverage returns (None, 0) (cModel.py:53-54)
+    if len(r0.d) < 2 or len(records) == 0:                  # getGenomeCoverage -> (None, 0) (cModel.py:53-54)
         return None
-    model = CoverageModel(np.stack([np.asarray(r0.ids), np.asarray(r0.X), np.asarray(r0.Y)], 1))
-    ds = {}
+    iva, ivb, wins = _stripe_windows(records)
+    with r0.lock:
+        counts, N = r0.chrom.sig_counts(wins, 0)
+    c = counts.astype(np.int64)
+    R = len(records)
+    ra, rb, rab = c[:, 0], c[:, 11], c[:, 22]
+    grid = c[:, 23:].reshape(R, 11, 11)[:, 1:, 1:].astype(np.float64)       # |region(A_k) & region(B_l)|, k, l = 1..10
+    rabs = grid.reshape(R, 100)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        share = np.where(grid > 0, grid / (c[:, 1:11].astype(np.float64)[:, :, None] * c[:, 12:22][:, None, :]), 0.0).reshape(R, 100)
+    lam = rabs.mean(axis=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        es = np.where(lam > 0, rab / (rabs.sum(1) / np.maximum((rabs > 0).sum(1), 1)), np.inf)
+    fdr = (rabs > rab[:, None]).sum(1) / float(100)
+    pop = np.maximum(1e-300, poisson.sf(rab - 1.0, lam))
+    nbp = np.maximum(1e-300, binom.sf(rab - 1.0, N - rab, share.mean(axis=1) * ra * rb / N))
+    rows = {}
     for i, r in enumerate(records):
-        chrom = r[0]
-        key = "%s-%s-%s" % (r[0], r[3], i)
-        iva = [max(0, r[1]), r[2]]
-        ivb = [max(0, r[4]), r[5]]
-        ra, rb, rab, es, es_ra, es_rb, fdr, pop, nbp = getStripePsFdr(iva, ivb, model, N)
-        ds[key] = {
-            "ra": ra, "rb": rb, "rab": rab, "ES": es, "ES_ra": es_ra, "ES_rb": es_rb, "FDR": fdr,
-            "poisson_p-value": pop, "binomial_p-value": nbp,
-            "iva": "%s:%s-%s" % (chrom, iva[0], iva[1]), "ivb": "%s:%s-%s" % (chrom, ivb[0], ivb[1]),
+        rows["%s-%s-%s" % (r[0], r[3], i)] = {
+            "ra": int(ra[i]), "rb": int(rb[i]), "rab": int(rab[i]), "ES": float(es[i]), "ES_ra": rab[i] / float(ra[i]),
+            "ES_rb": rab[i] / float(rb[i]), "FDR": float(fdr[i]), "poisson_p-value": float(pop[i]), "binomial_p-value": float(nbp[i]),
+            "iva": "%s:%s-%s" % (r[0], iva[i, 0], iva[i, 1]), "ivb": "%s:%s-%s" % (r[0], ivb[i, 0], ivb[i, 1]),
         }
-    if len(ds) == 0:
-        return None
-    return pd.DataFrame(ds).T
+    return pd.DataFrame(rows).T
 
 
 def markStripeSig(ds, escut=2.0, fdrcut=0.1, ppcut=1e-5, es_cut=0.2):

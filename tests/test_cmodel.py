@@ -24,16 +24,23 @@ def cpu_backend(monkeypatch):
     pipe.CACHE.clear()
 
 
-def test_set_based_restatement_identical(tmp_path):
-    """the literal set-based restatement (getIntSigFromMat) also reproduces the golden table"""
+@pytest.mark.skipif(not __import__("refload").available(), reason="reference checkout not present")
+def test_table_equals_reference_functions(tmp_path):
+    """cross-check against the reference's OWN getIntSig / markIntSig (imported from /root/reference through
+    tests/refload.py, py2 -> py3 patched in memory): same table, cell by cell"""
+    import refload
+    ns = refload.ref_cmodel_namespace()
     z, meta = pipe_checks.pipe_golden()
     X, Y = G.chr21_xy()
     mat = np.stack([np.arange(len(X)), X, Y], 1).astype(np.int64)
-    recs = [["chr21", int(a), int(b), "chr21", int(c), int(d)] for a, b, c, d in z["v2_filtered"]]
-    ds = cModel.markIntSig(cModel.getIntSigFromMat(mat, recs, [5], 0))
-    out = os.path.join(str(tmp_path), "x.loop")
-    ds.to_csv(out, sep="\t", index_label="loopId")
-    assert open(out).read() == open(os.path.join(G.GOLD, "chr21_v2.loop")).read()
+    f = os.path.join(str(tmp_path), "chr21-chr21.jd")
+    joblib.dump(mat, f)
+    recs = [["chr21", int(a), int(b), "chr21", int(c), int(d)] for a, b, c, d in z["v2_filtered"][:150]]
+    want = ns["markIntSig"](ns["getIntSig"](f, [list(r) for r in recs], [5], 0))
+    got = cModel.markIntSig(cModel.getIntSig(f, recs, [5], 0))
+    assert list(got.index) == list(want.index) and list(got.columns) == list(want.columns)
+    for col in want.columns:
+        assert got[col].tolist() == want[col].tolist(), col
 
 
 @pytest.mark.parametrize("variant", ["v2", "v1"])
@@ -55,24 +62,38 @@ def test_loop_file_identical(variant, hic, tmp_path):
     assert int(df["significant"].sum()) == (252 if hic else 202)
 
 
-def test_nearby_regions_floor_semantics():
-    ivas, ivbs = cModel.getNearbyPairRegions([101, 204], [1001, 1104])
+def test_windows_floor_semantics():
+    """the 22 windows of a record: Python-2 floor arithmetic of getNearbyPairRegions (cModel.py:89-93)"""
+    iva, ivb, dist, w = cModel._windows([["c", 101, 204, "c", 1001, 1104]])
+    lo, hi = w[0, :22], w[0, 22:]
     # ca = 305 // 2 = 152, sa = 103 // 2 = 51, step = (51 + 51) // 2 = 51
-    assert ivas[0] == [max(0, 152 - 5 * 51 - 51), max(0, 152 - 5 * 51 + 51)] and len(ivas) == 10 and len(ivbs) == 10
-    assert ivas[5] == [152 + 51 - 51, 152 + 51 + 51]
+    assert (lo[0], hi[0], lo[11], hi[11]) == (101, 204, 1001, 1104)
+    assert (lo[1], hi[1]) == (max(0, 152 - 5 * 51 - 51), max(0, 152 - 5 * 51 + 51))
+    assert (lo[6], hi[6]) == (152 + 51 - 51, 152 + 51 + 51)
+    assert dist[0] == abs((1001 + 1104) / 2.0 - (101 + 204) / 2.0)
 
 
 def test_counts_are_inclusive_and_use_row_positions():
-    mat = np.array([[10, 100, 500], [11, 150, 100], [12, 200, 150], [13, 100, 900]], dtype=np.int64)
-    m = cModel.CoverageModel(mat)
-    assert m.side([100, 150], 0).tolist() == [0, 1, 3]       # X in [100,150]
-    assert m.side([100, 150], 1).tolist() == [1, 2]          # Y in [100,150]
-    assert m.region([100, 150]).tolist() == [0, 1, 2, 3]
-    assert cModel.getPETsforRegions([100, 150], [500, 900], m) == (4, 2, 2)
+    import fake_backend
+    X = np.array([100, 150, 200, 100])
+    Y = np.array([500, 100, 150, 900])
+    m = fake_backend.IndexSets(X, Y)
+    assert m.side(100, 150, 0).tolist() == [0, 1, 3]       # X in [100,150]
+    assert m.side(100, 150, 1).tolist() == [1, 2]          # Y in [100,150]
+    assert m.region(100, 150).tolist() == [0, 1, 2, 3]
+    w = np.zeros((1, 44), np.int32)
+    w[0, 0], w[0, 22], w[0, 11], w[0, 33] = 100, 150, 500, 900
+    c, n = fake_backend.FakeChromosome(X, Y).sig_counts(w)
+    assert (c[0, 0], c[0, 11], c[0, 22], n) == (4, 2, 2, 4)      # ra, rb, rab (cModel.py:73-80), N
+
+
+def _one_end(xa, xb, ya, yb):
+    """interval overlap as the reference spells it (checkOneEndOverlap): one end of either inside the other"""
+    return ya <= xa <= yb or ya <= xb <= yb or xa <= ya <= xb or xa <= yb <= xb
 
 
 def test_overlap_lists_match_reference_predicate():
-    """the sweep-based candidate enumeration of removeDup == brute-force checkOverlap (cModel.py:174-195)"""
+    """the sweep-based candidate enumeration of the duplicate removal == the brute-force pair predicate (cModel.py:174-195)"""
     rng = np.random.default_rng(0)
     for t in range(12):
         L = int(rng.integers(1, 300))
@@ -87,6 +108,6 @@ def test_overlap_lists_match_reference_predicate():
         adj = cModel._overlap_lists(iv, chrom)
         for i in range(L):
             want = [j for j in range(i + 1, L)
-                    if cModel.checkOverlap([chrom[i], iv[i, 0], iv[i, 1]], [chrom[i], iv[i, 2], iv[i, 3]],
-                                           [chrom[j], iv[j, 0], iv[j, 1]], [chrom[j], iv[j, 2], iv[j, 3]])]
+                    if chrom[i] == chrom[j] and _one_end(iv[i, 0], iv[i, 1], iv[j, 0], iv[j, 1])
+                    and _one_end(iv[i, 2], iv[i, 3], iv[j, 2], iv[j, 3])]
             assert adj[i].tolist() == want

@@ -97,3 +97,94 @@ def test_filter_candidate_stripes_semantics():
                        ["c", 0, 209, "c", 0, 10, 300]]}       # 209 // 10 = 20, not > 20: dropped
     out = stripes.filterCandidateStripes(rs, pets=200, lengthFoldDiff=20)
     assert out[("c", "c")] == [["c", 0, 1000, "c", 0, 10, 300], ["c", 0, 10, "c", 0, 1000, 300]]
+
+
+# ---- resident-chromosome cache: a sweep keeps every handle it uses alive ---------------------------
+class _ClosableFake(fake_backend.FakeChromosome):
+    """like the real handle: close() destroys it, any later call fails"""
+    closed_calls = 0
+
+    def close(self):
+        self.dead = True
+
+    def cluster_async(self, *a, **kw):
+        if getattr(self, "dead", False):
+            type(self).closed_calls += 1
+            raise RuntimeError("null chromosome handle")
+        return fake_backend.FakeChromosome.cluster_async(self, *a, **kw)
+
+
+def _write_many_jd(tmp_path, n_files, n=400):
+    import joblib
+    from cloops_amd.synth import synth_chrom
+    fs = []
+    for k in range(n_files):
+        X, Y = synth_chrom(n, 200000, 900 + k)
+        f = str(tmp_path / ("c%d-c%d.jd" % (k, k)))
+        joblib.dump(np.stack([np.arange(n), X, Y], 1).astype(np.int64), f)
+        fs.append(f)
+    return fs
+
+
+def test_sweep_over_more_chromosomes_than_the_cache_keeps(monkeypatch, tmp_path):
+    """70 per-chromosome files > max_items = 64 (a scaffold-level assembly): no resident that the sweep
+    uses may be evicted / closed while the sweep runs; afterwards the cache shrinks back"""
+    monkeypatch.setattr(api, "Chromosome", _ClosableFake)
+    monkeypatch.setattr(api, "device_count", lambda: 1)
+    pipe.CACHE.clear()
+    fs = _write_many_jd(tmp_path, 70)
+    _ClosableFake.closed_calls = 0
+    dataI, cut, cuts, steps = pipe.runSweepFast(fs, [800], [4, 3], cut=0)
+    assert _ClosableFake.closed_calls == 0
+    assert len(steps) == 2 and steps[0]["n_in"] == 70 * 400
+    assert len(pipe.CACHE._items) <= pipe.CACHE.max_items
+    assert all(r.pins == 0 for r in pipe.CACHE._items.values())
+    pipe.CACHE.clear()
+
+
+def test_failed_enqueue_releases_every_lock(monkeypatch, tmp_path):
+    """cluster_async raising for chromosome k must not leave chromosomes 0..k-1 locked / in flight"""
+    class Failing(fake_backend.FakeChromosome):
+        def cluster_async(self, variant, eps, minPts, cut=0, want_labels=True):
+            if self.n == 403:
+                raise RuntimeError("boom")
+            return fake_backend.FakeChromosome.cluster_async(self, variant, eps, minPts, cut, want_labels)
+    monkeypatch.setattr(api, "Chromosome", Failing)
+    monkeypatch.setattr(api, "device_count", lambda: 1)
+    pipe.CACHE.clear()
+    from cloops_amd.synth import synth_chrom
+    fs = [pipe.CACHE.put_arrays("k%d-k%d" % (k, k), *synth_chrom(400 + k, 200000, 70 + k)) for k in range(5)]
+    with pytest.raises(RuntimeError):
+        pipe.runSweepFast(fs, [800], [4], cut=0)
+    for f in fs:
+        r = pipe.CACHE.get(f)
+        assert not r.lock.locked() and r.pins == 0
+        assert not getattr(r.chrom, "_pending", [])
+    pipe.CACHE.clear()
+
+
+def test_cache_get_without_device_preference_keeps_the_resident(monkeypatch, tmp_path):
+    """the significance stage asks for a chromosome without a device preference: the resident copy on
+    another GPU is reused, not reloaded onto GPU 0"""
+    monkeypatch.setattr(api, "Chromosome", fake_backend.FakeChromosome)
+    monkeypatch.setattr(api, "device_count", lambda: 2)
+    pipe.CACHE.clear()
+    f = _write_many_jd(tmp_path, 1)[0]
+    r1 = pipe.CACHE.get(f, 1)
+    assert r1.device == 1 and pipe.CACHE.get(f) is r1 and pipe.CACHE.get(f, None) is r1
+    assert pipe.CACHE.get(f, 0) is not r1
+    pipe.CACHE.clear()
+
+
+def test_cut_on_an_integer_boundary_is_settled_from_the_lists(cpu_pipe, monkeypatch):
+    """rcut = int(2 ** cut) truncates: when the statistics-based 2**cut lands within rounding noise of an integer
+    the step is re-derived from the distance lists like the reference does -- forced here by a huge margin;
+    the chain must not change and the steps say so"""
+    p, f = cpu_pipe
+    z, meta = pipe_checks.pipe_golden()
+    monkeypatch.setattr(p, "CUT_RECHECK_MARGIN", 10.0)
+    dataI, cut, cuts, steps = p.runSweepFast([f], [500, 1000, 2000], [5], cut=0)
+    assert all(s.get("cut_rechecked") for s in steps)
+    assert [s.get("cut_out") for s in steps] == [s.get("cut_out") for s in meta["v2"]["steps"]]
+    assert [s.get("frags") for s in steps] == [s.get("frags") for s in meta["v2"]["steps"]]
+    assert np.array_equal(dataI[("chr21", "chr21")]["boxes"], z["v2_filtered"])

@@ -49,10 +49,14 @@ def test_stripe_table_identical(chr21, name, tmp_path):
     assert int(tab["significant"].sum()) == meta[name + "_significant"]
 
 
-def test_nearby_stripes_floor_semantics():
-    ivas, ivbs = stripes.getNearbyStripes([100, 205], [1000, 1011])          # a longer: b slides by sb = 5
-    assert ivas == [[100, 205]] * 10
-    assert ivbs[0] == [1005 - 25 - 5, 1005 - 25 + 5] and ivbs[-1] == [1005 + 25 - 5, 1005 + 25 + 5]
-    ivas, ivbs = stripes.getNearbyStripes([10, 21], [1000, 2000])            # b longer: a slides, clipped at 0
-    assert ivbs == [[1000, 2000]] * 10 and ivas[0] == [0, 0] and ivas[5] == [15 + 5 - 5, 15 + 5 + 5]
-    assert stripes.getNearbyStripes([0, 10], [100, 110]) is None
+def test_stripe_windows_floor_semantics():
+    """background windows (scripts/callStripes:89-120, py2 floor arithmetic): the longer anchor stays, the shorter
+    slides by its half-length; equal lengths fail like the script does"""
+    iva, ivb, w = stripes._stripe_windows([["c", 100, 205, "c", 1000, 1011], ["c", 10, 21, "c", 1000, 2000]])
+    lo, hi = w[:, :22], w[:, 22:]
+    assert lo[0, :11].tolist() == [100] * 11 and hi[0, :11].tolist() == [205] * 11          # a longer: stays
+    assert (lo[0, 12], hi[0, 12]) == (1005 - 25 - 5, 1005 - 25 + 5) and (lo[0, 21], hi[0, 21]) == (1005 + 25 - 5, 1005 + 25 + 5)
+    assert lo[1, 11:].tolist() == [1000] * 11 and hi[1, 11:].tolist() == [2000] * 11        # b longer: stays
+    assert (lo[1, 1], hi[1, 1]) == (0, 0) and (lo[1, 6], hi[1, 6]) == (15 + 5 - 5, 15 + 5 + 5)   # clipped at 0
+    with pytest.raises(TypeError):
+        stripes._stripe_windows([["c", 0, 10, "c", 100, 110]])
