@@ -61,11 +61,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(SO_PATH):
+    path = SO_PATH
+    if os.environ.get("CLOOPS_DEVEL_LIB") == "1":          # developer build with ablation knobs (cloops_amd/build.py --devel)
+        path = SO_PATH.replace(".so", "_devel.so")
+    if not os.path.exists(path):
         raise ImportError(
             "libcloops_hip.so is missing (%s). Build it with `python -m cloops_amd.build` "
-            "(needs hipcc); there is no CPU fallback." % SO_PATH)
-    lib = ctypes.CDLL(SO_PATH)
+            "(needs hipcc); there is no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
     i32p = ctypes.POINTER(ctypes.c_int32)
     vp = ctypes.c_void_p
     lib.cl_last_error.restype = ctypes.c_char_p

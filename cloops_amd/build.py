@@ -23,16 +23,21 @@ def needs_build():
     return any(os.path.getmtime(p) > t for p in (SRC, HDR))
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, devel=False):
+    """`devel=True` builds libcloops_hip_devel.so with -DCLOOPS_DEVEL (ablation / shape knobs read from the
+    environment; loaded only when CLOOPS_DEVEL_LIB=1) -- the shipped library has none of them."""
+    out = OUT.replace(".so", "_devel.so") if devel else OUT
+    if not devel and not force and not needs_build():
         return OUT
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-Wall", "-Wno-unused-function", SRC, "-o", OUT]
+           "-ffp-contract=off", "-Wall", "-Wno-unused-function", SRC, "-o", out]
+    if devel:
+        cmd.insert(1, "-DCLOOPS_DEVEL")
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, devel="--devel" in sys.argv))

@@ -110,6 +110,10 @@ struct GridParams {
     int qbits;    // sort key = strip << (qbits+rbits) | q << rbits | (p mod eps): both coordinates ride
     int rbits;    //   in the key, so the sorted (q,p) arrays are DECODED, not gathered through row ids;
                   //   the radix sort skips the low rbits (they are payload, not order)
+    int peps;     // 1 << rbits.  The kernels never see p itself but its ORDER-PRESERVING re-encoding
+                  //   sp = strip << rbits | (p mod eps)   (the strip and remainder fields of the sort key):
+                  //   strip(p) = sp >> rbits (no division), and |p_j - p_i| <= eps  <=>  |sp_j - sp_i| <= peps
+                  //   (same strip: always; adjacent strips: both compare the remainders; two or more strips apart: never).
 };
 
 __device__ __forceinline__ int sat_add(int a, int b)
@@ -136,64 +140,13 @@ __device__ __forceinline__ int upper_bound_i(const int* __restrict__ sv, int lo,
     }
     return lo;
 }
-// Galloping variants anchored at position i (sv[i] is known to satisfy the predicate):
-// windows are short (tens of PETs), so doubling from i beats a full-strip bisect.
-__device__ __forceinline__ int gallop_left(const int* __restrict__ sv, int b, int i, int val)
-{   // first idx in [b,i] with sv[idx] >= val, given sv[i] >= val
-    int step = 1, hi = i, lo = i - 1;
-    while (lo >= b && sv[lo] >= val) { hi = lo; lo -= step; step <<= 1; }
-    if (lo < b) lo = b - 1;
-    // answer in (lo, hi]
-    return lower_bound_i(sv, lo + 1, hi, val);
-}
-__device__ __forceinline__ int gallop_right(const int* __restrict__ sv, int i, int e, int val)
-{   // first idx in (i,e] with sv[idx] > val (or e), given sv[i] <= val
-    int step = 1, lo = i, hi = i + 1;
-    while (hi < e && sv[hi] <= val) { lo = hi; hi += step; step <<= 1; }
-    if (hi > e) hi = e;
-    // answer in (lo, hi]
-    return upper_bound_i(sv, lo + 1, hi, val);
-}
-
 __device__ __forceinline__ int div_eps(const GridParams& g, int arel)
 {
     const u32 n = (u32)arel;                       // arel >= 0 by construction
     const u32 t1 = __umulhi(g.magic, n);
     return (int)((t1 + ((n - t1) >> g.sh1)) >> g.sh2);
 }
-__device__ __forceinline__ int strip_of(const GridParams& g, int arel) { return div_eps(g, arel) - g.s0; }
-
-// Visit every j != i with max(|a_j-a_i|, |v_j-v_i|) <= eps.  `which` selects the strips:
-// bit0 = strip s-1, bit1 = own strip (both directions), bit2 = strip s+1.
-template <typename F>
-__device__ __forceinline__ void for_each_neighbor(const GridParams& g, const int* __restrict__ sv,
-                                                  const int* __restrict__ sa,
-                                                  const int* __restrict__ strip_start, int i, int which, F&& f)
-{
-    const int vi = sv[i], ai = sa[i];
-    const int s = strip_of(g, ai);
-    const int vlo = sat_add(vi, -g.eps), vhi = sat_add(vi, g.eps);
-    if (which & 2) {
-        const int b = strip_start[s], e = strip_start[s + 1];
-        for (int j = i - 1; j >= b && sv[j] >= vlo; --j) f(j);
-        for (int j = i + 1; j < e && sv[j] <= vhi; ++j) f(j);
-    }
-#pragma unroll
-    for (int d = -1; d <= 1; d += 2) {
-        if (!(which & (d < 0 ? 1 : 4))) continue;
-        const int t = s + d;
-        if (t < 0 || t >= g.S) continue;
-        const int b = strip_start[t], e = strip_start[t + 1];
-        if (b == e) continue;
-        int j = lower_bound_i(sv, b, e, vlo);
-        for (; j < e; ++j) {
-            const int vj = sv[j];
-            if (vj > vhi) break;
-            const int da = sa[j] - ai;
-            if ((da < 0 ? -da : da) <= g.eps) f(j);
-        }
-    }
-}
+__device__ __forceinline__ int strip_of(const GridParams& g, int sp) { return sp >> g.rbits; }      // sp: see GridParams
 
 // ---- lock-free union-find with randomised linking ------------------------------------------
 // Every node has a fixed pseudo-random priority (a bijective hash of its index); a root is only
@@ -309,16 +262,17 @@ __global__ void k_make_keys(const int* __restrict__ X, const int* __restrict__ Y
 
 // K1b: sorted coordinates, decoded from the sorted keys (coalesced; no gather through row ids)
 __global__ void k_decode_sorted(int n, GridParams g, const u64* __restrict__ skeys,
-                                int* __restrict__ sv, int* __restrict__ sa)
+                                int* __restrict__ sv, int* __restrict__ sa, int* __restrict__ tile_s0)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u64 k = skeys[i];
     const int sh = g.qbits + g.rbits;
     const int strip = (int)(k >> sh);
-    if (strip >= g.S) { sv[i] = INT_MAX; sa[i] = 0; return; }
+    if ((i & 255) == 0) tile_s0[i >> 8] = min(strip, g.S);       // strip of every 256th sorted PET (K2 stages its strip-table slice from it)
+    if (strip >= g.S) { sv[i] = INT_MAX; sa[i] = g.S << g.rbits; return; }
     sv[i] = (int)((k >> g.rbits) & ((1ull << g.qbits) - 1ull));
-    sa[i] = (strip + g.s0) * g.eps + (int)(k & ((1ull << g.rbits) - 1ull));
+    sa[i] = (strip << g.rbits) | (int)(k & ((1ull << g.rbits) - 1ull));
 }
 
 // K1c: strip_start[t] = first sorted index whose strip >= t, t = 0..S+1
@@ -377,7 +331,7 @@ __global__ void k_max_int(const int* __restrict__ v, int n, int* __restrict__ ou
 __global__ void __launch_bounds__(HS_TPB)
 k_strip_sort(int n, GridParams g, const u64* __restrict__ keys, const u32* __restrict__ rows,
              const int* __restrict__ strip_start, int* __restrict__ sv, int* __restrict__ sa, u32* __restrict__ srow,
-             int* __restrict__ counters)
+             int* __restrict__ tile_s0, int* __restrict__ counters)
 {
     __shared__ u32 lq[HS_WIN];
     const int t0 = blockIdx.x * HS_TPB, base = t0 - HS_HALO;
@@ -397,7 +351,11 @@ k_strip_sort(int n, GridParams g, const u64* __restrict__ keys, const u32* __res
     const u64 k = kk[1];                                   // slot 1 of the thread is its own PET (HS_HALO == HS_TPB)
     static_assert(HS_HALO == HS_TPB, "own PET = staging slot 1");
     const int strip = (int)(k >> (g.qbits + g.rbits));
-    if (strip >= g.S) { sv[i] = INT_MAX; sa[i] = 0; srow[i] = row; return; }      // filtered rows keep their places
+    if (strip >= g.S) {                                                            // filtered rows keep their places
+        sv[i] = INT_MAX; sa[i] = g.S << g.rbits; srow[i] = row;
+        if ((i & 255) == 0) tile_s0[i >> 8] = g.S;
+        return;
+    }
     const int b = strip_start[strip], e = strip_start[strip + 1];
     if (e - b > HS_LMAX) { counters[CTR_OVERFLOW] = 4; return; }                  // cannot happen (strip_maxlen)
     const u32 qi = lq[i - base];
@@ -408,8 +366,9 @@ k_strip_sort(int n, GridParams g, const u64* __restrict__ keys, const u32* __res
     }
     const int dst = b + rank;
     sv[dst] = (int)qi;
-    sa[dst] = (strip + g.s0) * g.eps + (int)(k & ((1ull << g.rbits) - 1ull));
+    sa[dst] = (strip << g.rbits) | (int)(k & ((1ull << g.rbits) - 1ull));
     srow[dst] = row;
+    if ((dst & 255) == 0) tile_s0[dst >> 8] = strip;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -614,7 +573,9 @@ k_region_count(GridParams g, int ntiles, int n, const int* __restrict__ sv, cons
     const int wbeg = max(base, 0), wend = min(base + K2_WIN, M);
     const int i = t0 + threadIdx.x;
     const bool valid = i < M;
+#ifdef CLOOPS_DEVEL
     if (g.dbg & 32) { if (valid) cnt[i] = w[i].x + w[i].y; return; }        // developer knob: staging only
+#endif
     // ---- phase 0: one-read core test ----------------------------------------------------------
     // If the minPts-1 next (or previous) PETs of the own strip are within eps in q, the point is
     // core: interiors of clusters are settled by one or two LDS reads, without any search.  "Same
@@ -639,7 +600,9 @@ k_region_count(GridParams g, int ntiles, int n, const int* __restrict__ sv, cons
         }
         if (done) cnt[i] = g.minPts; else hard = true;
     }
+#ifdef CLOOPS_DEVEL
     if (g.dbg & 64) { if (valid && hard) cnt[i] = 0; return; }              // developer knob: phase 0 only
+#endif
     // ---- workgroup compaction: whole waves drop out of the search phases ------------------------
     const int total = block_compact_with<K2_TPB>(hard, l_list, l_wcount, [&]() { if (hard) l_sb[threadIdx.x] = sbv; });
     if ((int)threadIdx.x >= total) return;
@@ -680,7 +643,9 @@ k_region_count(GridParams g, int ntiles, int n, const int* __restrict__ sv, cons
             }
         }
         int c = hi - lo;
+#ifdef CLOOPS_DEVEL
         if (g.dbg & 128) { cnt[ii] = c; return; }                             // developer knob: no neighbour strips
+#endif
         // ---- phase 2: neighbour strips, only while not known to be core -------------------------
         if (EXACT || c < g.minPts) {
             // strip s-1 = [tb, b), strip s+1 = [e, te); an EMPTY strip counts as staged (the searches
@@ -713,36 +678,305 @@ k_region_count(GridParams g, int ntiles, int n, const int* __restrict__ sv, cons
                     const bool ina = (ja + k < b) && (va[k].x <= qhi), inb = (jb + k < te) && (vb[k].x <= qhi);
                     outA |= !ina; outB |= !inb;
                     const int da = va[k].y - pi, db = vb[k].y - pi;
-                    c += (ina && (da < 0 ? -da : da) <= g.eps) ? 1 : 0;
-                    c += (inb && (db < 0 ? -db : db) <= g.eps) ? 1 : 0;
+                    c += (ina && (da < 0 ? -da : da) <= g.peps) ? 1 : 0;
+                    c += (inb && (db < 0 ? -db : db) <= g.peps) ? 1 : 0;
                 }
                 if (EXACT || c < g.minPts) {
-                    if (!outA) c = k2_count_lds<EXACT, 4>(w, ja + 4, b, qhi, pi, g.eps, g.minPts, c);
-                    if (!outB && (EXACT || c < g.minPts)) c = k2_count_lds<EXACT, 4>(w, jb + 4, te, qhi, pi, g.eps, g.minPts, c);
+                    if (!outA) c = k2_count_lds<EXACT, 4>(w, ja + 4, b, qhi, pi, g.peps, g.minPts, c);
+                    if (!outB && (EXACT || c < g.minPts)) c = k2_count_lds<EXACT, 4>(w, jb + 4, te, qhi, pi, g.peps, g.minPts, c);
                 }
             } else {
                 if (tb < b) {
                     if (ldsA) {
                         const int j = (b - tb <= 63) ? lds_lower_bound8<6>(w, tb, b, qlo) : lds_lower_bound8<8>(w, tb, b, qlo);
-                        c = k2_count_lds<EXACT, 4>(w, j, b, qhi, pi, g.eps, g.minPts, c);
+                        c = k2_count_lds<EXACT, 4>(w, j, b, qhi, pi, g.peps, g.minPts, c);
                     } else {
                         const int j = lower_bound_4(sv, tb, b, qlo);
-                        c = k2_count_glb<EXACT, 8>(sv, sa, j, b, qhi, pi, g.eps, g.minPts, c);
+                        c = k2_count_glb<EXACT, 8>(sv, sa, j, b, qhi, pi, g.peps, g.minPts, c);
                     }
                 }
                 if ((EXACT || c < g.minPts) && e < te) {
                     if (ldsB) {
                         const int j = (te - e <= 63) ? lds_lower_bound8<6>(w, e, te, qlo) : lds_lower_bound8<8>(w, e, te, qlo);
-                        c = k2_count_lds<EXACT, 4>(w, j, te, qhi, pi, g.eps, g.minPts, c);
+                        c = k2_count_lds<EXACT, 4>(w, j, te, qhi, pi, g.peps, g.minPts, c);
                     } else {
                         const int j = lower_bound_4(sv, e, te, qlo);
-                        c = k2_count_glb<EXACT, 8>(sv, sa, j, te, qhi, pi, g.eps, g.minPts, c);
+                        c = k2_count_glb<EXACT, 8>(sv, sa, j, te, qhi, pi, g.peps, g.minPts, c);
                     }
                 }
             }
         }
         cnt[ii] = c;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2, clustering form (the roofline kernel).  DBSCAN does not need the neighbour count, only whether it
+// reaches minPts, so this kernel decides "core or not" with as little work per PET as it can:
+//   * a workgroup of 256 threads owns a tile of 256*U consecutive sorted PETs (U per thread) and stages the
+//     tile plus a halo as two int arrays q[], sp[] (sp: GridParams) -- the halo and the two barriers are
+//     amortised over U PETs per thread;
+//   * the strip bounds come from a SLICE of the strip table staged next to the window (the slice starts at
+//     the strip of the tile's first PET, which the sort phase left in tile_s0[]: one scalar load, then one
+//     coalesced load per thread -- no per-PET global loads at all);
+//   * phase 0, every PET: if the (minPts-1)-th next or previous PET lies in the same strip (one compare on
+//     the staged sp: strips are aligned blocks of sp) within eps in q, the PET is core -- two LDS reads per side;
+//   * the undecided PETs are appended to a list in LDS (one LDS atomic per wave) and handled by whole waves:
+//     own strip = an index difference of two bounded branch-free searches; the strips s-1 / s+1 only while
+//     the count is below minPts: both lower bounds by one paired search; where strips are long (dense data)
+//     both upper bounds as well, so that "own + everything in both q windows < minPts" rejects a PET
+//     without touching a candidate; candidates are tested 4 + 4 at a time (|dsp| <= peps is ONE compare
+//     per side: a candidate one strip below can only be too low).
+// Windows that leave the staged range fall back to global memory (pile-ups).  cl_neighbor_counts() (exact
+// counts) and minPts outside 2..128 use k_region_count above.
+// ------------------------------------------------------------------------------------------
+#define K2F_TPB 256
+#define K2F_NS 256        // staged strip-table slice: strips s0-1 .. s0+254 of the tile's first strip s0
+#define K2F_SLACK 128     // LDS entries behind the window that unclamped search probes may touch
+// The sorted arrays sv / sa carry SORT_PAD sentinel entries in front of index 0 and behind index n-1 (left: q = 0,
+// sp = INT_MIN; right: q = sp = INT_MAX -- "in no strip"), written once when the workspace is allocated: a tile
+// window is staged with unpredicated 16-byte loads, no bounds logic at all.
+#define SORT_PAD 4224     // >= largest tile + largest halo + slack
+
+#ifdef CLOOPS_DEVEL
+// developer build: cycle stamps at the phase boundaries of k_region_core, kept in registers and stored once per wave
+// at the very end (a store or atomic in the middle would be waited for by the next s_waitcnt and distort the phases)
+__device__ unsigned int g_k2t[1 << 21];
+#define K2T_INIT unsigned long long t_st[7]; t_st[0] = __builtin_readcyclecounter()
+#define K2T(k) t_st[(k) + 1] = __builtin_readcyclecounter()
+#define K2T_FLUSH do { if ((threadIdx.x & 63) == 0) { const unsigned w_ = (blockIdx.x * (K2F_TPB / 64) + (threadIdx.x >> 6)) & ((1u << 18) - 1u); \
+    for (int k_ = 0; k_ < 6; ++k_) g_k2t[w_ * 8 + k_] = (unsigned)(t_st[k_ + 1] - t_st[k_]); g_k2t[w_ * 8 + 6] = ((unsigned)nh << 16) | (unsigned)n2; g_k2t[w_ * 8 + 7] = 1u; } } while (0)
+#else
+#define K2T(k) do { } while (0)
+#define K2T_INIT do { } while (0)
+#define K2T_FLUSH do { } while (0)
+#endif
+
+// The searches of k_region_core are written on PREDICATES OF THE STAGED PAIRS (q, sp), not on index bounds: sorted
+// order is (strip, q) and strips are aligned blocks of sp, so "j is still before the window" is a monotone predicate
+// of (q_j, sp_j) alone -- a probe is one 8-byte LDS read at an immediate offset, two or three compares and a select;
+// no index compares, no clamps (probes may run a little past a strip: the window carries a halo and K2F_SLACK
+// sentinel entries), no divergent branches.  first_true<K>(w, pos, pred): first index of [pos, pos + 2^K - 1] whose
+// pair satisfies the monotone predicate (pos + 2^K - 1 if none does).
+template <int K, typename P>
+__device__ __forceinline__ int first_true(const int2* __restrict__ w, int pos, P&& pred)
+{
+#pragma unroll
+    for (int step = 1 << (K - 1); step >= 1; step >>= 1) {
+        const int2 v = w[pos + step - 1];
+        pos = pred(v) ? pos : pos + step;
+    }
+    return pos;
+}
+// same with the probe index clamped to `last` (long brackets that may leave the LDS window)
+template <int K, typename P>
+__device__ __forceinline__ int first_true_clamped(const int2* __restrict__ w, int pos, int last, P&& pred)
+{
+#pragma unroll
+    for (int step = 1 << (K - 1); step >= 1; step >>= 1) {
+        const int2 v = w[min(pos + step - 1, last)];
+        pos = pred(v) ? pos : pos + step;
+    }
+    return pos;
+}
+
+template <int U, int HALO>
+__global__ void __launch_bounds__(K2F_TPB)
+k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
+              const int* __restrict__ strip_start, const int* __restrict__ tile_s0, int* __restrict__ cnt)
+{
+    constexpr int TILE = K2F_TPB * U, WIN = TILE + 2 * HALO, NV = WIN / 4;
+    constexpr int FULL = NV / K2F_TPB, REST = NV % K2F_TPB;              // int4 staging slots: FULL for every thread + a partial one
+    constexpr int RUN = (2048 / TILE) > 0 ? (2048 / TILE) : 1;          // consecutive tiles per XCD (halo reuse in its L2)
+    static_assert(HALO % 4 == 0 && HALO >= 128 && TILE + HALO + K2F_SLACK <= SORT_PAD && TILE % 256 == 0, "window shape");
+    __shared__ __attribute__((aligned(16))) int2 lw[WIN + K2F_SLACK];   // (q, sp) pairs, window index = sorted index - (t0 - HALO)
+    __shared__ int l_st[K2F_NS + 4];
+    __shared__ unsigned int l_list[TILE];                                // undecided PETs, one region of 64*U entries per wave
+    const int xcd = blockIdx.x & 7, kseq = blockIdx.x >> 3;
+    const int tile = ((kseq / RUN) * 8 + xcd) * RUN + (kseq % RUN);
+    if (tile >= ntiles) return;
+    K2T_INIT;
+    const int t0 = tile * TILE;
+    const int s0 = tile_s0[t0 >> 8];                    // strip of the tile's first PET; S = the tile lies in the filtered tail
+    const int M = strip_start[g.S];                     // PETs that passed the cut filter (device-side count)
+    if (s0 >= g.S) return;
+    K2T(0);
+    {
+        // stage the window: unpredicated 16-byte loads (the arrays are padded with sentinels), every load of the
+        // thread in flight before the first LDS store; pairs are interleaved on the way into LDS
+        const int4* __restrict__ gq = reinterpret_cast<const int4*>(sv + (t0 - HALO));
+        const int4* __restrict__ gp = reinterpret_cast<const int4*>(sa + (t0 - HALO));
+        int4* l4 = reinterpret_cast<int4*>(lw);
+        static_assert(REST == 0, "the window is a whole number of 16-byte slots per thread");
+        int4 qv[FULL], pv[FULL];
+#pragma unroll
+        for (int u = 0; u < FULL; ++u) { qv[u] = gq[threadIdx.x + u * K2F_TPB]; pv[u] = gp[threadIdx.x + u * K2F_TPB]; }
+        const int st = strip_start[min(max(s0 - 1 + (int)threadIdx.x, 0), g.S)];
+#pragma unroll
+        for (int u = 0; u < FULL; ++u) {
+            const int k = (int)threadIdx.x + u * K2F_TPB;
+            l4[2 * k] = make_int4(qv[u].x, pv[u].x, qv[u].y, pv[u].y);
+            l4[2 * k + 1] = make_int4(qv[u].z, pv[u].z, qv[u].w, pv[u].w);
+        }
+        l_st[threadIdx.x] = st;
+        if (threadIdx.x < 4) l_st[K2F_NS + threadIdx.x] = 0;
+        if (threadIdx.x < K2F_SLACK) lw[WIN + threadIdx.x] = make_int2(INT_MAX, INT_MAX);
+    }
+    K2T(1);
+    __syncthreads();
+    K2T(2);
+    const int m1 = g.minPts - 1;                        // 1 <= m1 <= 127 < HALO (the host guarantees it)
+    const int eps = g.eps, peps = g.peps, minPts = g.minPts;
+    const int nmask = ~(peps - 1);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned int* my_list = l_list + wv * (64 * U);
+    int nh = 0;                                         // undecided PETs of this wave (wave-uniform)
+    // ---- phase 0: one-read core test, U PETs per thread -------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int tix = (int)threadIdx.x + u * K2F_TPB, li = HALO + tix;
+        const int2 me = lw[li], rr = lw[li + m1], ll = lw[li - m1];
+        const int pbeg = me.y & nmask;
+        const bool valid = t0 + tix < M;
+        // the (minPts-1)-th next / previous PET is in the same strip and within eps in q (unsigned add: a sentinel q wraps harmlessly)
+        const bool core = ((rr.y < pbeg + peps) & (rr.x <= (int)((unsigned)me.x + (unsigned)eps))) | ((ll.y >= pbeg) & (ll.x >= me.x - eps));
+        if (valid & core) cnt[t0 + tix] = minPts;
+        const bool hard = valid & !core;
+        const unsigned long long bal = __ballot(hard);
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        if (hard) my_list[nh + before] = (unsigned)tix;
+        nh += __popcll(bal);
+    }
+    K2T(3);
+    __syncthreads();                                    // (the lists are per wave; the barrier only orders the LDS writes)
+    K2T(4);
+    // ---- phase 1: own strip.  Phase 0 failed on both sides, so the q window ends before the (minPts-1)-th PET on
+    // either side (or at the strip ends): lo = first PET of the own strip with q >= qlo, hi = first PET behind the own
+    // strip's PETs with q <= qhi, both inside +-(minPts-1) positions.  PETs still below minPts go on to phase 2
+    // through a second list, written over the first one (a round appends at most as many entries as it has consumed).
+    int n2 = 0;
+    for (int h0 = 0; h0 < nh; h0 += 64) {
+        const int h = h0 + lane;
+        const bool act = h < nh;
+        const int tix = act ? (int)my_list[h] : 0, li = HALO + tix;
+        const int2 me = lw[li];
+        const int qlo = me.x - eps, qhi = me.x + eps;   // q < 2^30, eps < 2^30: no overflow
+        const int pbeg = me.y & nmask, pend = pbeg + peps;
+        int lo, hi;
+        auto inL = [&](int2 v) { return (v.y >= pbeg) & (v.x >= qlo); };            // monotone false -> true up to li
+        auto outR = [&](int2 v) { return !((v.y < pend) & (v.x <= qhi)); };         // monotone false -> true from li + 1
+        if (m1 <= 4) { lo = first_true<2>(lw, li - 3, inL); hi = first_true<2>(lw, li + 1, outR); }
+        else if (m1 <= 8) { lo = first_true<3>(lw, li - 7, inL); hi = first_true<3>(lw, li + 1, outR); }
+        else if (m1 <= 32) { lo = first_true<5>(lw, li - 31, inL); hi = first_true<5>(lw, li + 1, outR); }
+        else { lo = first_true<7>(lw, li - 127, inL); hi = first_true<7>(lw, li + 1, outR); }
+        const int c = hi - lo;
+        const bool need = act & (c < minPts);
+        if (act & !need) cnt[t0 + tix] = c;
+        const unsigned long long bal = __ballot(need);
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        if (need) my_list[n2 + before] = (unsigned)tix | ((unsigned)c << 16);
+        n2 += __popcll(bal);
+    }
+    // ---- phase 2: neighbour strips s-1 = [tb, b) and s+1 = [e, te) -------------------------------------------
+    const int off = HALO - t0;                          // window index = global sorted index + off
+    const int wlo = max(t0 - HALO, 0) + off, whi = min(t0 - HALO + WIN, M) + off;      // staged valid range, window indices
+    for (int h = lane; h < n2; h += 64) {
+        const unsigned ent = my_list[h];
+        const int tix = (int)(ent & 0xffffu), li = HALO + tix;
+        int c = (int)(ent >> 16);
+        const int2 me = lw[li];
+        const int qi = me.x, pi = me.y;
+        const int qlo = qi - eps, qhi = qi + eps;
+        const int pbeg = pi & nmask, pend2 = pbeg + 2 * peps;
+        const int plo = pi - peps, phi = pi + peps;
+        const int kk = (pi >> g.rbits) - s0;            // >= 0: the tile's PETs are in strips >= s0
+        const int kc = min(kk, K2F_NS);                 // beyond the staged slice: dummy slots, fixed up below
+        int tb = l_st[kc], b = l_st[kc + 1], e = l_st[kc + 2], te = l_st[kc + 3];
+        if (kk + 3 >= K2F_NS) {
+            const int s = kk + s0;
+            tb = strip_start[max(s - 1, 0)]; b = strip_start[s]; e = strip_start[s + 1]; te = strip_start[min(s + 2, g.S)];
+        }
+        const int longest = max(b - tb, te - e);
+        tb += off; e += off; te += off;
+        if ((tb >= wlo) & (te <= whi)) {
+            auto inA = [&](int2 v) { return (v.y >= pbeg) | (v.x >= qlo); };    // from tb on: past the PETs of s-1 below qlo
+            auto inB = [&](int2 v) { return (v.y >= pend2) | (v.x >= qlo); };   // from e on: past the PETs of s+1 below qlo
+            if (!__any(longest > 31)) {
+                // sparse data: 5-step searches, then the first two candidates of both strips at once
+                const int ja = first_true<5>(lw, tb, inA), jb = first_true<5>(lw, e, inB);
+                int2 va[2], vb[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { va[k] = lw[ja + k]; vb[k] = lw[jb + k]; }
+                bool moreA = true, moreB = true;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const bool ia = (va[k].y < pbeg) & (va[k].x <= qhi), ib = (vb[k].y < pend2) & (vb[k].x <= qhi);
+                    moreA &= ia; moreB &= ib;
+                    c += (ia & (va[k].y >= plo)) ? 1 : 0;           // one strip below: sp can only be too low
+                    c += (ib & (vb[k].y <= phi)) ? 1 : 0;           // one strip above: only too high
+                }
+                if (__any((c < minPts) & (moreA | moreB))) {
+                    for (int j = ja + 2; moreA & (c < minPts); ++j) {
+                        const int2 v = lw[j];
+                        moreA = (v.y < pbeg) & (v.x <= qhi);
+                        c += (moreA & (v.y >= plo)) ? 1 : 0;
+                    }
+                    for (int j = jb + 2; moreB & (c < minPts); ++j) {
+                        const int2 v = lw[j];
+                        moreB = (v.y < pend2) & (v.x <= qhi);
+                        c += (moreB & (v.y <= phi)) ? 1 : 0;
+                    }
+                }
+            } else {
+                // dense data: both q windows [ja, ka), [jb, kb) first -- if even all of their PETs cannot lift the
+                // count to minPts the PET is not core and no candidate is read
+                auto outA = [&](int2 v) { return (v.y >= pbeg) | (v.x > qhi); };
+                auto outB = [&](int2 v) { return (v.y >= pend2) | (v.x > qhi); };
+                const int last = WIN + K2F_SLACK - 1;
+                int ja, jb, ka, kb;
+                if (!__any(longest > 127)) {
+                    ja = first_true<7>(lw, tb, inA); jb = first_true<7>(lw, e, inB);
+                    ka = first_true<7>(lw, ja, outA); kb = first_true<7>(lw, jb, outB);
+                } else if (!__any(longest > 511)) {
+                    ja = first_true_clamped<9>(lw, tb, last, inA); jb = first_true_clamped<9>(lw, e, last, inB);
+                    ka = first_true_clamped<9>(lw, ja, last, outA); kb = first_true_clamped<9>(lw, jb, last, outB);
+                } else {
+                    ja = first_true_clamped<12>(lw, tb, last, inA); jb = first_true_clamped<12>(lw, e, last, inB);
+                    ka = first_true_clamped<12>(lw, ja, last, outA); kb = first_true_clamped<12>(lw, jb, last, outB);
+                }
+                if (c + (ka - ja) + (kb - jb) >= minPts) {
+                    for (int j = ja; (j < ka) & (c < minPts); j += 4) {
+                        int2 v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = lw[j + k];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) c += ((j + k < ka) & (v[k].y >= plo)) ? 1 : 0;
+                    }
+                    for (int j = jb; (j < kb) & (c < minPts); j += 4) {
+                        int2 v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = lw[j + k];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) c += ((j + k < kb) & (v[k].y <= phi)) ? 1 : 0;
+                    }
+                }
+            }
+        } else {
+            // a neighbour strip reaches outside the staged window (pile-up): global memory, sorted index space
+            const int gtb = tb - off, ge = e - off, gte = te - off;
+            if (gtb < b) {
+                const int j = lower_bound_4(sv, gtb, b, qlo);
+                c = k2_count_glb<false, 8>(sv, sa, j, b, qhi, pi, peps, minPts, c);
+            }
+            if (c < minPts && ge < gte) {
+                const int j = lower_bound_4(sv, ge, gte, qlo);
+                c = k2_count_glb<false, 8>(sv, sa, j, gte, qhi, pi, peps, minPts, c);
+            }
+        }
+        cnt[t0 + tix] = c;
+    }
+    K2T(5);
+    K2T_FLUSH;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -911,7 +1145,7 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
         // variant 2: head of the PET's rotated cell (strip, q / eps) = first PET of the sorted order that is
         // neither in an earlier strip nor below the cell's lower q edge -- a bisection on the staged tile
         // instead of head flags + a max-scan over all PETs (variant 2 runs with A0 = V0 = 0)
-        const int p0 = div_eps(g, me.y) * g.eps, q0 = div_eps(g, me.x) * g.eps;
+        const int p0 = me.y & ~(g.peps - 1), q0 = div_eps(g, me.x) * g.eps;      // lower edges of the rotated cell (sp space / q space)
         int pos = t.wbeg;
 #pragma unroll
         for (int step = 256; step >= 1; step >>= 1) {
@@ -1025,7 +1259,7 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
             // "within eps in p" is p_j >= p_i - eps.  In a well-filled strip the walk jumps past a chain once
             // it has been touched (its last core has q = chain_qend[chain]): a window covered by one chain
             // costs one candidate instead of a hundred.
-            const int T = me.y - g.eps;
+            const int T = me.y - g.peps;
             const bool dense = b - tb > 48;
             // search depth chosen per wave (a per-lane choice would make most waves run every variant)
             int j;
@@ -1064,7 +1298,7 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
             //  * the window end k1 is found up front (no q loads in the walk),
             //  * whole 32-PET blocks are skipped on their summary pmax32 (8 summaries per round trip),
             //  * inside a block the candidates are fetched UNION_CH at a time.
-            const int T = me.y - g.eps;
+            const int T = me.y - g.peps;
             int k = lower_bound_4(sv, tb, b, qlo);
             const int k1 = lower_bound_4(sv, k, b, sat_add(qhi, 1));
             while (k < k1) {
@@ -1245,9 +1479,9 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
     };
     tile_visit_own(t, sv, root, i, b, e, qlo, qhi, 3, [&](int j, int r) { see(j, r); return false; });
     tile_visit_segment(t, sv, sa, root, tb, b, qlo, qhi, [&](int j, int, int pj, int r) {
-        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.eps) see(j, r); });
+        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.peps) see(j, r); });
     tile_visit_segment(t, sv, sa, root, e, te, qlo, qhi, [&](int j, int, int pj, int r) {
-        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.eps) see(j, r); });
+        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.peps) see(j, r); });
     const int o = (v1 && tbest >= 0) ? tbest : best;
     owner[i] = o < 0 ? -1 : (contested ? (o | OWNER_CONTESTED) : o);
     // counts per owning component, reduced over the lanes of the wave that share the owner.  Only
@@ -1346,9 +1580,9 @@ k_emit_records(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
     };
     tile_visit_own(t, sv, root, i, b, e, qlo, qhi, 3, [&](int, int r) { see(r); return false; });
     tile_visit_segment(t, sv, sa, root, tb, b, qlo, qhi, [&](int, int, int pj, int r) {
-        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.eps) see(r); });
+        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.peps) see(r); });
     tile_visit_segment(t, sv, sa, root, e, te, qlo, qhi, [&](int, int, int pj, int r) {
-        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.eps) see(r); });
+        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.peps) see(r); });
     if (overflow) atomicExch(&counters[CTR_OVERFLOW], 1);
     if (!any_u) return;
     const int idx = atomicAdd(&counters[CTR_NREC], 1);
@@ -1576,7 +1810,8 @@ k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __r
             if (o >= 0) lab = rlabel[o];
             labels[srow[i]] = lab;
             // X = (v - a) / 2, Y = (v + a) / 2 exactly (v and a have equal parity)
-            int pp = sa[i] + g.A0, qq = sv[i] + g.V0;
+            const int spv = sa[i];
+            int pp = ((spv >> g.rbits) + g.s0) * g.eps + (spv & (g.peps - 1)) + g.A0, qq = sv[i] + g.V0;
             int a = g.swap ? qq : pp, v = g.swap ? pp : qq;
             x = (v - a) / 2; y = (v + a) / 2;
         }
@@ -2321,9 +2556,11 @@ __global__ void k8_count_valid(const u64* __restrict__ t, int n, int* __restrict
 // ------------------------------------------------------------------------------------------
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
+    bool fresh = false;               // (re)allocated since the flag was last cleared
     int ensure(size_t need)
     {
         if (need <= bytes) return CL_OK;
+        fresh = true;
         if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
         size_t want = need + need / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
@@ -2346,7 +2583,7 @@ struct cl_chrom {
     // workspace
     DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, scan_tmp;
     DevBuf sv, sa, strip, cnt, parent, root, head, headidx, cellfirst, compkey, ncore, bsize, owner, state;
-    DevBuf flag, rankscan, ulist, lo, hi, recs, counters, chainflag, chainhead, usize, b_cstart, b_ckey, b_nb, b_cx, b_cy;
+    DevBuf flag, rankscan, ulist, lo, hi, recs, counters, chainflag, chainhead, usize, b_cstart, b_ckey, b_nb, b_cx, b_cy, tile_s0;
     int* h_pinned = nullptr;          // small pinned staging (stats, block scalars)
     struct StripPlan { int layout, eps, maxlen; };
     std::vector<StripPlan> plans;     // longest strip over all rows per (layout, eps): picks the sort path
@@ -2390,7 +2627,7 @@ static void free_chrom(cl_chrom* c)
     DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
-                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy};
+                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0};
     for (DevBuf* b : bufs) b->release();
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -2422,6 +2659,16 @@ extern "C" const int32_t* cl_labels_device(const cl_chrom* c)
 }
 
 static inline int nblocks(long long n, int tpb = TPB) { return (int)((n + tpb - 1) / tpb); }
+
+__global__ void k_init_pads(int* __restrict__ svbuf, int* __restrict__ sabuf, long long n)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= 2 * SORT_PAD) return;
+    const bool left = k < SORT_PAD;
+    const long long idx = left ? k : (long long)SORT_PAD + n + (k - SORT_PAD);
+    svbuf[idx] = left ? 0 : INT_MAX;
+    sabuf[idx] = left ? INT_MIN : INT_MAX;
+}
 
 extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const int32_t* y, int64_t n,
                                int on_device, cl_chrom** out)
@@ -2497,14 +2744,19 @@ static int ensure_workspace(cl_chrom* c, int S)
     int rc;
 #define ENS(buf, bytes) if ((rc = c->buf.ensure(bytes))) return rc
     ENS(keys_in, n * 8); ENS(keys_out, n * 8); ENS(vals_in, n * 4); ENS(vals_out, n * 4);
-    ENS(sv, n * 4); ENS(sa, n * 4); ENS(strip, ((size_t)S + 2) * 4); ENS(cnt, n * 4);
+    ENS(sv, (n + 2 * SORT_PAD) * 4); ENS(sa, (n + 2 * SORT_PAD) * 4); ENS(strip, ((size_t)S + 2) * 4); ENS(cnt, n * 4);
     ENS(parent, n * 4); ENS(root, n * 4); ENS(head, n * 4); ENS(headidx, n * 4); ENS(cellfirst, n * 4);
     ENS(compkey, n * 4); ENS(ncore, n * 4); ENS(bsize, n * 4); ENS(owner, n * 4); ENS(state, n * 4);
     ENS(flag, (n + 1) * 4); ENS(rankscan, (n + 1) * 4); ENS(hdr, 256);
     ENS(slot[c->cur].labels, n * 4); ENS(slot[c->cur].table, (n + 1) * sizeof(cl_box));
     ENS(ulist, n * 4); ENS(lo, n * 4); ENS(hi, n * 4); ENS(recs, n * sizeof(Rec)); ENS(counters, 256);
-    ENS(chainflag, n * 4); ENS(chainhead, n * 4); ENS(usize, n * 4);
+    ENS(chainflag, n * 4); ENS(chainhead, n * 4); ENS(usize, n * 4); ENS(tile_s0, (n / 256 + 2) * 4);
 #undef ENS
+    if (c->sv.fresh || c->sa.fresh) {
+        // sentinel pads around the sorted arrays (k_region_core stages its windows without bounds checks)
+        hipLaunchKernelGGL(k_init_pads, dim3(nblocks(2 * SORT_PAD)), dim3(TPB), 0, c->stream, c->sv.as<int>(), c->sa.as<int>(), (long long)n);
+        c->sv.fresh = c->sa.fresh = false;
+    }
     // rocPRIM temporary storage
     size_t sort_bytes = 0, scan_bytes = 0, scan2 = 0;
     hipError_t e = rocprim::radix_sort_pairs<SortConfig>(nullptr, sort_bytes, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr,
@@ -2529,7 +2781,11 @@ static int bits_for(unsigned v) { int b = 0; while (v) { ++b; v >>= 1; } return 
 static int make_grid(cl_chrom* c, int variant, int eps, int minPts, int cut, GridParams* g)
 {
     g->eps = eps; g->minPts = minPts; g->cut = cut; g->variant = variant;
+    g->dbg = 0;
+#ifdef CLOOPS_DEVEL
+    // developer build only (-DCLOOPS_DEVEL): ablation knobs that can change results; never in the shipped library
     { const char* e = getenv("CLOOPS_DBG"); g->dbg = e ? atoi(e) : 0; }
+#endif
     g->swap = (g->dbg & 16) ? 0 : 1;
     {
         const unsigned d = (unsigned)eps;
@@ -2554,6 +2810,10 @@ static int make_grid(cl_chrom* c, int variant, int eps, int minPts, int cut, Gri
     (void)qmin;
     g->qbits = std::max(1, bits_for((unsigned)((long long)qmax - g->V0)));
     g->rbits = bits_for((unsigned)(eps - 1));
+    g->peps = 1 << g->rbits;
+    // the strip coordinate lives in the kernels as sp = strip << rbits | remainder (GridParams): sp + peps must stay an int
+    if ((S + 2) << g->rbits > (long long)INT_MAX)
+        return fail(CL_ERR_GRID, "coordinate extent too large for this eps (X+Y range + 2*eps must stay below 2^30)");
     return CL_OK;
 }
 
@@ -2614,17 +2874,63 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     if (hybrid) {
         c->srow = c->vals_in.as<u32>();                  // the unsorted row ids are dead after the sort
         hipLaunchKernelGGL(k_strip_sort, dim3(nblocks(n, HS_TPB)), dim3(HS_TPB), 0, c->stream, n, g, c->keys_out.as<u64>(),
-                           c->vals_out.as<u32>(), c->strip.as<int>(), c->sv.as<int>(), c->sa.as<int>(), c->srow, c->counters.as<int>());
+                           c->vals_out.as<u32>(), c->strip.as<int>(), (c->sv.as<int>() + SORT_PAD), (c->sa.as<int>() + SORT_PAD), c->srow, c->tile_s0.as<int>(), c->counters.as<int>());
     } else {
         c->srow = c->vals_out.as<u32>();
-        LAUNCH(k_decode_sorted, n, n, g, c->keys_out.as<u64>(), c->sv.as<int>(), c->sa.as<int>());
+        LAUNCH(k_decode_sorted, n, n, g, c->keys_out.as<u64>(), (c->sv.as<int>() + SORT_PAD), (c->sa.as<int>() + SORT_PAD), c->tile_s0.as<int>());
     }
     ev_record(c, 2);
     {
-        const int ntiles = nblocks(n, K2_TPB);
-        const int grid = ((ntiles + 8 * K2_RUN - 1) / (8 * K2_RUN)) * (8 * K2_RUN);
-        if (exact) hipLaunchKernelGGL(k_region_count<true>, dim3(grid), dim3(K2_TPB), 0, c->stream, g, ntiles, n, c->sv.as<int>(), c->sa.as<int>(), c->strip.as<int>(), c->cnt.as<int>());
-        else hipLaunchKernelGGL(k_region_count<false>, dim3(grid), dim3(K2_TPB), 0, c->stream, g, ntiles, n, c->sv.as<int>(), c->sa.as<int>(), c->strip.as<int>(), c->cnt.as<int>());
+        const int m1 = g.minPts - 1;
+        if (!exact && m1 >= 1 && m1 <= 127) {
+            // clustering form: tile / halo picked from the mean strip population (long strips need a wide window)
+            const long long avg = (long long)n / std::max(1, g.S);
+            int shape = avg <= 40 ? 0 : (avg <= 400 ? 1 : 2);
+#ifdef CLOOPS_DEVEL
+            if (const char* e = getenv("CLOOPS_K2_SHAPE")) shape = atoi(e);
+#endif
+#define K2F_LAUNCH(UU, HH)                                                                                              \
+            {                                                                                                           \
+                const int tile = K2F_TPB * UU, ntiles = nblocks(n, tile), run = std::max(1, 2048 / tile);               \
+                const int grid = ((ntiles + 8 * run - 1) / (8 * run)) * (8 * run);                                      \
+                hipLaunchKernelGGL((k_region_core<UU, HH>), dim3(grid), dim3(K2F_TPB), 0, c->stream, g, ntiles,         \
+                                   (c->sv.as<int>() + SORT_PAD), (c->sa.as<int>() + SORT_PAD), c->strip.as<int>(), c->tile_s0.as<int>(), c->cnt.as<int>()); \
+            }
+            // window = tile + 2 * halo entries; shapes keep it a multiple of 1024 (every thread stages whole 16-byte slots)
+            switch (shape) {
+            case 0: K2F_LAUNCH(3, 128) break;
+            case 1: K2F_LAUNCH(4, 512) break;
+            case 2: K2F_LAUNCH(4, 1024) break;
+#ifdef CLOOPS_DEVEL
+            case 3: K2F_LAUNCH(2, 256) break;
+            case 4: K2F_LAUNCH(6, 256) break;
+            case 5: K2F_LAUNCH(2, 768) break;
+            case 6: K2F_LAUNCH(1, 384) break;
+            case 7: K2F_LAUNCH(8, 1024) break;
+#endif
+            default: K2F_LAUNCH(4, 1024) break;
+            }
+#undef K2F_LAUNCH
+#ifdef CLOOPS_DEVEL
+            if (getenv("CLOOPS_K2_CLOCK")) {
+                static std::vector<unsigned> h(1 << 21);
+                (void)hipStreamSynchronize(c->stream);
+                (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_k2t), h.size() * 4);
+                double sum[6] = {0, 0, 0, 0, 0, 0}; long long nw = 0, s1 = 0, s2 = 0;
+                for (size_t w = 0; w < (1u << 18); ++w) if (h[w * 8 + 7]) { ++nw; for (int k = 0; k < 6; ++k) sum[k] += h[w * 8 + k]; s1 += h[w * 8 + 6] >> 16; s2 += h[w * 8 + 6] & 0xffff; }
+                fprintf(stderr, "[k2 clock] undecided after phase 0: %lld, after the own strip: %lld (of %d rows)\n", s1, s2, n);
+                fprintf(stderr, "[k2 clock] %lld waves; mean cycles per wave: scalar %.0f | stage %.0f | barrier1 %.0f | phase0 %.0f | barrier2 %.0f | hard %.0f\n",
+                        nw, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw, sum[5] / nw);
+                std::fill(h.begin(), h.end(), 0u);
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k2t), h.data(), h.size() * 4);
+            }
+#endif
+        } else {
+            const int ntiles = nblocks(n, K2_TPB);
+            const int grid = ((ntiles + 8 * K2_RUN - 1) / (8 * K2_RUN)) * (8 * K2_RUN);
+            if (exact) hipLaunchKernelGGL(k_region_count<true>, dim3(grid), dim3(K2_TPB), 0, c->stream, g, ntiles, n, (c->sv.as<int>() + SORT_PAD), (c->sa.as<int>() + SORT_PAD), c->strip.as<int>(), c->cnt.as<int>());
+            else hipLaunchKernelGGL(k_region_count<false>, dim3(grid), dim3(K2_TPB), 0, c->stream, g, ntiles, n, (c->sv.as<int>() + SORT_PAD), (c->sa.as<int>() + SORT_PAD), c->strip.as<int>(), c->cnt.as<int>());
+        }
     }
     ev_record(c, 3);
     HIP_TRY(hipGetLastError());
@@ -2774,7 +3080,11 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
     if (c->deq == c->enq) return fail(CL_ERR_ARG, "cl_wait: no run in flight");
     const int w = c->deq & 1;
     cl_chrom::Slot& sl = c->slot[w];
+#ifdef CLOOPS_DEVEL
     static const bool dbg_wait = getenv("CLOOPS_DBG_WAIT") != nullptr;
+#else
+    const bool dbg_wait = false;
+#endif
     timespec ts0{}, ts1{};
     if (dbg_wait) {
         clock_gettime(CLOCK_MONOTONIC, &ts0);
@@ -2886,8 +3196,8 @@ static int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_
     }
     u64* skeys = c->keys_out.as<u64>();
     u32* srow = c->vals_out.as<u32>();
-    int* sx = c->sv.as<int>();
-    int* sy = c->sa.as<int>();
+    int* sx = (c->sv.as<int>() + SORT_PAD);
+    int* sy = (c->sa.as<int>() + SORT_PAD);
     int* headflag = c->chainflag.as<int>();
     int* cidp1 = c->chainhead.as<int>();
     LAUNCH(k_blk_gather, n, p, skeys, sx, sy, headflag, sc);
@@ -3082,8 +3392,8 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     if ((rc = ensure_events(c))) return rc;
     const int n = (int)c->n;
     int* strip = c->strip.as<int>();
-    int* sv = c->sv.as<int>();
-    int* sa = c->sa.as<int>();
+    int* sv = (c->sv.as<int>() + SORT_PAD);
+    int* sa = (c->sa.as<int>() + SORT_PAD);
     int* cnt = c->cnt.as<int>();
     int* counters = c->counters.as<int>();
     const int ntiles = nblocks(n);
