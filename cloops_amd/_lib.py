@@ -28,6 +28,7 @@ SYMBOLS = [
     "cl_cluster", "cl_get_boxes", "cl_neighbor_counts", "cl_labels_device", "cl_set_profiling",
     "cl_get_timing", "cl_version", "cl_host_alloc", "cl_host_free", "cl_cluster_async", "cl_wait", "cl_boxes_host",
     "cl_dist_stats", "cl_dist_sqdev", "cl_dist_hist", "cl_last_n_in", "cl_sig_counts", "cl_cluster_weighted",
+    "cl_set_layout_reuse",
 ]
 
 
@@ -109,6 +110,8 @@ def load():
     lib.cl_labels_device.argtypes = [vp]
     lib.cl_set_profiling.restype = None
     lib.cl_set_profiling.argtypes = [vp, ctypes.c_int]
+    lib.cl_set_layout_reuse.restype = None
+    lib.cl_set_layout_reuse.argtypes = [vp, ctypes.c_int]
     lib.cl_get_timing.restype = ctypes.c_int
     lib.cl_get_timing.argtypes = [vp, ctypes.POINTER(ClTiming)]
     lib.cl_host_alloc.restype = vp

@@ -115,6 +115,11 @@ class Chromosome(object):
         self._profiling = bool(on)
         self._lib.cl_set_profiling(self._h, 1 if on else 0)
 
+    def set_layout_reuse(self, on=True):
+        """keep the sorted arrays of the last eps and start further runs at that eps from a compaction by the cut
+        (default on; results identical either way -- cl_set_layout_reuse of include/cloops_hip.h)"""
+        self._lib.cl_set_layout_reuse(self._h, 1 if on else 0)
+
     def timing(self):
         t = _lib.ClTiming()
         _lib.check(self._lib.cl_get_timing(self._h, ctypes.byref(t)))

@@ -262,11 +262,13 @@ __global__ void k_make_keys(const int* __restrict__ X, const int* __restrict__ Y
 
 // K1b: sorted coordinates, decoded from the sorted keys (coalesced; no gather through row ids)
 __global__ void k_decode_sorted(int n, GridParams g, const u64* __restrict__ skeys,
-                                int* __restrict__ sv, int* __restrict__ sa, int* __restrict__ tile_s0)
+                                int* __restrict__ sv, int* __restrict__ sa, int* __restrict__ tile_s0,
+                                const u32* __restrict__ rows_in, u32* __restrict__ rows_out)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u64 k = skeys[i];
+    if (rows_out) rows_out[i] = rows_in[i];
     const int sh = g.qbits + g.rbits;
     const int strip = (int)(k >> sh);
     if ((i & 255) == 0) tile_s0[i >> 8] = min(strip, g.S);       // strip of every 256th sorted PET (K2 stages its strip-table slice from it)
@@ -304,7 +306,7 @@ __global__ void k_strip_table(const u64* __restrict__ skeys, int n, int S, int s
 #define HS_HALO 256
 #define HS_WIN (HS_TPB + 2 * HS_HALO)
 #define HS_LMAX 256          // longest strip the in-strip ranking accepts (must be <= HS_HALO)
-enum { CTR_MAXLEN = 48 };
+enum { CTR_MAXLEN = 48, CTR_M = 49 };
 
 __global__ void k_strip_hist(const int* __restrict__ X, const int* __restrict__ Y, int n, GridParams g, int* __restrict__ hist)
 {
@@ -2588,6 +2590,16 @@ struct cl_chrom {
     struct StripPlan { int layout, eps, maxlen; };
     std::vector<StripPlan> plans;     // longest strip over all rows per (layout, eps): picks the sort path
     u32* srow = nullptr;              // sorted position -> input row of the run being enqueued
+    // working set of the run being enqueued: sorted (q, sp), strip table, tile table.  They alias either the
+    // workspace buffers (sv, sa, strip, tile_s0) or, for a run without cut filter, the base layout itself.
+    int *w_sv = nullptr, *w_sa = nullptr, *w_strip = nullptr, *w_tile = nullptr;
+    // Base layout: the sorted arrays of ALL rows (cut = 0) for one (variant layout, eps), kept until eps changes.
+    // The sort order does not depend on minPts and a cut only REMOVES rows, so every further run of a sweep at this
+    // eps is one stable stream compaction of the base layout instead of five radix passes (cLoops/pipe.py:241-281
+    // walks eps in the outer loop).  Nothing of a result is kept: neighbour counts, components, labels are redone.
+    DevBuf bq, bsp, brow, bstrip, btile, sel_tmp;
+    struct BaseLayout { bool valid = false; int layout = -1, eps = 0; } base;
+    bool reuse_layout = true;
     // Result slots: two runs may be in flight (cl_cluster_async) -- the labels / table / header of
     // run k live in slot k & 1, so the D2H copy of run k (copy stream) overlaps the kernels of run k+1.
     struct Slot {
@@ -2627,7 +2639,7 @@ static void free_chrom(cl_chrom* c)
     DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
-                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0};
+                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp};
     for (DevBuf* b : bufs) b->release();
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -2647,6 +2659,7 @@ static void free_chrom(cl_chrom* c)
 extern "C" void cl_chrom_destroy(cl_chrom* c) { free_chrom(c); }
 extern "C" int64_t cl_chrom_size(const cl_chrom* c) { return c ? c->n : -1; }
 extern "C" void cl_set_profiling(cl_chrom* c, int enabled) { if (c) c->profiling = enabled != 0; }
+extern "C" void cl_set_layout_reuse(cl_chrom* c, int enabled) { if (c) { c->reuse_layout = enabled != 0; c->base.valid = false; } }
 extern "C" int cl_get_timing(const cl_chrom* c, cl_timing* out)
 {
     if (!c || !out) return fail(CL_ERR_ARG, "cl_get_timing: null argument");
@@ -2735,6 +2748,86 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
     if (rc != CL_OK) { std::string keep = g_err; free_chrom(c); g_err = keep; return rc; }
     *out = c;
     return CL_OK;
+}
+
+// ---- cut filter as a stream compaction of the base layout ------------------------------------------------
+// pipe.py:59-62 keeps d = Y - X >= cut; in the strip layout d = q + V0, so the test reads the sorted q alone.
+// Stable compaction in three small steps: per-block counts (4 B/PET read), an exclusive scan over the block
+// counts, then the scatter (12 B/PET read, 12 B per kept PET written); block-local ranks by wave ballots.
+#define CMP_TPB 256
+#define CMP_PER 8                       // elements per thread
+#define CMP_BLOCK (CMP_TPB * CMP_PER)
+__global__ void __launch_bounds__(CMP_TPB)
+k_cut_count(int n, int thr, const int* __restrict__ bq, int* __restrict__ blockcount)
+{
+    __shared__ int red[CMP_TPB / 64];
+    const int base = blockIdx.x * CMP_BLOCK;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < CMP_PER; ++k) {
+        const int i = base + k * CMP_TPB + (int)threadIdx.x;
+        c += (i < n && bq[i] >= thr) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < CMP_TPB / 64; ++w) t += red[w]; blockcount[blockIdx.x] = t; }
+}
+__global__ void __launch_bounds__(CMP_TPB)
+k_cut_scatter(int n, int thr, const int* __restrict__ bq, const int* __restrict__ bsp, const u32* __restrict__ brow,
+              const int* __restrict__ blockoff, const int* __restrict__ blockcount,
+              int* __restrict__ sv, int* __restrict__ sa, u32* __restrict__ srow, int* __restrict__ d_M)
+{
+    __shared__ int l_cnt[CMP_PER * (CMP_TPB / 64)];
+    const int base = blockIdx.x * CMP_BLOCK;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int q[CMP_PER], sp[CMP_PER]; u32 row[CMP_PER]; int before[CMP_PER];
+    bool keep[CMP_PER];
+#pragma unroll
+    for (int k = 0; k < CMP_PER; ++k) {
+        const int i = base + k * CMP_TPB + (int)threadIdx.x;
+        q[k] = 0; sp[k] = 0; row[k] = 0u;
+        if (i < n) { q[k] = bq[i]; sp[k] = bsp[i]; row[k] = brow[i]; }
+        keep[k] = i < n && q[k] >= thr;
+        const unsigned long long bal = __ballot(keep[k]);
+        before[k] = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        if (lane == 0) l_cnt[k * (CMP_TPB / 64) + wv] = __popcll(bal);
+    }
+    __syncthreads();
+    // exclusive prefix over the (k, wave) segments, in element order
+    int pre = blockoff[blockIdx.x];
+    int mine[CMP_PER];
+#pragma unroll
+    for (int k = 0; k < CMP_PER; ++k) {
+#pragma unroll
+        for (int w = 0; w < CMP_TPB / 64; ++w) {
+            if (w == wv) mine[k] = pre;
+            pre += l_cnt[k * (CMP_TPB / 64) + w];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CMP_PER; ++k) {
+        if (keep[k]) { const int dst = mine[k] + before[k]; sv[dst] = q[k]; sa[dst] = sp[k]; srow[dst] = row[k]; }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) d_M[0] = blockoff[blockIdx.x] + blockcount[blockIdx.x];
+}
+
+// after the compaction: strip table by bisection of the compacted sp (strip = sp >> rbits), tile table, and
+// sentinels behind the last kept PET (the tile kernels stage windows a little past M)
+__global__ void k_after_compact(int n, int S, int rbits, const int* __restrict__ d_M, const int* __restrict__ sa,
+                                int* __restrict__ sv_w, int* __restrict__ sa_w, int* __restrict__ strip_start, int* __restrict__ tile_s0)
+{
+    const int M = d_M[0];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t <= S + 1) {
+        int lo = 0, hi = M;
+        if (t == S + 1) lo = n;
+        else if (t == S) lo = M;
+        else while (lo < hi) { const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1); if ((sa[mid] >> rbits) < t) lo = mid + 1; else hi = mid; }
+        strip_start[t] = lo;
+    }
+    if (t <= n / 256) { const int idx = t * 256; tile_s0[t] = idx < M ? (sa[idx] >> rbits) : S; }
+    if (t < SORT_PAD && M + t < n) { sv_w[M + t] = INT_MAX; sa_w[M + t] = S << rbits; }
 }
 
 // workspace for a run over n rows
@@ -2848,8 +2941,10 @@ static int strip_maxlen(cl_chrom* c, const GridParams& g, int* out)
     return CL_OK;
 }
 
-// K0 + K1 + K2: keys, sort, strip table, neighbour counts.  Leaves sorted arrays in the workspace.
-static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
+// K0 + K1: keys, sort, strip table, decoded sorted arrays for the rows that pass `g.cut`, written to the given
+// destination buffers (sorted arrays with their sentinel pads already in place)
+static int sort_layout(cl_chrom* c, const GridParams& g, int* dsv, int* dsa, u32* drow /* or null: c->srow aliases a sort buffer */,
+                       int* dstrip, int* dtile)
 {
     const int n = (int)c->n;
     const int sh = g.qbits + g.rbits, strip_bits = std::max(1, bits_for((unsigned)g.S));
@@ -2870,14 +2965,78 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     hipError_t e = rocprim::radix_sort_pairs<SortConfig>(c->sort_tmp.p, tmp_bytes, c->keys_in.as<u64>(), c->keys_out.as<u64>(),
                                              c->vals_in.as<u32>(), c->vals_out.as<u32>(), (size_t)n, hybrid ? sh : g.rbits, end_bit, c->stream);
     if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs", hipGetErrorString(e));
-    LAUNCH(k_strip_table, g.S + 2, c->keys_out.as<u64>(), n, g.S, sh, c->strip.as<int>());
+    LAUNCH(k_strip_table, g.S + 2, c->keys_out.as<u64>(), n, g.S, sh, dstrip);
     if (hybrid) {
-        c->srow = c->vals_in.as<u32>();                  // the unsorted row ids are dead after the sort
+        u32* rows = drow ? drow : c->vals_in.as<u32>();  // the unsorted row ids are dead after the sort
         hipLaunchKernelGGL(k_strip_sort, dim3(nblocks(n, HS_TPB)), dim3(HS_TPB), 0, c->stream, n, g, c->keys_out.as<u64>(),
-                           c->vals_out.as<u32>(), c->strip.as<int>(), (c->sv.as<int>() + SORT_PAD), (c->sa.as<int>() + SORT_PAD), c->srow, c->tile_s0.as<int>(), c->counters.as<int>());
+                           c->vals_out.as<u32>(), dstrip, dsv, dsa, rows, dtile, c->counters.as<int>());
+        c->srow = rows;
     } else {
-        c->srow = c->vals_out.as<u32>();
-        LAUNCH(k_decode_sorted, n, n, g, c->keys_out.as<u64>(), (c->sv.as<int>() + SORT_PAD), (c->sa.as<int>() + SORT_PAD), c->tile_s0.as<int>());
+        LAUNCH(k_decode_sorted, n, n, g, c->keys_out.as<u64>(), dsv, dsa, dtile, c->vals_out.as<u32>(), drow);
+        c->srow = drow ? drow : c->vals_out.as<u32>();
+    }
+    return CL_OK;
+}
+
+// K0 + K1 + K2: sorted working set of the run (keys / sort, or a compaction of the base layout), then the neighbour
+// counts.  Leaves c->w_sv, w_sa, srow, w_strip, w_tile pointing at the sorted arrays of this run.
+static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
+{
+    const int n = (int)c->n;
+    int rc;
+    int* wsv = c->sv.as<int>() + SORT_PAD;
+    int* wsa = c->sa.as<int>() + SORT_PAD;
+    if (!c->reuse_layout) {
+        // every run sorts for itself (the cut filter rides in the keys: filtered rows go behind the last strip)
+        if ((rc = sort_layout(c, g, wsv, wsa, nullptr, c->strip.as<int>(), c->tile_s0.as<int>()))) return rc;
+        c->w_sv = wsv; c->w_sa = wsa; c->w_strip = c->strip.as<int>(); c->w_tile = c->tile_s0.as<int>();
+    } else {
+        const int layout = (g.variant == CL_VARIANT_CDBSCAN2 ? 2 : 0) | (g.swap ? 1 : 0);
+        if (!c->base.valid || c->base.layout != layout || c->base.eps != g.eps) {
+            c->base.valid = false;
+            if ((rc = c->bq.ensure(((size_t)n + 2 * SORT_PAD) * 4)) || (rc = c->bsp.ensure(((size_t)n + 2 * SORT_PAD) * 4)) ||
+                (rc = c->brow.ensure((size_t)n * 4)) || (rc = c->bstrip.ensure(((size_t)g.S + 2) * 4)) ||
+                (rc = c->btile.ensure(((size_t)n / 256 + 2) * 4))) return rc;
+            if (c->bq.fresh || c->bsp.fresh) {
+                hipLaunchKernelGGL(k_init_pads, dim3(nblocks(2 * SORT_PAD)), dim3(TPB), 0, c->stream, c->bq.as<int>(), c->bsp.as<int>(), (long long)n);
+                c->bq.fresh = c->bsp.fresh = false;
+            }
+            GridParams g0 = g;
+            g0.cut = 0;
+            if ((rc = sort_layout(c, g0, c->bq.as<int>() + SORT_PAD, c->bsp.as<int>() + SORT_PAD, c->brow.as<u32>(),
+                                  c->bstrip.as<int>(), c->btile.as<int>()))) return rc;
+            c->base.valid = true; c->base.layout = layout; c->base.eps = g.eps;
+        } else {
+            ev_record(c, 0);
+            ev_record(c, 1);
+        }
+        const long long dmin = g.swap ? c->st.amin : 0;   // swap == 0 is a developer layout: always compacts
+        if (g.cut <= 0 || (g.swap && (long long)g.cut <= dmin)) {
+            // no row is filtered: the run works on the base layout itself
+            c->w_sv = c->bq.as<int>() + SORT_PAD; c->w_sa = c->bsp.as<int>() + SORT_PAD; c->srow = c->brow.as<u32>();
+            c->w_strip = c->bstrip.as<int>(); c->w_tile = c->btile.as<int>();
+        } else {
+            if (!g.swap) return fail(CL_ERR_ARG, "internal: layout reuse needs the v-band layout");
+            // stable compaction of the base layout by d = q + V0 >= cut (pipe.py:59-62): same order as sorting the
+            // filtered rows, one pass over 12 B/PET
+            const int nb = nblocks(n, CMP_BLOCK);
+            if ((rc = c->sel_tmp.ensure((size_t)nb * 8 + 64))) return rc;
+            int* bcount = c->sel_tmp.as<int>();
+            int* boff = bcount + nb;
+            int* d_M = c->counters.as<int>() + CTR_M;
+            const int thr = g.cut - g.V0;
+            const int* bq = c->bq.as<int>() + SORT_PAD;
+            hipLaunchKernelGGL(k_cut_count, dim3(nb), dim3(CMP_TPB), 0, c->stream, n, thr, bq, bcount);
+            size_t tb = c->scan_tmp.bytes;
+            hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, bcount, boff, 0, (size_t)nb, rocprim::plus<int>(), c->stream);
+            if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan(cut)", hipGetErrorString(e));
+            hipLaunchKernelGGL(k_cut_scatter, dim3(nb), dim3(CMP_TPB), 0, c->stream, n, thr, bq, (const int*)(c->bsp.as<int>() + SORT_PAD),
+                               (const u32*)c->brow.as<u32>(), (const int*)boff, (const int*)bcount, wsv, wsa, c->vals_out.as<u32>(), d_M);
+            const int span = std::max(std::max(g.S + 2, n / 256 + 1), SORT_PAD);
+            LAUNCH(k_after_compact, span, n, g.S, g.rbits, d_M, wsa, wsv, wsa, c->strip.as<int>(), c->tile_s0.as<int>());
+            c->w_sv = wsv; c->w_sa = wsa; c->srow = c->vals_out.as<u32>();
+            c->w_strip = c->strip.as<int>(); c->w_tile = c->tile_s0.as<int>();
+        }
     }
     ev_record(c, 2);
     {
@@ -2894,7 +3053,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
                 const int tile = K2F_TPB * UU, ntiles = nblocks(n, tile), run = std::max(1, 2048 / tile);               \
                 const int grid = ((ntiles + 8 * run - 1) / (8 * run)) * (8 * run);                                      \
                 hipLaunchKernelGGL((k_region_core<UU, HH>), dim3(grid), dim3(K2F_TPB), 0, c->stream, g, ntiles,         \
-                                   (c->sv.as<int>() + SORT_PAD), (c->sa.as<int>() + SORT_PAD), c->strip.as<int>(), c->tile_s0.as<int>(), c->cnt.as<int>()); \
+                                   c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->cnt.as<int>()); \
             }
             // window = tile + 2 * halo entries; shapes keep it a multiple of 1024 (every thread stages whole 16-byte slots)
             switch (shape) {
@@ -2928,8 +3087,8 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
         } else {
             const int ntiles = nblocks(n, K2_TPB);
             const int grid = ((ntiles + 8 * K2_RUN - 1) / (8 * K2_RUN)) * (8 * K2_RUN);
-            if (exact) hipLaunchKernelGGL(k_region_count<true>, dim3(grid), dim3(K2_TPB), 0, c->stream, g, ntiles, n, (c->sv.as<int>() + SORT_PAD), (c->sa.as<int>() + SORT_PAD), c->strip.as<int>(), c->cnt.as<int>());
-            else hipLaunchKernelGGL(k_region_count<false>, dim3(grid), dim3(K2_TPB), 0, c->stream, g, ntiles, n, (c->sv.as<int>() + SORT_PAD), (c->sa.as<int>() + SORT_PAD), c->strip.as<int>(), c->cnt.as<int>());
+            if (exact) hipLaunchKernelGGL(k_region_count<true>, dim3(grid), dim3(K2_TPB), 0, c->stream, g, ntiles, n, c->w_sv, c->w_sa, c->w_strip, c->cnt.as<int>());
+            else hipLaunchKernelGGL(k_region_count<false>, dim3(grid), dim3(K2_TPB), 0, c->stream, g, ntiles, n, c->w_sv, c->w_sa, c->w_strip, c->cnt.as<int>());
         }
     }
     ev_record(c, 3);
@@ -2985,7 +3144,7 @@ extern "C" int cl_neighbor_counts(cl_chrom* c, int32_t eps, int32_t cut, int32_t
     if ((rc = run_sort_and_count(c, g, true))) return rc;
     const int n = (int)c->n;
     HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
-    LAUNCH(k_scatter_counts, n, c->strip.as<int>(), g.S, c->srow, c->cnt.as<int>(), c->slot[c->cur].labels.as<int>());
+    LAUNCH(k_scatter_counts, n, c->w_strip, g.S, c->srow, c->cnt.as<int>(), c->slot[c->cur].labels.as<int>());
     HIP_TRY(hipMemcpyAsync(counts_out, c->slot[c->cur].labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->profiling) {
@@ -3391,9 +3550,6 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     if ((rc = ensure_workspace(c, g.S))) return rc;
     if ((rc = ensure_events(c))) return rc;
     const int n = (int)c->n;
-    int* strip = c->strip.as<int>();
-    int* sv = (c->sv.as<int>() + SORT_PAD);
-    int* sa = (c->sa.as<int>() + SORT_PAD);
     int* cnt = c->cnt.as<int>();
     int* counters = c->counters.as<int>();
     const int ntiles = nblocks(n);
@@ -3404,6 +3560,9 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     // filter need the -1 fill
     if (cut > 0) HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
     if ((rc = run_sort_and_count(c, g, false))) return rc;
+    int* strip = c->w_strip;
+    int* sv = c->w_sv;
+    int* sa = c->w_sa;
     const u32* srow = c->srow;
 
     // K3

@@ -199,6 +199,14 @@ const int32_t* cl_labels_device(const cl_chrom* c);
 void cl_set_profiling(cl_chrom* c, int enabled);
 int cl_get_timing(const cl_chrom* c, cl_timing* out);
 
+/* Sorted-layout reuse (default: enabled).  The sorted order of a chromosome's PETs depends on eps only (not on
+ * minPts; a cut only removes rows), and the sweep of cLoops/pipe.py:241-281 walks eps in its OUTER loop: with reuse
+ * enabled the handle keeps the sorted arrays of the last eps and every further run at that eps starts from one
+ * stable stream compaction by the cut (pipe.py:59-62) instead of a sort.  Results are identical either way; nothing
+ * of a result is kept between runs.  enabled = 0: every run sorts for itself (used by benchmarks that repeat one
+ * (eps, minPts) and must pay the whole run every time). */
+void cl_set_layout_reuse(cl_chrom* c, int enabled);
+
 /* Page-locked host memory for result buffers (labels_out / boxes_out / counts_out): D2H
  * copies into pinned memory run at PCIe rate instead of through a staging buffer.  Plain
  * malloc'ed memory works everywhere too, only slower. */

@@ -1,0 +1,66 @@
+"""GPU: sorted-layout reuse (cl_set_layout_reuse).  A handle that keeps the sorted arrays of the last eps and starts
+further runs from a stream compaction by the cut must give exactly the labels / tables of a handle that sorts every
+run for itself, in any order of (eps, minPts, cut) -- and both equal the CPU oracle."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle
+from cloops_amd import api
+from cloops_amd.synth import synth_chrom
+
+pytestmark = pytest.mark.gpu
+
+# sweeps as pipe() issues them (eps outer loop, minPts inner, the cut changing every run) plus returns to an earlier eps
+SEQ = [(500, 5, 0), (500, 4, 4601), (500, 6, 300), (1000, 5, 4601), (1000, 5, 0), (1000, 8, 13532), (2000, 5, 11103),
+       (500, 5, 4601), (2000, 3, 10 ** 9), (2000, 5, 0)]
+
+
+@pytest.mark.parametrize("variant", ["v2", "v1"])
+def test_reuse_equals_fresh_sort_chr21(variant):
+    X, Y = G.chr21_xy()
+    a = api.Chromosome(X, Y)
+    b = api.Chromosome(X, Y)
+    b.set_layout_reuse(False)
+    for k, (eps, m, cut) in enumerate(SEQ):
+        ra = a.cluster(variant, eps, m, cut)
+        rb = b.cluster(variant, eps, m, cut)
+        assert np.array_equal(ra.labels, rb.labels), (variant, eps, m, cut)
+        assert ra.n_clusters == rb.n_clusters and np.array_equal(ra.boxes, rb.boxes)
+        assert a.last_n_in() == b.last_n_in() == int(((Y - X) >= cut).sum())
+        if k in (1, 3, 6):
+            want = oracle.single_dbscan(variant, X, Y, eps, m, cut)["labels"]
+            assert np.array_equal(ra.labels, want)
+    a.close()
+    b.close()
+
+
+def test_reuse_async_sweep_dense():
+    """the asynchronous form the sweep driver uses, on dense synthetic data with long strips (general sort path)"""
+    X, Y = synth_chrom(1500000, 20000000, 77)
+    a = api.Chromosome(X, Y)
+    b = api.Chromosome(X, Y)
+    b.set_layout_reuse(False)
+    runs = [(5000, 30, 0), (5000, 20, 4000), (7500, 30, 5200), (7500, 20, 4800), (5000, 30, 0)]
+    for eps, m, cut in runs:
+        a.cluster_async("v2", eps, m, cut)
+        b.cluster_async("v2", eps, m, cut)
+        ra, rb = a.wait(copy=True), b.wait(copy=True)
+        assert np.array_equal(ra.labels, rb.labels), (eps, m, cut)
+        assert np.array_equal(ra.boxes, rb.boxes)
+    want = oracle.single_dbscan("v2", X, Y, 7500, 20, 4800)["labels"]
+    a.cluster_async("v2", 7500, 20, 4800)
+    assert np.array_equal(a.wait().labels, want)
+    a.close()
+    b.close()
+
+
+def test_neighbor_counts_with_reuse():
+    X, Y = synth_chrom(200000, 5000000, 5)
+    a = api.Chromosome(X, Y)
+    b = api.Chromosome(X, Y)
+    b.set_layout_reuse(False)
+    for eps, cut in ((1500, 0), (1500, 2500), (3000, 2500)):
+        assert np.array_equal(a.neighbor_counts(eps, cut), b.neighbor_counts(eps, cut))
+    a.close()
+    b.close()
