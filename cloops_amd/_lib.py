@@ -27,8 +27,8 @@ SYMBOLS = [
     "cl_last_error", "cl_device_count", "cl_chrom_create", "cl_chrom_destroy", "cl_chrom_size",
     "cl_cluster", "cl_get_boxes", "cl_neighbor_counts", "cl_labels_device", "cl_set_profiling",
     "cl_get_timing", "cl_version", "cl_host_alloc", "cl_host_free", "cl_cluster_async", "cl_wait", "cl_boxes_host",
-    "cl_dist_stats", "cl_dist_sqdev", "cl_dist_hist", "cl_last_n_in", "cl_sig_counts", "cl_cluster_weighted",
-    "cl_set_layout_reuse",
+    "cl_dist_summary", "cl_dist_bin_hist", "cl_last_n_in", "cl_sig_counts", "cl_cluster_weighted",
+    "cl_set_layout_reuse", "cl_set_device_labels",
 ]
 
 
@@ -44,8 +44,12 @@ class ClTiming(ctypes.Structure):
                 ("n_strips", ctypes.c_int64), ("ms_bracket", ctypes.c_float)]
 
 
-class ClDstats(ctypes.Structure):
-    _fields_ = [("n_all", ctypes.c_int64 * 2), ("n_pos", ctypes.c_int64 * 2), ("sumlog", ctypes.c_double * 2)]
+DIST_LOGBINS = 3840
+
+
+class ClDsummary(ctypes.Structure):
+    _fields_ = [("n_all", ctypes.c_int64 * 2), ("n_pos", ctypes.c_int64 * 2), ("sumx", ctypes.c_double * 2),
+                ("sumxx", ctypes.c_double * 2), ("xshift", ctypes.c_double), ("loghist", ctypes.c_uint64 * DIST_LOGBINS)]
 
 
 class CloopsHipError(RuntimeError):
@@ -92,12 +96,12 @@ def load():
     lib.cl_wait.argtypes = [vp, i32p, i32p]
     lib.cl_boxes_host.restype = vp
     lib.cl_boxes_host.argtypes = [vp]
-    lib.cl_dist_stats.restype = ctypes.c_int
-    lib.cl_dist_stats.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(ClDstats)]
-    lib.cl_dist_sqdev.restype = ctypes.c_int
-    lib.cl_dist_sqdev.argtypes = [vp, ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
-    lib.cl_dist_hist.restype = ctypes.c_int
-    lib.cl_dist_hist.argtypes = [vp, ctypes.c_int32, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    lib.cl_dist_summary.restype = ctypes.c_int
+    lib.cl_dist_summary.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(ClDsummary)]
+    lib.cl_dist_bin_hist.restype = ctypes.c_int
+    lib.cl_dist_bin_hist.argtypes = [vp, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    lib.cl_set_device_labels.restype = None
+    lib.cl_set_device_labels.argtypes = [vp, ctypes.c_int]
     lib.cl_sig_counts.restype = ctypes.c_int
     lib.cl_sig_counts.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp, vp, ctypes.POINTER(ctypes.c_int64)]
     lib.cl_last_n_in.restype = ctypes.c_int64

@@ -115,6 +115,11 @@ class Chromosome(object):
         self._profiling = bool(on)
         self._lib.cl_set_profiling(self._h, 1 if on else 0)
 
+    def set_device_labels(self, on=True):
+        """row-aligned device labels for runs without a host destination (default on); the sweep driver switches
+        them off: it only needs tables and distance statistics (cl_set_device_labels)"""
+        self._lib.cl_set_device_labels(self._h, 1 if on else 0)
+
     def set_layout_reuse(self, on=True):
         """keep the sorted arrays of the last eps and start further runs at that eps from a compaction by the cut
         (default on; results identical either way -- cl_set_layout_reuse of include/cloops_hip.h)"""
@@ -192,23 +197,21 @@ class Chromosome(object):
         return int(self._lib.cl_last_n_in(self._h))
 
     # ---- distance statistics of the last completed run (K7; inputs of ests.estIntSelCutFrag) ----
-    def dist_stats(self, cut=0):
-        """-> dict(n_all=[inter, self], n_pos=[...], sumlog=[...]) (cl_dist_stats)."""
-        st = _lib.ClDstats()
-        _lib.check(self._lib.cl_dist_stats(self._h, int(cut), ctypes.byref(st)))
+    def dist_summary(self, cut=0):
+        """-> dict(n_all=[inter, self], n_pos=[...], sumx=[...], sumxx=[...], xshift, loghist=uint64[3840])
+        (cl_dist_summary: one pass; x = log2|d| - xshift)."""
+        st = _lib.ClDsummary()
+        _lib.check(self._lib.cl_dist_summary(self._h, int(cut), ctypes.byref(st)))
         return {"n_all": [int(st.n_all[0]), int(st.n_all[1])], "n_pos": [int(st.n_pos[0]), int(st.n_pos[1])],
-                "sumlog": [float(st.sumlog[0]), float(st.sumlog[1])]}
+                "sumx": [float(st.sumx[0]), float(st.sumx[1])], "sumxx": [float(st.sumxx[0]), float(st.sumxx[1])],
+                "xshift": float(st.xshift), "loghist": np.ctypeslib.as_array(st.loghist).astype(np.int64)}
 
-    def dist_sqdev(self, cut, mean_inter, mean_self):
-        out = (ctypes.c_double * 2)()
-        _lib.check(self._lib.cl_dist_sqdev(self._h, int(cut), float(mean_inter), float(mean_self), out))
-        return [float(out[0]), float(out[1])]
-
-    def dist_hist(self, cut, group, prefix, shift):
-        out = np.zeros(256, dtype=np.uint64)
-        _lib.check(self._lib.cl_dist_hist(self._h, int(cut), int(group), int(prefix), int(shift),
-                                          out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
-        return out
+    def dist_bin_hist(self, cut, lo, hi, shift):
+        """histogram (int64[2048]) of (|d| - lo) >> shift over the self group's lo <= |d| < hi (cl_dist_bin_hist)"""
+        out = np.zeros(2048, dtype=np.uint64)
+        _lib.check(self._lib.cl_dist_bin_hist(self._h, int(cut), int(lo), int(hi), int(shift),
+                                              out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+        return out.astype(np.int64)
 
     def sig_counts(self, windows, cut=0):
         """K8: interval counts for the significance test.  windows: int32 [R, 44] (lo[22], hi[22];

@@ -1796,10 +1796,12 @@ __device__ __forceinline__ void table_flush(const Table& t, TableLds& h)
 // usually carries a handful of labels and a giant cluster costs 5 atomics per wave, not
 // 5 per PET.
 #define FINAL_CHUNKS 4          // PETs per workgroup = FINAL_CHUNKS * BIGTPB: one LDS table, one flush
+// slab[i] = label of sorted position i (coalesced; what the distance statistics K7 read); labels[row] (the scatter to
+// input-row order, 4-byte stores all over the array) only when the caller wants row-aligned labels
 __global__ void __launch_bounds__(BIGTPB)
 k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ sv,
                const int* __restrict__ sa, const u32* __restrict__ srow, const int* __restrict__ owner,
-               const int* __restrict__ rlabel, int* __restrict__ labels, Table t)
+               const int* __restrict__ rlabel, int* __restrict__ labels, int* __restrict__ slab, Table t)
 {
     __shared__ TableLds h;
     table_lds_init(h);
@@ -1810,7 +1812,8 @@ k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __r
         if (i < M) {
             const int o = owner_root(owner[i]);
             if (o >= 0) lab = rlabel[o];
-            labels[srow[i]] = lab;
+            slab[i] = lab;
+            if (labels) labels[srow[i]] = lab;
             // X = (v - a) / 2, Y = (v + a) / 2 exactly (v and a have equal parity)
             const int spv = sa[i];
             int pp = ((spv >> g.rbits) + g.s0) * g.eps + (spv & (g.peps - 1)) + g.A0, qq = sv[i] + g.V0;
@@ -2332,106 +2335,119 @@ __global__ void k7_classify(const int* __restrict__ hdr, Table t, signed char* _
     cls[k] = c;
 }
 
-__device__ __forceinline__ int k7_group(int r, const int* __restrict__ X, const int* __restrict__ Y,
-                                        const int* __restrict__ labels, const signed char* __restrict__ cls, int cut, int* ad)
+// Source of the per-PET (distance, label) pairs of the last completed run:
+//   sorted  the run's sorted arrays: d = q + V0 and the label of sorted position i (rotated variants; the PETs
+//           removed by the cut are not in them and come from the input rows: d = Y - X < cut)
+//   rows    input-row order (variants that only produce row-order labels)
+struct K7Src {
+    int sorted; int n; int M; int v0;
+    const int* X; const int* Y; const int* labels;      // input rows (+ row-order labels)
+    const int* sv; const int* slab;                     // sorted q and sorted-order labels of [0, M)
+};
+#define K7_LOGBINS 3840          // 30 octaves x 128: bin = floor(log2 d) * 128 + the next 7 bits of d (monotone in d)
+#define K7_FINE 2048
+#define K7_XSHIFT 11.0           // sums are taken over x = log2|d| - K7_XSHIFT (less cancellation in sum x^2 - (sum x)^2 / n)
+
+__device__ __forceinline__ int k7_logbin(unsigned d)      // d >= 1
 {
-    const int d = Y[r] - X[r];
-    *ad = d < 0 ? -d : d;                         // ests.py:42-43 np.abs
-    if (cut > 0 && d < cut) return 1;             // pipe.py:63: short PETs go to dss
-    const int lab = labels[r];
-    return lab >= 0 ? (int)cls[lab] : -1;
+    const int e = 31 - __clz((int)d);
+    const unsigned m = e >= 7 ? ((d >> (e - 7)) & 127u) : ((d << (7 - e)) & 127u);
+    return e * 128 + (int)m;
 }
-
-struct K7Part { double sumlog[2]; long long n_all[2]; long long n_pos[2]; };
-
-// pass 1: counts and sum of log2 per group; one partial per workgroup (fixed row ranges)
-__global__ void __launch_bounds__(TPB)
-k7_pass1(int n, int cut, const int* __restrict__ X, const int* __restrict__ Y, const int* __restrict__ labels,
-         const signed char* __restrict__ cls, K7Part* __restrict__ parts)
+// f(group, |d|) for every PET of a group, in a fixed order per thread (deterministic partial sums): the block works
+// on fixed contiguous ranges of the sources
+template <typename F>
+__device__ __forceinline__ void k7_for_each(const K7Src& s, int cut, const signed char* __restrict__ cls, F&& f)
 {
-    double sl[2] = {0.0, 0.0};
-    long long na[2] = {0, 0}, np_[2] = {0, 0};
-    const int per = (n + gridDim.x - 1) / gridDim.x;
-    const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
-    for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
-        int ad;
-        const int g = k7_group(r, X, Y, labels, cls, cut, &ad);
-        if (g < 0) continue;
-        na[g]++;
-        if (ad > 0) { np_[g]++; sl[g] += log2((double)ad); }
-    }
-    __shared__ double s_sl[2][TPB / 64];
-    __shared__ long long s_n[4][TPB / 64];
-    for (int g = 0; g < 2; ++g) {
-        for (int o = 32; o > 0; o >>= 1) {
-            sl[g] += __shfl_down(sl[g], o);
-            na[g] += __shfl_down(na[g], o);
-            np_[g] += __shfl_down(np_[g], o);
+    if (s.sorted) {
+        const int per = (s.M + gridDim.x - 1) / gridDim.x;
+        const int i0 = blockIdx.x * per, i1 = min(s.M, i0 + per);
+        for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+            const int lab = s.slab[i];
+            const int g = lab >= 0 ? (int)cls[lab] : -1;
+            const int d = s.sv[i] + s.v0;
+            if (g >= 0) f(g, d < 0 ? -d : d);                      // ests.py:42-43 np.abs
+        }
+        if (cut > 0) {                                             // pipe.py:63: short PETs go to dss
+            const int perr = (s.n + gridDim.x - 1) / gridDim.x;
+            const int r0 = blockIdx.x * perr, r1 = min(s.n, r0 + perr);
+            for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+                const int d = s.Y[r] - s.X[r];
+                if (d < cut) f(1, d < 0 ? -d : d);
+            }
+        }
+    } else {
+        const int perr = (s.n + gridDim.x - 1) / gridDim.x;
+        const int r0 = blockIdx.x * perr, r1 = min(s.n, r0 + perr);
+        for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+            const int d = s.Y[r] - s.X[r];
+            int g = 1;
+            if (!(cut > 0 && d < cut)) { const int lab = s.labels[r]; g = lab >= 0 ? (int)cls[lab] : -1; }
+            if (g >= 0) f(g, d < 0 ? -d : d);
         }
     }
+}
+
+struct K7Part { double sx[2]; double sxx[2]; long long n_all[2]; long long n_pos[2]; };
+
+// one pass: counts, sum x and sum x^2 (x = log2|d| - K7_XSHIFT over d != 0) for both groups, and the log-binned
+// histogram of the self group's |d| (first level of the exact median)
+__global__ void __launch_bounds__(TPB)
+k7_summary(K7Src s, int cut, const signed char* __restrict__ cls, K7Part* __restrict__ parts, unsigned long long* __restrict__ loghist)
+{
+    __shared__ unsigned int h[K7_LOGBINS];
+    for (int k = threadIdx.x; k < K7_LOGBINS; k += blockDim.x) h[k] = 0u;
+    __syncthreads();
+    double sx[2] = {0.0, 0.0}, sxx[2] = {0.0, 0.0};
+    long long na[2] = {0, 0}, np_[2] = {0, 0};
+    k7_for_each(s, cut, cls, [&](int g, int ad) {
+        na[g]++;
+        if (ad > 0) {
+            const double x = log2((double)ad) - K7_XSHIFT;
+            np_[g]++; sx[g] += x; sxx[g] += x * x;
+            if (g == 1) atomicAdd(&h[k7_logbin((unsigned)ad)], 1u);
+        }
+    });
+    __shared__ double s_d[4][TPB / 64];
+    __shared__ long long s_n[4][TPB / 64];
+    for (int g = 0; g < 2; ++g)
+        for (int o = 32; o > 0; o >>= 1) {
+            sx[g] += __shfl_down(sx[g], o); sxx[g] += __shfl_down(sxx[g], o);
+            na[g] += __shfl_down(na[g], o); np_[g] += __shfl_down(np_[g], o);
+        }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) { s_sl[0][wv] = sl[0]; s_sl[1][wv] = sl[1]; s_n[0][wv] = na[0]; s_n[1][wv] = na[1]; s_n[2][wv] = np_[0]; s_n[3][wv] = np_[1]; }
+    if (lane == 0) {
+        s_d[0][wv] = sx[0]; s_d[1][wv] = sx[1]; s_d[2][wv] = sxx[0]; s_d[3][wv] = sxx[1];
+        s_n[0][wv] = na[0]; s_n[1][wv] = na[1]; s_n[2][wv] = np_[0]; s_n[3][wv] = np_[1];
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         K7Part p;
         for (int g = 0; g < 2; ++g) {
-            double a = 0; long long b = 0, c = 0;
-            for (int w = 0; w < TPB / 64; ++w) { a += s_sl[g][w]; b += s_n[g][w]; c += s_n[2 + g][w]; }
-            p.sumlog[g] = a; p.n_all[g] = b; p.n_pos[g] = c;
+            double a = 0, b = 0; long long c = 0, d = 0;
+            for (int w = 0; w < TPB / 64; ++w) { a += s_d[g][w]; b += s_d[2 + g][w]; c += s_n[g][w]; d += s_n[2 + g][w]; }
+            p.sx[g] = a; p.sxx[g] = b; p.n_all[g] = c; p.n_pos[g] = d;
         }
         parts[blockIdx.x] = p;
     }
+    for (int k = threadIdx.x; k < K7_LOGBINS; k += blockDim.x)
+        if (h[k]) atomicAdd(&loghist[k], (unsigned long long)h[k]);
 }
 
-// pass 2: sum of squared deviations of log2(|d|) from the given (global) means
+// refinement pass of the exact median: histogram of (|d| - lo) >> shift over the self group's lo <= |d| < hi
 __global__ void __launch_bounds__(TPB)
-k7_pass2(int n, int cut, const int* __restrict__ X, const int* __restrict__ Y, const int* __restrict__ labels,
-         const signed char* __restrict__ cls, double mean0, double mean1, double* __restrict__ parts /* 2 per block */)
+k7_bin_hist(K7Src s, int cut, const signed char* __restrict__ cls, unsigned lo, unsigned hi, int shift, unsigned long long* __restrict__ hist)
 {
-    double sq[2] = {0.0, 0.0};
-    const int per = (n + gridDim.x - 1) / gridDim.x;
-    const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
-    for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
-        int ad;
-        const int g = k7_group(r, X, Y, labels, cls, cut, &ad);
-        if (g < 0 || ad <= 0) continue;
-        const double x = log2((double)ad) - (g == 0 ? mean0 : mean1);
-        sq[g] += x * x;
-    }
-    __shared__ double s_sq[2][TPB / 64];
-    for (int g = 0; g < 2; ++g)
-        for (int o = 32; o > 0; o >>= 1) sq[g] += __shfl_down(sq[g], o);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) { s_sq[0][wv] = sq[0]; s_sq[1][wv] = sq[1]; }
+    __shared__ unsigned int h[K7_FINE];
+    for (int k = threadIdx.x; k < K7_FINE; k += blockDim.x) h[k] = 0u;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int g = 0; g < 2; ++g) {
-            double a = 0;
-            for (int w = 0; w < TPB / 64; ++w) a += s_sq[g][w];
-            parts[2 * blockIdx.x + g] = a;
-        }
-    }
-}
-
-// one radix-select pass: histogram of the byte (|d| >> shift) & 255 over the positive distances of
-// `group` whose higher bits equal `prefix` (top pass: shift = 24, everything matches)
-__global__ void __launch_bounds__(TPB)
-k7_hist(int n, int cut, const int* __restrict__ X, const int* __restrict__ Y, const int* __restrict__ labels,
-        const signed char* __restrict__ cls, int group, unsigned prefix, int shift, unsigned long long* __restrict__ hist)
-{
-    __shared__ unsigned int h[256];
-    h[threadIdx.x] = 0;                               // TPB == 256
-    __syncthreads();
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        int ad;
-        const int g = k7_group(r, X, Y, labels, cls, cut, &ad);
-        if (g != group || ad <= 0) continue;
+    k7_for_each(s, cut, cls, [&](int g, int ad) {
         const unsigned u = (unsigned)ad;
-        if (shift < 24 && (u >> (shift + 8)) != prefix) continue;
-        atomicAdd(&h[(u >> shift) & 255u], 1u);
-    }
+        if (g == 1 && u >= lo && u < hi) atomicAdd(&h[min((u - lo) >> shift, (unsigned)(K7_FINE - 1))], 1u);
+    });
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+    for (int k = threadIdx.x; k < K7_FINE; k += blockDim.x)
+        if (h[k]) atomicAdd(&hist[k], (unsigned long long)h[k]);
 }
 
 // ==========================================================================================
@@ -2612,7 +2628,13 @@ struct cl_chrom {
         cl_box* h_boxes = nullptr;    // pinned host copy of the cluster table
         size_t h_boxes_cap = 0;
         int32_t* labels_out = nullptr;
+        DevBuf slab;                  // labels in sorted order (rotated variants)
+        bool rows_valid = false;      // `labels` (row order) was produced by the run
+        bool sorted_src = false;      // the run left sorted (q, label) arrays for the distance statistics
+        const int* k7_sv = nullptr;   // sorted q of the run
+        int k7_v0 = 0;                // d = q + k7_v0
     } slot[2];
+    bool device_labels = true;        // produce row-order device labels even without a host destination (cl_set_device_labels)
     DevBuf hdr;                       // device result headers, 16 ints per slot
     DevBuf k7_cls, k7_parts;          // K7: class per cluster id, per-workgroup partials
     DevBuf sig_tx, sig_ty, sig_tmp, sig_sorttmp, sig_m, sig_win, sig_out;   // K8: sorted PET tables, windows, counts
@@ -2638,7 +2660,7 @@ static void free_chrom(cl_chrom* c)
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
-                      &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
+                      &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
                       &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp};
     for (DevBuf* b : bufs) b->release();
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
@@ -2668,8 +2690,9 @@ extern "C" int cl_get_timing(const cl_chrom* c, cl_timing* out)
 }
 extern "C" const int32_t* cl_labels_device(const cl_chrom* c)
 {
-    return (c && c->last_slot >= 0) ? (const int32_t*)c->slot[c->last_slot].labels.p : nullptr;
+    return (c && c->last_slot >= 0 && c->slot[c->last_slot].rows_valid) ? (const int32_t*)c->slot[c->last_slot].labels.p : nullptr;
 }
+extern "C" void cl_set_device_labels(cl_chrom* c, int enabled) { if (c) c->device_labels = enabled != 0; }
 
 static inline int nblocks(long long n, int tpb = TPB) { return (int)((n + tpb - 1) / tpb); }
 
@@ -2841,7 +2864,7 @@ static int ensure_workspace(cl_chrom* c, int S)
     ENS(parent, n * 4); ENS(root, n * 4); ENS(head, n * 4); ENS(headidx, n * 4); ENS(cellfirst, n * 4);
     ENS(compkey, n * 4); ENS(ncore, n * 4); ENS(bsize, n * 4); ENS(owner, n * 4); ENS(state, n * 4);
     ENS(flag, (n + 1) * 4); ENS(rankscan, (n + 1) * 4); ENS(hdr, 256);
-    ENS(slot[c->cur].labels, n * 4); ENS(slot[c->cur].table, (n + 1) * sizeof(cl_box));
+    ENS(slot[c->cur].labels, n * 4); ENS(slot[c->cur].table, (n + 1) * sizeof(cl_box)); ENS(slot[c->cur].slab, n * 4);
     ENS(ulist, n * 4); ENS(lo, n * 4); ENS(hi, n * 4); ENS(recs, n * sizeof(Rec)); ENS(counters, 256);
     ENS(chainflag, n * 4); ENS(chainhead, n * 4); ENS(usize, n * 4); ENS(tile_s0, (n / 256 + 2) * 4);
 #undef ENS
@@ -3405,6 +3428,7 @@ static int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_
     HIP_TRY(hipGetLastError());
     // blockDBSCAN.py:74: an empty (fully filtered) mat raises only when the class is called
     // on it; pipe.py:64-65 returns before that, so cut > 0 with no survivors is just empty.
+    { cl_chrom::Slot& sl = c->slot[c->cur]; sl.rows_valid = true; sl.sorted_src = false; }
     return finish_enqueue(c, p.R + 1, &sc->M, labels_out);
 }
 
@@ -3475,6 +3499,7 @@ static int run_weighted(cl_chrom* c, int eps, int minPts, int wx, int wy, int32_
     hipLaunchKernelGGL(k64_final, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, n, c->d_x, c->d_y, srow, c->owner.as<int>(),
                        c->chainhead.as<int>(), c->slot[c->cur].labels.as<int>(), t);
     HIP_TRY(hipGetLastError());
+    { cl_chrom::Slot& sl = c->slot[c->cur]; sl.rows_valid = true; sl.sorted_src = false; }
     return finish_enqueue(c, g.S + 2, strip + g.S, labels_out);
 }
 
@@ -3556,10 +3581,15 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     const int tgrid = tile_grid(ntiles);
 
     LAUNCH(k_init_flags, n + 1, n, c->flag.as<int>(), counters);
-    // k_final_labels writes the label (or -1) of every PET that entered DBSCAN; only rows removed by the cut
-    // filter need the -1 fill
-    if (cut > 0) HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
+    // row-aligned labels only when somebody reads them: k_final_labels then writes the label (or -1) of every PET that
+    // entered DBSCAN and only the rows removed by the cut filter need the -1 fill
+    const bool rows = labels_out != nullptr || c->device_labels;
+    if (rows && cut > 0) HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
     if ((rc = run_sort_and_count(c, g, false))) return rc;
+    {
+        cl_chrom::Slot& sl = c->slot[c->cur];
+        sl.rows_valid = rows; sl.sorted_src = g.swap != 0; sl.k7_sv = c->w_sv; sl.k7_v0 = g.V0;
+    }
     int* strip = c->w_strip;
     int* sv = c->w_sv;
     int* sa = c->w_sa;
@@ -3628,7 +3658,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     LAUNCH(k_root_labels, n, g, strip, c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
            c->state.as<int>(), c->rankscan.as<int>(), c->chainhead.as<int>());
     hipLaunchKernelGGL(k_final_labels, dim3(nblocks(n, BIGTPB * FINAL_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow, c->owner.as<int>(),
-                       c->chainhead.as<int>(), c->slot[c->cur].labels.as<int>(), t);
+                       c->chainhead.as<int>(), rows ? c->slot[c->cur].labels.as<int>() : (int*)nullptr, c->slot[c->cur].slab.as<int>(), t);
     HIP_TRY(hipGetLastError());
     return finish_enqueue(c, g.S + 2, strip + g.S, labels_out);
 }
@@ -3644,7 +3674,7 @@ static int k7_prepare(cl_chrom* c)
     HIP_TRY(hipSetDevice(c->device));
     int rc;
     if ((rc = c->k7_cls.ensure((size_t)c->n + 16))) return rc;
-    if ((rc = c->k7_parts.ensure(K7_BLOCKS * sizeof(K7Part) + 4096))) return rc;
+    if ((rc = c->k7_parts.ensure(K7_BLOCKS * sizeof(K7Part) + K7_LOGBINS * 8 + 4096))) return rc;
     if (!c->k7_classified) {
         int* dh = c->hdr.as<int>() + 16 * c->last_slot;
         LAUNCH(k7_classify, c->n + 1, dh, make_table_slot(c, c->last_slot), c->k7_cls.as<signed char>());
@@ -3653,61 +3683,55 @@ static int k7_prepare(cl_chrom* c)
     return CL_OK;
 }
 
-extern "C" int cl_dist_stats(cl_chrom* c, int32_t cut, cl_dstats* out)
+static K7Src k7_source(cl_chrom* c)
 {
-    if (!out) return fail(CL_ERR_ARG, "cl_dist_stats: out is null");
+    cl_chrom::Slot& sl = c->slot[c->last_slot];
+    K7Src s{};
+    s.sorted = sl.sorted_src ? 1 : 0; s.n = (int)c->n; s.M = sl.h_hdr[2]; s.v0 = sl.k7_v0;
+    s.X = c->d_x; s.Y = c->d_y; s.labels = sl.labels.as<int>(); s.sv = sl.k7_sv; s.slab = sl.slab.as<int>();
+    return s;
+}
+
+extern "C" int cl_dist_summary(cl_chrom* c, int32_t cut, cl_dsummary* out)
+{
+    if (!out) return fail(CL_ERR_ARG, "cl_dist_summary: out is null");
     memset(out, 0, sizeof(*out));
+    out->xshift = K7_XSHIFT;
     if (c && c->n == 0) return CL_OK;
     int rc = k7_prepare(c);
     if (rc) return rc;
-    cl_chrom::Slot& sl = c->slot[c->last_slot];
-    const int n = (int)c->n;
-    hipLaunchKernelGGL(k7_pass1, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, n, cut, c->d_x, c->d_y, sl.labels.as<int>(),
-                       c->k7_cls.as<signed char>(), c->k7_parts.as<K7Part>());
-    std::vector<K7Part> h(K7_BLOCKS);
-    HIP_TRY(hipMemcpyAsync(h.data(), c->k7_parts.p, K7_BLOCKS * sizeof(K7Part), hipMemcpyDeviceToHost, c->stream));
+    if (!c->slot[c->last_slot].sorted_src && !c->slot[c->last_slot].rows_valid) return fail(CL_ERR_ARG, "cl_dist_summary: the last run left no labels");
+    unsigned long long* dh = (unsigned long long*)((char*)c->k7_parts.p + K7_BLOCKS * sizeof(K7Part));
+    HIP_TRY(hipMemsetAsync(dh, 0, K7_LOGBINS * 8, c->stream));
+    hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, k7_source(c), cut, c->k7_cls.as<signed char>(), c->k7_parts.as<K7Part>(), dh);
+    std::vector<char> h(K7_BLOCKS * sizeof(K7Part) + K7_LOGBINS * 8);
+    HIP_TRY(hipMemcpyAsync(h.data(), c->k7_parts.p, h.size(), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    const K7Part* parts = (const K7Part*)h.data();
     for (int g = 0; g < 2; ++g) {
-        double a = 0; long long b = 0, d = 0;
-        for (int k = 0; k < K7_BLOCKS; ++k) { a += h[k].sumlog[g]; b += h[k].n_all[g]; d += h[k].n_pos[g]; }
-        out->sumlog[g] = a; out->n_all[g] = b; out->n_pos[g] = d;
+        double a = 0, b = 0; long long na = 0, np = 0;
+        for (int k = 0; k < K7_BLOCKS; ++k) { a += parts[k].sx[g]; b += parts[k].sxx[g]; na += parts[k].n_all[g]; np += parts[k].n_pos[g]; }   // fixed order
+        out->sumx[g] = a; out->sumxx[g] = b; out->n_all[g] = na; out->n_pos[g] = np;
     }
+    memcpy(out->loghist, h.data() + K7_BLOCKS * sizeof(K7Part), K7_LOGBINS * 8);
     return CL_OK;
 }
 
-extern "C" int cl_dist_sqdev(cl_chrom* c, int32_t cut, double mean_inter, double mean_self, double* out2)
+extern "C" int cl_dist_bin_hist(cl_chrom* c, int32_t cut, uint32_t lo, uint32_t hi, int shift, uint64_t* hist2048)
 {
-    if (!out2) return fail(CL_ERR_ARG, "cl_dist_sqdev: out is null");
-    out2[0] = out2[1] = 0.0;
+    if (!hist2048) return fail(CL_ERR_ARG, "cl_dist_bin_hist: out is null");
+    memset(hist2048, 0, K7_FINE * sizeof(uint64_t));
+    if (shift < 0 || shift > 31 || hi < lo || (((uint64_t)hi - lo + ((1ull << shift) - 1)) >> shift) > K7_FINE)
+        return fail(CL_ERR_ARG, "cl_dist_bin_hist: (hi - lo) >> shift must fit 2048 bins");
     if (c && c->n == 0) return CL_OK;
     int rc = k7_prepare(c);
     if (rc) return rc;
-    cl_chrom::Slot& sl = c->slot[c->last_slot];
-    const int n = (int)c->n;
-    hipLaunchKernelGGL(k7_pass2, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, n, cut, c->d_x, c->d_y, sl.labels.as<int>(),
-                       c->k7_cls.as<signed char>(), mean_inter, mean_self, c->k7_parts.as<double>());
-    std::vector<double> h(2 * K7_BLOCKS);
-    HIP_TRY(hipMemcpyAsync(h.data(), c->k7_parts.p, 2 * K7_BLOCKS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int k = 0; k < K7_BLOCKS; ++k) { out2[0] += h[2 * k]; out2[1] += h[2 * k + 1]; }
-    return CL_OK;
-}
-
-extern "C" int cl_dist_hist(cl_chrom* c, int32_t cut, int group, uint32_t prefix, int shift, uint64_t* hist256)
-{
-    if (!hist256) return fail(CL_ERR_ARG, "cl_dist_hist: out is null");
-    memset(hist256, 0, 256 * sizeof(uint64_t));
-    if (group < 0 || group > 1 || shift < 0 || shift > 24 || (shift & 7)) return fail(CL_ERR_ARG, "cl_dist_hist: bad group / shift");
-    if (c && c->n == 0) return CL_OK;
-    int rc = k7_prepare(c);
-    if (rc) return rc;
-    cl_chrom::Slot& sl = c->slot[c->last_slot];
-    const int n = (int)c->n;
     unsigned long long* dh = (unsigned long long*)c->k7_parts.p;
-    HIP_TRY(hipMemsetAsync(dh, 0, 256 * 8, c->stream));
-    hipLaunchKernelGGL(k7_hist, dim3(std::min(nblocks(n), 2048)), dim3(TPB), 0, c->stream, n, cut, c->d_x, c->d_y, sl.labels.as<int>(),
-                       c->k7_cls.as<signed char>(), group, (unsigned)prefix, shift, dh);
-    HIP_TRY(hipMemcpyAsync(hist256, dh, 256 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(dh, 0, K7_FINE * 8, c->stream));
+    const int n = (int)c->n;
+    hipLaunchKernelGGL(k7_bin_hist, dim3(std::min(nblocks(n), K7_BLOCKS)), dim3(TPB), 0, c->stream, k7_source(c), cut, c->k7_cls.as<signed char>(),
+                       (unsigned)lo, (unsigned)hi, shift, dh);
+    HIP_TRY(hipMemcpyAsync(hist2048, dh, K7_FINE * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return CL_OK;
 }

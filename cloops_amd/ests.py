@@ -30,7 +30,7 @@ def estIntSelCutFrag(di, ds, log=1):
 
 
 def estIntSelCutFrag_from_stats(n_pos, sumlog, sqdev, median_pair, with_margin=False):
-    """The same estimator from pre-reduced statistics (cl_dist_stats / cl_dist_sqdev / radix select
+    """The same estimator from pre-reduced statistics (cl_dist_summary / cl_dist_bin_hist
     of the GPU library) instead of the raw distance lists:
       n_pos      [inter, self]  number of non-zero distances
       sumlog     [inter, self]  sum of log2|d|
@@ -55,3 +55,21 @@ def estIntSelCutFrag_from_stats(n_pos, sumlog, sqdev, median_pair, with_margin=F
         raw = float(2 ** cut)
         return rcut, rfrags, abs(raw - round(raw))
     return rcut, rfrags
+
+
+# ---- the log-binned first level of the exact median (cl_dist_summary of include/cloops_hip.h) -----------------
+def logbin(d):
+    """bin of a distance d >= 1: floor(log2 d) * 128 + the 7 bits below the leading one (monotone in d)"""
+    d = int(d)
+    e = d.bit_length() - 1
+    m = ((d >> (e - 7)) if e >= 7 else (d << (7 - e))) & 127
+    return e * 128 + m
+
+
+def logbin_range(b):
+    """[lo, hi) of the distances that fall into log bin b"""
+    e, m = divmod(int(b), 128)
+    if e >= 7:
+        return (128 + m) << (e - 7), (128 + m + 1) << (e - 7)
+    lo = (128 + m) >> (7 - e)
+    return lo, lo + 1

@@ -117,6 +117,7 @@ class ChromCache(object):
         r.ids = np.arange(len(r.X), dtype=np.int64) if ids is None else np.asarray(ids)
         r.d = r.Y.astype(np.int64) - r.X.astype(np.int64)
         r.chrom = api.Chromosome(r.X, r.Y, device=device)
+        r.chrom.set_device_labels(False)        # runs without a host destination (the sweep) skip the row-order scatter
         with self._lock:
             old = self._items.pop(f, None)
             self._items[f] = r
@@ -155,6 +156,7 @@ class ChromCache(object):
             r.ids = r.X = r.Y = np.zeros(0, np.int64)
         r.d = r.Y - r.X
         r.chrom = api.Chromosome(r.X, r.Y, device=device)
+        r.chrom.set_device_labels(False)
         with self._lock:
             old = self._items.pop(f, None)
             self._items[f] = r
@@ -392,32 +394,44 @@ def _pmap(pool, fn, items):
     return list(pool.map(fn, items))
 
 
-def _select_kth(chroms, cut, group, ranks, allsum=None, pool=None):
-    """Exact order statistics (0-based `ranks`, ascending) of the |d| of `group` over the union of
-    the chromosomes (of all ranks): 4-pass radix select; every pass sums one 256-bin histogram per
-    chromosome (and, with `allsum`, over the ranks)."""
-    out = []
-    cache = {}
+def _select_kth(chroms, cut, loghist, ranks, allsum=None, pool=None):
+    """Exact order statistics (0-based `ranks`, ascending) of the self group's |d| over the union of the chromosomes
+    (of all ranks).  `loghist` = the genome-wide log-binned histogram of cl_dist_summary (bins monotone in |d|): it
+    locates the bin of a rank; the bin is then refined with 2048-bin histograms of (|d| - lo) >> shift summed over the
+    chromosomes (and, with `allsum`, over the ranks) until single distances are resolved -- one refinement pass for
+    bins up to 2048 distances wide (|d| < 2^18), two beyond."""
+    from .ests import logbin_range
+    cum = np.cumsum(np.asarray(loghist, dtype=np.int64))
+    out, cache = [], {}
     for rank in ranks:
-        prefix, rem = 0, rank
-        for shift in (24, 16, 8, 0):
-            key = (prefix, shift)
+        b = int(np.searchsorted(cum, rank, side="right"))
+        rem = rank - (int(cum[b - 1]) if b > 0 else 0)
+        lo, hi = logbin_range(b)
+        while hi - lo > 1:
+            shift = 0
+            while ((hi - lo + (1 << shift) - 1) >> shift) > 2048:
+                shift += 1
+            key = (lo, hi, shift)
             if key not in cache:
-                h = np.zeros(256, dtype=np.uint64)
-                for hh in _pmap(pool, lambda r: r.chrom.dist_hist(cut, group, prefix, shift), chroms):
+                h = np.zeros(2048, dtype=np.int64)
+                for hh in _pmap(pool, lambda r: r.chrom.dist_bin_hist(cut, lo, hi, shift), chroms):
                     h += hh
-                if allsum is not None:
-                    h = allsum(h.astype(np.int64)).astype(np.uint64)
-                cache[key] = h
-            c = np.cumsum(cache[key].astype(np.int64))
-            digit = int(np.searchsorted(c, rem, side="right"))
-            rem -= int(c[digit - 1]) if digit > 0 else 0
-            prefix = (prefix << 8) | digit
-        out.append(prefix)
+                cache[key] = allsum(h) if allsum is not None else h
+            c = np.cumsum(cache[key])
+            k = int(np.searchsorted(c, rem, side="right"))
+            rem -= int(c[k - 1]) if k > 0 else 0
+            lo, hi = lo + (k << shift), min(hi, lo + ((k + 1) << shift))
+        out.append(lo)
     return out
 
 
 SWEEP_THREADS = 8
+
+
+def _lib_logbins():
+    from ._lib import DIST_LOGBINS
+    return DIST_LOGBINS
+
 #: |2**cut - nearest integer| below which runSweepFast re-derives the cut from the distance lists (ests.py:57 truncates)
 CUT_RECHECK_MARGIN = 1e-6
 
@@ -487,7 +501,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                             probe(f, ep, m, step_cut, res)
                         dI, dS = _boxes_classified(r, res)
                         n_in = r.chrom.last_n_in()
-                        s1 = r.chrom.dist_stats(step_cut) if len(dI) else None
+                        s1 = r.chrom.dist_summary(step_cut) if len(dI) else None
                     finally:
                         r.lock.release()
                     return f, r, dI, len(dS), n_in, s1
@@ -495,7 +509,9 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                 step_I = {}
                 used = []
                 nS = n_in = 0
-                tot = {"n_all": [0, 0], "n_pos": [0, 0], "sumlog": [0.0, 0.0]}
+                tot = {"n_all": [0, 0], "n_pos": [0, 0], "sumx": [0.0, 0.0], "sumxx": [0.0, 0.0]}
+                loghist = np.zeros(_lib_logbins(), dtype=np.int64)
+                xshift = 0.0
                 for f, r, dI, ndS, nin, s1 in _pmap(pool, collect, live):
                     nS += ndS
                     n_in += nin
@@ -505,9 +521,10 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                     used.append(r)
                     acc.setdefault(r.key, {"f": f, "steps": []})["steps"].append(dI)
                     for gg in (0, 1):
-                        tot["n_all"][gg] += s1["n_all"][gg]
-                        tot["n_pos"][gg] += s1["n_pos"][gg]
-                        tot["sumlog"][gg] += s1["sumlog"][gg]
+                        for kk in ("n_all", "n_pos", "sumx", "sumxx"):
+                            tot[kk][gg] += s1[kk][gg]
+                    loghist += s1["loghist"]
+                    xshift = s1["xshift"]
                 g = gsum(np.asarray([sum(len(v["boxes"]) for v in step_I.values()), nS, n_in, len(step_I)], dtype=np.int64))
                 st = {"eps": ep, "minPts": m, "cut_in": int(cut), "n_inter": int(g[0]), "n_self": int(g[1]), "n_in": int(g[2])}
                 steps.append(st)
@@ -515,20 +532,21 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                     if log:
                         log("ERROR: no inter-ligation PETs detected for eps %s minPts %s,can't model the distance cutoff,continue anyway" % (ep, m))
                     continue
+                # the genome-wide statistics: everything is additive over chromosomes and ranks
                 gi = gsum(np.asarray(tot["n_all"] + tot["n_pos"], dtype=np.int64))
-                gf = gsum(np.asarray(tot["sumlog"], dtype=np.float64))
-                tot = {"n_all": [int(gi[0]), int(gi[1])], "n_pos": [int(gi[2]), int(gi[3])], "sumlog": [float(gf[0]), float(gf[1])]}
+                gf = gsum(np.asarray(tot["sumx"] + tot["sumxx"] + [xshift if used else 0.0, 1.0 if used else 0.0], dtype=np.float64))
+                loghist = gsum(loghist)
+                xshift = float(gf[4]) / max(float(gf[5]), 1.0)            # the library constant (ranks without a chromosome report 0)
+                tot = {"n_all": [int(gi[0]), int(gi[1])], "n_pos": [int(gi[2]), int(gi[3])]}
                 if tot["n_all"][0] > 0 and tot["n_all"][1] > 0:      # pipe.py:256-259
                     if tot["n_pos"][0] == 0 or tot["n_pos"][1] == 0:
                         raise ValueError("cannot convert float NaN to integer")      # what int(2 ** nan) raises in ests.py:57
-                    mi, ms = tot["sumlog"][0] / tot["n_pos"][0], tot["sumlog"][1] / tot["n_pos"][1]
-                    sq = [0.0, 0.0]
-                    for q in _pmap(pool, lambda r: r.chrom.dist_sqdev(step_cut, mi, ms), used):
-                        sq[0] += q[0]
-                        sq[1] += q[1]
-                    sq = [float(v) for v in gsum(np.asarray(sq, dtype=np.float64))]
+                    # sum log2|d| and the sum of squared deviations from the group mean, from sum x and sum x^2 (x = log2|d| - xshift)
+                    sumlog = [float(gf[0]) + xshift * tot["n_pos"][0], float(gf[1]) + xshift * tot["n_pos"][1]]
+                    sq = [float(gf[2]) - float(gf[0]) ** 2 / tot["n_pos"][0], float(gf[3]) - float(gf[1]) ** 2 / tot["n_pos"][1]]
+                    tot["sumlog"] = sumlog
                     n1 = tot["n_pos"][1]
-                    med = _select_kth(used, cut, 1, sorted({(n1 - 1) // 2, n1 // 2}), allsum, pool)
+                    med = _select_kth(used, cut, loghist, sorted({(n1 - 1) // 2, n1 // 2}), allsum, pool)
                     cut_2, frags, margin = estIntSelCutFrag_from_stats(tot["n_pos"], tot["sumlog"], sq, (med[0], med[-1]), with_margin=True)
                     if margin < CUT_RECHECK_MARGIN and allsum is None:
                         # 2**cut sits on an integer boundary within the rounding noise of the reduction order: settle

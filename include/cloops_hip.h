@@ -161,21 +161,27 @@ int cl_neighbor_counts(cl_chrom* c, int32_t eps, int32_t cut, int32_t* counts_ou
  * (estIntSelCutFrag), reduced on the GPU instead of materialising the reference's `dis` / `dss`
  * lists (cLoops/pipe.py:63,106-109).  Group 0 = PETs of inter-ligation clusters, group 1 = PETs of
  * self-ligation clusters plus the PETs removed by `cut` (pass the SAME cut as to cl_cluster).
- *   cl_dist_stats : n_all  = len(dis) / len(dss);  n_pos, sumlog = count and sum of log2|d| over d != 0
- *   cl_dist_sqdev : sum of (log2|d| - mean)^2 over d != 0 for the given (genome-wide) means
- *   cl_dist_hist  : one pass of an exact radix select for the median: histogram of the byte
- *                   (|d| >> shift) & 255 over the |d| of `group` whose higher bits equal `prefix`
- *                   (shift = 24, 16, 8, 0; prefix ignored at shift 24)
- * All three are additive over chromosomes (and over GPUs), which is what the sweep driver uses.
+ *   cl_dist_summary  : ONE pass: n_all = len(dis) / len(dss); n_pos, sumx, sumxx = count, sum and sum of squares of
+ *                      x = log2|d| - xshift over d != 0 (mean and standard deviation follow from them); loghist =
+ *                      histogram of the self group's |d| over bins that are monotone in |d|:
+ *                      bin = floor(log2 d) * 128 + (the 7 bits below the leading one)  -- the first level of the EXACT
+ *                      median (ests.py:52,58), fine enough to end the search in one more pass for any realistic data
+ *   cl_dist_bin_hist : refinement: histogram of (|d| - lo) >> shift over the self group's lo <= |d| < hi (2048 bins)
+ * Both are additive over chromosomes (and over GPUs), which is what the sweep driver uses.  The kernels read the
+ * run's sorted arrays (distance = the in-strip coordinate) and its labels in sorted order -- no row-aligned labels
+ * are needed.
  */
+#define CL_DIST_LOGBINS 3840
 typedef struct {
     int64_t n_all[2];
     int64_t n_pos[2];
-    double sumlog[2];
-} cl_dstats;
-int cl_dist_stats(cl_chrom* c, int32_t cut, cl_dstats* out);
-int cl_dist_sqdev(cl_chrom* c, int32_t cut, double mean_inter, double mean_self, double* out2);
-int cl_dist_hist(cl_chrom* c, int32_t cut, int group, uint32_t prefix, int shift, uint64_t* hist256);
+    double sumx[2];
+    double sumxx[2];
+    double xshift;
+    uint64_t loghist[CL_DIST_LOGBINS];
+} cl_dsummary;
+int cl_dist_summary(cl_chrom* c, int32_t cut, cl_dsummary* out);
+int cl_dist_bin_hist(cl_chrom* c, int32_t cut, uint32_t lo, uint32_t hi, int shift, uint64_t* hist2048);
 
 /*
  * Interval counting for the significance test of candidate loops (cLoops/cModel.py:60-80,108-143):
@@ -192,8 +198,14 @@ int cl_dist_hist(cl_chrom* c, int32_t cut, int group, uint32_t prefix, int shift
 int cl_sig_counts(cl_chrom* c, int32_t cut, int32_t n_records, const int32_t* windows, int32_t* out, int64_t* n_pets);
 
 /* Device pointer to the labels of the last run (n int32, row aligned) -- lets the caller
- * keep results on the GPU (e.g. to hand them to RCCL) without a host round trip. */
+ * keep results on the GPU (e.g. to hand them to RCCL) without a host round trip.  NULL if the run did not
+ * produce row-aligned labels (see cl_set_device_labels). */
 const int32_t* cl_labels_device(const cl_chrom* c);
+
+/* Row-aligned device labels for runs WITHOUT a host destination (labels_out == NULL): enabled = 1 (default) keeps
+ * producing them (for cl_labels_device); enabled = 0 skips the scatter to input-row order -- the sweep driver only
+ * needs the cluster table and the distance statistics, which work on the sorted order. */
+void cl_set_device_labels(cl_chrom* c, int enabled);
 
 /* Enable (1) / disable (0) HIP-event timing of the kernels of subsequent runs. */
 void cl_set_profiling(cl_chrom* c, int enabled);

@@ -23,6 +23,9 @@ class FakeChromosome(object):
     def set_layout_reuse(self, on=True):
         pass
 
+    def set_device_labels(self, on=True):
+        pass
+
     def cluster(self, variant, eps, minPts, cut=0, want_labels=True, want_boxes=True, pinned=False):
         vname = {1: "v1", 2: "v2", 3: "block"}[api.VARIANTS[variant]]
         lab = oracle.single_dbscan(vname, self.X, self.Y, eps, minPts, cut)["labels"]
@@ -66,31 +69,33 @@ class FakeChromosome(object):
             g = np.where(d < cut, 1, g)
         return g, np.abs(d)
 
-    def dist_stats(self, cut=0):
+    def dist_summary(self, cut=0):
+        from cloops_amd import ests
         g, ad = self._groups(cut)
-        out = {"n_all": [], "n_pos": [], "sumlog": []}
+        xshift = 11.0
+        out = {"n_all": [], "n_pos": [], "sumx": [], "sumxx": [], "xshift": xshift, "loghist": np.zeros(3840, np.int64)}
         for k in (0, 1):
             a = ad[g == k]
             out["n_all"].append(int(len(a)))
             a = a[a > 0]
             out["n_pos"].append(int(len(a)))
-            out["sumlog"].append(float(np.log2(a.astype(np.float64)).sum()) if len(a) else 0.0)
+            x = np.log2(a.astype(np.float64)) - xshift
+            out["sumx"].append(float(x.sum()))
+            out["sumxx"].append(float((x * x).sum()))
+            if k == 1 and len(a):
+                a = a.astype(np.int64)
+                e = np.floor(np.log2(a.astype(np.float64))).astype(np.int64)
+                e = np.where((np.int64(1) << e) > a, e - 1, e)                  # guard against a rounded-up log2
+                e = np.where((np.int64(1) << (e + 1)) <= a, e + 1, e)
+                m = np.where(e >= 7, a >> np.maximum(e - 7, 0), a << np.maximum(7 - e, 0)) & 127
+                out["loghist"] = np.bincount(e * 128 + m, minlength=3840).astype(np.int64)
+                assert ests.logbin(int(a[0])) == int(e[0] * 128 + m[0])
         return out
 
-    def dist_sqdev(self, cut, mean_inter, mean_self):
+    def dist_bin_hist(self, cut, lo, hi, shift):
         g, ad = self._groups(cut)
-        out = []
-        for k, m in ((0, mean_inter), (1, mean_self)):
-            a = ad[(g == k) & (ad > 0)].astype(np.float64)
-            out.append(float(((np.log2(a) - m) ** 2).sum()) if len(a) else 0.0)
-        return out
-
-    def dist_hist(self, cut, group, prefix, shift):
-        g, ad = self._groups(cut)
-        a = ad[(g == group) & (ad > 0)].astype(np.uint64)
-        if shift < 24:
-            a = a[(a >> np.uint64(shift + 8)) == np.uint64(prefix)]
-        return np.bincount(((a >> np.uint64(shift)) & np.uint64(255)).astype(np.int64), minlength=256).astype(np.uint64)
+        a = ad[(g == 1) & (ad >= lo) & (ad < hi)].astype(np.int64)
+        return np.bincount((a - lo) >> shift, minlength=2048).astype(np.int64)
 
     def sig_counts(self, windows, cut=0):
         """numpy stand-in of kernel K8 on explicit index sets (sorted arrays of row positions)"""

@@ -34,33 +34,43 @@ def test_sweep_fast_gpu_statistics(jd):
     pipe_checks.check_sweep_fast(pipe, jd)
 
 
-def test_dist_stats_match_numpy(jd):
-    """K7 reductions against numpy on the lists the reference would build (pipe.py:63,106-109)."""
+@pytest.mark.parametrize("variant", ["v2", "v1", "block"])
+@pytest.mark.parametrize("device_labels", [True, False])
+def test_dist_stats_match_numpy(jd, variant, device_labels):
+    """K7 reductions against numpy on the lists the reference would build (pipe.py:63,106-109): one-pass summary
+    (counts, sum / sum of squares of the shifted log2 distances, log-binned histogram) and the exact median through
+    the bin refinement -- from the sorted arrays (rotated variants, with and without row-order labels) and from
+    row-order labels (block variant)."""
     import oracle
     import golden_util as G
-    from cloops_amd import api
+    from cloops_amd import api, ests
     X, Y = G.chr21_xy()
     ch = api.Chromosome(X, Y)
-    for eps, minPts, cut in ((500, 5, 0), (1000, 5, 4601)):
-        ch.cluster("v2", eps, minPts, cut, want_labels=False)
-        ref = oracle.single_dbscan("v2", X, Y, eps, minPts, cut)
-        st = ch.dist_stats(cut)
+    ch.set_device_labels(device_labels)
+    for eps, minPts, cut in ((500, 5, 0), (1000, 5, 4601), (1000, 4, 300)):
+        ch.cluster(variant, eps, minPts, cut, want_labels=False)
+        ref = oracle.single_dbscan(variant, X, Y, eps, minPts, cut)
+        st = ch.dist_summary(cut)
         assert st["n_all"] == [len(ref["dis"]), len(ref["dss"])]
         for g, arr in ((0, ref["dis"]), (1, ref["dss"])):
             a = np.abs(arr)
             a = a[a > 0]
             assert st["n_pos"][g] == len(a)
-            assert abs(st["sumlog"][g] - np.log2(a).sum()) < 1e-6 * max(1.0, np.log2(a).sum())
-        mi, ms = st["sumlog"][0] / st["n_pos"][0], st["sumlog"][1] / st["n_pos"][1]
-        sq = ch.dist_sqdev(cut, mi, ms)
+            sumlog = st["sumx"][g] + st["xshift"] * len(a)
+            assert abs(sumlog - np.log2(a).sum()) < 1e-6 * max(1.0, np.log2(a).sum())
+            sq = st["sumxx"][g] - st["sumx"][g] ** 2 / len(a)
+            assert abs(np.sqrt(sq / len(a)) - np.log2(a).std()) < 1e-9
         a = np.abs(ref["dss"]); a = a[a > 0]
-        assert abs(np.sqrt(sq[1] / len(a)) - np.log2(a).std()) < 1e-9
         srt = np.sort(a).astype(np.int64)
+        assert np.array_equal(st["loghist"], np.bincount([ests.logbin(d) for d in srt.tolist()], minlength=3840))
         n1 = len(srt)
         class R(object):
             chrom = ch
-        got = pipe._select_kth([R], cut, 1, sorted({(n1 - 1) // 2, n1 // 2}))
+        got = pipe._select_kth([R], cut, st["loghist"], sorted({(n1 - 1) // 2, n1 // 2}))
         assert got[0] == srt[(n1 - 1) // 2] and got[-1] == srt[n1 // 2]
+        # any rank, also in wide bins (two refinement passes)
+        for rk in (0, n1 // 7, n1 - 1):
+            assert pipe._select_kth([R], cut, st["loghist"], [rk])[0] == srt[rk]
     ch.close()
 
 
