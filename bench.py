@@ -12,8 +12,11 @@ A "step" is one pass of the hot path over the batch: ONE whole 12-run sweep over
 resident in HBM" to "deduplicated, distance-filtered candidate-loop table on the host" (cluster tables cross
 PCIe every run; labels stay on the device -- the sweep never needs them).  `value` = PETs that entered DBSCAN,
 summed over the 12 runs and the K timed sweeps, / wall time; `sweep_wall_s` = ms_per_step / 1000 is the second
-half of the metric.  Every sweep redoes everything (keys, sort, region query ... table) for every run; the first
-sweep of the process (allocations) is reported separately as `first_sweep_s`.
+half of the metric.  Every sweep does all of its own work: one sort per (chromosome, eps) -- the sorted order does not
+depend on minPts and a cut only removes rows, so the four minPts runs of an eps start from a stable compaction of
+that layout by their cut (cl_set_layout_reuse; the layout of the previous sweep's last eps never matches the next
+sweep's first) -- and region query, components, borders, cluster table and distance statistics for every run.  The
+first sweep of the process (allocations) is reported separately as `first_sweep_s`.
 
 With N > 1 (`--gpus N` spawns N ranks through torch.distributed.run when not already launched by it) the 23
 chromosomes are LPT-sharded over the ranks (cloops_amd.dist.shard_chromosomes; chromosomes are independent units,
@@ -22,8 +25,10 @@ genome-wide estimate) and the final candidate tables are all-gathered once per s
 exchanges.  Total work is fixed (the same 200 M PETs): "scaling": "strong".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  "roofline"      K2 region-query kernel, measured INSIDE the timed sweeps on chr1 (16.4 M PETs) with HIP events:
-                  algorithmic bytes / launch duration, overall and per eps
+  "roofline"      K2 region-query kernel on chr1 (16.4 M PETs) at the sweep's own 12 (eps, minPts, cut) settings, timed
+                  with HIP events on the library's stream right after the timed sweeps, chr1 ALONE on the GPU: inside a
+                  sweep the kernels of the 23 chromosomes overlap on the device, so an event bracket there measures
+                  contention, not the kernel (that figure is kept as `in_sweep_avg_launch_ms`)
   "secondary_5M"  BASELINE.json configs[1] (5 M PETs, one chromosome, eps 2000, minPts 5), the round-1 headline
   "cpu_baseline"  the CPU oracle (C port of cDBSCAN2) on this box's host cores, one process per chromosome
 """
@@ -194,8 +199,17 @@ def main(argv=None):
                        "parallelism": "23 chromosomes LPT-sharded over %d GPU(s)" % world,
                        "synthesis_s_rank0": round(t_gen, 2)},
         }
-        if k2_log:
-            line["roofline"] = roofline_block(k2_log, len(pipe.CACHE.get(probe_f).d))
+        if k2_log and on_gpu:
+            # replay the sweep's settings on the probe chromosome alone (3 launches each): the kernel without neighbours
+            r = pipe.CACHE.get(probe_f)
+            solo = []
+            for st in steps:
+                for rep in range(3):
+                    r.chrom.cluster_async(VARIANT, st["eps"], st["minPts"], st["cut_in"], want_labels=False)
+                    res = r.chrom.wait()
+                    solo.append((st["eps"], st["minPts"], st["cut_in"], dict(res.timing)))
+            line["roofline"] = roofline_block(solo, len(r.d))
+            line["roofline"]["in_sweep_avg_launch_ms"] = sum(max(t[3]["ms_region"] - t[3]["ms_bracket"], 1e-6) for t in k2_log) / len(k2_log)
     # the secondary single-eps figure and the CPU baseline: rank 0, single GPU only
     if rank == 0 and world == 1 and on_gpu:
         pipe.CACHE.clear()
@@ -230,9 +244,9 @@ def k2_bytes(tm):
 
 
 def roofline_block(k2_log, n_probe):
-    """K2 (k_region_count) inside the timed sweeps on the probe chromosome: K2 is the only kernel between its two
-    events; the bracket around an EMPTY kernel (event packets + dispatch gap, calibrated by the library) is taken
-    out of every launch -- rocprofv3's kernel duration has no such term (profiles/README.md)."""
+    """K2 (k_region_core) on the probe chromosome: K2 is the only kernel between its two events; the bracket around
+    an EMPTY kernel (event packets + dispatch gap, calibrated by the library) is taken out of every launch --
+    rocprofv3's kernel duration has no such term (profiles/README.md)."""
     def agg(rows):
         b = sum(k2_bytes(tm) for _, _, _, tm in rows)
         raw = sum(tm["ms_region"] for _, _, _, tm in rows)
@@ -254,9 +268,9 @@ def roofline_block(k2_log, n_probe):
             traffic, src = tj.get("hbm_bytes_per_launch"), "profiles/k2_traffic.json (%s; %s)" % (tj.get("workload"), tj.get("source"))
         except Exception:
             pass
-    return {"bound": "hbm", "kernel": "k_region_count", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    return {"bound": "hbm", "kernel": "k_region_core", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
-            "launches": len(k2_log), "probe": "chr1 of the genome (%d PETs), every run of the timed sweeps" % n_probe,
+            "launches": len(k2_log), "probe": "chr1 of the genome (%d PETs) alone on the GPU, the sweep's 12 (eps, minPts, cut) settings x 3 launches" % n_probe,
             "algorithmic_bytes_per_launch": b // len(k2_log), "avg_launch_ms": net / len(k2_log),
             "avg_event_bracket_ms": raw / len(k2_log), "empty_kernel_bracket_ms": float(k2_log[0][3]["ms_bracket"]),
             "per_eps": per_eps}
@@ -269,6 +283,7 @@ def secondary_5m(api, synth_chrom, steps=20, warmup=3):
     X, Y = synth_chrom(N_5M, CHR1_LEN, 2000)
     ch = api.Chromosome(X, Y, device=0)
     ch.set_profiling(True)
+    ch.set_layout_reuse(False)             # one (eps, minPts) repeated: every step must pay its whole run, sort included
 
     def run(nsteps, k2):
         res = None

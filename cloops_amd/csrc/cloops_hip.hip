@@ -987,8 +987,9 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
 // Same tiling as K2: a workgroup owns 256 consecutive sorted PETs and stages them plus a halo
 // as (q,p) pairs and one int of per-PET payload (neighbour count or component root).  Strip
 // segments inside the staged range are walked in LDS; anything else falls back to global memory.
-#define T_HALO 128
-#define T_WIN (TPB + 2 * T_HALO)
+// Two shapes: NT = 256 PETs + 128 halo where strips are short (sparse data), NT = 1024 + 512 where strips hold hundreds
+// of PETs (dense data at large eps: the three strips of a query must fit the window, or the walk falls back to global memory).
+#define T_STEPS_LONG 11          // search depth for staged segments of 256 .. 2047 PETs
 
 struct Tile {
     LdsPairs w;         // (q, p), indexed by global sorted index
@@ -1005,15 +1006,17 @@ __device__ __forceinline__ int tile_of_block(int bid)
 static inline int tile_grid(int ntiles) { return ((ntiles + 8 * K2_RUN - 1) / (8 * K2_RUN)) * (8 * K2_RUN); }
 
 // all threads of the workgroup; returns false (for the whole workgroup) if the tile is empty
+template <int NT, int HALO>
 __device__ __forceinline__ bool tile_stage(Tile& t, int2* lw, int* lx, int ntiles, int M,
                                            const int* __restrict__ gq, const int* __restrict__ gp,
                                            const int* __restrict__ gx)
 {
+    constexpr int T_WIN = NT + 2 * HALO;
     const int tile = tile_of_block(blockIdx.x);
-    t.t0 = tile * TPB;
+    t.t0 = tile * NT;
     if (tile >= ntiles || t.t0 >= M) return false;
-    const int base = t.t0 - T_HALO;
-    for (int k = threadIdx.x; k < T_WIN; k += TPB) {
+    const int base = t.t0 - HALO;
+    for (int k = threadIdx.x; k < T_WIN; k += NT) {
         const int gi = base + k;
         const bool in = gi >= 0 && gi < M;
         lw[k] = in ? make_int2(gq[gi], gp[gi]) : make_int2(0, 0);
@@ -1032,8 +1035,8 @@ __device__ __forceinline__ void tile_visit_segment(const Tile& t, const int* __r
                                                    const int* __restrict__ gx, int sb, int se, int qlo, int qhi, F&& f)
 {
     if (sb >= se) return;
-    if (sb >= t.wbeg && se <= t.wend && se - sb <= 255) {
-        int j = lds_lower_bound8(t.w, sb, se, qlo);
+    if (sb >= t.wbeg && se <= t.wend && se - sb <= 2047) {
+        int j = (se - sb <= 255) ? lds_lower_bound8(t.w, sb, se, qlo) : lds_lower_bound8<T_STEPS_LONG>(t.w, sb, se, qlo);
         for (; j < se; ++j) {
             const int2 c = t.w[j];
             if (c.x > qhi) break;
@@ -1126,20 +1129,21 @@ __global__ void k_init_arrays(int n, int* __restrict__ parent, int* __restrict__
 // max-scan then gives every core its chain head.  The union-find forest starts flat
 // (parent = chain head), so no million-long pointer chains ever exist -- dense diagonals
 // (self-ligation PETs) become one chain per strip.
-__global__ void __launch_bounds__(TPB)
+template <int NT, int HALO>
+__global__ void __launch_bounds__(NT)
 k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const int* __restrict__ sa,
               const int* __restrict__ strip_start, const int* __restrict__ cnt, int* __restrict__ chainflag,
               int* __restrict__ chainlast, int* __restrict__ head)
 {
-    __shared__ int2 lw[T_WIN];
-    __shared__ int lx[T_WIN];
+    __shared__ int2 lw[NT + 2 * HALO];
+    __shared__ int lx[NT + 2 * HALO];
     const int M = strip_start[g.S];
     if (head) {                                          // filtered tail: singleton cells (keys of the cellfirst scan)
-        const int ig = tile_of_block(blockIdx.x) * TPB + threadIdx.x;
+        const int ig = tile_of_block(blockIdx.x) * NT + threadIdx.x;
         if (ig >= M && ig < n) head[ig] = ig;
     }
     Tile t;
-    if (!tile_stage(t, lw, lx, ntiles, M, sv, sa, cnt)) return;
+    if (!tile_stage<NT, HALO>(t, lw, lx, ntiles, M, sv, sa, cnt)) return;
     const int i = t.t0 + threadIdx.x;
     if (i >= M) return;
     const int2 me = t.w[i];
@@ -1149,8 +1153,10 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
         // instead of head flags + a max-scan over all PETs (variant 2 runs with A0 = V0 = 0)
         const int p0 = me.y & ~(g.peps - 1), q0 = div_eps(g, me.x) * g.eps;      // lower edges of the rotated cell (sp space / q space)
         int pos = t.wbeg;
+        constexpr int TOP = (NT + HALO <= 512) ? 256 : ((NT + HALO <= 1024) ? 512 : 1024);      // 2 * TOP - 1 >= the staged range up to i
+        static_assert(2 * TOP > NT + HALO, "cell-head bisection covers the window");
 #pragma unroll
-        for (int step = 256; step >= 1; step >>= 1) {
+        for (int step = TOP; step >= 1; step >>= 1) {
             const int idx = pos + step - 1;
             const int2 c = t.w[min(idx, i)];
             pos = (idx <= i && (c.y < p0 || c.x < q0)) ? pos + step : pos;
@@ -1217,20 +1223,21 @@ __global__ void k_block_pmax(int n, const int* __restrict__ chainid, const int* 
     for (int o = 16; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
     if ((threadIdx.x & 31) == 0 && i < n) pmax32[i >> 5] = v;
 }
-__global__ void __launch_bounds__(TPB)
+template <int NT, int HALO>
+__global__ void __launch_bounds__(NT)
 k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
               const int* __restrict__ strip_start, const int* __restrict__ chainid, const int* __restrict__ chain_qend,
               const int* __restrict__ pmax32, int* parent)
 {
-    __shared__ int2 lw[T_WIN];
-    __shared__ int lx[T_WIN];
-    __shared__ short l_list[TPB];
-    __shared__ int l_wcount[TPB / 64];
+    __shared__ int2 lw[NT + 2 * HALO];
+    __shared__ int lx[NT + 2 * HALO];
+    __shared__ short l_list[NT];
+    __shared__ int l_wcount[NT / 64];
     const int M = strip_start[g.S];
     Tile t;
-    if (!tile_stage(t, lw, lx, ntiles, M, sv, sa, chainid)) return;
+    if (!tile_stage<NT, HALO>(t, lw, lx, ntiles, M, sv, sa, chainid)) return;
     const int i0 = t.t0 + threadIdx.x;
-    const int total = block_compact(i0 < M && t.x[i0 < M ? i0 : t.t0] >= 0, l_list, l_wcount);
+    const int total = block_compact<NT>(i0 < M && t.x[i0 < M ? i0 : t.t0] >= 0, l_list, l_wcount);
     if ((int)threadIdx.x >= total) return;
     const int i = t.t0 + l_list[threadIdx.x];
     const int2 me = t.w[i];
@@ -1256,7 +1263,7 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
                 uf_unite(parent, A, B);                    // more chains than slots: unite right away
             }
         };
-        if (tb >= t.wbeg && b - tb <= 255) {
+        if (tb >= t.wbeg && b - tb <= 2047) {
             // short strips: the whole neighbour strip is staged.  Every candidate lies one strip below, so
             // "within eps in p" is p_j >= p_i - eps.  In a well-filled strip the walk jumps past a chain once
             // it has been touched (its last core has q = chain_qend[chain]): a window covered by one chain
@@ -1265,9 +1272,11 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
             const bool dense = b - tb > 48;
             // search depth chosen per wave (a per-lane choice would make most waves run every variant)
             int j;
+            const bool longA = __any(b - tb > 255);
             if (!__any(b - tb > 31)) j = lds_lower_bound8<5>(t.w, tb, b, qlo);
             else if (!__any(b - tb > 63)) j = lds_lower_bound8<6>(t.w, tb, b, qlo);
-            else j = lds_lower_bound8<8>(t.w, tb, b, qlo);
+            else if (!longA) j = lds_lower_bound8<8>(t.w, tb, b, qlo);
+            else j = lds_lower_bound8<T_STEPS_LONG>(t.w, tb, b, qlo);
             while (j < b) {
                 // four candidates per round, all LDS reads in flight before the first compare
                 int2 cv[4]; int bv[4];
@@ -1284,7 +1293,7 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
                         if (dense) {
                             const int qe = chain_qend[bv[u]];
                             stop = true;
-                            next = (qe >= qhi) ? b : lds_upper_bound8(t.w, j + u + 1, b, qe);
+                            next = (qe >= qhi) ? b : (longA ? lds_upper_bound8<T_STEPS_LONG>(t.w, j + u + 1, b, qe) : lds_upper_bound8(t.w, j + u + 1, b, qe));
                         }
                     }
                 }
@@ -1440,26 +1449,27 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
 #define OWNER_CONTESTED 0x40000000
 __device__ __forceinline__ int owner_root(int o) { return o < 0 ? -1 : (o & (OWNER_CONTESTED - 1)); }
 
-__global__ void __launch_bounds__(TPB)
+template <int NT, int HALO>
+__global__ void __launch_bounds__(NT)
 k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
          const int* __restrict__ strip_start, const int* __restrict__ root, const int* __restrict__ compkey,
          const int* __restrict__ ncore, const u32* __restrict__ srow, int* __restrict__ owner, int* __restrict__ bsize,
          int* __restrict__ usize)
 {
-    __shared__ int2 lw[T_WIN];
-    __shared__ int lx[T_WIN];
-    __shared__ short l_list[TPB];
-    __shared__ int l_wcount[TPB / 64];
+    __shared__ int2 lw[NT + 2 * HALO];
+    __shared__ int lx[NT + 2 * HALO];
+    __shared__ short l_list[NT];
+    __shared__ int l_wcount[NT / 64];
     const int M = strip_start[g.S];
     Tile t;
-    if (!tile_stage(t, lw, lx, ntiles, M, sv, sa, root)) return;
+    if (!tile_stage<NT, HALO>(t, lw, lx, ntiles, M, sv, sa, root)) return;
     const int i0 = t.t0 + threadIdx.x;
     bool border = false;
     if (i0 < M) {
         const int ri = t.x[i0];
         if (ri >= 0) owner[i0] = ri; else border = true;
     }
-    const int total = block_compact(border, l_list, l_wcount);
+    const int total = block_compact<NT>(border, l_list, l_wcount);
     if ((int)threadIdx.x >= total) return;
     const int i = t.t0 + l_list[threadIdx.x];
     const int2 me = t.w[i];
@@ -1530,16 +1540,17 @@ __global__ void k_mark_uncertain(GridParams g, const int* __restrict__ strip_sta
 // bound) distinct adjacent components in ascending key order
 struct Rec { int pt; int r[4]; };
 
-__global__ void __launch_bounds__(TPB)
+template <int NT, int HALO>
+__global__ void __launch_bounds__(NT)
 k_emit_records(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
                const int* __restrict__ strip_start, const int* __restrict__ root, const int* __restrict__ compkey,
                const int* __restrict__ state, const int* __restrict__ owner, Rec* __restrict__ recs, int rec_cap,
                int* __restrict__ counters)
 {
-    __shared__ int2 lw[T_WIN];
-    __shared__ int lx[T_WIN];
-    __shared__ short l_list[TPB];
-    __shared__ int l_wcount[TPB / 64];
+    __shared__ int2 lw[NT + 2 * HALO];
+    __shared__ int lx[NT + 2 * HALO];
+    __shared__ short l_list[NT];
+    __shared__ int l_wcount[NT / 64];
     if (counters[CTR_NU] == 0) return;
     const int M = strip_start[g.S];
     {
@@ -1547,17 +1558,17 @@ k_emit_records(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
         // UNCERTAIN can change hands: the fix-up walks a record's components in key order and a component
         // that is surely live ends the walk (k_resolve_release), so a record that starts with a live component
         // contributes nothing.  Nearly all tiles have no such point and leave before staging anything.
-        const int ip = tile_of_block(blockIdx.x) * TPB + threadIdx.x;
+        const int ip = tile_of_block(blockIdx.x) * NT + threadIdx.x;
         const int op = ip < M ? owner[ip] : -1;
         const bool cand = op >= 0 && (op & OWNER_CONTESTED) && state[owner_root(op)] == ST_UNKNOWN;
         if (!__syncthreads_or(cand)) return;
     }
     Tile t;
-    if (!tile_stage(t, lw, lx, ntiles, M, sv, sa, root)) return;
+    if (!tile_stage<NT, HALO>(t, lw, lx, ntiles, M, sv, sa, root)) return;
     const int i0 = t.t0 + threadIdx.x;
     const bool act = i0 < M && t.x[i0] < 0 && owner[i0] >= 0 && (owner[i0] & OWNER_CONTESTED) &&
                      state[owner_root(owner[i0])] == ST_UNKNOWN;
-    const int total = block_compact(act, l_list, l_wcount);
+    const int total = block_compact<NT>(act, l_list, l_wcount);
     if ((int)threadIdx.x >= total) return;
     const int i = t.t0 + l_list[threadIdx.x];
     const int2 me = t.w[i];
@@ -3577,8 +3588,21 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     const int n = (int)c->n;
     int* cnt = c->cnt.as<int>();
     int* counters = c->counters.as<int>();
-    const int ntiles = nblocks(n);
+    // tile shape of the traversal kernels.  The wide shape (1024 PETs + 512 halo: long strips stay in LDS) measured SLOWER
+    // than the narrow one on the dense workloads (chr1 of the 200 M genome, eps 5000-10000: K3 +7 %, K4 +12..22 %): the
+    // walks are bound by the candidates they touch, not by where those live -- it stays a developer knob.
+    int wide = 0;
+#ifdef CLOOPS_DEVEL
+    if (const char* e = getenv("CLOOPS_TILE_WIDE")) wide = atoi(e);
+#endif
+    const int tile_nt = wide ? 1024 : TPB;
+    const int ntiles = nblocks(n, tile_nt);
     const int tgrid = tile_grid(ntiles);
+#define TILE_LAUNCH(kernel, ...)                                                                                     \
+    do {                                                                                                             \
+        if (wide) hipLaunchKernelGGL((kernel<1024, 512>), dim3(tgrid), dim3(1024), 0, c->stream, __VA_ARGS__);       \
+        else hipLaunchKernelGGL((kernel<TPB, 128>), dim3(tgrid), dim3(TPB), 0, c->stream, __VA_ARGS__);              \
+    } while (0)
 
     LAUNCH(k_init_flags, n + 1, n, c->flag.as<int>(), counters);
     // row-aligned labels only when somebody reads them: k_final_labels then writes the label (or -1) of every PET that
@@ -3599,7 +3623,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     {
         // own-strip chains by scan; variant 2: the same tile kernel also finds every PET's cell head
         int* head = variant == CL_VARIANT_CDBSCAN2 ? c->head.as<int>() : nullptr;
-        hipLaunchKernelGGL(k_chain_flags, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, n, sv, sa, strip, cnt, c->chainflag.as<int>(),
+        TILE_LAUNCH(k_chain_flags, g, ntiles, n, sv, sa, strip, cnt, c->chainflag.as<int>(),
                            c->headidx.as<int>(), head);
         if (head) {
             // cellfirst: segmented suffix-min of the input rows, keyed by the cell's head index, so that
@@ -3625,19 +3649,19 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         pmax32 = c->hi.as<int>();
         LAUNCH(k_block_pmax, n, n, c->chainflag.as<int>(), sa, pmax32);
     }
-    hipLaunchKernelGGL(k_union_cores, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
+    TILE_LAUNCH(k_union_cores, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
                        pmax32, c->parent.as<int>());
     hipLaunchKernelGGL(k_flatten, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
            c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>());
     ev_record(c, 4);
     // K4
-    hipLaunchKernelGGL(k_border, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(),
+    TILE_LAUNCH(k_border, g, ntiles, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(),
                        c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>());
     if (variant == CL_VARIANT_CDBSCAN2) {
         const int rec_cap = n;
         LAUNCH(k_mark_uncertain, n, g, strip, c->root.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->state.as<int>(),
                c->ulist.as<int>(), counters);
-        hipLaunchKernelGGL(k_emit_records, dim3(tgrid), dim3(TPB), 0, c->stream, g, ntiles, sv, sa, strip, c->root.as<int>(),
+        TILE_LAUNCH(k_emit_records, g, ntiles, sv, sa, strip, c->root.as<int>(),
                            c->compkey.as<int>(), c->state.as<int>(), c->owner.as<int>(), c->recs.as<Rec>(), rec_cap, counters);
         hipLaunchKernelGGL(k_resolve_release, dim3(1), dim3(1024), 0, c->stream, minPts, c->ncore.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                            c->ulist.as<int>(), c->recs.as<Rec>(), c->lo.as<int>(), c->hi.as<int>(), counters);

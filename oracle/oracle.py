@@ -106,17 +106,25 @@ def single_dbscan(variant, X, Y, eps, minPts, cut=0):
     full[keep] = lab
     xs, ys = X[keep], Y[keep]
     dis = []
-    for c in np.unique(lab[lab >= 0]):            # set(labels.values) iterates ascending
-        m = lab == c
-        x0, x1, y0, y1 = xs[m].min(), xs[m].max(), ys[m].min(), ys[m].max()
-        if x0 == x1 or y0 == y1:                  # pipe.py:83-85
-            continue
-        if x1 < y0:                               # pipe.py:97
-            res["dataI"].append([int(x0), int(x1), int(y0), int(y1)])
-            dis.append((ys[m] - xs[m]).astype(np.float64))
-        else:
-            res["dataS"].append([int(x0), int(x1), int(y0), int(y1)])
-            dss.append((ys[m] - xs[m]).astype(np.float64))
+    # per-cluster bounding boxes by one sort of the labelled points (the reference loops over the clusters with a
+    # boolean mask each, pipe.py:78-102: O(K * N))
+    sel = np.flatnonzero(lab >= 0)
+    if len(sel):
+        order = sel[np.argsort(lab[sel], kind="stable")]
+        ls = lab[order]
+        starts = np.flatnonzero(np.concatenate([[True], ls[1:] != ls[:-1]]))
+        xo, yo = xs[order], ys[order]
+        x0, x1 = np.minimum.reduceat(xo, starts), np.maximum.reduceat(xo, starts)
+        y0, y1 = np.minimum.reduceat(yo, starts), np.maximum.reduceat(yo, starts)
+        ok = (x0 != x1) & (y0 != y1)                  # pipe.py:83-85
+        inter = ok & (x1 < y0)                        # pipe.py:97
+        selfl = ok & ~inter
+        res["dataI"] = np.stack([x0, x1, y0, y1], 1)[inter].astype(np.int64).tolist()      # ascending cluster id
+        res["dataS"] = np.stack([x0, x1, y0, y1], 1)[selfl].astype(np.int64).tolist()
+        cls_of_point = np.repeat(np.where(inter, 1, np.where(selfl, 2, 0)), np.diff(np.concatenate([starts, [len(ls)]])))
+        dd = (yo - xo).astype(np.float64)
+        dis.append(dd[cls_of_point == 1])
+        dss.append(dd[cls_of_point == 2])
     res["dis"] = np.concatenate(dis) if dis else np.zeros(0)
     res["dss"] = np.concatenate(dss) if dss else np.zeros(0)
     return res
