@@ -17,6 +17,7 @@ CL_ERR_EMPTY = -3
 CL_ERR_DOMAIN = -4
 CL_ERR_GRID = -5
 CL_ERR_NODEVICE = -6
+CL_ERR_HASH = -7
 
 VARIANT_CDBSCAN1 = 1
 VARIANT_CDBSCAN2 = 2
@@ -28,7 +29,7 @@ SYMBOLS = [
     "cl_cluster", "cl_get_boxes", "cl_neighbor_counts", "cl_labels_device", "cl_set_profiling",
     "cl_get_timing", "cl_version", "cl_host_alloc", "cl_host_free", "cl_cluster_async", "cl_wait", "cl_boxes_host",
     "cl_dist_summary", "cl_dist_bin_hist", "cl_last_n_in", "cl_sig_counts", "cl_cluster_weighted",
-    "cl_set_layout_reuse", "cl_set_device_labels",
+    "cl_set_layout_reuse", "cl_set_device_labels", "cl_set_table_export", "cl_cand_reset", "cl_cand_append", "cl_cand_finish",
 ]
 
 
@@ -102,6 +103,15 @@ def load():
     lib.cl_dist_bin_hist.argtypes = [vp, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
     lib.cl_set_device_labels.restype = None
     lib.cl_set_device_labels.argtypes = [vp, ctypes.c_int]
+    lib.cl_set_table_export.restype = None
+    lib.cl_set_table_export.argtypes = [vp, ctypes.c_int]
+    i64p = ctypes.POINTER(ctypes.c_int64)
+    lib.cl_cand_reset.restype = ctypes.c_int
+    lib.cl_cand_reset.argtypes = [vp]
+    lib.cl_cand_append.restype = ctypes.c_int
+    lib.cl_cand_append.argtypes = [vp, ctypes.c_int32, i64p, i64p]
+    lib.cl_cand_finish.restype = ctypes.c_int
+    lib.cl_cand_finish.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int64, i64p]
     lib.cl_sig_counts.restype = ctypes.c_int
     lib.cl_sig_counts.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp, vp, ctypes.POINTER(ctypes.c_int64)]
     lib.cl_last_n_in.restype = ctypes.c_int64

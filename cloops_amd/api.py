@@ -120,6 +120,31 @@ class Chromosome(object):
         them off: it only needs tables and distance statistics (cl_set_device_labels)"""
         self._lib.cl_set_device_labels(self._h, 1 if on else 0)
 
+    def set_table_export(self, on=True):
+        """copy of the cluster table to pinned host memory at the end of a run (default on; cl_set_table_export)"""
+        if getattr(self, "_export", True) != bool(on):
+            self._lib.cl_set_table_export(self._h, 1 if on else 0)
+            self._export = bool(on)
+
+    # ---- candidate loops of a sweep, kept on the device (K10) ----
+    def cand_reset(self):
+        _lib.check(self._lib.cl_cand_reset(self._h))
+
+    def cand_append(self, step):
+        """classify the last run's cluster table (pipe.py:83-97) and append its inter-ligation boxes under `step`
+        -> (n_inter, n_self)"""
+        ni, ns = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(self._lib.cl_cand_append(self._h, int(step), ctypes.byref(ni), ctypes.byref(ns)))
+        return int(ni.value), int(ns.value)
+
+    def cand_finish(self, final_cut, capacity):
+        """combineTwice + filterClusterByDis over everything appended since cand_reset -> int32 [k, 4] boxes
+        (minX, maxX, minY, maxY) in append order"""
+        out = np.empty((max(int(capacity), 1), 4), dtype=np.int32)
+        k = ctypes.c_int64(0)
+        _lib.check(self._lib.cl_cand_finish(self._h, int(final_cut), out.ctypes.data_as(ctypes.c_void_p), int(capacity), ctypes.byref(k)))
+        return out[: int(k.value)]
+
     def set_layout_reuse(self, on=True):
         """keep the sorted arrays of the last eps and start further runs at that eps from a compaction by the cut
         (default on; results identical either way -- cl_set_layout_reuse of include/cloops_hip.h)"""
@@ -138,24 +163,26 @@ class Chromosome(object):
         view = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_int32)), shape=(k * 5,)).view(BOX_DTYPE)
         return view.copy() if copy else view
 
-    def cluster_async(self, variant, eps, minPts, cut=0, want_labels=True):
+    def cluster_async(self, variant, eps, minPts, cut=0, want_labels=True, want_boxes=True):
         """Enqueue one run without blocking (at most two in flight); pair with wait().
-        Labels land in one of two reusable pinned buffers (or stay on the device)."""
+        Labels land in one of two reusable pinned buffers (or stay on the device); `want_boxes=False`
+        leaves the cluster table on the device too (cand_append / the distance statistics read it there)."""
         v = VARIANTS[variant]
+        self.set_table_export(want_boxes)
         labels = self._pinned_labels(self._enq & 1) if want_labels else None
         _lib.check(self._lib.cl_cluster_async(self._h, v, int(eps), int(minPts), int(cut),
                                               labels.ctypes.data_as(ctypes.c_void_p) if want_labels else None))
-        self._inflight.append(labels)
+        self._inflight.append((labels, bool(want_boxes)))
         self._enq += 1
 
     def wait(self, copy=False):
         """Complete the oldest in-flight run -> ClusterResult (labels / boxes are VIEWS of pinned
         buffers that stay valid until two more runs have been enqueued, unless copy=True)."""
-        labels = self._inflight.pop(0)
+        labels, exported = self._inflight.pop(0)
         nc = ctypes.c_int32(0)
         ml = ctypes.c_int32(-1)
         _lib.check(self._lib.cl_wait(self._h, ctypes.byref(nc), ctypes.byref(ml)))
-        boxes = self._boxes(ml.value, copy)
+        boxes = self._boxes(ml.value, copy) if exported else None
         if labels is not None and copy:
             labels = labels.copy()
         return ClusterResult(labels, nc.value, ml.value, boxes, self.timing() if self._profiling else None)
@@ -167,6 +194,7 @@ class Chromosome(object):
         v = VARIANTS[variant]
         if self._inflight:
             raise RuntimeError("asynchronous runs in flight: call wait() first")
+        self.set_table_export(True)
         if want_labels:
             labels = self._pinned_labels(0) if pinned else np.empty(self.n, dtype=np.int32)
         else:

@@ -92,7 +92,7 @@ extern "C" int cl_device_count(void)
 #define TPB 256
 
 enum { ST_LIVE = 0, ST_DEAD = 1, ST_UNKNOWN = 2 };          // variant-2 release state of a component
-enum { CTR_NU = 0, CTR_NREC = 1, CTR_OVERFLOW = 2 };         // device counters
+enum { CTR_NU = 0, CTR_NREC = 1, CTR_OVERFLOW = 2, CTR_NROOT = 3 };         // device counters
 
 struct GridParams {
     int eps;      // cell / strip width (cDBSCAN.py:29, cDBSCAN2.py:30: cw = eps)
@@ -121,6 +121,31 @@ __device__ __forceinline__ int sat_add(int a, int b)
     long long s = (long long)a + (long long)b;
     return s > INT_MAX ? INT_MAX : (s < INT_MIN ? INT_MIN : (int)s);
 }
+
+// ---- wave64 reductions on the DPP network (no LDS crossbar traffic, a handful of VALU instructions) ------------
+// quad_perm [1,0,3,2], [2,3,0,1], row_shr:4, row_shr:8 leave every 16-lane row's total in its lane 15; row_bcast:15 then
+// lanes 31 / 63 hold the totals of lanes 0..31 / 32..63; row_bcast:31 completes lane 63.  min / max are idempotent, so
+// lanes that receive nothing combine with their own value.
+#define CL_DPP(v, ctrl, rowmask) __builtin_amdgcn_update_dpp((v), (v), (ctrl), (rowmask), 0xf, false)
+template <typename Op>
+__device__ __forceinline__ int dpp_reduce_halves(int v, Op op)       // result: lane 31 <- lanes 0..31, lane 63 <- lanes 32..63
+{
+    v = op(v, CL_DPP(v, 0xb1, 0xf));
+    v = op(v, CL_DPP(v, 0x4e, 0xf));
+    v = op(v, CL_DPP(v, 0x114, 0xf));
+    v = op(v, CL_DPP(v, 0x118, 0xf));
+    v = op(v, CL_DPP(v, 0x142, 0xa));
+    return v;
+}
+template <typename Op>
+__device__ __forceinline__ int dpp_reduce_wave(int v, Op op)         // wave-uniform result
+{
+    v = dpp_reduce_halves(v, op);
+    v = op(v, CL_DPP(v, 0x143, 0xc));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+struct OpMin { __device__ __forceinline__ int operator()(int a, int b) const { return min(a, b); } };
+struct OpMax { __device__ __forceinline__ int operator()(int a, int b) const { return max(a, b); } };
 
 // first index in [lo,hi) with sv[idx] >= val
 __device__ __forceinline__ int lower_bound_i(const int* __restrict__ sv, int lo, int hi, int val)
@@ -1219,9 +1244,8 @@ __global__ void k_block_pmax(int n, const int* __restrict__ chainid, const int* 
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int v = (i < n && chainid[i] >= 0) ? sa[i] : INT_MIN;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    if ((threadIdx.x & 31) == 0 && i < n) pmax32[i >> 5] = v;
+    v = dpp_reduce_halves(v, OpMax());                     // lanes 31 and 63 hold the maxima of their 32-PET blocks
+    if ((threadIdx.x & 31) == 31 && (i - 31) < n) pmax32[i >> 5] = v;
 }
 template <int NT, int HALO>
 __global__ void __launch_bounds__(NT)
@@ -1355,7 +1379,7 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         bool rep = false;
         while (pending) {
             const int leader = __ffsll((long long)pending) - 1;
-            const int LA = __shfl(A, leader), LB = __shfl(B, leader);
+            const int LA = __builtin_amdgcn_readlane(A, leader), LB = __builtin_amdgcn_readlane(B, leader);
             const unsigned long long m = __ballot(B >= 0 && A == LA && B == LB);
             if (lane == leader) rep = true;
             pending &= ~m;
@@ -1394,10 +1418,13 @@ __global__ void __launch_bounds__(BIGTPB)
 k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ cnt,
           int* parent, const u32* __restrict__ srow,
           const int* __restrict__ head, const int* __restrict__ cellfirst,
-          int* __restrict__ root, int* __restrict__ compkey, int* __restrict__ ncore)
+          int* __restrict__ root, int* __restrict__ compkey, int* __restrict__ ncore,
+          int* __restrict__ rootlist /* or null */, int* __restrict__ counters)
 {
     __shared__ int hkey[AGG_H], hmin[AGG_H], hcnt[AGG_H];
+    __shared__ int l_nroot, l_rootbase;
     if (threadIdx.x < AGG_H) { hkey[threadIdx.x] = -1; hmin[threadIdx.x] = INT_MAX; hcnt[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) l_nroot = 0;
     __syncthreads();
     const int M = strip_start[g.S];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1410,16 +1437,29 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
         root[i] = r;
     }
     const int lane = threadIdx.x & 63;
+    // the components' roots as a compact list (the per-component kernels that follow walk K entries instead of
+    // testing every PET): ranks inside the workgroup through LDS, one global atomic per workgroup
+    int myslot = -1;
+    if (rootlist) {
+        const bool isroot = r == i && r >= 0;
+        const unsigned long long rb = __ballot(isroot);
+        if (rb) {
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&l_nroot, __popcll(rb));
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            if (isroot) myslot = wbase + __builtin_amdgcn_mbcnt_hi((unsigned)(rb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)rb, 0u));
+        }
+    }
     unsigned long long pending = __ballot(r >= 0);
     while (pending) {
         const int leader = __ffsll((long long)pending) - 1;
-        const int R = __shfl(r, leader);
+        const int R = __builtin_amdgcn_readlane(r, leader);
         const unsigned long long m = __ballot(r == R);
         const bool mine = r == R;
         const int cm = __popcll(m);
         if (cm >= 4) {
             int mk = mine ? key : INT_MAX;
-            for (int o = 32; o > 0; o >>= 1) mk = min(mk, __shfl_xor(mk, o));
+            mk = dpp_reduce_wave(mk, OpMin());
             if (lane == leader) {
                 const int sl = agg_slot(hkey, R);
                 if (sl >= 0) { atomicMin(&hmin[sl], mk); atomicAdd(&hcnt[sl], cm); }
@@ -1435,6 +1475,11 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
     if (threadIdx.x < AGG_H && hkey[threadIdx.x] >= 0) {
         atomicMin(&compkey[hkey[threadIdx.x]], hmin[threadIdx.x]);
         atomicAdd(&ncore[hkey[threadIdx.x]], hcnt[threadIdx.x]);
+    }
+    if (rootlist) {
+        if (threadIdx.x == 0) l_rootbase = l_nroot ? atomicAdd(&counters[CTR_NROOT], l_nroot) : 0;
+        __syncthreads();
+        if (myslot >= 0) rootlist[l_rootbase + myslot] = i;
     }
 }
 
@@ -1505,7 +1550,7 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
         unsigned long long pending = __ballot(cnt_me);
         while (pending) {
             const int leader = __ffsll((long long)pending) - 1;
-            const int O = __shfl(o, leader);
+            const int O = __builtin_amdgcn_readlane(o, leader);
             const unsigned long long m = __ballot(cnt_me && o == O);
             const unsigned long long mu = __ballot(cnt_me && o == O && !contested);
             if (lane == leader) {
@@ -1669,6 +1714,41 @@ __global__ void k_apply_records(const Rec* __restrict__ recs, const int* __restr
 // ------------------------------------------------------------------------------------------
 // K5: cluster ids = rank of the component key among the kept components; labels; table
 // ------------------------------------------------------------------------------------------
+// the same three per-component steps on the root list of k_flatten (K entries instead of a test per PET)
+__global__ void k_mark_uncertain_l(GridParams g, const int* __restrict__ rootlist, const int* __restrict__ ncore, const int* __restrict__ bsize,
+                                   int* __restrict__ state, int* __restrict__ ulist, int* __restrict__ counters)
+{
+    const int K = counters[CTR_NROOT];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        const int i = rootlist[k];
+        if (ncore[i] + bsize[i] < g.minPts) {
+            state[i] = ST_UNKNOWN;
+            ulist[atomicAdd(&counters[CTR_NU], 1)] = i;
+        }
+    }
+}
+__global__ void k_rank_flags_l(GridParams g, const int* __restrict__ rootlist, const int* __restrict__ counters,
+                               const int* __restrict__ compkey, const int* __restrict__ state, int* __restrict__ flag)
+{
+    const int K = counters[CTR_NROOT];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        const int i = rootlist[k];
+        if (g.variant == CL_VARIANT_CDBSCAN2 && state[i] == ST_DEAD) continue;      // cDBSCAN2.py:183-185 / cDBSCAN.py:136-152
+        flag[compkey[i]] = 1;
+    }
+}
+__global__ void k_root_labels_l(GridParams g, const int* __restrict__ rootlist, const int* __restrict__ counters,
+                                const int* __restrict__ compkey, const int* __restrict__ ncore, const int* __restrict__ bsize,
+                                const int* __restrict__ state, const int* __restrict__ rankscan, int* __restrict__ rlabel)
+{
+    const int K = counters[CTR_NROOT];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        const int i = rootlist[k];
+        const bool keep = (g.variant == CL_VARIANT_CDBSCAN2) ? (state[i] != ST_DEAD)
+                                                             : (ncore[i] + bsize[i] >= g.minPts);   // cDBSCAN.py:149-152
+        rlabel[i] = keep ? rankscan[compkey[i]] : -1;
+    }
+}
 __global__ void k_rank_flags(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ root,
                              const int* __restrict__ compkey, const int* __restrict__ state, int* __restrict__ flag)
 {
@@ -1718,8 +1798,8 @@ __global__ void k_init_table(Table t, const int* __restrict__ rankscan, int n)
 }
 
 __device__ __forceinline__ int je_minus(const int* __restrict__ cstart, int j) { return cstart[j + 1] - cstart[j]; }
-__device__ __forceinline__ int wave_min_i(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return v; }
-__device__ __forceinline__ int wave_max_i(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ int wave_min_i(int v) { return dpp_reduce_wave(v, OpMin()); }
+__device__ __forceinline__ int wave_max_i(int v) { return dpp_reduce_wave(v, OpMax()); }
 
 // Cluster table (pipe.py:78-102) by the two-level reduce-by-key above; called by all threads
 // of a BIGTPB workgroup (sorted order keeps a cluster's PETs in neighbouring lanes, so a wave
@@ -1751,7 +1831,7 @@ __device__ __forceinline__ void table_accumulate(const Table& t, TableLds& h, in
     unsigned long long pending = __ballot(lab >= 0);
     while (pending) {
         const int leader = __ffsll((long long)pending) - 1;
-        const int L = __shfl(lab, leader);
+        const int L = __builtin_amdgcn_readlane(lab, leader);
         const unsigned long long m = __ballot(lab == L);
         const bool mine = lab == L;
         const int cm = __popcll(m);
@@ -2258,12 +2338,12 @@ k_blk_flatten(const BlkScalars* __restrict__ sc, const int* __restrict__ corec, 
     unsigned long long pending = __ballot(r >= 0);
     while (pending) {
         const int leader = __ffsll((long long)pending) - 1;
-        const int R = __shfl(r, leader);
+        const int R = __builtin_amdgcn_readlane(r, leader);
         const unsigned long long m = __ballot(r == R);
         const bool mine = r == R;
         if (__popcll(m) >= 4) {
             int mk = mine ? key : INT_MAX;
-            for (int o = 32; o > 0; o >>= 1) mk = min(mk, __shfl_xor(mk, o));
+            mk = dpp_reduce_wave(mk, OpMin());
             if (lane == leader) {
                 const int sl = agg_slot(hkey, R);
                 if (sl >= 0) atomicMin(&hmin[sl], mk); else atomicMin(&compkey[R], mk);
@@ -2462,6 +2542,113 @@ k7_bin_hist(K7Src s, int cut, const signed char* __restrict__ cls, unsigned lo, 
 }
 
 // ==========================================================================================
+// K10: the candidate loops of a sweep, kept on the device
+// ==========================================================================================
+// The sweep driver used to pull every run's cluster table over PCIe, classify it with numpy and, at the end, dedup
+// the concatenation of all steps on the host (combineTwice, cLoops/pipe.py:155-174: a box is kept in the step where
+// it FIRST appears; duplicates inside one step all stay) and filter it by the final cut (filterClusterByDis,
+// pipe.py:130-143, Python-2 floor mid-points).  Here a run's inter-ligation boxes (pipe.py:83-97) are appended, in
+// ascending cluster id, to a per-chromosome device buffer together with their step number; at the end of the sweep
+// one 64-bit-hash radix sort groups equal boxes (stable: the first of a group is its first appearance), the exact
+// boxes are compared inside a group, and the survivors are compacted in append order -- the order the reference's
+// record lists have.  Only the final table crosses PCIe.
+#define CAND_BLOCK 2048
+__global__ void __launch_bounds__(256)
+k_cand_count(int K, const signed char* __restrict__ cls, int* __restrict__ bcount /* [nb] inter, [nb] self */, int nb)
+{
+    __shared__ int red[2][4];
+    const int base = blockIdx.x * CAND_BLOCK;
+    int ci = 0, cs = 0;
+    for (int k = threadIdx.x; k < CAND_BLOCK; k += 256) {
+        const int i = base + k;
+        const int c = i < K ? (int)cls[i] : -1;
+        ci += c == 0; cs += c == 1;
+    }
+    for (int o = 32; o > 0; o >>= 1) { ci += __shfl_down(ci, o); cs += __shfl_down(cs, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ci; red[1][threadIdx.x >> 6] = cs; }
+    __syncthreads();
+    if (threadIdx.x == 0) { bcount[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3]; bcount[nb + blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3]; }
+}
+// ordered scatter of the flagged elements of [0, N): dst = base + boff[block] + rank inside the block (element order)
+template <typename F, typename W>
+__device__ __forceinline__ void ordered_scatter_block(int N, const int* __restrict__ boff, F&& flagged, W&& write)
+{
+    __shared__ int l_cnt[(CAND_BLOCK / 256) * 4];
+    const int base = blockIdx.x * CAND_BLOCK;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bool keep[CAND_BLOCK / 256]; int before[CAND_BLOCK / 256];
+#pragma unroll
+    for (int k = 0; k < CAND_BLOCK / 256; ++k) {
+        const int i = base + k * 256 + (int)threadIdx.x;
+        keep[k] = i < N && flagged(i);
+        const unsigned long long bal = __ballot(keep[k]);
+        before[k] = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        if (lane == 0) l_cnt[k * 4 + wv] = __popcll(bal);
+    }
+    __syncthreads();
+    int pre = boff[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < CAND_BLOCK / 256; ++k) {
+        int mine = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if (w == wv) mine = pre; pre += l_cnt[k * 4 + w]; }
+        if (keep[k]) write(base + k * 256 + (int)threadIdx.x, mine + before[k]);
+    }
+}
+__global__ void __launch_bounds__(256)
+k_cand_append(int K, const signed char* __restrict__ cls, Table t, const int* __restrict__ boff, int base, int step, int cap,
+              int4* __restrict__ cbox, int* __restrict__ cstep)
+{
+    ordered_scatter_block(K, boff, [&](int i) { return cls[i] == 0; },
+                          [&](int i, int r) { const int d = base + r; if (d < cap) { cbox[d] = make_int4(t.minx[i], t.maxx[i], t.miny[i], t.maxy[i]); cstep[d] = step; } });
+}
+__device__ __forceinline__ u64 box_hash(int4 b, u64 salt)
+{
+    u64 h = salt ^ ((u64)(u32)b.x * 0x9E3779B97F4A7C15ull) ^ ((u64)(u32)b.y * 0xC2B2AE3D27D4EB4Full) ^ ((u64)(u32)b.z * 0x165667B19E3779F9ull) ^ ((u64)(u32)b.w * 0xD6E8FEB86659FD93ull);
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    return h;
+}
+__global__ void k_cand_hash(int N, const int4* __restrict__ cbox, u64 salt, u64* __restrict__ keys, u32* __restrict__ vals)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) { keys[i] = box_hash(cbox[i], salt); vals[i] = (u32)i; }
+}
+__device__ __forceinline__ long long floordiv2(long long a) { return a >> 1; }      // floor(a / 2) for any sign (pipe.py:138 on Python-2 ints)
+__global__ void k_cand_mark(int N, const u64* __restrict__ skeys, const u32* __restrict__ svals, const int4* __restrict__ cbox,
+                            const int* __restrict__ cstep, int final_cut, unsigned char* __restrict__ keep, int* __restrict__ flags)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const u64 key = skeys[j];
+    int j0 = j, guard = 0;
+    while (j0 > 0 && skeys[j0 - 1] == key && guard < 65536) { --j0; ++guard; }
+    if (guard >= 65536) atomicExch(&flags[0], 2);
+    const u32 p = svals[j], hp = svals[j0];              // stable sort: the head of a group is its first appearance
+    const int4 b = cbox[p], hb = cbox[hp];
+    const bool same = b.x == hb.x && b.y == hb.y && b.z == hb.z && b.w == hb.w;
+    if (!same) atomicExch(&flags[0], 1);                 // two different boxes share a 64-bit hash: the caller redoes this chromosome exactly
+    const long long d = floordiv2((long long)b.z + b.w) - floordiv2((long long)b.x + b.y);
+    keep[p] = (same && cstep[p] == cstep[hp] && d >= (long long)final_cut) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256)
+k_flag_count(int N, const unsigned char* __restrict__ keep, int* __restrict__ bcount)
+{
+    __shared__ int red[4];
+    const int base = blockIdx.x * CAND_BLOCK;
+    int c = 0;
+    for (int k = threadIdx.x; k < CAND_BLOCK; k += 256) { const int i = base + k; c += (i < N && keep[i]) ? 1 : 0; }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) bcount[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void __launch_bounds__(256)
+k_cand_emit(int N, const unsigned char* __restrict__ keep, const int4* __restrict__ cbox, const int* __restrict__ boff, int4* __restrict__ out)
+{
+    ordered_scatter_block(N, boff, [&](int i) { return keep[i] != 0; }, [&](int i, int r) { out[r] = cbox[i]; });
+}
+
+// ==========================================================================================
 // K8: interval counting for the significance test (cLoops/cModel.py:60-80, 108-143)
 // ==========================================================================================
 // For a candidate loop with anchors iva, ivb the reference builds Python sets of the PETs that have
@@ -2640,12 +2827,16 @@ struct cl_chrom {
         size_t h_boxes_cap = 0;
         int32_t* labels_out = nullptr;
         DevBuf slab;                  // labels in sorted order (rotated variants)
+        bool exported = true;         // the table rows were stored to h_boxes
         bool rows_valid = false;      // `labels` (row order) was produced by the run
         bool sorted_src = false;      // the run left sorted (q, label) arrays for the distance statistics
         const int* k7_sv = nullptr;   // sorted q of the run
         int k7_v0 = 0;                // d = q + k7_v0
     } slot[2];
     bool device_labels = true;        // produce row-order device labels even without a host destination (cl_set_device_labels)
+    bool export_table = true;         // copy the cluster table to pinned host memory at the end of a run (cl_set_table_export)
+    DevBuf cand_box, cand_step, cand_keep, cand_out;   // K10: candidate loops of the running sweep
+    long long cand_n = 0, cand_cap = 0;
     DevBuf hdr;                       // device result headers, 16 ints per slot
     DevBuf k7_cls, k7_parts;          // K7: class per cluster id, per-workgroup partials
     DevBuf sig_tx, sig_ty, sig_tmp, sig_sorttmp, sig_m, sig_win, sig_out;   // K8: sorted PET tables, windows, counts
@@ -2672,7 +2863,7 @@ static void free_chrom(cl_chrom* c)
     DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
-                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp};
+                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out};
     for (DevBuf* b : bufs) b->release();
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -2704,6 +2895,7 @@ extern "C" const int32_t* cl_labels_device(const cl_chrom* c)
     return (c && c->last_slot >= 0 && c->slot[c->last_slot].rows_valid) ? (const int32_t*)c->slot[c->last_slot].labels.p : nullptr;
 }
 extern "C" void cl_set_device_labels(cl_chrom* c, int enabled) { if (c) c->device_labels = enabled != 0; }
+extern "C" void cl_set_table_export(cl_chrom* c, int enabled) { if (c) c->export_table = enabled != 0; }
 
 static inline int nblocks(long long n, int tpb = TPB) { return (int)((n + tpb - 1) / tpb); }
 
@@ -2722,7 +2914,7 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
 {
     if (!out) return fail(CL_ERR_ARG, "cl_chrom_create: out is null");
     *out = nullptr;
-    if (n < 0 || n > (1LL << 30)) return fail(CL_ERR_ARG, "cl_chrom_create: n out of range (0 .. 2^30)");
+    if (n < 0 || n >= (1LL << 31) - 1024) return fail(CL_ERR_ARG, "cl_chrom_create: n out of range (0 .. 2^31 - 1024)");
     if (n > 0 && (!x || !y)) return fail(CL_ERR_ARG, "cl_chrom_create: null coordinates");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(CL_ERR_NODEVICE, "no HIP device visible");
@@ -3216,18 +3408,22 @@ __global__ void k_pack_header(int* __restrict__ hdr, const int* __restrict__ ran
 __global__ void k_export_table(int* __restrict__ hdr, Table t, cl_box* __restrict__ host_rows, int cap)
 {
     const int K = hdr[0];
+    const bool store = cap >= 0;                        // cap < 0: count the non-empty ids only (the caller does not read the rows)
+    const int lim = store ? min(K, cap) : K;
     int nc = 0, ml = -1;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K && k < cap; k += gridDim.x * blockDim.x) {
-        cl_box b = t.get(k);
-        if (b.count > 0) { ++nc; ml = k; } else { b.min_x = b.max_x = b.min_y = b.max_y = 0; }
-        host_rows[k] = b;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < lim; k += gridDim.x * blockDim.x) {
+        if (store) {
+            cl_box b = t.get(k);
+            if (b.count > 0) { ++nc; ml = k; } else { b.min_x = b.max_x = b.min_y = b.max_y = 0; }
+            host_rows[k] = b;
+        } else if (t.count[k] > 0) { ++nc; ml = k; }
     }
     for (int o = 32; o > 0; o >>= 1) { nc += __shfl_down(nc, o); ml = max(ml, __shfl_down(ml, o)); }
     if ((threadIdx.x & 63) == 0) {
         if (nc) atomicAdd(&hdr[3], nc);
         if (ml >= 0) atomicMax(&hdr[4], ml);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && K > cap) hdr[5] = 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && store && K > cap) hdr[5] = 1;
 }
 
 static Table make_table_slot(cl_chrom* c, int slot)
@@ -3251,7 +3447,10 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
         sl.h_boxes_cap = cap;
     }
     hipLaunchKernelGGL(k_pack_header, dim3(1), dim3(64), 0, c->stream, dh, c->rankscan.as<int>() + n, c->counters.as<int>(), d_M);
-    hipLaunchKernelGGL(k_export_table, dim3(256), dim3(TPB), 0, c->stream, dh, make_table(c), sl.h_boxes, (int)std::min<size_t>(sl.h_boxes_cap, 0x7fffffff));
+    // (without export the kernel still counts the non-empty ids for the header; cap 0 = no row is stored)
+    hipLaunchKernelGGL(k_export_table, dim3(256), dim3(TPB), 0, c->stream, dh, make_table(c), sl.h_boxes,
+                       c->export_table ? (int)std::min<size_t>(sl.h_boxes_cap, 0x7fffffff) : -1);
+    sl.exported = c->export_table;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sl.ev_done, c->stream));
     ev_record(c, 6);
@@ -3491,7 +3690,7 @@ static int run_weighted(cl_chrom* c, int eps, int minPts, int wx, int wy, int32_
     ev_record(c, 3);
     LAUNCH(k64_union, n, n, g, sk, p64, strip, cnt, c->parent.as<int>());
     hipLaunchKernelGGL(k_flatten, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, gi, strip, cnt, c->parent.as<int>(), srow,
-                       c->head.as<int>(), c->cellfirst.as<int>(), c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>());
+                       c->head.as<int>(), c->cellfirst.as<int>(), c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), (int*)nullptr, counters);
     ev_record(c, 4);
     LAUNCH(k64_border, n, n, g, sk, p64, strip, c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), srow,
            c->owner.as<int>(), c->bsize.as<int>());
@@ -3652,15 +3851,16 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     TILE_LAUNCH(k_union_cores, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
                        pmax32, c->parent.as<int>());
     hipLaunchKernelGGL(k_flatten, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
-           c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>());
+           c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->chainflag.as<int>() /* root list: the chain ids are dead */, counters);
+    int* rootlist = c->chainflag.as<int>();
     ev_record(c, 4);
     // K4
     TILE_LAUNCH(k_border, g, ntiles, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(),
                        c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>());
     if (variant == CL_VARIANT_CDBSCAN2) {
         const int rec_cap = n;
-        LAUNCH(k_mark_uncertain, n, g, strip, c->root.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->state.as<int>(),
-               c->ulist.as<int>(), counters);
+        hipLaunchKernelGGL(k_mark_uncertain_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, c->ncore.as<int>(), c->bsize.as<int>(), c->state.as<int>(),
+                           c->ulist.as<int>(), counters);
         TILE_LAUNCH(k_emit_records, g, ntiles, sv, sa, strip, c->root.as<int>(),
                            c->compkey.as<int>(), c->state.as<int>(), c->owner.as<int>(), c->recs.as<Rec>(), rec_cap, counters);
         hipLaunchKernelGGL(k_resolve_release, dim3(1), dim3(1024), 0, c->stream, minPts, c->ncore.as<int>(), c->usize.as<int>(), c->state.as<int>(),
@@ -3669,7 +3869,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     }
     ev_record(c, 5);
     // K5
-    LAUNCH(k_rank_flags, n, g, strip, c->root.as<int>(), c->compkey.as<int>(), c->state.as<int>(), c->flag.as<int>());
+    hipLaunchKernelGGL(k_rank_flags_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, counters, c->compkey.as<int>(), c->state.as<int>(), c->flag.as<int>());
     {
         size_t tb = c->scan_tmp.bytes;
         hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, c->flag.as<int>(), c->rankscan.as<int>(), 0, (size_t)n + 1,
@@ -3679,8 +3879,8 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     Table t = make_table(c);
     LAUNCH(k_init_table, n + 1, t, c->rankscan.as<int>(), n);
     // rlabel reuses the chainhead buffer (free after k_chain_parent)
-    LAUNCH(k_root_labels, n, g, strip, c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
-           c->state.as<int>(), c->rankscan.as<int>(), c->chainhead.as<int>());
+    hipLaunchKernelGGL(k_root_labels_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, counters, c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
+                       c->state.as<int>(), c->rankscan.as<int>(), c->chainhead.as<int>());
     hipLaunchKernelGGL(k_final_labels, dim3(nblocks(n, BIGTPB * FINAL_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow, c->owner.as<int>(),
                        c->chainhead.as<int>(), rows ? c->slot[c->cur].labels.as<int>() : (int*)nullptr, c->slot[c->cur].slab.as<int>(), t);
     HIP_TRY(hipGetLastError());
@@ -3760,6 +3960,107 @@ extern "C" int cl_dist_bin_hist(cl_chrom* c, int32_t cut, uint32_t lo, uint32_t 
     return CL_OK;
 }
 
+// ---- K10 host entry points -----------------------------------------------------------------------
+extern "C" int cl_cand_reset(cl_chrom* c)
+{
+    if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
+    c->cand_n = 0;
+    return CL_OK;
+}
+
+extern "C" int cl_cand_append(cl_chrom* c, int32_t step, int64_t* n_inter, int64_t* n_self)
+{
+    if (n_inter) *n_inter = 0;
+    if (n_self) *n_self = 0;
+    if (c && c->n == 0) return CL_OK;
+    int rc = k7_prepare(c);                              // classifies the table of the last completed run (pipe.py:83-97)
+    if (rc) return rc;
+    cl_chrom::Slot& sl = c->slot[c->last_slot];
+    const int K = sl.h_hdr[0];
+    if (K <= 0) return CL_OK;
+    if (c->cand_cap == 0) {
+        const long long cap = std::max<long long>(c->n / 2, 1 << 20);
+        if ((rc = c->cand_box.ensure((size_t)cap * 16)) || (rc = c->cand_step.ensure((size_t)cap * 4))) return rc;
+        c->cand_cap = cap;
+    }
+    const int nb = nblocks(K, CAND_BLOCK);
+    if ((rc = c->sel_tmp.ensure((size_t)nb * 12 + 64))) return rc;
+    int* bcount = c->sel_tmp.as<int>();
+    int* boff = bcount + 2 * nb;
+    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(256), 0, c->stream, K, c->k7_cls.as<signed char>(), bcount, nb);
+    size_t tb = c->scan_tmp.bytes;
+    hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, bcount, boff, 0, (size_t)nb, rocprim::plus<int>(), c->stream);
+    if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan(cand)", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_cand_append, dim3(nb), dim3(256), 0, c->stream, K, c->k7_cls.as<signed char>(), make_table_slot(c, c->last_slot),
+                       (const int*)boff, (int)c->cand_n, (int)step, (int)std::min<long long>(c->cand_cap, INT_MAX), c->cand_box.as<int4>(), c->cand_step.as<int>());
+    std::vector<int> h(2 * nb);
+    HIP_TRY(hipMemcpyAsync(h.data(), bcount, (size_t)2 * nb * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    long long ni = 0, ns = 0;
+    for (int k = 0; k < nb; ++k) { ni += h[k]; ns += h[nb + k]; }
+    if (c->cand_n + ni > c->cand_cap) return fail(CL_ERR_GRID, "candidate buffer full (more inter-ligation boxes over the sweep than n / 2)");
+    c->cand_n += ni;
+    if (n_inter) *n_inter = ni;
+    if (n_self) *n_self = ns;
+    return CL_OK;
+}
+
+extern "C" int cl_cand_finish(cl_chrom* c, int32_t final_cut, int32_t* boxes_out, int64_t capacity, int64_t* n_out)
+{
+    if (!c || !n_out) return fail(CL_ERR_ARG, "cl_cand_finish: null argument");
+    *n_out = 0;
+    const long long N = c->cand_n;
+    if (N == 0) return CL_OK;
+    if (c->enq != c->deq) return fail(CL_ERR_ARG, "cl_cand_finish: asynchronous runs still in flight");
+    if (N > c->n) return fail(CL_ERR_GRID, "cl_cand_finish: more candidates than PETs");      // (the sort workspace is sized for n pairs)
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_workspace(c, 1))) return rc;
+    if ((rc = c->cand_keep.ensure((size_t)N + 64)) || (rc = c->cand_out.ensure((size_t)N * 16))) return rc;
+    const int n = (int)N;
+    int* flags = c->counters.as<int>() + 60;
+    // two different boxes sharing a 64-bit hash would be merged: the exact compare inside k_cand_mark notices, and the
+    // pass is redone under another salt (a collision under four independent hashes does not happen)
+    int hflag = 0;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        HIP_TRY(hipMemsetAsync(flags, 0, 4, c->stream));
+        LAUNCH(k_cand_hash, n, n, c->cand_box.as<int4>(), (u64)attempt * 0x9FB21C651E98DF25ull, c->keys_in.as<u64>(), c->vals_in.as<u32>());
+        size_t tmp_bytes = c->sort_tmp.bytes;
+        hipError_t e = rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->keys_in.as<u64>(), c->keys_out.as<u64>(), c->vals_in.as<u32>(), c->vals_out.as<u32>(),
+                                                 (size_t)n, 0, 64, c->stream);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs(cand)", hipGetErrorString(e));
+        LAUNCH(k_cand_mark, n, n, c->keys_out.as<u64>(), c->vals_out.as<u32>(), c->cand_box.as<int4>(), c->cand_step.as<int>(), (int)final_cut,
+               c->cand_keep.as<unsigned char>(), flags);
+        HIP_TRY(hipMemcpyAsync(&hflag, flags, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (hflag == 0) break;
+    }
+    if (hflag != 0) return fail(CL_ERR_HASH, "candidate dedup: hash collisions under four salts");
+    hipError_t e;
+    const int nb = nblocks(n, CAND_BLOCK);
+    if ((rc = c->sel_tmp.ensure((size_t)nb * 8 + 64))) return rc;
+    int* bcount = c->sel_tmp.as<int>();
+    int* boff = bcount + nb;
+    hipLaunchKernelGGL(k_flag_count, dim3(nb), dim3(256), 0, c->stream, n, c->cand_keep.as<unsigned char>(), bcount);
+    size_t tb = c->scan_tmp.bytes;
+    e = rocprim::exclusive_scan(c->scan_tmp.p, tb, bcount, boff, 0, (size_t)nb, rocprim::plus<int>(), c->stream);
+    if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan(cand out)", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_cand_emit, dim3(nb), dim3(256), 0, c->stream, n, c->cand_keep.as<unsigned char>(), c->cand_box.as<int4>(), (const int*)boff, c->cand_out.as<int4>());
+    int tail[2];
+    HIP_TRY(hipMemcpyAsync(&tail[0], boff + nb - 1, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&tail[1], bcount + nb - 1, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const long long kept = (long long)tail[0] + tail[1];
+    *n_out = kept;
+    if (kept > capacity) return fail(CL_ERR_ARG, "cl_cand_finish: boxes_out too small");
+    if (kept > 0) {
+        if (!boxes_out) return fail(CL_ERR_ARG, "cl_cand_finish: boxes_out is null");
+        HIP_TRY(hipMemcpyAsync(boxes_out, c->cand_out.p, (size_t)kept * 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return CL_OK;
+}
+
 // ---- K8 host entry point ------------------------------------------------------------------------
 extern "C" int cl_sig_counts(cl_chrom* c, int32_t cut, int32_t n_records, const int32_t* windows, int32_t* out,
                              int64_t* n_pets)
@@ -3813,6 +4114,7 @@ extern "C" int cl_get_boxes(cl_chrom* c, cl_box* boxes_out)
     const int K = c->last_K;
     if (K <= 0) return CL_OK;
     if (!boxes_out) return fail(CL_ERR_ARG, "boxes_out is null");
+    if (c->last_slot >= 0 && !c->slot[c->last_slot].exported) return fail(CL_ERR_ARG, "cl_get_boxes: the run was made with the table export switched off");
     memcpy(boxes_out, c->slot[c->last_slot].h_boxes, (size_t)K * sizeof(cl_box));
     return CL_OK;
 }
@@ -3825,6 +4127,6 @@ extern "C" int64_t cl_last_n_in(const cl_chrom* c)
 
 extern "C" const cl_box* cl_boxes_host(const cl_chrom* c)
 {
-    if (!c || !c->have_result || c->last_slot < 0 || c->last_K <= 0) return nullptr;
+    if (!c || !c->have_result || c->last_slot < 0 || c->last_K <= 0 || !c->slot[c->last_slot].exported) return nullptr;
     return c->slot[c->last_slot].h_boxes;
 }

@@ -460,15 +460,20 @@ def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, 
 
 
 def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gsum, probe=None):
-    acc = {}
     cuts = [cut]
     steps = []
     live = [(f, r) for f, r in zip(fs, res_all) if len(r.d)]
+    appended = {}                                        # f -> inter-ligation boxes appended on the device so far
     pool = ThreadPoolExecutor(max_workers=SWEEP_THREADS) if len(live) > 1 else None
     try:
+        for f, r in live:
+            r.chrom.cand_reset()
+        step_no = 0
         for ep in eps:
             for m in minPts:
                 step_cut = cut
+                this_step = step_no
+                step_no += 1
 
                 # chromosomes are independent inside a step: enqueue them all (each handle has its own
                 # streams), then collect -- the kernels of different chromosomes overlap on the GPU
@@ -478,7 +483,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                     for f, r in live:
                         r.lock.acquire()
                         try:
-                            r.chrom.cluster_async(variant, ep, m, step_cut, want_labels=False)
+                            r.chrom.cluster_async(variant, ep, m, step_cut, want_labels=False, want_boxes=False)
                         except Exception:
                             r.lock.release()
                             raise
@@ -499,33 +504,34 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                         res = r.chrom.wait()
                         if probe is not None:
                             probe(f, ep, m, step_cut, res)
-                        dI, dS = _boxes_classified(r, res)
+                        # the table stays on the device: classified there (pipe.py:83-97), its inter-ligation boxes
+                        # appended to the chromosome's candidate buffer under this step's number
+                        nI, nS = r.chrom.cand_append(this_step)
                         n_in = r.chrom.last_n_in()
-                        s1 = r.chrom.dist_summary(step_cut) if len(dI) else None
+                        s1 = r.chrom.dist_summary(step_cut) if nI else None
                     finally:
                         r.lock.release()
-                    return f, r, dI, len(dS), n_in, s1
+                    return f, r, nI, nS, n_in, s1
 
-                step_I = {}
                 used = []
-                nS = n_in = 0
+                nI_tot = nS = n_in = 0
                 tot = {"n_all": [0, 0], "n_pos": [0, 0], "sumx": [0.0, 0.0], "sumxx": [0.0, 0.0]}
                 loghist = np.zeros(_lib_logbins(), dtype=np.int64)
                 xshift = 0.0
-                for f, r, dI, ndS, nin, s1 in _pmap(pool, collect, live):
+                for f, r, nI, ndS, nin, s1 in _pmap(pool, collect, live):
                     nS += ndS
                     n_in += nin
-                    if len(dI) == 0:                          # runDBSCAN skips such chromosomes entirely (pipe.py:121-122)
+                    if nI == 0:                               # runDBSCAN skips such chromosomes entirely (pipe.py:121-122)
                         continue
-                    step_I[r.key] = {"f": f, "boxes": dI}
+                    nI_tot += nI
+                    appended[f] = appended.get(f, 0) + nI
                     used.append(r)
-                    acc.setdefault(r.key, {"f": f, "steps": []})["steps"].append(dI)
                     for gg in (0, 1):
                         for kk in ("n_all", "n_pos", "sumx", "sumxx"):
                             tot[kk][gg] += s1[kk][gg]
                     loghist += s1["loghist"]
                     xshift = s1["xshift"]
-                g = gsum(np.asarray([sum(len(v["boxes"]) for v in step_I.values()), nS, n_in, len(step_I)], dtype=np.int64))
+                g = gsum(np.asarray([nI_tot, nS, n_in, len(used)], dtype=np.int64))
                 st = {"eps": ep, "minPts": m, "cut_in": int(cut), "n_inter": int(g[0]), "n_self": int(g[1]), "n_in": int(g[2])}
                 steps.append(st)
                 if int(g[3]) == 0:                            # pipe.py:251-255
@@ -566,16 +572,17 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
             cut = int(np.max(pos)) if max_cut else int(np.min(pos))     # pipe.py:276-280
         else:
             raise ValueError("zero-size array to reduction operation minimum which has no identity")
-        # combineTwice over all steps (pipe.py:257,275), then filterClusterByDis (pipe.py:130-143, floor division)
+        # combineTwice over all steps (pipe.py:257,275), then filterClusterByDis (pipe.py:130-143, floor division): on the
+        # device, per chromosome; only the surviving boxes cross PCIe
         final_cut = cut
 
-        def combine(kv):
-            key, v = kv
-            b = _combine_steps(v["steps"]).astype(np.int64)
-            dmid = (b[:, 2] + b[:, 3]) // 2 - (b[:, 0] + b[:, 1]) // 2
-            return key, {"f": v["f"], "boxes": b[dmid >= final_cut]}
+        def finish(fr):
+            f, r = fr
+            with r.lock:
+                b = r.chrom.cand_finish(final_cut, appended[f])
+            return r.key, {"f": f, "boxes": b.astype(np.int64)}
 
-        dataI = dict(_pmap(pool, combine, list(acc.items())))
+        dataI = dict(_pmap(pool, finish, [(f, r) for f, r in live if appended.get(f, 0) > 0]))
     finally:
         if pool is not None:
             pool.shutdown(wait=True)

@@ -8,7 +8,7 @@
  *
  * The reference classes take `mat` = int64[N,3] rows [pointId, X, Y] (cLoops/io.py:192-217)
  * and produce `.labels` = {pointId: clusterId} for clustered points only.  Here a
- * chromosome's X and Y live in HBM as two int32 arrays (|X|,|Y| < 2^30) and labels come
+ * chromosome's X and Y live in HBM as two int32 arrays (|X|,|Y| < 2^29, n < 2^31 - 1024 rows) and labels come
  * back as an int32 array ALIGNED TO THE INPUT ROWS (-1 = absent from `.labels`); the host
  * wrapper (cloops_amd/) turns that into the dict lazily.
  */
@@ -27,12 +27,15 @@ extern "C" {
 #define CL_ERR_HIP       -2   /* a HIP runtime call failed; see cl_last_error()               */
 #define CL_ERR_EMPTY     -3   /* empty input where the reference raises IndexError
                                  (cLoops/cDBSCAN.py:77, cLoops/blockDBSCAN.py:74)             */
-#define CL_ERR_DOMAIN    -4   /* coordinates outside the supported domain: |X|,|Y| >= 2^30, or
+#define CL_ERR_DOMAIN    -4   /* coordinates outside the supported domain: |X|,|Y| >= 2^29, or
                                  (variant 2) X > Y / negative coordinate, where cDBSCAN2's
                                  trunc-toward-zero cell rule (cLoops/cDBSCAN2.py:69-70) stops
                                  being an exact grid                                          */
-#define CL_ERR_GRID      -5   /* eps so small that the strip/row table would exceed 2^28 rows */
+#define CL_ERR_GRID      -5   /* eps so small that the strip/row table would exceed 2^28 rows, or coordinate
+                                 extent so large that (X+Y range / eps + 2) * 2^ceil(log2 eps) leaves int32
+                                 (never for |X|,|Y| < 2^28); also: candidate buffer of a sweep full      */
 #define CL_ERR_NODEVICE  -6   /* no usable HIP device                                         */
+#define CL_ERR_HASH      -7   /* cl_cand_finish: two different boxes share a 64-bit hash (redo on the host) */
 
 /* ---- clustering variants ---------------------------------------------------------- */
 #define CL_VARIANT_CDBSCAN1  1   /* cLoops/cDBSCAN.py:6      class cDBSCAN      (scripts/callStripes:29,
@@ -201,6 +204,25 @@ int cl_sig_counts(cl_chrom* c, int32_t cut, int32_t n_records, const int32_t* wi
  * keep results on the GPU (e.g. to hand them to RCCL) without a host round trip.  NULL if the run did not
  * produce row-aligned labels (see cl_set_device_labels). */
 const int32_t* cl_labels_device(const cl_chrom* c);
+
+/*
+ * Candidate loops of a sweep, kept on the device (kernels K10).  Replaces, for one chromosome, the record lists that
+ * cLoops/pipe.py:241-281 carries from step to step: `cl_cand_append` classifies the cluster table of the last
+ * completed run like pipe.py:83-97 (skip degenerate boxes; inter-ligation iff maxX < minY) and appends the
+ * inter-ligation boxes, in ascending cluster id, with the given step number; it returns how many inter- and
+ * self-ligation boxes the run had.  `cl_cand_finish` applies combineTwice (pipe.py:155-174: a box survives in the
+ * step of its first appearance, duplicates inside one step all stay) and filterClusterByDis (pipe.py:130-143:
+ * floor mid-point distance >= final_cut) and copies the surviving boxes {minX, maxX, minY, maxY} to boxes_out in
+ * append order -- the order of the reference's record list.  capacity / *n_out in rows of 4 int32.
+ * cl_cand_reset starts a new sweep.
+ */
+int cl_cand_reset(cl_chrom* c);
+int cl_cand_append(cl_chrom* c, int32_t step, int64_t* n_inter, int64_t* n_self);
+int cl_cand_finish(cl_chrom* c, int32_t final_cut, int32_t* boxes_out, int64_t capacity, int64_t* n_out);
+
+/* The cluster table of a run goes to pinned host memory at its end (cl_boxes_host / cl_get_boxes); enabled = 0
+ * skips that copy for the following runs (callers that only use cl_cand_append / the distance statistics). */
+void cl_set_table_export(cl_chrom* c, int enabled);
 
 /* Row-aligned device labels for runs WITHOUT a host destination (labels_out == NULL): enabled = 1 (default) keeps
  * producing them (for cl_labels_device); enabled = 0 skips the scatter to input-row order -- the sweep driver only

@@ -37,7 +37,7 @@ class FakeChromosome(object):
         return api.ClusterResult(lab, int(len(np.unique(lab[lab >= 0]))), ml, boxes, None)
 
     # ---- the asynchronous / statistics surface used by pipe.runSweepFast -------------------------
-    def cluster_async(self, variant, eps, minPts, cut=0, want_labels=True):
+    def cluster_async(self, variant, eps, minPts, cut=0, want_labels=True, want_boxes=True):
         self._pending = getattr(self, "_pending", [])
         self._pending.append((variant, eps, minPts, cut))
 
@@ -46,6 +46,35 @@ class FakeChromosome(object):
         res = self.cluster(variant, eps, minPts, cut)
         self._last = (res, cut)
         return res
+
+    # ---- candidate loops of a sweep (kernels K10) -------------------------------------------------
+    def cand_reset(self):
+        self._cand = []
+
+    def cand_append(self, step):
+        res, _ = self._last
+        b = res.boxes
+        K = len(b)
+        if K == 0:
+            return 0, 0
+        t = np.stack([b["min_x"], b["max_x"], b["min_y"], b["max_y"]], 1).astype(np.int64)
+        ok = (b["count"] > 0) & (t[:, 0] != t[:, 1]) & (t[:, 2] != t[:, 3])
+        inter = ok & (t[:, 1] < t[:, 2])
+        if inter.any():
+            self._cand.append((step, t[inter]))
+        return int(inter.sum()), int((ok & ~inter).sum())
+
+    def cand_finish(self, final_cut, capacity):
+        from cloops_amd import pipe
+        by_step = {}
+        for step, rows in self._cand:
+            by_step.setdefault(step, []).append(rows)
+        b = pipe._combine_steps([np.concatenate(v) for _, v in sorted(by_step.items())]).astype(np.int64)
+        dmid = (b[:, 2] + b[:, 3]) // 2 - (b[:, 0] + b[:, 1]) // 2
+        return b[dmid >= final_cut].astype(np.int32)
+
+    def set_table_export(self, on=True):
+        pass
 
     def last_n_in(self):
         res, cut = self._last

@@ -145,10 +145,10 @@ def test_sweep_over_more_chromosomes_than_the_cache_keeps(monkeypatch, tmp_path)
 def test_failed_enqueue_releases_every_lock(monkeypatch, tmp_path):
     """cluster_async raising for chromosome k must not leave chromosomes 0..k-1 locked / in flight"""
     class Failing(fake_backend.FakeChromosome):
-        def cluster_async(self, variant, eps, minPts, cut=0, want_labels=True):
+        def cluster_async(self, variant, eps, minPts, cut=0, want_labels=True, want_boxes=True):
             if self.n == 403:
                 raise RuntimeError("boom")
-            return fake_backend.FakeChromosome.cluster_async(self, variant, eps, minPts, cut, want_labels)
+            return fake_backend.FakeChromosome.cluster_async(self, variant, eps, minPts, cut, want_labels, want_boxes)
     monkeypatch.setattr(api, "Chromosome", Failing)
     monkeypatch.setattr(api, "device_count", lambda: 1)
     pipe.CACHE.clear()

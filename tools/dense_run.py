@@ -17,13 +17,16 @@ cut = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 ci = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 n_total = int(float(sys.argv[6])) if len(sys.argv) > 6 else 200000000
+NOLABELS = os.environ.get("DENSE_NOLABELS") == "1"       # the sweep's form: no row-aligned labels, table only
 name, length, n = chrom_sizes(n_total)[ci]
 X, Y = synth_chrom(n, length, 1000 * 3 + ci)          # the cfg-3 genome of cloops_amd.synth.synth_genome
 ch = api.Chromosome(X, Y)
 ch.set_profiling(True)
+if NOLABELS:
+    ch.set_device_labels(False)
 for it in range(reps):
     t0 = time.perf_counter()
-    res = ch.cluster("v2", eps, minPts, cut, pinned=True)
+    res = ch.cluster("v2", eps, minPts, cut, pinned=True, want_labels=not NOLABELS)
     t1 = time.perf_counter()
     tm = res.timing
     print("%s n=%d eps=%d minPts=%d cut=%d iter %d wall %.2f ms K=%d | " % (name, n, eps, minPts, cut, it, (t1 - t0) * 1e3, res.n_clusters) +
