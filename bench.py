@@ -98,7 +98,8 @@ def main(argv=None):
     import numpy as np
     torch = dist = tdev = None
     if use_dist:
-        # torch first: its bundled HIP runtime then also serves libcloops_hip.so (same SONAME)
+        # torch first: its bundled HIP runtime then also serves libcloops_hip.so (same SONAME; the other order aborts
+        # at the first RCCL call)
         import torch
         import torch.distributed as dist
         if on_gpu:
@@ -130,7 +131,10 @@ def main(argv=None):
         X, Y = synth_chrom(n, length, 1000 * CFG + ci)
         fs.append(pipe.CACHE.put_arrays("%s-%s" % (name, name), X, Y, device=device))
     t_gen = time.perf_counter() - t_gen
-    allsum = make_allsum(device=tdev) if use_dist else None
+    # the per-run exchange of the chained cut is a few KB of host-side statistics: it goes over a gloo group on the host
+    # (no device round trip); RCCL carries the one real exchange of the path, the final gather of the candidate tables
+    stats_group = dist.new_group(backend="gloo") if (use_dist and on_gpu) else None
+    allsum = make_allsum(device=None, group=stats_group) if use_dist else None
     eps_list, minpts_list = MODE3
 
     # K2 is timed inside the sweeps on the largest local chromosome (chr1 on rank 0): HIP events on the library's stream

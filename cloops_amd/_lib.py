@@ -29,7 +29,7 @@ SYMBOLS = [
     "cl_cluster", "cl_get_boxes", "cl_neighbor_counts", "cl_labels_device", "cl_set_profiling",
     "cl_get_timing", "cl_version", "cl_host_alloc", "cl_host_free", "cl_cluster_async", "cl_wait", "cl_boxes_host",
     "cl_dist_summary", "cl_dist_bin_hist", "cl_last_n_in", "cl_sig_counts", "cl_cluster_weighted",
-    "cl_set_layout_reuse", "cl_set_device_labels", "cl_set_table_export", "cl_cand_reset", "cl_cand_append", "cl_cand_finish",
+    "cl_set_layout_reuse", "cl_set_device_labels", "cl_set_table_export", "cl_cand_reset", "cl_cand_append", "cl_cand_finish", "cl_cluster_step_async", "cl_step_result",
 ]
 
 
@@ -110,6 +110,10 @@ def load():
     lib.cl_cand_reset.argtypes = [vp]
     lib.cl_cand_append.restype = ctypes.c_int
     lib.cl_cand_append.argtypes = [vp, ctypes.c_int32, i64p, i64p]
+    lib.cl_cluster_step_async.restype = ctypes.c_int
+    lib.cl_cluster_step_async.argtypes = [vp, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    lib.cl_step_result.restype = ctypes.c_int
+    lib.cl_step_result.argtypes = [vp, i64p, i64p, ctypes.POINTER(ClDsummary)]
     lib.cl_cand_finish.restype = ctypes.c_int
     lib.cl_cand_finish.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int64, i64p]
     lib.cl_sig_counts.restype = ctypes.c_int

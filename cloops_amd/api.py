@@ -137,6 +137,22 @@ class Chromosome(object):
         _lib.check(self._lib.cl_cand_append(self._h, int(step), ctypes.byref(ni), ctypes.byref(ns)))
         return int(ni.value), int(ns.value)
 
+    def step_async(self, variant, eps, minPts, cut, step):
+        """one sweep step in one asynchronous call (cl_cluster_step_async): the run, then -- in its own stream -- the
+        classification of its table, the append of its inter-ligation boxes under `step` and the distance summary;
+        pair with wait(), then read step_result()"""
+        _lib.check(self._lib.cl_cluster_step_async(self._h, VARIANTS[variant], int(eps), int(minPts), int(cut), int(step)))
+        self._export = False
+        self._inflight.append((None, False))
+        self._enq += 1
+
+    def step_result(self):
+        """-> (n_inter, n_self, summary dict as dist_summary) of the last completed sweep step (no GPU work)"""
+        ni, ns = ctypes.c_int64(0), ctypes.c_int64(0)
+        st = _lib.ClDsummary()
+        _lib.check(self._lib.cl_step_result(self._h, ctypes.byref(ni), ctypes.byref(ns), ctypes.byref(st)))
+        return int(ni.value), int(ns.value), self._summary_dict(st)
+
     def cand_finish(self, final_cut, capacity):
         """combineTwice + filterClusterByDis over everything appended since cand_reset -> int32 [k, 4] boxes
         (minX, maxX, minY, maxY) in append order"""
@@ -230,6 +246,10 @@ class Chromosome(object):
         (cl_dist_summary: one pass; x = log2|d| - xshift)."""
         st = _lib.ClDsummary()
         _lib.check(self._lib.cl_dist_summary(self._h, int(cut), ctypes.byref(st)))
+        return self._summary_dict(st)
+
+    @staticmethod
+    def _summary_dict(st):
         return {"n_all": [int(st.n_all[0]), int(st.n_all[1])], "n_pos": [int(st.n_pos[0]), int(st.n_pos[1])],
                 "sumx": [float(st.sumx[0]), float(st.sumx[1])], "sumxx": [float(st.sumxx[0]), float(st.sumxx[1])],
                 "xshift": float(st.xshift), "loghist": np.ctypeslib.as_array(st.loghist).astype(np.int64)}

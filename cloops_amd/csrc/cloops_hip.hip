@@ -2432,9 +2432,11 @@ __global__ void k7_classify(const int* __restrict__ hdr, Table t, signed char* _
 //   rows    input-row order (variants that only produce row-order labels)
 struct K7Src {
     int sorted; int n; int M; int v0;
+    const int* dM;                                      // if set: M is read from the device (the run has not been waited for yet)
     const int* X; const int* Y; const int* labels;      // input rows (+ row-order labels)
     const int* sv; const int* slab;                     // sorted q and sorted-order labels of [0, M)
 };
+#define K7_BLOCKS 512            // workgroups (= fixed partial sums) of the K7 reductions
 #define K7_LOGBINS 3840          // 30 octaves x 128: bin = floor(log2 d) * 128 + the next 7 bits of d (monotone in d)
 #define K7_FINE 2048
 #define K7_XSHIFT 11.0           // sums are taken over x = log2|d| - K7_XSHIFT (less cancellation in sum x^2 - (sum x)^2 / n)
@@ -2451,8 +2453,9 @@ template <typename F>
 __device__ __forceinline__ void k7_for_each(const K7Src& s, int cut, const signed char* __restrict__ cls, F&& f)
 {
     if (s.sorted) {
-        const int per = (s.M + gridDim.x - 1) / gridDim.x;
-        const int i0 = blockIdx.x * per, i1 = min(s.M, i0 + per);
+        const int M = s.dM ? s.dM[0] : s.M;
+        const int per = (M + gridDim.x - 1) / gridDim.x;
+        const int i0 = blockIdx.x * per, i1 = min(M, i0 + per);
         for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
             const int lab = s.slab[i];
             const int g = lab >= 0 ? (int)cls[lab] : -1;
@@ -2554,9 +2557,10 @@ k7_bin_hist(K7Src s, int cut, const signed char* __restrict__ cls, unsigned lo, 
 // record lists have.  Only the final table crosses PCIe.
 #define CAND_BLOCK 2048
 __global__ void __launch_bounds__(256)
-k_cand_count(int K, const signed char* __restrict__ cls, int* __restrict__ bcount /* [nb] inter, [nb] self */, int nb)
+k_cand_count(const int* __restrict__ dK, const signed char* __restrict__ cls, int* __restrict__ bcount /* [nb] inter, [nb] self */, int nb)
 {
     __shared__ int red[2][4];
+    const int K = dK[0];
     const int base = blockIdx.x * CAND_BLOCK;
     int ci = 0, cs = 0;
     for (int k = threadIdx.x; k < CAND_BLOCK; k += 256) {
@@ -2596,11 +2600,22 @@ __device__ __forceinline__ void ordered_scatter_block(int N, const int* __restri
     }
 }
 __global__ void __launch_bounds__(256)
-k_cand_append(int K, const signed char* __restrict__ cls, Table t, const int* __restrict__ boff, int base, int step, int cap,
+k_cand_append(const int* __restrict__ dK, const signed char* __restrict__ cls, Table t, const int* __restrict__ boff, int base, int step, int cap,
               int4* __restrict__ cbox, int* __restrict__ cstep)
 {
-    ordered_scatter_block(K, boff, [&](int i) { return cls[i] == 0; },
+    ordered_scatter_block(dK[0], boff, [&](int i) { return cls[i] == 0; },
                           [&](int i, int r) { const int d = base + r; if (d < cap) { cbox[d] = make_int4(t.minx[i], t.maxx[i], t.miny[i], t.maxy[i]); cstep[d] = step; } });
+}
+// totals of a run's classification: out[0] = inter-ligation boxes (appended), out[1] = self-ligation boxes
+__global__ void k_cand_totals(const int* __restrict__ bcount, const int* __restrict__ boff, int nb, long long* __restrict__ out)
+{
+    __shared__ long long red[4];
+    long long s = 0;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) s += bcount[nb + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { out[0] = (long long)boff[nb - 1] + bcount[nb - 1]; out[1] = red[0] + red[1] + red[2] + red[3]; }
 }
 __device__ __forceinline__ u64 box_hash(int4 b, u64 salt)
 {
@@ -2828,6 +2843,9 @@ struct cl_chrom {
         int32_t* labels_out = nullptr;
         DevBuf slab;                  // labels in sorted order (rotated variants)
         bool exported = true;         // the table rows were stored to h_boxes
+        bool step_valid = false;      // the run carried the sweep-step tail (classification, candidate append, distance summary)
+        DevBuf d_step;                // device: {n_inter, n_self} + K7 partials + log histogram of that tail
+        char* h_step = nullptr;       // pinned host copy
         bool rows_valid = false;      // `labels` (row order) was produced by the run
         bool sorted_src = false;      // the run left sorted (q, label) arrays for the distance statistics
         const int* k7_sv = nullptr;   // sorted q of the run
@@ -2835,6 +2853,8 @@ struct cl_chrom {
     } slot[2];
     bool device_labels = true;        // produce row-order device labels even without a host destination (cl_set_device_labels)
     bool export_table = true;         // copy the cluster table to pinned host memory at the end of a run (cl_set_table_export)
+    int pending_step = -1;            // >= 0: the run being enqueued is step `pending_step` of a sweep (cl_cluster_step_async)
+    int pending_cut = 0;
     DevBuf cand_box, cand_step, cand_keep, cand_out;   // K10: candidate loops of the running sweep
     long long cand_n = 0, cand_cap = 0;
     DevBuf hdr;                       // device result headers, 16 ints per slot
@@ -2862,7 +2882,7 @@ static void free_chrom(cl_chrom* c)
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
-                      &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
+                      &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->slot[0].d_step, &c->slot[1].d_step, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
                       &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out};
     for (DevBuf* b : bufs) b->release();
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
@@ -2870,6 +2890,7 @@ static void free_chrom(cl_chrom* c)
     for (auto& sl : c->slot) {
         if (sl.h_boxes) (void)hipHostFree(sl.h_boxes);
         if (sl.h_hdr) (void)hipHostFree(sl.h_hdr);
+        if (sl.h_step) (void)hipHostFree(sl.h_step);
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
         if (sl.ev_copied) (void)hipEventDestroy(sl.ev_copied);
         if (c->ev_ready) for (auto& e : sl.ev) (void)hipEventDestroy(e);
@@ -3451,11 +3472,51 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
     hipLaunchKernelGGL(k_export_table, dim3(256), dim3(TPB), 0, c->stream, dh, make_table(c), sl.h_boxes,
                        c->export_table ? (int)std::min<size_t>(sl.h_boxes_cap, 0x7fffffff) : -1);
     sl.exported = c->export_table;
+    sl.step_valid = false;
+    if (c->pending_step >= 0) {
+        // sweep-step tail, still inside the run's stream: classify the table (pipe.py:83-97), append the inter-ligation
+        // boxes to the chromosome's candidate buffer, reduce the distance statistics -- the host gets everything with
+        // the run's own completion (one wait per chromosome and step)
+        int rc;
+        if ((rc = c->k7_cls.ensure((size_t)n + 16))) return rc;
+        if (c->cand_cap == 0) {
+            const long long cap = std::max<long long>(c->n / 2, 1 << 20);
+            if ((rc = c->cand_box.ensure((size_t)cap * 16)) || (rc = c->cand_step.ensure((size_t)cap * 4))) return rc;
+            c->cand_cap = cap;
+        }
+        const size_t step_bytes = 16 + K7_BLOCKS * sizeof(K7Part) + K7_LOGBINS * 8;
+        if ((rc = sl.d_step.ensure(step_bytes))) return rc;
+        if (!sl.h_step) HIP_TRY(hipHostMalloc((void**)&sl.h_step, step_bytes, hipHostMallocDefault));
+        const int nb = nblocks(n, CAND_BLOCK);                 // the number of ids K is only known on the device: K <= n
+        if ((rc = c->sel_tmp.ensure((size_t)nb * 12 + 64))) return rc;
+        int* bcount = c->sel_tmp.as<int>();
+        int* boff = bcount + 2 * nb;
+        Table t = make_table(c);
+        signed char* cls = c->k7_cls.as<signed char>();
+        LAUNCH(k7_classify, n + 1, dh, t, cls);
+        hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(256), 0, c->stream, (const int*)dh, cls, bcount, nb);
+        size_t tb = c->scan_tmp.bytes;
+        hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, bcount, boff, 0, (size_t)nb, rocprim::plus<int>(), c->stream);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan(step)", hipGetErrorString(e));
+        hipLaunchKernelGGL(k_cand_append, dim3(nb), dim3(256), 0, c->stream, (const int*)dh, cls, t, (const int*)boff, (int)c->cand_n, c->pending_step,
+                           (int)std::min<long long>(c->cand_cap, INT_MAX), c->cand_box.as<int4>(), c->cand_step.as<int>());
+        char* ds = (char*)sl.d_step.p;
+        hipLaunchKernelGGL(k_cand_totals, dim3(1), dim3(256), 0, c->stream, (const int*)bcount, (const int*)boff, nb, (long long*)ds);
+        K7Part* parts = (K7Part*)(ds + 16);
+        unsigned long long* lh = (unsigned long long*)(ds + 16 + K7_BLOCKS * sizeof(K7Part));
+        HIP_TRY(hipMemsetAsync(lh, 0, K7_LOGBINS * 8, c->stream));
+        K7Src src{};
+        src.sorted = sl.sorted_src ? 1 : 0; src.n = n; src.M = 0; src.v0 = sl.k7_v0; src.dM = d_M;
+        src.X = c->d_x; src.Y = c->d_y; src.labels = sl.labels.as<int>(); src.sv = sl.k7_sv; src.slab = sl.slab.as<int>();
+        hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, src, c->pending_cut, cls, parts, lh);
+        sl.step_valid = true;
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sl.ev_done, c->stream));
     ev_record(c, 6);
     HIP_TRY(hipStreamWaitEvent(c->copy_stream, sl.ev_done, 0));
     HIP_TRY(hipMemcpyAsync(sl.h_hdr, dh, 32, hipMemcpyDeviceToHost, c->copy_stream));
+    if (sl.step_valid) HIP_TRY(hipMemcpyAsync(sl.h_step, sl.d_step.p, 16 + K7_BLOCKS * sizeof(K7Part) + K7_LOGBINS * 8, hipMemcpyDeviceToHost, c->copy_stream));
     if (labels_out) HIP_TRY(hipMemcpyAsync(labels_out, sl.labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->copy_stream));
     if (c->profiling) (void)hipEventRecord(sl.ev[7], c->copy_stream);
     HIP_TRY(hipEventRecord(sl.ev_copied, c->copy_stream));
@@ -3519,7 +3580,12 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
     c->last_K = ml + 1;
     c->last_slot = w;
     c->have_result = true;
-    c->k7_classified = false;
+    c->k7_classified = sl.step_valid;                    // the step tail has classified this run's table already
+    if (sl.step_valid) {
+        const long long ni = ((const long long*)sl.h_step)[0];
+        if (c->cand_n + ni > c->cand_cap) return fail(CL_ERR_GRID, "candidate buffer full (more inter-ligation boxes over the sweep than n / 2)");
+        c->cand_n += ni;
+    }
     if (c->profiling) {
         cl_timing& tm = c->timing;
         memset(&tm, 0, sizeof(tm));
@@ -3745,6 +3811,39 @@ extern "C" int cl_cluster_async(cl_chrom* c, int variant, int32_t eps, int32_t m
     return run_rotated(c, variant, eps, min_pts, cut, labels_out);
 }
 
+extern "C" int cl_cluster_step_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut, int32_t step)
+{
+    if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
+    if (step < 0) return fail(CL_ERR_ARG, "cl_cluster_step_async: step must be >= 0");
+    if (variant == CL_VARIANT_BLOCK) return fail(CL_ERR_ARG, "cl_cluster_step_async: rotated variants only");
+    if (c->enq != c->deq) return fail(CL_ERR_ARG, "cl_cluster_step_async: one sweep step in flight per chromosome");
+    c->pending_step = step;
+    c->pending_cut = cut;
+    const int rc = cl_cluster_async(c, variant, eps, min_pts, cut, nullptr);
+    c->pending_step = -1;
+    return rc;
+}
+
+extern "C" int cl_step_result(cl_chrom* c, int64_t* n_inter, int64_t* n_self, cl_dsummary* out)
+{
+    if (!c || !out) return fail(CL_ERR_ARG, "cl_step_result: null argument");
+    if (!c->have_result || c->last_slot < 0 || !c->slot[c->last_slot].step_valid)
+        return fail(CL_ERR_ARG, "cl_step_result: the last completed run was not a sweep step");
+    const char* h = c->slot[c->last_slot].h_step;
+    if (n_inter) *n_inter = ((const long long*)h)[0];
+    if (n_self) *n_self = ((const long long*)h)[1];
+    memset(out, 0, sizeof(*out));
+    out->xshift = K7_XSHIFT;
+    const K7Part* parts = (const K7Part*)(h + 16);
+    for (int g = 0; g < 2; ++g) {
+        double a = 0, b = 0; long long na = 0, np = 0;
+        for (int k = 0; k < K7_BLOCKS; ++k) { a += parts[k].sx[g]; b += parts[k].sxx[g]; na += parts[k].n_all[g]; np += parts[k].n_pos[g]; }   // fixed order
+        out->sumx[g] = a; out->sumxx[g] = b; out->n_all[g] = na; out->n_pos[g] = np;
+    }
+    memcpy(out->loghist, h + 16 + K7_BLOCKS * sizeof(K7Part), K7_LOGBINS * 8);
+    return CL_OK;
+}
+
 extern "C" int cl_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
 {
     if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
@@ -3889,7 +3988,6 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
 
 
 // ---- K7 host entry points --------------------------------------------------------------------
-#define K7_BLOCKS 512
 static int k7_prepare(cl_chrom* c)
 {
     if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
@@ -3987,11 +4085,12 @@ extern "C" int cl_cand_append(cl_chrom* c, int32_t step, int64_t* n_inter, int64
     if ((rc = c->sel_tmp.ensure((size_t)nb * 12 + 64))) return rc;
     int* bcount = c->sel_tmp.as<int>();
     int* boff = bcount + 2 * nb;
-    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(256), 0, c->stream, K, c->k7_cls.as<signed char>(), bcount, nb);
+    const int* dK = c->hdr.as<int>() + 16 * c->last_slot;
+    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(256), 0, c->stream, dK, c->k7_cls.as<signed char>(), bcount, nb);
     size_t tb = c->scan_tmp.bytes;
     hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, bcount, boff, 0, (size_t)nb, rocprim::plus<int>(), c->stream);
     if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan(cand)", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_cand_append, dim3(nb), dim3(256), 0, c->stream, K, c->k7_cls.as<signed char>(), make_table_slot(c, c->last_slot),
+    hipLaunchKernelGGL(k_cand_append, dim3(nb), dim3(256), 0, c->stream, dK, c->k7_cls.as<signed char>(), make_table_slot(c, c->last_slot),
                        (const int*)boff, (int)c->cand_n, (int)step, (int)std::min<long long>(c->cand_cap, INT_MAX), c->cand_box.as<int4>(), c->cand_step.as<int>());
     std::vector<int> h(2 * nb);
     HIP_TRY(hipMemcpyAsync(h.data(), bcount, (size_t)2 * nb * 4, hipMemcpyDeviceToHost, c->stream));

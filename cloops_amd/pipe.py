@@ -483,7 +483,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                     for f, r in live:
                         r.lock.acquire()
                         try:
-                            r.chrom.cluster_async(variant, ep, m, step_cut, want_labels=False, want_boxes=False)
+                            r.chrom.step_async(variant, ep, m, step_cut, this_step)
                         except Exception:
                             r.lock.release()
                             raise
@@ -504,11 +504,11 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                         res = r.chrom.wait()
                         if probe is not None:
                             probe(f, ep, m, step_cut, res)
-                        # the table stays on the device: classified there (pipe.py:83-97), its inter-ligation boxes
-                        # appended to the chromosome's candidate buffer under this step's number
-                        nI, nS = r.chrom.cand_append(this_step)
+                        # the run carried its own tail on the device: the table classified (pipe.py:83-97), its
+                        # inter-ligation boxes appended to the chromosome's candidate buffer under this step's number,
+                        # the distance statistics reduced -- everything is on the host with the run's completion
+                        nI, nS, s1 = r.chrom.step_result()
                         n_in = r.chrom.last_n_in()
-                        s1 = r.chrom.dist_summary(step_cut) if nI else None
                     finally:
                         r.lock.release()
                     return f, r, nI, nS, n_in, s1
@@ -531,19 +531,19 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                             tot[kk][gg] += s1[kk][gg]
                     loghist += s1["loghist"]
                     xshift = s1["xshift"]
-                g = gsum(np.asarray([nI_tot, nS, n_in, len(used)], dtype=np.int64))
+                # the genome-wide statistics: everything is additive over chromosomes and ranks -- two small exchanges per
+                # step (one integer vector, one float vector), then the histograms of the median's refinement
+                gi = gsum(np.concatenate([np.asarray([nI_tot, nS, n_in, len(used)] + tot["n_all"] + tot["n_pos"], dtype=np.int64), loghist]))
+                gf = gsum(np.asarray(tot["sumx"] + tot["sumxx"] + [xshift if used else 0.0, 1.0 if used else 0.0], dtype=np.float64))
+                g, loghist = gi[:4], gi[8:]
                 st = {"eps": ep, "minPts": m, "cut_in": int(cut), "n_inter": int(g[0]), "n_self": int(g[1]), "n_in": int(g[2])}
                 steps.append(st)
                 if int(g[3]) == 0:                            # pipe.py:251-255
                     if log:
                         log("ERROR: no inter-ligation PETs detected for eps %s minPts %s,can't model the distance cutoff,continue anyway" % (ep, m))
                     continue
-                # the genome-wide statistics: everything is additive over chromosomes and ranks
-                gi = gsum(np.asarray(tot["n_all"] + tot["n_pos"], dtype=np.int64))
-                gf = gsum(np.asarray(tot["sumx"] + tot["sumxx"] + [xshift if used else 0.0, 1.0 if used else 0.0], dtype=np.float64))
-                loghist = gsum(loghist)
                 xshift = float(gf[4]) / max(float(gf[5]), 1.0)            # the library constant (ranks without a chromosome report 0)
-                tot = {"n_all": [int(gi[0]), int(gi[1])], "n_pos": [int(gi[2]), int(gi[3])]}
+                tot = {"n_all": [int(gi[4]), int(gi[5])], "n_pos": [int(gi[6]), int(gi[7])]}
                 if tot["n_all"][0] > 0 and tot["n_all"][1] > 0:      # pipe.py:256-259
                     if tot["n_pos"][0] == 0 or tot["n_pos"][1] == 0:
                         raise ValueError("cannot convert float NaN to integer")      # what int(2 ** nan) raises in ests.py:57

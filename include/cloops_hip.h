@@ -217,6 +217,11 @@ const int32_t* cl_labels_device(const cl_chrom* c);
  * cl_cand_reset starts a new sweep.
  */
 int cl_cand_reset(cl_chrom* c);
+/* One step of a sweep in ONE asynchronous call: cl_cluster_async(labels_out = NULL) followed, in the run's own stream,
+ * by what cl_cand_append and cl_dist_summary do for that run (same `cut`).  After cl_wait the results are on the host:
+ * cl_step_result copies them out without touching the GPU.  One step in flight per chromosome. */
+int cl_cluster_step_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut, int32_t step);
+int cl_step_result(cl_chrom* c, int64_t* n_inter, int64_t* n_self, cl_dsummary* out);
 int cl_cand_append(cl_chrom* c, int32_t step, int64_t* n_inter, int64_t* n_self);
 int cl_cand_finish(cl_chrom* c, int32_t final_cut, int32_t* boxes_out, int64_t capacity, int64_t* n_out);
 

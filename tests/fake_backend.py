@@ -64,6 +64,15 @@ class FakeChromosome(object):
             self._cand.append((step, t[inter]))
         return int(inter.sum()), int((ok & ~inter).sum())
 
+    def step_async(self, variant, eps, minPts, cut, step):
+        self.cluster_async(variant, eps, minPts, cut)
+        self._step = (step, cut)
+
+    def step_result(self):
+        step, cut = self._step
+        ni, ns = self.cand_append(step)
+        return ni, ns, self.dist_summary(cut)
+
     def cand_finish(self, final_cut, capacity):
         from cloops_amd import pipe
         by_step = {}
