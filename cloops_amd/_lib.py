@@ -50,7 +50,8 @@ DIST_LOGBINS = 3840
 
 class ClDsummary(ctypes.Structure):
     _fields_ = [("n_all", ctypes.c_int64 * 2), ("n_pos", ctypes.c_int64 * 2), ("sumx", ctypes.c_double * 2),
-                ("sumxx", ctypes.c_double * 2), ("xshift", ctypes.c_double), ("loghist", ctypes.c_uint64 * DIST_LOGBINS)]
+                ("sumxx", ctypes.c_double * 2), ("xshift", ctypes.c_double), ("loghist", ctypes.c_uint64 * DIST_LOGBINS),
+                ("fine_lo", ctypes.c_int64), ("fine", ctypes.c_uint64 * 2048)]
 
 
 class CloopsHipError(RuntimeError):
@@ -111,7 +112,7 @@ def load():
     lib.cl_cand_append.restype = ctypes.c_int
     lib.cl_cand_append.argtypes = [vp, ctypes.c_int32, i64p, i64p]
     lib.cl_cluster_step_async.restype = ctypes.c_int
-    lib.cl_cluster_step_async.argtypes = [vp, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    lib.cl_cluster_step_async.argtypes = [vp, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64]
     lib.cl_step_result.restype = ctypes.c_int
     lib.cl_step_result.argtypes = [vp, i64p, i64p, ctypes.POINTER(ClDsummary)]
     lib.cl_cand_finish.restype = ctypes.c_int

@@ -137,11 +137,11 @@ class Chromosome(object):
         _lib.check(self._lib.cl_cand_append(self._h, int(step), ctypes.byref(ni), ctypes.byref(ns)))
         return int(ni.value), int(ns.value)
 
-    def step_async(self, variant, eps, minPts, cut, step):
+    def step_async(self, variant, eps, minPts, cut, step, fine_lo=-1):
         """one sweep step in one asynchronous call (cl_cluster_step_async): the run, then -- in its own stream -- the
         classification of its table, the append of its inter-ligation boxes under `step` and the distance summary;
         pair with wait(), then read step_result()"""
-        _lib.check(self._lib.cl_cluster_step_async(self._h, VARIANTS[variant], int(eps), int(minPts), int(cut), int(step)))
+        _lib.check(self._lib.cl_cluster_step_async(self._h, VARIANTS[variant], int(eps), int(minPts), int(cut), int(step), int(fine_lo)))
         self._export = False
         self._inflight.append((None, False))
         self._enq += 1
@@ -252,7 +252,8 @@ class Chromosome(object):
     def _summary_dict(st):
         return {"n_all": [int(st.n_all[0]), int(st.n_all[1])], "n_pos": [int(st.n_pos[0]), int(st.n_pos[1])],
                 "sumx": [float(st.sumx[0]), float(st.sumx[1])], "sumxx": [float(st.sumxx[0]), float(st.sumxx[1])],
-                "xshift": float(st.xshift), "loghist": np.ctypeslib.as_array(st.loghist).astype(np.int64)}
+                "xshift": float(st.xshift), "loghist": np.ctypeslib.as_array(st.loghist).astype(np.int64),
+                "fine_lo": int(st.fine_lo), "fine": np.ctypeslib.as_array(st.fine).astype(np.int64) if st.fine_lo >= 0 else None}
 
     def dist_bin_hist(self, cut, lo, hi, shift):
         """histogram (int64[2048]) of (|d| - lo) >> shift over the self group's lo <= |d| < hi (cl_dist_bin_hist)"""

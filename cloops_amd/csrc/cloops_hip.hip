@@ -2487,19 +2487,27 @@ struct K7Part { double sx[2]; double sxx[2]; long long n_all[2]; long long n_pos
 // one pass: counts, sum x and sum x^2 (x = log2|d| - K7_XSHIFT over d != 0) for both groups, and the log-binned
 // histogram of the self group's |d| (first level of the exact median)
 __global__ void __launch_bounds__(TPB)
-k7_summary(K7Src s, int cut, const signed char* __restrict__ cls, K7Part* __restrict__ parts, unsigned long long* __restrict__ loghist)
+k7_summary(K7Src s, int cut, const signed char* __restrict__ cls, K7Part* __restrict__ parts, unsigned long long* __restrict__ loghist,
+           unsigned fine_lo, unsigned long long* __restrict__ fine /* or null: exact histogram of the self group's fine_lo <= |d| < fine_lo + 2048 */)
 {
     __shared__ unsigned int h[K7_LOGBINS];
+    __shared__ unsigned int hf[K7_FINE];
     for (int k = threadIdx.x; k < K7_LOGBINS; k += blockDim.x) h[k] = 0u;
+    for (int k = threadIdx.x; k < K7_FINE; k += blockDim.x) hf[k] = 0u;
     __syncthreads();
     double sx[2] = {0.0, 0.0}, sxx[2] = {0.0, 0.0};
     long long na[2] = {0, 0}, np_[2] = {0, 0};
+    const bool want_fine = fine != nullptr;
     k7_for_each(s, cut, cls, [&](int g, int ad) {
         na[g]++;
         if (ad > 0) {
             const double x = log2((double)ad) - K7_XSHIFT;
             np_[g]++; sx[g] += x; sxx[g] += x * x;
-            if (g == 1) atomicAdd(&h[k7_logbin((unsigned)ad)], 1u);
+            if (g == 1) {
+                atomicAdd(&h[k7_logbin((unsigned)ad)], 1u);
+                const unsigned off = (unsigned)ad - fine_lo;                  // wraps for ad < fine_lo: out of range
+                if (want_fine && off < (unsigned)K7_FINE) atomicAdd(&hf[off], 1u);
+            }
         }
     });
     __shared__ double s_d[4][TPB / 64];
@@ -2526,6 +2534,9 @@ k7_summary(K7Src s, int cut, const signed char* __restrict__ cls, K7Part* __rest
     }
     for (int k = threadIdx.x; k < K7_LOGBINS; k += blockDim.x)
         if (h[k]) atomicAdd(&loghist[k], (unsigned long long)h[k]);
+    if (want_fine)
+        for (int k = threadIdx.x; k < K7_FINE; k += blockDim.x)
+            if (hf[k]) atomicAdd(&fine[k], (unsigned long long)hf[k]);
 }
 
 // refinement pass of the exact median: histogram of (|d| - lo) >> shift over the self group's lo <= |d| < hi
@@ -2844,6 +2855,7 @@ struct cl_chrom {
         DevBuf slab;                  // labels in sorted order (rotated variants)
         bool exported = true;         // the table rows were stored to h_boxes
         bool step_valid = false;      // the run carried the sweep-step tail (classification, candidate append, distance summary)
+        long long fine_lo = -1;       // fine window of that tail's summary (-1 = none)
         DevBuf d_step;                // device: {n_inter, n_self} + K7 partials + log histogram of that tail
         char* h_step = nullptr;       // pinned host copy
         bool rows_valid = false;      // `labels` (row order) was produced by the run
@@ -2855,6 +2867,7 @@ struct cl_chrom {
     bool export_table = true;         // copy the cluster table to pinned host memory at the end of a run (cl_set_table_export)
     int pending_step = -1;            // >= 0: the run being enqueued is step `pending_step` of a sweep (cl_cluster_step_async)
     int pending_cut = 0;
+    long long pending_fine_lo = -1;   // >= 0: the step's summary also histograms the self group's [fine_lo, fine_lo + 2048) exactly
     DevBuf cand_box, cand_step, cand_keep, cand_out;   // K10: candidate loops of the running sweep
     long long cand_n = 0, cand_cap = 0;
     DevBuf hdr;                       // device result headers, 16 ints per slot
@@ -3484,7 +3497,7 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
             if ((rc = c->cand_box.ensure((size_t)cap * 16)) || (rc = c->cand_step.ensure((size_t)cap * 4))) return rc;
             c->cand_cap = cap;
         }
-        const size_t step_bytes = 16 + K7_BLOCKS * sizeof(K7Part) + K7_LOGBINS * 8;
+        const size_t step_bytes = 16 + K7_BLOCKS * sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8;
         if ((rc = sl.d_step.ensure(step_bytes))) return rc;
         if (!sl.h_step) HIP_TRY(hipHostMalloc((void**)&sl.h_step, step_bytes, hipHostMallocDefault));
         const int nb = nblocks(n, CAND_BLOCK);                 // the number of ids K is only known on the device: K <= n
@@ -3504,11 +3517,13 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
         hipLaunchKernelGGL(k_cand_totals, dim3(1), dim3(256), 0, c->stream, (const int*)bcount, (const int*)boff, nb, (long long*)ds);
         K7Part* parts = (K7Part*)(ds + 16);
         unsigned long long* lh = (unsigned long long*)(ds + 16 + K7_BLOCKS * sizeof(K7Part));
-        HIP_TRY(hipMemsetAsync(lh, 0, K7_LOGBINS * 8, c->stream));
+        HIP_TRY(hipMemsetAsync(lh, 0, K7_LOGBINS * 8 + K7_FINE * 8, c->stream));        // log histogram + the fine window behind it
         K7Src src{};
         src.sorted = sl.sorted_src ? 1 : 0; src.n = n; src.M = 0; src.v0 = sl.k7_v0; src.dM = d_M;
         src.X = c->d_x; src.Y = c->d_y; src.labels = sl.labels.as<int>(); src.sv = sl.k7_sv; src.slab = sl.slab.as<int>();
-        hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, src, c->pending_cut, cls, parts, lh);
+        hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, src, c->pending_cut, cls, parts, lh,
+                           (unsigned)c->pending_fine_lo, c->pending_fine_lo >= 0 ? lh + K7_LOGBINS : (unsigned long long*)nullptr);
+        sl.fine_lo = c->pending_fine_lo;
         sl.step_valid = true;
     }
     HIP_TRY(hipGetLastError());
@@ -3516,7 +3531,7 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
     ev_record(c, 6);
     HIP_TRY(hipStreamWaitEvent(c->copy_stream, sl.ev_done, 0));
     HIP_TRY(hipMemcpyAsync(sl.h_hdr, dh, 32, hipMemcpyDeviceToHost, c->copy_stream));
-    if (sl.step_valid) HIP_TRY(hipMemcpyAsync(sl.h_step, sl.d_step.p, 16 + K7_BLOCKS * sizeof(K7Part) + K7_LOGBINS * 8, hipMemcpyDeviceToHost, c->copy_stream));
+    if (sl.step_valid) HIP_TRY(hipMemcpyAsync(sl.h_step, sl.d_step.p, 16 + K7_BLOCKS * sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8, hipMemcpyDeviceToHost, c->copy_stream));
     if (labels_out) HIP_TRY(hipMemcpyAsync(labels_out, sl.labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->copy_stream));
     if (c->profiling) (void)hipEventRecord(sl.ev[7], c->copy_stream);
     HIP_TRY(hipEventRecord(sl.ev_copied, c->copy_stream));
@@ -3811,7 +3826,7 @@ extern "C" int cl_cluster_async(cl_chrom* c, int variant, int32_t eps, int32_t m
     return run_rotated(c, variant, eps, min_pts, cut, labels_out);
 }
 
-extern "C" int cl_cluster_step_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut, int32_t step)
+extern "C" int cl_cluster_step_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut, int32_t step, int64_t fine_lo)
 {
     if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
     if (step < 0) return fail(CL_ERR_ARG, "cl_cluster_step_async: step must be >= 0");
@@ -3819,6 +3834,7 @@ extern "C" int cl_cluster_step_async(cl_chrom* c, int variant, int32_t eps, int3
     if (c->enq != c->deq) return fail(CL_ERR_ARG, "cl_cluster_step_async: one sweep step in flight per chromosome");
     c->pending_step = step;
     c->pending_cut = cut;
+    c->pending_fine_lo = (fine_lo >= 0 && fine_lo < (1LL << 31)) ? fine_lo : -1;
     const int rc = cl_cluster_async(c, variant, eps, min_pts, cut, nullptr);
     c->pending_step = -1;
     return rc;
@@ -3841,6 +3857,8 @@ extern "C" int cl_step_result(cl_chrom* c, int64_t* n_inter, int64_t* n_self, cl
         out->sumx[g] = a; out->sumxx[g] = b; out->n_all[g] = na; out->n_pos[g] = np;
     }
     memcpy(out->loghist, h + 16 + K7_BLOCKS * sizeof(K7Part), K7_LOGBINS * 8);
+    out->fine_lo = c->slot[c->last_slot].fine_lo;
+    if (out->fine_lo >= 0) memcpy(out->fine, h + 16 + K7_BLOCKS * sizeof(K7Part) + K7_LOGBINS * 8, K7_FINE * 8);
     return CL_OK;
 }
 
@@ -4025,7 +4043,8 @@ extern "C" int cl_dist_summary(cl_chrom* c, int32_t cut, cl_dsummary* out)
     if (!c->slot[c->last_slot].sorted_src && !c->slot[c->last_slot].rows_valid) return fail(CL_ERR_ARG, "cl_dist_summary: the last run left no labels");
     unsigned long long* dh = (unsigned long long*)((char*)c->k7_parts.p + K7_BLOCKS * sizeof(K7Part));
     HIP_TRY(hipMemsetAsync(dh, 0, K7_LOGBINS * 8, c->stream));
-    hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, k7_source(c), cut, c->k7_cls.as<signed char>(), c->k7_parts.as<K7Part>(), dh);
+    hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, k7_source(c), cut, c->k7_cls.as<signed char>(), c->k7_parts.as<K7Part>(), dh,
+                       0u, (unsigned long long*)nullptr);
     std::vector<char> h(K7_BLOCKS * sizeof(K7Part) + K7_LOGBINS * 8);
     HIP_TRY(hipMemcpyAsync(h.data(), c->k7_parts.p, h.size(), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -4036,6 +4055,7 @@ extern "C" int cl_dist_summary(cl_chrom* c, int32_t cut, cl_dsummary* out)
         out->sumx[g] = a; out->sumxx[g] = b; out->n_all[g] = na; out->n_pos[g] = np;
     }
     memcpy(out->loghist, h.data() + K7_BLOCKS * sizeof(K7Part), K7_LOGBINS * 8);
+    out->fine_lo = -1;
     return CL_OK;
 }
 

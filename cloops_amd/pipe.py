@@ -394,16 +394,24 @@ def _pmap(pool, fn, items):
     return list(pool.map(fn, items))
 
 
-def _select_kth(chroms, cut, loghist, ranks, allsum=None, pool=None):
+def _select_kth(chroms, cut, loghist, ranks, allsum=None, pool=None, fine=None):
     """Exact order statistics (0-based `ranks`, ascending) of the self group's |d| over the union of the chromosomes
     (of all ranks).  `loghist` = the genome-wide log-binned histogram of cl_dist_summary (bins monotone in |d|): it
     locates the bin of a rank; the bin is then refined with 2048-bin histograms of (|d| - lo) >> shift summed over the
     chromosomes (and, with `allsum`, over the ranks) until single distances are resolved -- one refinement pass for
     bins up to 2048 distances wide (|d| < 2^18), two beyond."""
-    from .ests import logbin_range
+    from .ests import logbin_range, logbin
     cum = np.cumsum(np.asarray(loghist, dtype=np.int64))
     out, cache = [], {}
+    if fine is not None and fine[0] >= 1:
+        # `fine` = (lo, exact histogram of lo <= |d| < lo + 2048), lo a lower bin edge: a rank inside it needs no further pass
+        b0 = logbin(fine[0])
+        below = int(cum[b0 - 1]) if b0 > 0 else 0
+        fcum = np.cumsum(fine[1])
     for rank in ranks:
+        if fine is not None and fine[0] >= 1 and below <= rank < below + int(fcum[-1]):
+            out.append(fine[0] + int(np.searchsorted(fcum, rank - below, side="right")))
+            continue
         b = int(np.searchsorted(cum, rank, side="right"))
         rem = rank - (int(cum[b - 1]) if b > 0 else 0)
         lo, hi = logbin_range(b)
@@ -469,6 +477,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
         for f, r in live:
             r.chrom.cand_reset()
         step_no = 0
+        fine_lo = -1                                         # where the summary should look for the next median (see _select_kth)
         for ep in eps:
             for m in minPts:
                 step_cut = cut
@@ -483,7 +492,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                     for f, r in live:
                         r.lock.acquire()
                         try:
-                            r.chrom.step_async(variant, ep, m, step_cut, this_step)
+                            r.chrom.step_async(variant, ep, m, step_cut, this_step, fine_lo)
                         except Exception:
                             r.lock.release()
                             raise
@@ -517,6 +526,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                 nI_tot = nS = n_in = 0
                 tot = {"n_all": [0, 0], "n_pos": [0, 0], "sumx": [0.0, 0.0], "sumxx": [0.0, 0.0]}
                 loghist = np.zeros(_lib_logbins(), dtype=np.int64)
+                fine = np.zeros(2048, dtype=np.int64)
                 xshift = 0.0
                 for f, r, nI, ndS, nin, s1 in _pmap(pool, collect, live):
                     nS += ndS
@@ -530,12 +540,14 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                         for kk in ("n_all", "n_pos", "sumx", "sumxx"):
                             tot[kk][gg] += s1[kk][gg]
                     loghist += s1["loghist"]
+                    if s1.get("fine") is not None:
+                        fine += s1["fine"]
                     xshift = s1["xshift"]
                 # the genome-wide statistics: everything is additive over chromosomes and ranks -- two small exchanges per
                 # step (one integer vector, one float vector), then the histograms of the median's refinement
-                gi = gsum(np.concatenate([np.asarray([nI_tot, nS, n_in, len(used)] + tot["n_all"] + tot["n_pos"], dtype=np.int64), loghist]))
+                gi = gsum(np.concatenate([np.asarray([nI_tot, nS, n_in, len(used)] + tot["n_all"] + tot["n_pos"], dtype=np.int64), loghist, fine]))
                 gf = gsum(np.asarray(tot["sumx"] + tot["sumxx"] + [xshift if used else 0.0, 1.0 if used else 0.0], dtype=np.float64))
-                g, loghist = gi[:4], gi[8:]
+                g, loghist, fine = gi[:4], gi[8:8 + len(loghist)], gi[8 + len(loghist):]
                 st = {"eps": ep, "minPts": m, "cut_in": int(cut), "n_inter": int(g[0]), "n_self": int(g[1]), "n_in": int(g[2])}
                 steps.append(st)
                 if int(g[3]) == 0:                            # pipe.py:251-255
@@ -552,7 +564,12 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                     sq = [float(gf[2]) - float(gf[0]) ** 2 / tot["n_pos"][0], float(gf[3]) - float(gf[1]) ** 2 / tot["n_pos"][1]]
                     tot["sumlog"] = sumlog
                     n1 = tot["n_pos"][1]
-                    med = _select_kth(used, cut, loghist, sorted({(n1 - 1) // 2, n1 // 2}), allsum, pool)
+                    med = _select_kth(used, cut, loghist, sorted({(n1 - 1) // 2, n1 // 2}), allsum, pool,
+                                      fine=(fine_lo, fine) if fine_lo >= 1 else None)
+                    # the next step's summary also counts the distances around this median exactly (the median moves little
+                    # from step to step): lower edge of the log bin 1024 below it, so that the ranks below it are known
+                    from .ests import logbin, logbin_range
+                    fine_lo = logbin_range(logbin(max(1, med[0] - 1024)))[0]
                     cut_2, frags, margin = estIntSelCutFrag_from_stats(tot["n_pos"], tot["sumlog"], sq, (med[0], med[-1]), with_margin=True)
                     if margin < CUT_RECHECK_MARGIN and allsum is None:
                         # 2**cut sits on an integer boundary within the rounding noise of the reduction order: settle

@@ -182,6 +182,8 @@ typedef struct {
     double sumxx[2];
     double xshift;
     uint64_t loghist[CL_DIST_LOGBINS];
+    int64_t fine_lo;                 /* >= 0: `fine` holds the exact histogram of the self group's fine_lo <= |d| < fine_lo + 2048 */
+    uint64_t fine[2048];
 } cl_dsummary;
 int cl_dist_summary(cl_chrom* c, int32_t cut, cl_dsummary* out);
 int cl_dist_bin_hist(cl_chrom* c, int32_t cut, uint32_t lo, uint32_t hi, int shift, uint64_t* hist2048);
@@ -219,8 +221,10 @@ const int32_t* cl_labels_device(const cl_chrom* c);
 int cl_cand_reset(cl_chrom* c);
 /* One step of a sweep in ONE asynchronous call: cl_cluster_async(labels_out = NULL) followed, in the run's own stream,
  * by what cl_cand_append and cl_dist_summary do for that run (same `cut`).  After cl_wait the results are on the host:
- * cl_step_result copies them out without touching the GPU.  One step in flight per chromosome. */
-int cl_cluster_step_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut, int32_t step);
+ * cl_step_result copies them out without touching the GPU.  One step in flight per chromosome.  `fine_lo` >= 0 (a guess
+ * of where the self group's median will fall, e.g. the previous step's) makes the summary also histogram the distances
+ * fine_lo .. fine_lo + 2047 exactly: when the median lands there no refinement pass (cl_dist_bin_hist) is needed. */
+int cl_cluster_step_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut, int32_t step, int64_t fine_lo);
 int cl_step_result(cl_chrom* c, int64_t* n_inter, int64_t* n_self, cl_dsummary* out);
 int cl_cand_append(cl_chrom* c, int32_t step, int64_t* n_inter, int64_t* n_self);
 int cl_cand_finish(cl_chrom* c, int32_t final_cut, int32_t* boxes_out, int64_t capacity, int64_t* n_out);

@@ -64,14 +64,20 @@ class FakeChromosome(object):
             self._cand.append((step, t[inter]))
         return int(inter.sum()), int((ok & ~inter).sum())
 
-    def step_async(self, variant, eps, minPts, cut, step):
+    def step_async(self, variant, eps, minPts, cut, step, fine_lo=-1):
         self.cluster_async(variant, eps, minPts, cut)
-        self._step = (step, cut)
+        self._step = (step, cut, fine_lo)
 
     def step_result(self):
-        step, cut = self._step
+        step, cut, fine_lo = self._step
         ni, ns = self.cand_append(step)
-        return ni, ns, self.dist_summary(cut)
+        s = self.dist_summary(cut)
+        s["fine_lo"], s["fine"] = fine_lo, None
+        if fine_lo >= 0:
+            g, ad = self._groups(cut)
+            a = ad[(g == 1) & (ad >= fine_lo) & (ad < fine_lo + 2048)].astype(np.int64)
+            s["fine"] = np.bincount(a - fine_lo, minlength=2048).astype(np.int64)
+        return ni, ns, s
 
     def cand_finish(self, final_cut, capacity):
         from cloops_amd import pipe
