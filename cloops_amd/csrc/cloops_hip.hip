@@ -2436,7 +2436,8 @@ struct K7Src {
     const int* X; const int* Y; const int* labels;      // input rows (+ row-order labels)
     const int* sv; const int* slab;                     // sorted q and sorted-order labels of [0, M)
 };
-#define K7_BLOCKS 512            // workgroups (= fixed partial sums) of the K7 reductions
+#define K7_BLOCKS 2048           // workgroups (= fixed partial sums) of the K7 reductions: 8 waves per SIMD (512 left the loads
+                                 // of a 66-element sequential loop per thread uncovered: 177 us -> see DESIGN.md)
 #define K7_LOGBINS 3840          // 30 octaves x 128: bin = floor(log2 d) * 128 + the next 7 bits of d (monotone in d)
 #define K7_FINE 2048
 #define K7_XSHIFT 11.0           // sums are taken over x = log2|d| - K7_XSHIFT (less cancellation in sum x^2 - (sum x)^2 / n)
@@ -2537,6 +2538,33 @@ k7_summary(K7Src s, int cut, const signed char* __restrict__ cls, K7Part* __rest
     if (want_fine)
         for (int k = threadIdx.x; k < K7_FINE; k += blockDim.x)
             if (hf[k]) atomicAdd(&fine[k], (unsigned long long)hf[k]);
+}
+
+// fixed-order reduction of the workgroup partials into parts[0] (deterministic: thread t sums blocks t, t+256, ... in order,
+// then a fixed tree) -- the host reads 64 bytes instead of K7_BLOCKS partials
+__global__ void __launch_bounds__(256)
+k7_reduce_parts(K7Part* __restrict__ parts, int nparts)
+{
+    __shared__ double sd[4][256];
+    __shared__ long long sn[4][256];
+    double a[4] = {0, 0, 0, 0}; long long c[4] = {0, 0, 0, 0};
+    for (int k = threadIdx.x; k < nparts; k += 256) {
+        const K7Part p = parts[k];
+        a[0] += p.sx[0]; a[1] += p.sx[1]; a[2] += p.sxx[0]; a[3] += p.sxx[1];
+        c[0] += p.n_all[0]; c[1] += p.n_all[1]; c[2] += p.n_pos[0]; c[3] += p.n_pos[1];
+    }
+    for (int q = 0; q < 4; ++q) { sd[q][threadIdx.x] = a[q]; sn[q][threadIdx.x] = c[q]; }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) for (int q = 0; q < 4; ++q) { sd[q][threadIdx.x] += sd[q][threadIdx.x + o]; sn[q][threadIdx.x] += sn[q][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        K7Part p;
+        p.sx[0] = sd[0][0]; p.sx[1] = sd[1][0]; p.sxx[0] = sd[2][0]; p.sxx[1] = sd[3][0];
+        p.n_all[0] = sn[0][0]; p.n_all[1] = sn[1][0]; p.n_pos[0] = sn[2][0]; p.n_pos[1] = sn[3][0];
+        parts[0] = p;
+    }
 }
 
 // refinement pass of the exact median: histogram of (|d| - lo) >> shift over the self group's lo <= |d| < hi
@@ -3497,9 +3525,11 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
             if ((rc = c->cand_box.ensure((size_t)cap * 16)) || (rc = c->cand_step.ensure((size_t)cap * 4))) return rc;
             c->cand_cap = cap;
         }
-        const size_t step_bytes = 16 + K7_BLOCKS * sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8;
-        if ((rc = sl.d_step.ensure(step_bytes))) return rc;
-        if (!sl.h_step) HIP_TRY(hipHostMalloc((void**)&sl.h_step, step_bytes, hipHostMallocDefault));
+        // step output (device and pinned host): 16 B box totals | the reduced statistics (one K7Part) | log histogram | fine window;
+        // the workgroup partials live behind it on the device only
+        const size_t out_bytes = 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8;
+        if ((rc = sl.d_step.ensure(out_bytes + K7_BLOCKS * sizeof(K7Part)))) return rc;
+        if (!sl.h_step) HIP_TRY(hipHostMalloc((void**)&sl.h_step, out_bytes, hipHostMallocDefault));
         const int nb = nblocks(n, CAND_BLOCK);                 // the number of ids K is only known on the device: K <= n
         if ((rc = c->sel_tmp.ensure((size_t)nb * 12 + 64))) return rc;
         int* bcount = c->sel_tmp.as<int>();
@@ -3515,14 +3545,16 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
                            (int)std::min<long long>(c->cand_cap, INT_MAX), c->cand_box.as<int4>(), c->cand_step.as<int>());
         char* ds = (char*)sl.d_step.p;
         hipLaunchKernelGGL(k_cand_totals, dim3(1), dim3(256), 0, c->stream, (const int*)bcount, (const int*)boff, nb, (long long*)ds);
-        K7Part* parts = (K7Part*)(ds + 16);
-        unsigned long long* lh = (unsigned long long*)(ds + 16 + K7_BLOCKS * sizeof(K7Part));
+        unsigned long long* lh = (unsigned long long*)(ds + 16 + sizeof(K7Part));
+        K7Part* parts = (K7Part*)(ds + out_bytes);
         HIP_TRY(hipMemsetAsync(lh, 0, K7_LOGBINS * 8 + K7_FINE * 8, c->stream));        // log histogram + the fine window behind it
         K7Src src{};
         src.sorted = sl.sorted_src ? 1 : 0; src.n = n; src.M = 0; src.v0 = sl.k7_v0; src.dM = d_M;
         src.X = c->d_x; src.Y = c->d_y; src.labels = sl.labels.as<int>(); src.sv = sl.k7_sv; src.slab = sl.slab.as<int>();
         hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, src, c->pending_cut, cls, parts, lh,
                            (unsigned)c->pending_fine_lo, c->pending_fine_lo >= 0 ? lh + K7_LOGBINS : (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, parts, K7_BLOCKS);
+        HIP_TRY(hipMemcpyAsync(ds + 16, parts, sizeof(K7Part), hipMemcpyDeviceToDevice, c->stream));
         sl.fine_lo = c->pending_fine_lo;
         sl.step_valid = true;
     }
@@ -3531,7 +3563,7 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
     ev_record(c, 6);
     HIP_TRY(hipStreamWaitEvent(c->copy_stream, sl.ev_done, 0));
     HIP_TRY(hipMemcpyAsync(sl.h_hdr, dh, 32, hipMemcpyDeviceToHost, c->copy_stream));
-    if (sl.step_valid) HIP_TRY(hipMemcpyAsync(sl.h_step, sl.d_step.p, 16 + K7_BLOCKS * sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8, hipMemcpyDeviceToHost, c->copy_stream));
+    if (sl.step_valid) HIP_TRY(hipMemcpyAsync(sl.h_step, sl.d_step.p, 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8, hipMemcpyDeviceToHost, c->copy_stream));
     if (labels_out) HIP_TRY(hipMemcpyAsync(labels_out, sl.labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->copy_stream));
     if (c->profiling) (void)hipEventRecord(sl.ev[7], c->copy_stream);
     HIP_TRY(hipEventRecord(sl.ev_copied, c->copy_stream));
@@ -3850,15 +3882,11 @@ extern "C" int cl_step_result(cl_chrom* c, int64_t* n_inter, int64_t* n_self, cl
     if (n_self) *n_self = ((const long long*)h)[1];
     memset(out, 0, sizeof(*out));
     out->xshift = K7_XSHIFT;
-    const K7Part* parts = (const K7Part*)(h + 16);
-    for (int g = 0; g < 2; ++g) {
-        double a = 0, b = 0; long long na = 0, np = 0;
-        for (int k = 0; k < K7_BLOCKS; ++k) { a += parts[k].sx[g]; b += parts[k].sxx[g]; na += parts[k].n_all[g]; np += parts[k].n_pos[g]; }   // fixed order
-        out->sumx[g] = a; out->sumxx[g] = b; out->n_all[g] = na; out->n_pos[g] = np;
-    }
-    memcpy(out->loghist, h + 16 + K7_BLOCKS * sizeof(K7Part), K7_LOGBINS * 8);
+    const K7Part* part = (const K7Part*)(h + 16);           // reduced on the device in a fixed order (k7_reduce_parts)
+    for (int g = 0; g < 2; ++g) { out->sumx[g] = part->sx[g]; out->sumxx[g] = part->sxx[g]; out->n_all[g] = part->n_all[g]; out->n_pos[g] = part->n_pos[g]; }
+    memcpy(out->loghist, h + 16 + sizeof(K7Part), K7_LOGBINS * 8);
     out->fine_lo = c->slot[c->last_slot].fine_lo;
-    if (out->fine_lo >= 0) memcpy(out->fine, h + 16 + K7_BLOCKS * sizeof(K7Part) + K7_LOGBINS * 8, K7_FINE * 8);
+    if (out->fine_lo >= 0) memcpy(out->fine, h + 16 + sizeof(K7Part) + K7_LOGBINS * 8, K7_FINE * 8);
     return CL_OK;
 }
 
@@ -4045,16 +4073,12 @@ extern "C" int cl_dist_summary(cl_chrom* c, int32_t cut, cl_dsummary* out)
     HIP_TRY(hipMemsetAsync(dh, 0, K7_LOGBINS * 8, c->stream));
     hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, k7_source(c), cut, c->k7_cls.as<signed char>(), c->k7_parts.as<K7Part>(), dh,
                        0u, (unsigned long long*)nullptr);
-    std::vector<char> h(K7_BLOCKS * sizeof(K7Part) + K7_LOGBINS * 8);
-    HIP_TRY(hipMemcpyAsync(h.data(), c->k7_parts.p, h.size(), hipMemcpyDeviceToHost, c->stream));
+    hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->k7_parts.as<K7Part>(), K7_BLOCKS);
+    K7Part part;
+    HIP_TRY(hipMemcpyAsync(&part, c->k7_parts.p, sizeof(K7Part), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out->loghist, dh, K7_LOGBINS * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    const K7Part* parts = (const K7Part*)h.data();
-    for (int g = 0; g < 2; ++g) {
-        double a = 0, b = 0; long long na = 0, np = 0;
-        for (int k = 0; k < K7_BLOCKS; ++k) { a += parts[k].sx[g]; b += parts[k].sxx[g]; na += parts[k].n_all[g]; np += parts[k].n_pos[g]; }   // fixed order
-        out->sumx[g] = a; out->sumxx[g] = b; out->n_all[g] = na; out->n_pos[g] = np;
-    }
-    memcpy(out->loghist, h.data() + K7_BLOCKS * sizeof(K7Part), K7_LOGBINS * 8);
+    for (int g = 0; g < 2; ++g) { out->sumx[g] = part.sx[g]; out->sumxx[g] = part.sxx[g]; out->n_all[g] = part.n_all[g]; out->n_pos[g] = part.n_pos[g]; }
     out->fine_lo = -1;
     return CL_OK;
 }
