@@ -807,7 +807,10 @@ __device__ __forceinline__ int first_true_clamped(const int2* __restrict__ w, in
     return pos;
 }
 
-template <int U, int HALO>
+// TAIL: the run has a cut, i.e. the sorted arrays end in a filtered tail whose tiles leave right after the scalar load of
+// tile_s0 (before staging anything); without a cut every tile has work and the staging loads are issued BEFORE that load
+// is waited for (its latency hides behind them).
+template <int U, int HALO, bool TAIL>
 __global__ void __launch_bounds__(K2F_TPB)
 k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
               const int* __restrict__ strip_start, const int* __restrict__ tile_s0, int* __restrict__ cnt)
@@ -824,9 +827,9 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     if (tile >= ntiles) return;
     K2T_INIT;
     const int t0 = tile * TILE;
-    const int s0 = tile_s0[t0 >> 8];                    // strip of the tile's first PET; S = the tile lies in the filtered tail
+    int s0 = 0;                                         // strip of the tile's first PET; S = the tile lies in the filtered tail
+    if (TAIL) { s0 = tile_s0[t0 >> 8]; if (s0 >= g.S) return; }
     const int M = strip_start[g.S];                     // PETs that passed the cut filter (device-side count)
-    if (s0 >= g.S) return;
     K2T(0);
     {
         // stage the window: unpredicated 16-byte loads (the arrays are padded with sentinels), every load of the
@@ -838,6 +841,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         int4 qv[FULL], pv[FULL];
 #pragma unroll
         for (int u = 0; u < FULL; ++u) { qv[u] = gq[threadIdx.x + u * K2F_TPB]; pv[u] = gp[threadIdx.x + u * K2F_TPB]; }
+        if (!TAIL) { s0 = tile_s0[t0 >> 8]; if (s0 >= g.S) return; }
         const int st = strip_start[min(max(s0 - 1 + (int)threadIdx.x, 0), g.S)];
 #pragma unroll
         for (int u = 0; u < FULL; ++u) {
@@ -858,11 +862,17 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned int* my_list = l_list + wv * (64 * U);
     int nh = 0;                                         // undecided PETs of this wave (wave-uniform)
-    // ---- phase 0: one-read core test, U PETs per thread -------------------------------------------------
+    // ---- phase 0: one-read core test, U PETs per thread (all 3 * U LDS reads in flight before the first compare) ------
+    int2 p_me[U], p_rr[U], p_ll[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int tix = (int)threadIdx.x + u * K2F_TPB, li = HALO + tix;
-        const int2 me = lw[li], rr = lw[li + m1], ll = lw[li - m1];
+        const int li = HALO + (int)threadIdx.x + u * K2F_TPB;
+        p_me[u] = lw[li]; p_rr[u] = lw[li + m1]; p_ll[u] = lw[li - m1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int tix = (int)threadIdx.x + u * K2F_TPB;
+        const int2 me = p_me[u], rr = p_rr[u], ll = p_ll[u];
         const int pbeg = me.y & nmask;
         const bool valid = t0 + tix < M;
         // the (minPts-1)-th next / previous PET is in the same strip and within eps in q (unsigned add: a sentinel q wraps harmlessly)
@@ -875,7 +885,12 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         nh += __popcll(bal);
     }
     K2T(3);
-    __syncthreads();                                    // (the lists are per wave; the barrier only orders the LDS writes)
+    // the lists are per wave: a wave only reads what its own lanes wrote, and the LDS executes a wave's operations in order
+    // -- no workgroup barrier, only "all my LDS writes have been issued" and a scheduling fence for the compiler
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     K2T(4);
     // ---- phase 1: own strip.  Phase 0 failed on both sides, so the q window ends before the (minPts-1)-th PET on
     // either side (or at the strip ends): lo = first PET of the own strip with q >= qlo, hi = first PET behind the own
@@ -3340,7 +3355,9 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
             {                                                                                                           \
                 const int tile = K2F_TPB * UU, ntiles = nblocks(n, tile), run = std::max(1, 2048 / tile);               \
                 const int grid = ((ntiles + 8 * run - 1) / (8 * run)) * (8 * run);                                      \
-                hipLaunchKernelGGL((k_region_core<UU, HH>), dim3(grid), dim3(K2F_TPB), 0, c->stream, g, ntiles,         \
+                if (g.cut > 0) hipLaunchKernelGGL((k_region_core<UU, HH, true>), dim3(grid), dim3(K2F_TPB), 0, c->stream, g, ntiles, \
+                                   c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->cnt.as<int>());                            \
+                else hipLaunchKernelGGL((k_region_core<UU, HH, false>), dim3(grid), dim3(K2F_TPB), 0, c->stream, g, ntiles, \
                                    c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->cnt.as<int>()); \
             }
             // window = tile + 2 * halo entries; shapes keep it a multiple of 1024 (every thread stages whole 16-byte slots)
