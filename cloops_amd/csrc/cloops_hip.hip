@@ -263,6 +263,17 @@ __global__ void k_stats(const int* __restrict__ X, const int* __restrict__ Y, lo
     }
 }
 
+// histogram of the distances d = Y - X below 65536 (one-off per upload): the host keeps its running sum, so that the number of
+// PETs that pass a cut (pipe.py:59-62) is known when a run is ENQUEUED -- grids and scans are then sized by M, not by n
+#define DCUM_BINS 65537
+__global__ void k_dhist(const int* __restrict__ X, const int* __restrict__ Y, long long n, int* __restrict__ hist)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long d = (long long)Y[i] - X[i];
+        atomicAdd(&hist[d < 0 ? 0 : (d > DCUM_BINS - 1 ? DCUM_BINS - 1 : (int)d)], 1);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K0: keys
 // ------------------------------------------------------------------------------------------
@@ -2882,6 +2893,9 @@ struct cl_chrom {
     // walks eps in the outer loop).  Nothing of a result is kept: neighbour counts, components, labels are redone.
     DevBuf bq, bsp, brow, bstrip, btile, sel_tmp;
     struct BaseLayout { bool valid = false; int layout = -1, eps = 0; } base;
+    std::vector<long long> dcum;      // dcum[k] = number of PETs with Y - X < k, k = 0 .. 65536 (empty: unknown)
+    int run_m = 0;                    // PETs that enter DBSCAN in the run being enqueued (exact when run_m_exact, else n)
+    bool run_m_exact = false;
     bool reuse_layout = true;
     // Result slots: two runs may be in flight (cl_cluster_async) -- the labels / table / header of
     // run k live in slot k & 1, so the D2H copy of run k (copy stream) overlaps the kernels of run k+1.
@@ -2899,6 +2913,7 @@ struct cl_chrom {
         bool exported = true;         // the table rows were stored to h_boxes
         bool step_valid = false;      // the run carried the sweep-step tail (classification, candidate append, distance summary)
         long long fine_lo = -1;       // fine window of that tail's summary (-1 = none)
+        int kmax = 0;                 // upper bound of the number of cluster ids of the run (host-known; the count itself is on the device)
         DevBuf d_step;                // device: {n_inter, n_self} + K7 partials + log histogram of that tail
         char* h_step = nullptr;       // pinned host copy
         bool rows_valid = false;      // `labels` (row order) was produced by the run
@@ -3041,6 +3056,18 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
             hipError_t e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) { rc = fail(CL_ERR_HIP, "stats sync", hipGetErrorString(e)); break; }
             c->st = *hs;
+            {
+                // distance histogram below 65536 -> running sum on the host (see k_dhist)
+                if ((rc = c->sel_tmp.ensure((size_t)DCUM_BINS * 4))) break;
+                std::vector<int> hh(DCUM_BINS);
+                if (hipMemsetAsync(c->sel_tmp.p, 0, (size_t)DCUM_BINS * 4, c->stream) != hipSuccess) { rc = fail(CL_ERR_HIP, "dhist memset"); break; }
+                hipLaunchKernelGGL(k_dhist, dim3(std::min(nblocks(n), 2048)), dim3(TPB), 0, c->stream, c->d_x, c->d_y, (long long)n, c->sel_tmp.as<int>());
+                if (hipMemcpyAsync(hh.data(), c->sel_tmp.p, (size_t)DCUM_BINS * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                    hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CL_ERR_HIP, "dhist readback"); break; }
+                c->dcum.assign(DCUM_BINS, 0);
+                long long run = 0;
+                for (int k = 0; k < DCUM_BINS; ++k) { c->dcum[k] = run; run += hh[k]; }      // dcum[k] = #(d < k)
+            }
             const int LIM = 1 << 29;
             if (c->st.xmin <= -LIM || c->st.xmax >= LIM || c->st.ymin <= -LIM || c->st.ymax >= LIM) {
                 rc = fail(CL_ERR_DOMAIN, "coordinates must satisfy |X|,|Y| < 2^29");
@@ -3118,10 +3145,12 @@ k_cut_scatter(int n, int thr, const int* __restrict__ bq, const int* __restrict_
 // after the compaction: strip table by bisection of the compacted sp (strip = sp >> rbits), tile table, and
 // sentinels behind the last kept PET (the tile kernels stage windows a little past M)
 __global__ void k_after_compact(int n, int S, int rbits, const int* __restrict__ d_M, const int* __restrict__ sa,
-                                int* __restrict__ sv_w, int* __restrict__ sa_w, int* __restrict__ strip_start, int* __restrict__ tile_s0)
+                                int* __restrict__ sv_w, int* __restrict__ sa_w, int* __restrict__ strip_start, int* __restrict__ tile_s0,
+                                int expect_m, int* __restrict__ counters)
 {
     const int M = d_M[0];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && expect_m >= 0 && expect_m != M) counters[CTR_OVERFLOW] = 8;      // the host sized the run by a wrong M: fail loudly
     if (t <= S + 1) {
         int lo = 0, hi = M;
         if (t == S + 1) lo = n;
@@ -3287,6 +3316,9 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
 {
     const int n = (int)c->n;
     int rc;
+    // M = PETs that pass the cut, from the distance histogram of the upload (exact for cut <= 65536)
+    c->run_m = n; c->run_m_exact = g.cut <= 0;
+    if (g.cut > 0 && g.cut < DCUM_BINS && !c->dcum.empty()) { c->run_m = (int)(n - c->dcum[g.cut]); c->run_m_exact = true; }
     int* wsv = c->sv.as<int>() + SORT_PAD;
     int* wsa = c->sa.as<int>() + SORT_PAD;
     if (!c->reuse_layout) {
@@ -3336,7 +3368,8 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
             hipLaunchKernelGGL(k_cut_scatter, dim3(nb), dim3(CMP_TPB), 0, c->stream, n, thr, bq, (const int*)(c->bsp.as<int>() + SORT_PAD),
                                (const u32*)c->brow.as<u32>(), (const int*)boff, (const int*)bcount, wsv, wsa, c->vals_out.as<u32>(), d_M);
             const int span = std::max(std::max(g.S + 2, n / 256 + 1), SORT_PAD);
-            LAUNCH(k_after_compact, span, n, g.S, g.rbits, d_M, wsa, wsv, wsa, c->strip.as<int>(), c->tile_s0.as<int>());
+            LAUNCH(k_after_compact, span, n, g.S, g.rbits, d_M, wsa, wsv, wsa, c->strip.as<int>(), c->tile_s0.as<int>(),
+                   c->run_m_exact ? c->run_m : -1, c->counters.as<int>());
             c->w_sv = wsv; c->w_sa = wsa; c->srow = c->vals_out.as<u32>();
             c->w_strip = c->strip.as<int>(); c->w_tile = c->tile_s0.as<int>();
         }
@@ -3353,7 +3386,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
 #endif
 #define K2F_LAUNCH(UU, HH)                                                                                              \
             {                                                                                                           \
-                const int tile = K2F_TPB * UU, ntiles = nblocks(n, tile), run = std::max(1, 2048 / tile);               \
+                const int tile = K2F_TPB * UU, ntiles = nblocks(std::max(1, c->run_m), tile), run = std::max(1, 2048 / tile); \
                 const int grid = ((ntiles + 8 * run - 1) / (8 * run)) * (8 * run);                                      \
                 if (g.cut > 0) hipLaunchKernelGGL((k_region_core<UU, HH, true>), dim3(grid), dim3(K2F_TPB), 0, c->stream, g, ntiles, \
                                    c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->cnt.as<int>());                            \
@@ -3527,8 +3560,10 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
     }
     hipLaunchKernelGGL(k_pack_header, dim3(1), dim3(64), 0, c->stream, dh, c->rankscan.as<int>() + n, c->counters.as<int>(), d_M);
     // (without export the kernel still counts the non-empty ids for the header; cap 0 = no row is stored)
-    hipLaunchKernelGGL(k_export_table, dim3(256), dim3(TPB), 0, c->stream, dh, make_table(c), sl.h_boxes,
-                       c->export_table ? (int)std::min<size_t>(sl.h_boxes_cap, 0x7fffffff) : -1);
+    if (c->export_table || c->pending_step < 0)
+        hipLaunchKernelGGL(k_export_table, dim3(256), dim3(TPB), 0, c->stream, dh, make_table(c), sl.h_boxes,
+                           c->export_table ? (int)std::min<size_t>(sl.h_boxes_cap, 0x7fffffff) : -1);
+    // (a sweep step reads neither the rows nor n_clusters / max_label: its header keeps the values of k_pack_header)
     sl.exported = c->export_table;
     sl.step_valid = false;
     if (c->pending_step >= 0) {
@@ -3547,13 +3582,14 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
         const size_t out_bytes = 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8;
         if ((rc = sl.d_step.ensure(out_bytes + K7_BLOCKS * sizeof(K7Part)))) return rc;
         if (!sl.h_step) HIP_TRY(hipHostMalloc((void**)&sl.h_step, out_bytes, hipHostMallocDefault));
-        const int nb = nblocks(n, CAND_BLOCK);                 // the number of ids K is only known on the device: K <= n
+        const int kmax = std::max(1, std::min(sl.kmax, n));     // the number of ids K is only known on the device: K <= kmax
+        const int nb = nblocks(kmax, CAND_BLOCK);
         if ((rc = c->sel_tmp.ensure((size_t)nb * 12 + 64))) return rc;
         int* bcount = c->sel_tmp.as<int>();
         int* boff = bcount + 2 * nb;
         Table t = make_table(c);
         signed char* cls = c->k7_cls.as<signed char>();
-        LAUNCH(k7_classify, n + 1, dh, t, cls);
+        LAUNCH(k7_classify, kmax + 1, dh, t, cls);
         hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(256), 0, c->stream, (const int*)dh, cls, bcount, nb);
         size_t tb = c->scan_tmp.bytes;
         hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, bcount, boff, 0, (size_t)nb, rocprim::plus<int>(), c->stream);
@@ -3619,7 +3655,8 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
     c->deq++;
     const int K = sl.h_hdr[0];
     if (sl.h_hdr[1] != 0)
-        return fail(CL_ERR_HIP, sl.h_hdr[1] == 4 ? "internal: strip longer than the hybrid sort accepts"
+        return fail(CL_ERR_HIP, sl.h_hdr[1] == 8 ? "internal: the number of PETs that passed the cut differs from the host's count"
+                                : sl.h_hdr[1] == 4 ? "internal: strip longer than the hybrid sort accepts"
                                                  : "internal: release-record overflow (border point with > 4 adjacent components)");
     // the table rows are already in the slot's pinned cache (k_export_table); only if that cache was
     // too small (K > capacity, reported in the header) grow it and fetch the rows with a copy
@@ -3957,8 +3994,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     if (const char* e = getenv("CLOOPS_TILE_WIDE")) wide = atoi(e);
 #endif
     const int tile_nt = wide ? 1024 : TPB;
-    const int ntiles = nblocks(n, tile_nt);
-    const int tgrid = tile_grid(ntiles);
+    int ntiles = 0, tgrid = 0;                          // set once the number of PETs that pass the cut is known
 #define TILE_LAUNCH(kernel, ...)                                                                                     \
     do {                                                                                                             \
         if (wide) hipLaunchKernelGGL((kernel<1024, 512>), dim3(tgrid), dim3(1024), 0, c->stream, __VA_ARGS__);       \
@@ -3974,33 +4010,41 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     {
         cl_chrom::Slot& sl = c->slot[c->cur];
         sl.rows_valid = rows; sl.sorted_src = g.swap != 0; sl.k7_sv = c->w_sv; sl.k7_v0 = g.V0;
+        // variant 2 hands an id only to a live cluster, which has >= minPts members (cDBSCAN2.py:180-185): K <= n / minPts;
+        // variant 1 numbers every component, dropped ones included (cDBSCAN.py:136-152): K <= n
+        sl.kmax = (variant == CL_VARIANT_CDBSCAN2 && minPts >= 1) ? n / minPts + 1 : n;
     }
     int* strip = c->w_strip;
     int* sv = c->w_sv;
     int* sa = c->w_sa;
     const u32* srow = c->srow;
+    // everything behind the sort works on the nm = M PETs that passed the cut (known on the host from the upload's distance
+    // histogram; nm = n when it is not): grids, tiles and scans are sized by it
+    const int nm = std::max(1, c->run_m);
+    ntiles = nblocks(nm, tile_nt);
+    tgrid = tile_grid(ntiles);
 
     // K3
     {
         // own-strip chains by scan; variant 2: the same tile kernel also finds every PET's cell head
         int* head = variant == CL_VARIANT_CDBSCAN2 ? c->head.as<int>() : nullptr;
-        TILE_LAUNCH(k_chain_flags, g, ntiles, n, sv, sa, strip, cnt, c->chainflag.as<int>(),
+        TILE_LAUNCH(k_chain_flags, g, ntiles, nm, sv, sa, strip, cnt, c->chainflag.as<int>(),
                            c->headidx.as<int>(), head);
         if (head) {
             // cellfirst: segmented suffix-min of the input rows, keyed by the cell's head index, so that
             // cellfirst[head] = smallest row of the whole cell (replaces one atomicMin per PET)
             size_t tb = c->scan_tmp.bytes;
-            hipError_t e = rocprim::inclusive_scan_by_key(c->scan_tmp.p, tb, rocprim::make_reverse_iterator(head + n),
-                                               rocprim::make_reverse_iterator((int*)srow + n),
-                                               rocprim::make_reverse_iterator(c->cellfirst.as<int>() + n), (size_t)n,
+            hipError_t e = rocprim::inclusive_scan_by_key(c->scan_tmp.p, tb, rocprim::make_reverse_iterator(head + nm),
+                                               rocprim::make_reverse_iterator((int*)srow + nm),
+                                               rocprim::make_reverse_iterator(c->cellfirst.as<int>() + nm), (size_t)nm,
                                                rocprim::minimum<int>(), rocprim::equal_to<int>(), c->stream);
             if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan_by_key", hipGetErrorString(e));
         }
         size_t tb = c->scan_tmp.bytes;
-        hipError_t e = rocprim::inclusive_scan(c->scan_tmp.p, tb, c->chainflag.as<int>(), c->chainhead.as<int>(), (size_t)n,
+        hipError_t e = rocprim::inclusive_scan(c->scan_tmp.p, tb, c->chainflag.as<int>(), c->chainhead.as<int>(), (size_t)nm,
                                                rocprim::maximum<int>(), c->stream);
         if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan(chain)", hipGetErrorString(e));
-        LAUNCH(k_chain_parent, n, strip, g.S, cnt, g.minPts, c->chainhead.as<int>(), c->parent.as<int>(), c->chainflag.as<int>(),
+        LAUNCH(k_chain_parent, nm, strip, g.S, cnt, g.minPts, c->chainhead.as<int>(), c->parent.as<int>(), c->chainflag.as<int>(),
                c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                c->headidx.as<int>(), sv, c->lo.as<int>());   // chain ends live in `lo` until the release fix-up reuses it
     }
@@ -4008,11 +4052,11 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     int* pmax32 = nullptr;
     if ((long long)n > 64LL * g.S) {
         pmax32 = c->hi.as<int>();
-        LAUNCH(k_block_pmax, n, n, c->chainflag.as<int>(), sa, pmax32);
+        LAUNCH(k_block_pmax, nm, nm, c->chainflag.as<int>(), sa, pmax32);
     }
     TILE_LAUNCH(k_union_cores, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
                        pmax32, c->parent.as<int>());
-    hipLaunchKernelGGL(k_flatten, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
+    hipLaunchKernelGGL(k_flatten, dim3(nblocks(nm, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
            c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->chainflag.as<int>() /* root list: the chain ids are dead */, counters);
     int* rootlist = c->chainflag.as<int>();
     ev_record(c, 4);
@@ -4027,7 +4071,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
                            c->compkey.as<int>(), c->state.as<int>(), c->owner.as<int>(), c->recs.as<Rec>(), rec_cap, counters);
         hipLaunchKernelGGL(k_resolve_release, dim3(1), dim3(1024), 0, c->stream, minPts, c->ncore.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                            c->ulist.as<int>(), c->recs.as<Rec>(), c->lo.as<int>(), c->hi.as<int>(), counters);
-        LAUNCH(k_apply_records, n, c->recs.as<Rec>(), c->state.as<int>(), c->owner.as<int>(), counters);
+        LAUNCH(k_apply_records, nm, c->recs.as<Rec>(), c->state.as<int>(), c->owner.as<int>(), counters);
     }
     ev_record(c, 5);
     // K5
@@ -4039,11 +4083,11 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan", hipGetErrorString(e));
     }
     Table t = make_table(c);
-    LAUNCH(k_init_table, n + 1, t, c->rankscan.as<int>(), n);
+    LAUNCH(k_init_table, c->slot[c->cur].kmax + 1, t, c->rankscan.as<int>(), n);
     // rlabel reuses the chainhead buffer (free after k_chain_parent)
     hipLaunchKernelGGL(k_root_labels_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, counters, c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
                        c->state.as<int>(), c->rankscan.as<int>(), c->chainhead.as<int>());
-    hipLaunchKernelGGL(k_final_labels, dim3(nblocks(n, BIGTPB * FINAL_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow, c->owner.as<int>(),
+    hipLaunchKernelGGL(k_final_labels, dim3(nblocks(nm, BIGTPB * FINAL_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow, c->owner.as<int>(),
                        c->chainhead.as<int>(), rows ? c->slot[c->cur].labels.as<int>() : (int*)nullptr, c->slot[c->cur].slab.as<int>(), t);
     HIP_TRY(hipGetLastError());
     return finish_enqueue(c, g.S + 2, strip + g.S, labels_out);

@@ -14,7 +14,9 @@ iv.sort()
 t_end = iv[-1][1]
 # steady-state sweep = the last 45 % of the trace time span after the first long gap ... simpler: take the last sweep by time: find the
 # biggest gap between consecutive kernels in the second half (host work between the two timed sweeps is small), so use the last 0.6 s
-span0 = t_end - int(0.55e9)
+import re
+rep = [float(m) for m in re.findall(r"chained cut\) ([0-9.]+) s", open("/tmp/gb_out.txt").read())]
+span0 = t_end - int(rep[-1] * 1e9)        # the last (steady-state) sweep
 sel = [(a, b) for a, b, _ in iv if a >= span0]
 busy = 0; cur_a, cur_b = sel[0]
 gaps = []
