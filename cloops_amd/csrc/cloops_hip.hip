@@ -270,7 +270,8 @@ __global__ void k_dhist(const int* __restrict__ X, const int* __restrict__ Y, lo
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const long long d = (long long)Y[i] - X[i];
-        atomicAdd(&hist[d < 0 ? 0 : (d > DCUM_BINS - 1 ? DCUM_BINS - 1 : (int)d)], 1);
+        // distances >= 65536 need no bin (the running sum stops there); counting them would put half of the PETs on one address
+        if (d < DCUM_BINS - 1) atomicAdd(&hist[d < 0 ? 0 : (int)d], 1);
     }
 }
 
