@@ -33,11 +33,14 @@ for k in sorted(set(fe) | set(wr)):
     out[k] = {"FETCH_SIZE_KB_avg": round(sum(fe[k]) / max(1, len(fe[k])), 1), "WRITE_SIZE_KB_avg": round(sum(wr[k]) / max(1, len(wr[k])), 1),
               "launches_FETCH_SIZE": len(fe[k]), "launches_WRITE_SIZE": len(wr[k])}
 json.dump(out, open("$OUT/pmc_fetch_write_k2replay.json", "w"), indent=1)
-k2 = [k for k in out if "k_region_core" in k][0]
-t = {"workload": "chr1 (16.4 M PETs) of synthetic-200M-23chr, the mode-3 sweep's 12 (eps, minPts, cut) settings", "kernel": k2,
-     "FETCH_SIZE_KB": out[k2]["FETCH_SIZE_KB_avg"], "WRITE_SIZE_KB": out[k2]["WRITE_SIZE_KB_avg"],
+k2s = [k for k in out if "k_region_core" in k]            # both instantiations (runs with / without a cut), weighted by their launches
+nl = sum(out[k]["launches_FETCH_SIZE"] for k in k2s)
+fetch = sum(out[k]["FETCH_SIZE_KB_avg"] * out[k]["launches_FETCH_SIZE"] for k in k2s) / nl
+write = sum(out[k]["WRITE_SIZE_KB_avg"] * out[k]["launches_WRITE_SIZE"] for k in k2s) / sum(out[k]["launches_WRITE_SIZE"] for k in k2s)
+t = {"workload": "chr1 (16.4 M PETs) of synthetic-200M-23chr, the mode-3 sweep's 12 (eps, minPts, cut) settings", "kernel": " + ".join(k2s), "launches": nl,
+     "FETCH_SIZE_KB": round(fetch, 1), "WRITE_SIZE_KB": round(write, 1),
      "correction": "gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is 1:1",
-     "hbm_bytes_per_launch": int(round((2 * out[k2]["FETCH_SIZE_KB_avg"] + out[k2]["WRITE_SIZE_KB_avg"]) * 1024)),
+     "hbm_bytes_per_launch": int(round((2 * fetch + write) * 1024)),
      "source": "tools/profile_bench.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over tools/k2_replay.py)"}
 json.dump(t, open("$OUT/k2_traffic.json", "w"), indent=1)
 print(json.dumps(t))
