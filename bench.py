@@ -44,6 +44,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# two hardware queues serve the per-chromosome streams best (cloops_amd/_lib.py has the measurements); set here as well because
+# with --gpus N torch initialises the HIP runtime before libcloops_hip.so is loaded
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 N_TOTAL = 200000000
 MODE3 = ([5000, 7500, 10000], [50, 40, 30, 20])        # cLoops/pipe.py:337-340
