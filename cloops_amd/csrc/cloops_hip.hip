@@ -1089,10 +1089,19 @@ __device__ __forceinline__ void tile_visit_segment(const Tile& t, const int* __r
     if (sb >= se) return;
     if (sb >= t.wbeg && se <= t.wend && se - sb <= 2047) {
         int j = (se - sb <= 255) ? lds_lower_bound8(t.w, sb, se, qlo) : lds_lower_bound8<T_STEPS_LONG>(t.w, sb, se, qlo);
-        for (; j < se; ++j) {
-            const int2 c = t.w[j];
-            if (c.x > qhi) break;
-            f(j, c.x, c.y, t.x[j]);
+        // four candidates per round, all LDS reads in flight before the first of them is looked at
+        while (j < se) {
+            int2 c[4]; int x[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int idx = min(j + k, se - 1); c[k] = t.w[idx]; x[k] = t.x[idx]; }
+            bool out = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (out || j + k >= se || c[k].x > qhi) { out = true; continue; }
+                f(j + k, c[k].x, c[k].y, x[k]);
+            }
+            if (out) break;
+            j += 4;
         }
     } else {
         // the segment is not staged (a strip longer than the window: dense data at large eps): global

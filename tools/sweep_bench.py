@@ -19,6 +19,8 @@ FAST_ONLY = "--fast-only" in sys.argv
 if FAST_ONLY:
     sys.argv.remove("--fast-only")
 
+if os.environ.get("SWEEP_THREADS"):
+    pipe.SWEEP_THREADS = int(os.environ["SWEEP_THREADS"])
 n_total = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20000000
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 eps, minPts = MODES[mode]
