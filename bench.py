@@ -153,13 +153,13 @@ def main(argv=None):
     def one_sweep(log_k2):
         dataI, cut, cuts, steps = pipe.runSweepFast(fs, eps_list, minpts_list, cut=0, variant=VARIANT, allsum=allsum,
                                                     probe=probe if (log_k2 and rank == 0) else None)
-        rows = [v["boxes"] for v in dataI.values() if len(v["boxes"])]
-        tab = np.concatenate(rows).astype(np.int32) if rows else np.zeros((0, 4), np.int32)
         if use_dist:
             # the path's final exchange (cLoops/pipe.py:119-127 merges its workers' results): all candidate tables
+            rows = [v["boxes"] for v in dataI.values() if len(v["boxes"])]
+            tab = np.concatenate(rows).astype(np.int32) if rows else np.zeros((0, 4), np.int32)
             ncand = sum(len(t) for t in gather_tables(tab, device=tdev))
         else:
-            ncand = len(tab)
+            ncand = sum(len(v["boxes"]) for v in dataI.values())
         return cut, steps, ncand
 
     first_sweep_s = None

@@ -1250,21 +1250,31 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
 // core points and -1 for everything else (what the union kernel stages as its payload)
 // Every component root is a chain head, so the per-root accumulators are reset here, by the chain
 // heads only, instead of memset-ing five N-sized arrays per run.
+// pmax32 (optional): the 32-PET block summaries of the union scan (max strip coordinate over the block's CORE PETs, see
+// k_union_cores) come out of the same pass -- every thread already knows whether its PET is a core
 __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const int* __restrict__ cnt, int minPts,
                                const int* __restrict__ chainhead, int* __restrict__ parent, int* __restrict__ chainid,
                                int* __restrict__ compkey, int* __restrict__ ncore, int* __restrict__ bsize,
                                int* __restrict__ usize, int* __restrict__ state, const int* __restrict__ chainlast,
-                               const int* __restrict__ sv, int* __restrict__ chain_qend)
+                               const int* __restrict__ sv, int* __restrict__ chain_qend,
+                               const int* __restrict__ sa, int* __restrict__ pmax32 /* or null */)
 {
     const int M = strip_start[S];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    const bool core = cnt[i] >= minPts;
-    const int h = core ? chainhead[i] - 1 : -1;
-    parent[i] = core ? h : i;
-    chainid[i] = h;
-    if (h == i) { compkey[i] = INT_MAX; ncore[i] = 0; bsize[i] = 0; usize[i] = 0; state[i] = ST_LIVE; }
-    if (core && chainlast[i]) chain_qend[h] = sv[i];        // indexed by chain head
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool core = false;
+    if (i < M) {
+        core = cnt[i] >= minPts;
+        const int h = core ? chainhead[i] - 1 : -1;
+        parent[i] = core ? h : i;
+        chainid[i] = h;
+        if (h == i) { compkey[i] = INT_MAX; ncore[i] = 0; bsize[i] = 0; usize[i] = 0; state[i] = ST_LIVE; }
+        if (core && chainlast[i]) chain_qend[h] = sv[i];        // indexed by chain head
+    }
+    if (pmax32) {                                              // uniform: every lane of the wave takes part in the reduction
+        int v = core ? sa[i] : INT_MIN;
+        v = dpp_reduce_halves(v, OpMax());                     // lanes 31 and 63 hold the maxima of their 32-PET blocks
+        if ((threadIdx.x & 31) == 31 && (i - 31) < M) pmax32[i >> 5] = v;
+    }
 }
 
 // Cross-strip edges: a core i of strip s against the cores of strip s-1 in its window (the
@@ -1274,15 +1284,6 @@ __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const
 // the (latency-bound, global-memory) union-find step -- directly on the chain heads.
 #define UNION_MAXB 4
 
-// pmax32[k] = max strip coordinate p over the CORE PETs of sorted positions [32k, 32k+32) (INT_MIN if none).
-// k_union_cores skips 32 candidates of a long strip with one load when none of them can be within eps in p.
-__global__ void k_block_pmax(int n, const int* __restrict__ chainid, const int* __restrict__ sa, int* __restrict__ pmax32)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int v = (i < n && chainid[i] >= 0) ? sa[i] : INT_MIN;
-    v = dpp_reduce_halves(v, OpMax());                     // lanes 31 and 63 hold the maxima of their 32-PET blocks
-    if ((threadIdx.x & 31) == 31 && (i - 31) < n) pmax32[i >> 5] = v;
-}
 template <int NT, int HALO>
 __global__ void __launch_bounds__(NT)
 k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
@@ -4035,6 +4036,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     tgrid = tile_grid(ntiles);
 
     // K3
+    int* pmax32 = nullptr;
     {
         // own-strip chains by scan; variant 2: the same tile kernel also finds every PET's cell head
         int* head = variant == CL_VARIANT_CDBSCAN2 ? c->head.as<int>() : nullptr;
@@ -4054,15 +4056,11 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         hipError_t e = rocprim::inclusive_scan(c->scan_tmp.p, tb, c->chainflag.as<int>(), c->chainhead.as<int>(), (size_t)nm,
                                                rocprim::maximum<int>(), c->stream);
         if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan(chain)", hipGetErrorString(e));
+        // long strips (dense data at large eps): 32-PET block summaries for the union scan (`hi` is free until K4)
+        pmax32 = ((long long)n > 64LL * g.S) ? c->hi.as<int>() : nullptr;
         LAUNCH(k_chain_parent, nm, strip, g.S, cnt, g.minPts, c->chainhead.as<int>(), c->parent.as<int>(), c->chainflag.as<int>(),
                c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
-               c->headidx.as<int>(), sv, c->lo.as<int>());   // chain ends live in `lo` until the release fix-up reuses it
-    }
-    // long strips (dense data at large eps): 32-PET block summaries for the union scan (`hi` is free until K4)
-    int* pmax32 = nullptr;
-    if ((long long)n > 64LL * g.S) {
-        pmax32 = c->hi.as<int>();
-        LAUNCH(k_block_pmax, nm, nm, c->chainflag.as<int>(), sa, pmax32);
+               c->headidx.as<int>(), sv, c->lo.as<int>(), sa, pmax32);   // chain ends live in `lo` until the release fix-up reuses it
     }
     TILE_LAUNCH(k_union_cores, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
                        pmax32, c->parent.as<int>());

@@ -459,7 +459,7 @@ def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, 
     `probe` (optional): called as probe(f, eps, minPts, cut_in, result) for every completed run (bench.py reads
     the HIP-event kernel timings of profiled handles through it).
 
-    returns (dataI {key: {"f": f, "boxes": int64[k,4]}} of the local chromosomes, cut, cuts, steps)."""
+    returns (dataI {key: {"f": f, "boxes": int32[k,4]}} of the local chromosomes, cut, cuts, steps)."""
     variant = variant or DBSCAN_VARIANT
     gsum = allsum if allsum is not None else (lambda a: a)
     devs = _devices()
@@ -597,7 +597,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
             f, r = fr
             with r.lock:
                 b = r.chrom.cand_finish(final_cut, appended[f])
-            return r.key, {"f": f, "boxes": b.astype(np.int64)}
+            return r.key, {"f": f, "boxes": b}                # int32 [k, 4] rows (minX, maxX, minY, maxY), append order
 
         dataI = dict(_pmap(pool, finish, [(f, r) for f, r in live if appended.get(f, 0) > 0]))
     finally:
