@@ -1841,7 +1841,7 @@ __device__ __forceinline__ int wave_max_i(int v) { return dpp_reduce_wave(v, OpM
 // Cluster table (pipe.py:78-102) by the two-level reduce-by-key above; called by all threads
 // of a BIGTPB workgroup (sorted order keeps a cluster's PETs in neighbouring lanes, so a wave
 // usually carries a handful of labels).
-#define TAB_H 2048
+#define TAB_H 512
 struct TableLds { int key[TAB_H], cnt[TAB_H], mnx[TAB_H], mxx[TAB_H], mny[TAB_H], mxy[TAB_H]; };
 
 __device__ __forceinline__ void table_lds_init(TableLds& h)
@@ -1853,7 +1853,7 @@ __device__ __forceinline__ void table_lds_init(TableLds& h)
 }
 __device__ __forceinline__ int tab_slot(int* keys, int key)
 {
-    unsigned h = ((unsigned)key * 2654435761u) >> 21;            // 11 bits
+    unsigned h = ((unsigned)key * 2654435761u) >> 23;            // 9 bits = log2(TAB_H)
     for (int probe = 0; probe < 16; ++probe) {
         const int old = atomicCAS(&keys[h], -1, key);
         if (old == -1 || old == key) return (int)h;
