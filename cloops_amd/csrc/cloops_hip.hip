@@ -271,7 +271,7 @@ __global__ void k_dhist(const int* __restrict__ X, const int* __restrict__ Y, lo
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const long long d = (long long)Y[i] - X[i];
         // distances >= 65536 need no bin (the running sum stops there); counting them would put half of the PETs on one address
-        if (d < DCUM_BINS - 1) atomicAdd(&hist[d < 0 ? 0 : (int)d], 1);
+        if (d < DCUM_BINS - 1) atomicAdd(&hist[d < 0 ? DCUM_BINS : (int)d], 1);      // slot DCUM_BINS: d < 0 (X > Y rows)
     }
 }
 
@@ -998,7 +998,9 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
                     ja = first_true_clamped<12>(lw, tb, last, inA); jb = first_true_clamped<12>(lw, e, last, inB);
                     ka = first_true_clamped<12>(lw, ja, last, outA); kb = first_true_clamped<12>(lw, jb, last, outB);
                 }
-                if (c + (ka - ja) + (kb - jb) >= minPts) {
+                const int ub = c + (ka - ja) + (kb - jb);
+                if (ub < minPts) c = ub;                // not core; what is stored is an upper bound of the count (k_border: <= 1 = isolated)
+                else {
                     for (int j = ja; (j < ka) & (c < minPts); j += 4) {
                         int2 v[4];
 #pragma unroll
@@ -1084,11 +1086,19 @@ __device__ __forceinline__ bool tile_stage(Tile& t, int2* lw, int* lx, int ntile
 // f(j, q_j, p_j, x_j)
 template <typename F>
 __device__ __forceinline__ void tile_visit_segment(const Tile& t, const int* __restrict__ gq, const int* __restrict__ gp,
-                                                   const int* __restrict__ gx, int sb, int se, int qlo, int qhi, F&& f)
+                                                   const int* __restrict__ gx, int sb, int se, int qlo, int qhi, F&& f, int dbg = 0)
 {
     if (sb >= se) return;
-    if (sb >= t.wbeg && se <= t.wend && se - sb <= 2047) {
+    // Only the part of the segment that can hold the q window has to be staged: the segment is sorted by q, so if the
+    // first staged PET of it lies below qlo everything in front of the window does, and if the last staged one lies
+    // above qhi everything behind it does (long strips: the PET-weighted strip length of dense data is several
+    // times the mean, whole strips are rarely inside a window).
+    bool staged = true;
+    if (sb < t.wbeg) { if (t.wbeg < se && t.w[t.wbeg].x < qlo) sb = t.wbeg; else staged = false; }
+    if (staged && se > t.wend) { if (t.wend > sb && t.w[t.wend - 1].x > qhi) se = t.wend; else staged = false; }
+    if (staged && se - sb <= 2047) {
         int j = (se - sb <= 255) ? lds_lower_bound8(t.w, sb, se, qlo) : lds_lower_bound8<T_STEPS_LONG>(t.w, sb, se, qlo);
+        if (dbg & 4096) { if (j == 12345678) f(j, 0, 0, 0); return; }
         // four candidates per round, all LDS reads in flight before the first of them is looked at
         while (j < se) {
             int2 c[4]; int x[4];
@@ -1106,6 +1116,7 @@ __device__ __forceinline__ void tile_visit_segment(const Tile& t, const int* __r
     } else {
         // the segment is not staged (a strip longer than the window: dense data at large eps): global
         // memory, with the loads of 4 candidates in flight before the first of them is looked at
+        if (dbg & 2048) return;
         int j = lower_bound_4(gq, sb, se, qlo);
         while (j < se) {
             int q[4], p[4], x[4];
@@ -1142,6 +1153,52 @@ __device__ __forceinline__ void tile_visit_own(const Tile& t, const int* __restr
             if (q > qhi) break;
             if (f(j, in ? t.x[j] : gx[j])) break;
         }
+}
+
+// own strip, every PET of the q window (no early exit): four candidates per LDS round trip while the walk stays inside
+// the staged range, the one-by-one walk of tile_visit_own for what is left
+template <typename F>
+__device__ __forceinline__ void tile_visit_own_all(const Tile& t, const int* __restrict__ gq, const int* __restrict__ gx,
+                                                   int i, int b, int e, int qlo, int qhi, F&& f)
+{
+    int j = i - 1;
+    while (j >= b && j - 3 >= t.wbeg) {
+        int q[4], x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int idx = max(j - k, b); q[k] = t.w[idx].x; x[k] = t.x[idx]; }
+        bool out = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (out || j - k < b || q[k] < qlo) { out = true; continue; }
+            f(j - k, x[k]);
+        }
+        if (out) { j = b - 1; break; }
+        j -= 4;
+    }
+    for (; j >= b; --j) {
+        const bool in = j >= t.wbeg;
+        if ((in ? t.w[j].x : gq[j]) < qlo) break;
+        f(j, in ? t.x[j] : gx[j]);
+    }
+    j = i + 1;
+    while (j < e && j + 3 < t.wend) {
+        int q[4], x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int idx = min(j + k, e - 1); q[k] = t.w[idx].x; x[k] = t.x[idx]; }
+        bool out = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (out || j + k >= e || q[k] > qhi) { out = true; continue; }
+            f(j + k, x[k]);
+        }
+        if (out) { j = e; break; }
+        j += 4;
+    }
+    for (; j < e; ++j) {
+        const bool in = j < t.wend;
+        if ((in ? t.w[j].x : gq[j]) > qhi) break;
+        f(j, in ? t.x[j] : gx[j]);
+    }
 }
 
 // scatter counts back to input-row order (cl_neighbor_counts)
@@ -1309,8 +1366,12 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     for (int k = 0; k < UNION_MAXB; ++k) Bs[k] = -1;
     int nb = 0;
     if (s > 0) {
-        const int tb = strip_start[s - 1], b = strip_start[s];
+        int tb = strip_start[s - 1];
+        const int b = strip_start[s];
         const int qlo = sat_add(me.x, -g.eps), qhi = sat_add(me.x, g.eps);
+        // strip s-1 ends where strip s begins, i.e. inside the staged range; if its first staged PET lies below qlo the
+        // part in front of the window cannot hold a candidate (sorted by q) and the staged part is the whole search range
+        if (tb < t.wbeg && t.wbeg < b && t.w[t.wbeg].x < qlo) tb = t.wbeg;
         auto touch = [&](int B) {
             bool seen = false;
 #pragma unroll
@@ -1536,7 +1597,7 @@ __global__ void __launch_bounds__(NT)
 k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
          const int* __restrict__ strip_start, const int* __restrict__ root, const int* __restrict__ compkey,
          const int* __restrict__ ncore, const u32* __restrict__ srow, int* __restrict__ owner, int* __restrict__ bsize,
-         int* __restrict__ usize)
+         int* __restrict__ usize, const int* __restrict__ cnt)
 {
     __shared__ int2 lw[NT + 2 * HALO];
     __shared__ int lx[NT + 2 * HALO];
@@ -1549,10 +1610,15 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
     bool border = false;
     if (i0 < M) {
         const int ri = t.x[i0];
-        if (ri >= 0) owner[i0] = ri; else border = true;
+        if (ri >= 0) owner[i0] = ri;
+        else if (cnt[i0] <= 1) owner[i0] = -1;           // K2 left the neighbour count of a non-core PET (itself included) or an upper
+        else border = true;                              // bound of it: nothing within eps -- most of the background noise ends here
     }
     const int total = block_compact<NT>(border, l_list, l_wcount);
     if ((int)threadIdx.x >= total) return;
+#ifdef CLOOPS_DEVEL
+    if (g.dbg & 256) return;
+#endif
     const int i = t.t0 + l_list[threadIdx.x];
     const int2 me = t.w[i];
     const int s = strip_of(g, me.y);
@@ -1571,11 +1637,19 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
         if (k < bestk) { bestk = k; best = r; }
         if (v1 && (int)srow[j] == k && k > tk) { tk = k; tbest = r; }     // j is its component's start point
     };
-    tile_visit_own(t, sv, root, i, b, e, qlo, qhi, 3, [&](int j, int r) { see(j, r); return false; });
+#ifdef CLOOPS_DEVEL
+    if (!(g.dbg & 512))
+#endif
+    tile_visit_own_all(t, sv, root, i, b, e, qlo, qhi, [&](int j, int r) { see(j, r); });
+#ifdef CLOOPS_DEVEL
+    if (!(g.dbg & 1024))
+#endif
+    {
     tile_visit_segment(t, sv, sa, root, tb, b, qlo, qhi, [&](int j, int, int pj, int r) {
-        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.peps) see(j, r); });
+        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.peps) see(j, r); }, g.dbg);
     tile_visit_segment(t, sv, sa, root, e, te, qlo, qhi, [&](int j, int, int pj, int r) {
-        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.peps) see(j, r); });
+        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.peps) see(j, r); }, g.dbg);
+    }
     const int o = (v1 && tbest >= 0) ? tbest : best;
     owner[i] = o < 0 ? -1 : (contested ? (o | OWNER_CONTESTED) : o);
     // counts per owning component, reduced over the lanes of the wave that share the owner.  Only
@@ -1673,7 +1747,7 @@ k_emit_records(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
         kk[q] = k; rr[q] = r;
         if (state[r] == ST_UNKNOWN) any_u = true;
     };
-    tile_visit_own(t, sv, root, i, b, e, qlo, qhi, 3, [&](int, int r) { see(r); return false; });
+    tile_visit_own_all(t, sv, root, i, b, e, qlo, qhi, [&](int, int r) { see(r); });
     tile_visit_segment(t, sv, sa, root, tb, b, qlo, qhi, [&](int, int, int pj, int r) {
         const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.peps) see(r); });
     tile_visit_segment(t, sv, sa, root, e, te, qlo, qhi, [&](int, int, int pj, int r) {
@@ -2472,6 +2546,8 @@ struct K7Src {
     const int* dM;                                      // if set: M is read from the device (the run has not been waited for yet)
     const int* X; const int* Y; const int* labels;      // input rows (+ row-order labels)
     const int* sv; const int* slab;                     // sorted q and sorted-order labels of [0, M)
+    const int* dh;                                      // if set: dh[d] = number of input rows with Y - X == d for 0 <= d < cut, and no row has
+                                                        // Y - X < 0: the PETs dropped by the cut come from it, not from a pass over the rows
 };
 #define K7_BLOCKS 2048           // workgroups (= fixed partial sums) of the K7 reductions: 8 waves per SIMD (512 left the loads
                                  // of a 66-element sequential loop per thread uncovered: 177 us -> see DESIGN.md)
@@ -2498,14 +2574,19 @@ __device__ __forceinline__ void k7_for_each(const K7Src& s, int cut, const signe
             const int lab = s.slab[i];
             const int g = lab >= 0 ? (int)cls[lab] : -1;
             const int d = s.sv[i] + s.v0;
-            if (g >= 0) f(g, d < 0 ? -d : d);                      // ests.py:42-43 np.abs
+            if (g >= 0) f(g, d < 0 ? -d : d, 1);                   // ests.py:42-43 np.abs
         }
-        if (cut > 0) {                                             // pipe.py:63: short PETs go to dss
+        if (cut > 0 && s.dh) {                                     // pipe.py:63: short PETs go to dss -- all PETs of one distance at once
+            for (int d = blockIdx.x * blockDim.x + threadIdx.x; d < cut; d += gridDim.x * blockDim.x) {
+                const int w = s.dh[d];
+                if (w) f(1, d, w);
+            }
+        } else if (cut > 0) {
             const int perr = (s.n + gridDim.x - 1) / gridDim.x;
             const int r0 = blockIdx.x * perr, r1 = min(s.n, r0 + perr);
             for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
                 const int d = s.Y[r] - s.X[r];
-                if (d < cut) f(1, d < 0 ? -d : d);
+                if (d < cut) f(1, d < 0 ? -d : d, 1);
             }
         }
     } else {
@@ -2515,7 +2596,7 @@ __device__ __forceinline__ void k7_for_each(const K7Src& s, int cut, const signe
             const int d = s.Y[r] - s.X[r];
             int g = 1;
             if (!(cut > 0 && d < cut)) { const int lab = s.labels[r]; g = lab >= 0 ? (int)cls[lab] : -1; }
-            if (g >= 0) f(g, d < 0 ? -d : d);
+            if (g >= 0) f(g, d < 0 ? -d : d, 1);
         }
     }
 }
@@ -2536,15 +2617,15 @@ k7_summary(K7Src s, int cut, const signed char* __restrict__ cls, K7Part* __rest
     double sx[2] = {0.0, 0.0}, sxx[2] = {0.0, 0.0};
     long long na[2] = {0, 0}, np_[2] = {0, 0};
     const bool want_fine = fine != nullptr;
-    k7_for_each(s, cut, cls, [&](int g, int ad) {
-        na[g]++;
+    k7_for_each(s, cut, cls, [&](int g, int ad, int w) {                  // w PETs of this group and distance
+        na[g] += w;
         if (ad > 0) {
-            const double x = log2((double)ad) - K7_XSHIFT;
-            np_[g]++; sx[g] += x; sxx[g] += x * x;
+            const double x = log2((double)ad) - K7_XSHIFT, wx = (double)w * x;
+            np_[g] += w; sx[g] += wx; sxx[g] += wx * x;
             if (g == 1) {
-                atomicAdd(&h[k7_logbin((unsigned)ad)], 1u);
+                atomicAdd(&h[k7_logbin((unsigned)ad)], (unsigned)w);
                 const unsigned off = (unsigned)ad - fine_lo;                  // wraps for ad < fine_lo: out of range
-                if (want_fine && off < (unsigned)K7_FINE) atomicAdd(&hf[off], 1u);
+                if (want_fine && off < (unsigned)K7_FINE) atomicAdd(&hf[off], (unsigned)w);
             }
         }
     });
@@ -2611,9 +2692,9 @@ k7_bin_hist(K7Src s, int cut, const signed char* __restrict__ cls, unsigned lo, 
     __shared__ unsigned int h[K7_FINE];
     for (int k = threadIdx.x; k < K7_FINE; k += blockDim.x) h[k] = 0u;
     __syncthreads();
-    k7_for_each(s, cut, cls, [&](int g, int ad) {
+    k7_for_each(s, cut, cls, [&](int g, int ad, int w) {
         const unsigned u = (unsigned)ad;
-        if (g == 1 && u >= lo && u < hi) atomicAdd(&h[min((u - lo) >> shift, (unsigned)(K7_FINE - 1))], 1u);
+        if (g == 1 && u >= lo && u < hi) atomicAdd(&h[min((u - lo) >> shift, (unsigned)(K7_FINE - 1))], (unsigned)w);
     });
     __syncthreads();
     for (int k = threadIdx.x; k < K7_FINE; k += blockDim.x)
@@ -2905,6 +2986,8 @@ struct cl_chrom {
     DevBuf bq, bsp, brow, bstrip, btile, sel_tmp;
     struct BaseLayout { bool valid = false; int layout = -1, eps = 0; } base;
     std::vector<long long> dcum;      // dcum[k] = number of PETs with Y - X < k, k = 0 .. 65536 (empty: unknown)
+    DevBuf dhist;                     // device: number of PETs with Y - X == d, d = 0 .. 65535 (+ one slot for d < 0)
+    long long n_neg = 0;              // PETs with Y - X < 0
     int run_m = 0;                    // PETs that enter DBSCAN in the run being enqueued (exact when run_m_exact, else n)
     bool run_m_exact = false;
     bool reuse_layout = true;
@@ -2965,7 +3048,7 @@ static void free_chrom(cl_chrom* c)
     DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->slot[0].d_step, &c->slot[1].d_step, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
-                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out};
+                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out, &c->dhist};
     for (DevBuf* b : bufs) b->release();
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -3069,14 +3152,16 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
             c->st = *hs;
             {
                 // distance histogram below 65536 -> running sum on the host (see k_dhist)
-                if ((rc = c->sel_tmp.ensure((size_t)DCUM_BINS * 4))) break;
-                std::vector<int> hh(DCUM_BINS);
-                if (hipMemsetAsync(c->sel_tmp.p, 0, (size_t)DCUM_BINS * 4, c->stream) != hipSuccess) { rc = fail(CL_ERR_HIP, "dhist memset"); break; }
-                hipLaunchKernelGGL(k_dhist, dim3(std::min(nblocks(n), 2048)), dim3(TPB), 0, c->stream, c->d_x, c->d_y, (long long)n, c->sel_tmp.as<int>());
-                if (hipMemcpyAsync(hh.data(), c->sel_tmp.p, (size_t)DCUM_BINS * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                // the histogram itself stays on the device: K7 takes the PETs below a cut from it instead of from the rows
+                if ((rc = c->dhist.ensure((size_t)(DCUM_BINS + 1) * 4))) break;
+                std::vector<int> hh(DCUM_BINS + 1);
+                if (hipMemsetAsync(c->dhist.p, 0, (size_t)(DCUM_BINS + 1) * 4, c->stream) != hipSuccess) { rc = fail(CL_ERR_HIP, "dhist memset"); break; }
+                hipLaunchKernelGGL(k_dhist, dim3(std::min(nblocks(n), 2048)), dim3(TPB), 0, c->stream, c->d_x, c->d_y, (long long)n, c->dhist.as<int>());
+                if (hipMemcpyAsync(hh.data(), c->dhist.p, (size_t)(DCUM_BINS + 1) * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                     hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CL_ERR_HIP, "dhist readback"); break; }
                 c->dcum.assign(DCUM_BINS, 0);
-                long long run = 0;
+                c->n_neg = hh[DCUM_BINS];
+                long long run = c->n_neg;
                 for (int k = 0; k < DCUM_BINS; ++k) { c->dcum[k] = run; run += hh[k]; }      // dcum[k] = #(d < k)
             }
             const int LIM = 1 << 29;
@@ -3559,6 +3644,12 @@ static Table make_table_slot(cl_chrom* c, int slot)
 }
 static Table make_table(cl_chrom* c) { return make_table_slot(c, c->cur); }
 
+// the upload's distance histogram, when it covers every PET a cut of `cut` drops (K7Src::dh)
+static const int* k7_hist_for(cl_chrom* c, int cut)
+{
+    return (cut > 0 && cut < DCUM_BINS && c->n_neg == 0 && !c->dcum.empty() && c->dhist.p) ? c->dhist.as<int>() : (const int*)nullptr;
+}
+
 static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* labels_out)
 {
     const int n = (int)c->n;
@@ -3615,6 +3706,7 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
         K7Src src{};
         src.sorted = sl.sorted_src ? 1 : 0; src.n = n; src.M = 0; src.v0 = sl.k7_v0; src.dM = d_M;
         src.X = c->d_x; src.Y = c->d_y; src.labels = sl.labels.as<int>(); src.sv = sl.k7_sv; src.slab = sl.slab.as<int>();
+        src.dh = k7_hist_for(c, c->pending_cut);
         hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, src, c->pending_cut, cls, parts, lh,
                            (unsigned)c->pending_fine_lo, c->pending_fine_lo >= 0 ? lh + K7_LOGBINS : (unsigned long long*)nullptr);
         hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, parts, K7_BLOCKS);
@@ -4004,13 +4096,15 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
 #ifdef CLOOPS_DEVEL
     if (const char* e = getenv("CLOOPS_TILE_WIDE")) wide = atoi(e);
 #endif
-    const int tile_nt = wide ? 1024 : TPB;
+    const int tile_nt = wide == 1 ? 1024 : TPB;
     int ntiles = 0, tgrid = 0;                          // set once the number of PETs that pass the cut is known
-#define TILE_LAUNCH(kernel, ...)                                                                                     \
+#define TILE_LAUNCH_H(bighalo, kernel, ...)                                                                          \
     do {                                                                                                             \
-        if (wide) hipLaunchKernelGGL((kernel<1024, 512>), dim3(tgrid), dim3(1024), 0, c->stream, __VA_ARGS__);       \
+        if (wide == 1) hipLaunchKernelGGL((kernel<1024, 512>), dim3(tgrid), dim3(1024), 0, c->stream, __VA_ARGS__);  \
+        else if (bighalo) hipLaunchKernelGGL((kernel<TPB, 512>), dim3(tgrid), dim3(TPB), 0, c->stream, __VA_ARGS__); \
         else hipLaunchKernelGGL((kernel<TPB, 128>), dim3(tgrid), dim3(TPB), 0, c->stream, __VA_ARGS__);              \
     } while (0)
+#define TILE_LAUNCH(kernel, ...) TILE_LAUNCH_H(wide == 2, kernel, __VA_ARGS__)
 
     LAUNCH(k_init_flags, n + 1, n, c->flag.as<int>(), counters);
     // row-aligned labels only when somebody reads them: k_final_labels then writes the label (or -1) of every PET that
@@ -4062,15 +4156,15 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
                c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                c->headidx.as<int>(), sv, c->lo.as<int>(), sa, pmax32);   // chain ends live in `lo` until the release fix-up reuses it
     }
-    TILE_LAUNCH(k_union_cores, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
+    TILE_LAUNCH_H(wide == 2 || wide == 4, k_union_cores, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
                        pmax32, c->parent.as<int>());
     hipLaunchKernelGGL(k_flatten, dim3(nblocks(nm, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
            c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->chainflag.as<int>() /* root list: the chain ids are dead */, counters);
     int* rootlist = c->chainflag.as<int>();
     ev_record(c, 4);
     // K4
-    TILE_LAUNCH(k_border, g, ntiles, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(),
-                       c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>());
+    TILE_LAUNCH_H(wide >= 2, k_border, g, ntiles, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(),
+                       c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), cnt);
     if (variant == CL_VARIANT_CDBSCAN2) {
         const int rec_cap = n;
         hipLaunchKernelGGL(k_mark_uncertain_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, c->ncore.as<int>(), c->bsize.as<int>(), c->state.as<int>(),
@@ -4120,10 +4214,11 @@ static int k7_prepare(cl_chrom* c)
     return CL_OK;
 }
 
-static K7Src k7_source(cl_chrom* c)
+static K7Src k7_source(cl_chrom* c, int cut)
 {
     cl_chrom::Slot& sl = c->slot[c->last_slot];
     K7Src s{};
+    s.dh = k7_hist_for(c, cut);
     s.sorted = sl.sorted_src ? 1 : 0; s.n = (int)c->n; s.M = sl.h_hdr[2]; s.v0 = sl.k7_v0;
     s.X = c->d_x; s.Y = c->d_y; s.labels = sl.labels.as<int>(); s.sv = sl.k7_sv; s.slab = sl.slab.as<int>();
     return s;
@@ -4140,7 +4235,7 @@ extern "C" int cl_dist_summary(cl_chrom* c, int32_t cut, cl_dsummary* out)
     if (!c->slot[c->last_slot].sorted_src && !c->slot[c->last_slot].rows_valid) return fail(CL_ERR_ARG, "cl_dist_summary: the last run left no labels");
     unsigned long long* dh = (unsigned long long*)((char*)c->k7_parts.p + K7_BLOCKS * sizeof(K7Part));
     HIP_TRY(hipMemsetAsync(dh, 0, K7_LOGBINS * 8, c->stream));
-    hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, k7_source(c), cut, c->k7_cls.as<signed char>(), c->k7_parts.as<K7Part>(), dh,
+    hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, k7_source(c, cut), cut, c->k7_cls.as<signed char>(), c->k7_parts.as<K7Part>(), dh,
                        0u, (unsigned long long*)nullptr);
     hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->k7_parts.as<K7Part>(), K7_BLOCKS);
     K7Part part;
@@ -4164,7 +4259,7 @@ extern "C" int cl_dist_bin_hist(cl_chrom* c, int32_t cut, uint32_t lo, uint32_t 
     unsigned long long* dh = (unsigned long long*)c->k7_parts.p;
     HIP_TRY(hipMemsetAsync(dh, 0, K7_FINE * 8, c->stream));
     const int n = (int)c->n;
-    hipLaunchKernelGGL(k7_bin_hist, dim3(std::min(nblocks(n), K7_BLOCKS)), dim3(TPB), 0, c->stream, k7_source(c), cut, c->k7_cls.as<signed char>(),
+    hipLaunchKernelGGL(k7_bin_hist, dim3(std::min(nblocks(n), K7_BLOCKS)), dim3(TPB), 0, c->stream, k7_source(c, cut), cut, c->k7_cls.as<signed char>(),
                        (unsigned)lo, (unsigned)hi, shift, dh);
     HIP_TRY(hipMemcpyAsync(hist2048, dh, K7_FINE * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
