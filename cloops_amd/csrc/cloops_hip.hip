@@ -822,6 +822,12 @@ __device__ __forceinline__ int first_true_clamped(const int2* __restrict__ w, in
 // TAIL: the run has a cut, i.e. the sorted arrays end in a filtered tail whose tiles leave right after the scalar load of
 // tile_s0 (before staging anything); without a cut every tile has work and the staging loads are issued BEFORE that load
 // is waited for (its latency hides behind them).
+// hints of k_region_core for the non-core PETs (negative words in cnt[]): bit 30 isolated, bits 0..13 / 14..27 the distance
+// (in sorted positions) back to the start of its window in strip s-1 / forward to the one in strip s+1, all ones = no hints
+#define K2H_BITS 14
+#define K2H_MASK 0x3fffu
+#define K2H_ISOLATED 0x40000000u
+#define K2H_NONE 0x0fffffffu
 template <int U, int HALO, bool TAIL>
 __global__ void __launch_bounds__(K2F_TPB)
 k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
@@ -831,6 +837,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     constexpr int FULL = NV / K2F_TPB, REST = NV % K2F_TPB;              // int4 staging slots: FULL for every thread + a partial one
     constexpr int RUN = (2048 / TILE) > 0 ? (2048 / TILE) : 1;          // consecutive tiles per XCD (halo reuse in its L2)
     static_assert(HALO % 4 == 0 && HALO >= 128 && TILE + HALO + K2F_SLACK <= SORT_PAD && TILE % 256 == 0, "window shape");
+    static_assert(WIN + K2F_SLACK < (int)K2H_MASK, "window offsets fit the hint fields");
     __shared__ __attribute__((aligned(16))) int2 lw[WIN + K2F_SLACK];   // (q, sp) pairs, window index = sorted index - (t0 - HALO)
     __shared__ int l_st[K2F_NS + 4];
     __shared__ unsigned int l_list[TILE];                                // undecided PETs, one region of 64*U entries per wave
@@ -952,12 +959,14 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         }
         const int longest = max(b - tb, te - e);
         tb += off; e += off; te += off;
+        int hja = -1, hjb = -1;                         // window starts in strips s-1 / s+1 (window indices), if found in LDS
         if ((tb >= wlo) & (te <= whi)) {
             auto inA = [&](int2 v) { return (v.y >= pbeg) | (v.x >= qlo); };    // from tb on: past the PETs of s-1 below qlo
             auto inB = [&](int2 v) { return (v.y >= pend2) | (v.x >= qlo); };   // from e on: past the PETs of s+1 below qlo
             if (!__any(longest > 31)) {
                 // sparse data: 5-step searches, then the first two candidates of both strips at once
                 const int ja = first_true<5>(lw, tb, inA), jb = first_true<5>(lw, e, inB);
+                hja = ja; hjb = jb;
                 int2 va[2], vb[2];
 #pragma unroll
                 for (int k = 0; k < 2; ++k) { va[k] = lw[ja + k]; vb[k] = lw[jb + k]; }
@@ -998,6 +1007,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
                     ja = first_true_clamped<12>(lw, tb, last, inA); jb = first_true_clamped<12>(lw, e, last, inB);
                     ka = first_true_clamped<12>(lw, ja, last, outA); kb = first_true_clamped<12>(lw, jb, last, outB);
                 }
+                hja = ja; hjb = jb;
                 const int ub = c + (ka - ja) + (kb - jb);
                 if (ub < minPts) c = ub;                // not core; what is stored is an upper bound of the count (k_border: <= 1 = isolated)
                 else {
@@ -1029,7 +1039,16 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
                 c = k2_count_glb<false, 8>(sv, sa, j, gte, qhi, pi, peps, minPts, c);
             }
         }
-        cnt[t0 + tix] = c;
+        // a non-core PET leaves a NEGATIVE word (every consumer tests cnt >= minPts): K2H_ISOLATED if nothing can be within
+        // eps of it, and where its windows in the neighbour strips start, relative to itself -- k_border walks them without
+        // searching again (and without the strip table)
+        int outv = c;
+        if (c < minPts) {
+            unsigned enc = 0x80000000u | (c <= 1 ? K2H_ISOLATED : 0u);
+            enc |= (hja >= 0) ? ((unsigned)(li - hja) | ((unsigned)(hjb - li) << K2H_BITS)) : K2H_NONE;
+            outv = (int)enc;
+        }
+        cnt[t0 + tix] = outv;
     }
     K2T(5);
     K2T_FLUSH;
@@ -1050,6 +1069,31 @@ struct Tile {
     LdsInts x;          // payload, indexed by global sorted index
     int wbeg, wend;     // staged index range [wbeg, wend)
     int t0;             // first PET of the tile
+    const unsigned long long* m;   // optional: bit k of word w = "the staged PET with window index 64 w + k has a payload >= 0" (a core)
+    // first staged PET of [j, end) with a payload >= 0, or end ([j, end) inside the staged range)
+    __device__ __forceinline__ int next_set(int j, int end) const
+    {
+        int k = j - w.base;
+        const int kend = end - w.base;
+        while (k < kend) {
+            const unsigned long long bits = m[k >> 6] >> (k & 63);
+            if (bits) return min(k + __ffsll((long long)bits) - 1, kend) + w.base;
+            k = (k | 63) + 1;
+        }
+        return end;
+    }
+    // last staged PET of [beg, j] with a payload >= 0, or beg - 1
+    __device__ __forceinline__ int prev_set(int j, int beg) const
+    {
+        int k = j - w.base;
+        const int kbeg = beg - w.base;
+        while (k >= kbeg) {
+            const unsigned long long bits = m[k >> 6] << (63 - (k & 63));
+            if (bits) { k -= __clzll((long long)bits); return (k >= kbeg ? k : kbeg - 1) + w.base; }
+            k = (k & ~63) - 1;
+        }
+        return beg - 1;
+    }
 };
 
 __device__ __forceinline__ int tile_of_block(int bid)
@@ -1060,45 +1104,92 @@ __device__ __forceinline__ int tile_of_block(int bid)
 static inline int tile_grid(int ntiles) { return ((ntiles + 8 * K2_RUN - 1) / (8 * K2_RUN)) * (8 * K2_RUN); }
 
 // all threads of the workgroup; returns false (for the whole workgroup) if the tile is empty
+// The (q, p) arrays are the padded sorted arrays (SORT_PAD sentinels on both sides): unpredicated 16-byte loads, pairs
+// interleaved on the way into LDS (lw must be 16-byte aligned).  The payload array is not padded: predicated dwords.
+// lmask (optional, (NT + 2 * HALO) / 64 words): Tile::m, built from the payload loads with one ballot per wave and pass.
 template <int NT, int HALO>
 __device__ __forceinline__ bool tile_stage(Tile& t, int2* lw, int* lx, int ntiles, int M,
                                            const int* __restrict__ gq, const int* __restrict__ gp,
-                                           const int* __restrict__ gx)
+                                           const int* __restrict__ gx, unsigned long long* lmask = nullptr)
 {
-    constexpr int T_WIN = NT + 2 * HALO;
+    constexpr int T_WIN = NT + 2 * HALO, NV = T_WIN / 4;
+    static_assert(NT % 64 == 0 && HALO % 64 == 0 && NT + HALO + 64 <= SORT_PAD, "window shape");
     const int tile = tile_of_block(blockIdx.x);
     t.t0 = tile * NT;
     if (tile >= ntiles || t.t0 >= M) return false;
     const int base = t.t0 - HALO;
+    {
+        const int4* __restrict__ gq4 = reinterpret_cast<const int4*>(gq + base);
+        const int4* __restrict__ gp4 = reinterpret_cast<const int4*>(gp + base);
+        int4* l4 = reinterpret_cast<int4*>(lw);
+        for (int c = threadIdx.x; c < NV; c += NT) {
+            const int4 q = gq4[c], p = gp4[c];
+            l4[2 * c] = make_int4(q.x, p.x, q.y, p.y);
+            l4[2 * c + 1] = make_int4(q.z, p.z, q.w, p.w);
+        }
+    }
     for (int k = threadIdx.x; k < T_WIN; k += NT) {
         const int gi = base + k;
         const bool in = gi >= 0 && gi < M;
-        lw[k] = in ? make_int2(gq[gi], gp[gi]) : make_int2(0, 0);
-        lx[k] = in ? gx[gi] : 0;
+        const int x = in ? gx[gi] : -1;                  // every payload test is `>= (something >= 0)`
+        lx[k] = x;
+        if (lmask) {
+            const unsigned long long bal = __ballot(in && x >= 0);
+            if ((threadIdx.x & 63) == 0) lmask[k >> 6] = bal;
+        }
     }
     __syncthreads();
-    t.w.a = lw; t.w.base = base; t.x.a = lx; t.x.base = base;
+    t.w.a = lw; t.w.base = base; t.x.a = lx; t.x.base = base; t.m = lmask;
     t.wbeg = max(base, 0); t.wend = min(base + T_WIN, M);
     return true;
 }
 
 // visit, in ascending order, every j of the strip segment [sb,se) with q_j in [qlo,qhi]:
-// f(j, q_j, p_j, x_j)
-template <typename F>
+// f(j, q_j, p_j, x_j).  SET: only the PETs with a payload >= 0 need a visit (the tile carries the mask Tile::m): the walk
+// goes from set bit to set bit -- a window of background noise costs one or two mask words instead of its candidates.
+template <bool SET = false, typename F>
 __device__ __forceinline__ void tile_visit_segment(const Tile& t, const int* __restrict__ gq, const int* __restrict__ gp,
-                                                   const int* __restrict__ gx, int sb, int se, int qlo, int qhi, F&& f, int dbg = 0)
+                                                   const int* __restrict__ gx, int sb, int se, int qlo, int qhi, F&& f)
 {
     if (sb >= se) return;
     // Only the part of the segment that can hold the q window has to be staged: the segment is sorted by q, so if the
     // first staged PET of it lies below qlo everything in front of the window does, and if the last staged one lies
-    // above qhi everything behind it does (long strips: the PET-weighted strip length of dense data is several
-    // times the mean, whole strips are rarely inside a window).
+    // above qhi everything behind it does (the windows of the neighbour strips lie about one strip population away
+    // from the PET: whole strips are rarely inside the staged range).
     bool staged = true;
     if (sb < t.wbeg) { if (t.wbeg < se && t.w[t.wbeg].x < qlo) sb = t.wbeg; else staged = false; }
     if (staged && se > t.wend) { if (t.wend > sb && t.w[t.wend - 1].x > qhi) se = t.wend; else staged = false; }
     if (staged && se - sb <= 2047) {
         int j = (se - sb <= 255) ? lds_lower_bound8(t.w, sb, se, qlo) : lds_lower_bound8<T_STEPS_LONG>(t.w, sb, se, qlo);
-        if (dbg & 4096) { if (j == 12345678) f(j, 0, 0, 0); return; }
+        if (SET) {
+            const int2* __restrict__ lw = t.w.a; const int* __restrict__ lx = t.x.a;
+            const int base = t.w.base, kend = se - base;
+            int k = j - base;
+            while (k < kend) {
+                unsigned long long bits = t.m[k >> 6] >> (k & 63);
+                bool out = false;
+                while (bits) {                                  // two set bits per round, their LDS reads in flight together
+                    const int i0 = k + __ffsll((long long)bits) - 1;
+                    bits &= bits - 1;
+                    const bool two = bits != 0;
+                    const int i1 = two ? k + __ffsll((long long)bits) - 1 : i0;
+                    bits &= bits - 1;                           // (0 stays 0)
+                    if (i0 >= kend) { out = true; break; }
+                    const int i1c = min(i1, kend - 1);
+                    const int2 c0 = lw[i0], c1 = lw[i1c];
+                    const int x0 = lx[i0], x1 = lx[i1c];
+                    if (c0.x > qhi) { out = true; break; }
+                    f(i0 + base, c0.x, c0.y, x0);
+                    if (two) {
+                        if (i1 >= kend || c1.x > qhi) { out = true; break; }
+                        f(i1 + base, c1.x, c1.y, x1);
+                    }
+                }
+                if (out) break;
+                k = (k | 63) + 1;
+            }
+            return;
+        }
         // four candidates per round, all LDS reads in flight before the first of them is looked at
         while (j < se) {
             int2 c[4]; int x[4];
@@ -1114,9 +1205,8 @@ __device__ __forceinline__ void tile_visit_segment(const Tile& t, const int* __r
             j += 4;
         }
     } else {
-        // the segment is not staged (a strip longer than the window: dense data at large eps): global
-        // memory, with the loads of 4 candidates in flight before the first of them is looked at
-        if (dbg & 2048) return;
+        // the window is not staged (a strip population beyond the halo): global memory, with the loads of 4 candidates
+        // in flight before the first of them is looked at
         int j = lower_bound_4(gq, sb, se, qlo);
         while (j < se) {
             int q[4], p[4], x[4];
@@ -1133,6 +1223,70 @@ __device__ __forceinline__ void tile_visit_segment(const Tile& t, const int* __r
         }
     }
 }
+// Walk the sorted order from j on while more(pair) holds (a monotone predicate: the end of a q window inside one strip);
+// see(j, x_j) for every PET with a payload >= 0 whose pair passes acc().  The first four candidates are read at once
+// (most windows of non-core PETs end there); longer windows go from set bit to set bit of the tile's mask, and the pair at
+// the start of the next mask word tells whether the window reaches it.  What lies outside the staged range (the
+// sentinel pads included in it) is read from global memory.
+template <int T_WIN, typename MORE, typename ACC, typename SEE>
+__device__ __forceinline__ void tile_walk_from(const Tile& t, const int* __restrict__ gq, const int* __restrict__ gp,
+                                               const int* __restrict__ gx, int M, int j, MORE&& more, ACC&& acc, SEE&& see)
+{
+    const int base = t.w.base;
+    int k = j - base;
+    if (k >= 0 && k + 4 <= T_WIN) {
+        const int2* __restrict__ lw = t.w.a; const int* __restrict__ lx = t.x.a;
+        {
+            int2 c[4]; int x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { c[u] = lw[k + u]; x[u] = lx[k + u]; }
+            bool out = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (out || !more(c[u])) { out = true; continue; }
+                if (x[u] >= 0 && acc(c[u])) see(j + u, x[u]);
+            }
+            if (out) return;
+        }
+        k += 4;
+        while (k < T_WIN) {
+            const int knext = (k | 63) + 1;
+            unsigned long long bits = t.m[k >> 6] >> (k & 63);
+            const int2 cn = lw[min(knext, T_WIN - 1)];
+            const bool goes_on = knext >= T_WIN || more(cn);
+            while (bits) {                                      // two set bits per round
+                const int i0 = k + __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                const bool two = bits != 0;
+                const int i1 = two ? k + __ffsll((long long)bits) - 1 : i0;
+                bits &= bits - 1;
+                const int2 c0 = lw[i0], c1 = lw[i1];
+                const int x0 = lx[i0], x1 = lx[i1];
+                if (!more(c0)) return;
+                if (acc(c0)) see(i0 + base, x0);
+                if (two) {
+                    if (!more(c1)) return;
+                    if (acc(c1)) see(i1 + base, x1);
+                }
+            }
+            if (!goes_on) return;
+            k = knext;
+        }
+        j = k + base;
+    }
+    for (;;) {
+        int q[4], p[4], x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { q[u] = gq[j + u]; p[u] = gp[j + u]; x[u] = j + u < M ? gx[j + u] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!more(make_int2(q[u], p[u]))) return;
+            if (x[u] >= 0 && acc(make_int2(q[u], p[u]))) see(j + u, x[u]);
+        }
+        j += 4;
+    }
+}
+
 // own strip: walk left from i-1 down to b while q >= qlo, then right from i+1 up to e while
 // q <= qhi; f(j, x_j) returns true to stop that direction early.  `dirs`: bit0 left, bit1 right.
 template <typename F>
@@ -1253,7 +1407,7 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
               const int* __restrict__ strip_start, const int* __restrict__ cnt, int* __restrict__ chainflag,
               int* __restrict__ chainlast, int* __restrict__ head)
 {
-    __shared__ int2 lw[NT + 2 * HALO];
+    __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
     __shared__ int lx[NT + 2 * HALO];
     const int M = strip_start[g.S];
     if (head) {                                          // filtered tail: singleton cells (keys of the cellfirst scan)
@@ -1271,7 +1425,7 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
         // instead of head flags + a max-scan over all PETs (variant 2 runs with A0 = V0 = 0)
         const int p0 = me.y & ~(g.peps - 1), q0 = div_eps(g, me.x) * g.eps;      // lower edges of the rotated cell (sp space / q space)
         int pos = t.wbeg;
-        constexpr int TOP = (NT + HALO <= 512) ? 256 : ((NT + HALO <= 1024) ? 512 : 1024);      // 2 * TOP - 1 >= the staged range up to i
+        constexpr int TOP = (NT + HALO < 512) ? 256 : ((NT + HALO < 1024) ? 512 : 1024);      // 2 * TOP - 1 >= the staged range up to i
         static_assert(2 * TOP > NT + HALO, "cell-head bisection covers the window");
 #pragma unroll
         for (int step = TOP; step >= 1; step >>= 1) {
@@ -1347,7 +1501,7 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
               const int* __restrict__ strip_start, const int* __restrict__ chainid, const int* __restrict__ chain_qend,
               const int* __restrict__ pmax32, int* parent)
 {
-    __shared__ int2 lw[NT + 2 * HALO];
+    __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
     __shared__ int lx[NT + 2 * HALO];
     __shared__ short l_list[NT];
     __shared__ int l_wcount[NT / 64];
@@ -1599,33 +1753,34 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
          const int* __restrict__ ncore, const u32* __restrict__ srow, int* __restrict__ owner, int* __restrict__ bsize,
          int* __restrict__ usize, const int* __restrict__ cnt)
 {
-    __shared__ int2 lw[NT + 2 * HALO];
+    __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
     __shared__ int lx[NT + 2 * HALO];
     __shared__ short l_list[NT];
     __shared__ int l_wcount[NT / 64];
+    __shared__ unsigned long long l_mask[(NT + 2 * HALO) / 64];
+    __shared__ int l_enc[NT];
     const int M = strip_start[g.S];
     Tile t;
-    if (!tile_stage<NT, HALO>(t, lw, lx, ntiles, M, sv, sa, root)) return;
+    if (!tile_stage<NT, HALO>(t, lw, lx, ntiles, M, sv, sa, root, l_mask)) return;
     const int i0 = t.t0 + threadIdx.x;
     bool border = false;
     if (i0 < M) {
         const int ri = t.x[i0];
         if (ri >= 0) owner[i0] = ri;
-        else if (cnt[i0] <= 1) owner[i0] = -1;           // K2 left the neighbour count of a non-core PET (itself included) or an upper
-        else border = true;                              // bound of it: nothing within eps -- most of the background noise ends here
+        else {
+            // K2 left either the neighbour count of a non-core PET (itself included) or its hint word (k_region_core):
+            // nothing within eps -- most of the background noise ends here
+            const int enc = cnt[i0];
+            l_enc[threadIdx.x] = enc;
+            if (enc < 0 ? (((unsigned)enc & K2H_ISOLATED) != 0u) : (enc <= 1)) owner[i0] = -1; else border = true;
+        }
     }
     const int total = block_compact<NT>(border, l_list, l_wcount);
     if ((int)threadIdx.x >= total) return;
-#ifdef CLOOPS_DEVEL
-    if (g.dbg & 256) return;
-#endif
     const int i = t.t0 + l_list[threadIdx.x];
+    const int enc = l_enc[l_list[threadIdx.x]];
     const int2 me = t.w[i];
-    const int s = strip_of(g, me.y);
     const int qlo = sat_add(me.x, -g.eps), qhi = sat_add(me.x, g.eps);
-    const int b = strip_start[s], e = strip_start[s + 1];
-    const int tb = s > 0 ? strip_start[s - 1] : b;
-    const int te = s + 1 < g.S ? strip_start[s + 2] : e;
     const bool v1 = g.variant == CL_VARIANT_CDBSCAN1;
     int bestk = INT_MAX, best = -1, tk = -1, tbest = -1, lastr = -1, lastk = 0, first = -1;
     bool contested = false;
@@ -1637,18 +1792,52 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
         if (k < bestk) { bestk = k; best = r; }
         if (v1 && (int)srow[j] == k && k > tk) { tk = k; tbest = r; }     // j is its component's start point
     };
-#ifdef CLOOPS_DEVEL
-    if (!(g.dbg & 512))
-#endif
-    tile_visit_own_all(t, sv, root, i, b, e, qlo, qhi, [&](int j, int r) { see(j, r); });
-#ifdef CLOOPS_DEVEL
-    if (!(g.dbg & 1024))
-#endif
-    {
-    tile_visit_segment(t, sv, sa, root, tb, b, qlo, qhi, [&](int j, int, int pj, int r) {
-        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.peps) see(j, r); }, g.dbg);
-    tile_visit_segment(t, sv, sa, root, e, te, qlo, qhi, [&](int j, int, int pj, int r) {
-        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.peps) see(j, r); }, g.dbg);
+    // Only core PETs count (see() ignores the rest).  Own strip: a non-core PET has fewer than minPts PETs of its strip
+    // in its q window, so for minPts <= 128 the window lies inside the staged range and at most minPts - 1 positions
+    // away.  All cores on ONE side of it are within eps of each other (same strip, q inside one eps) -- one component:
+    // for variant 2 the nearest core on either side, found in the mask, stands for all of them.  Variant 1 needs every
+    // neighbour (its start-point rule looks at single PETs), as do windows that may leave the staged range.
+    const bool hinted = !v1 && enc < 0 && ((unsigned)enc & K2H_NONE) != K2H_NONE;
+    if (hinted) {
+        // variant 2 with K2's hints: no strip table, no searches.  Strips are aligned blocks of the strip coordinate:
+        // "same strip" and "still inside the neighbour strip" are predicates of the staged pairs.
+        constexpr int T_WIN = NT + 2 * HALO;
+        const int pbeg = me.y & ~(g.peps - 1), pend = pbeg + g.peps, pend2 = pend + g.peps;
+        const int plo = me.y - g.peps, phi = me.y + g.peps;
+        {
+            const int lb = max(i - (g.minPts - 1), t.w.base), re = min(i + g.minPts, t.w.base + T_WIN);
+            const int jl = t.prev_set(i - 1, lb), jr = t.next_set(i + 1, re);
+            const bool hl = jl >= lb, hr = jr < re;
+            const int2 cl = t.w[hl ? jl : i], cr = t.w[hr ? jr : i];
+            const int rl = t.x[hl ? jl : i], rr = t.x[hr ? jr : i];
+            if (hl && cl.y >= pbeg && cl.x >= qlo) see(jl, rl);
+            if (hr && cr.y < pend && cr.x <= qhi) see(jr, rr);
+        }
+        const int ja = i - (int)((unsigned)enc & K2H_MASK), jb = i + (int)(((unsigned)enc >> K2H_BITS) & K2H_MASK);
+        tile_walk_from<T_WIN>(t, sv, sa, root, M, ja, [&](int2 c) { return (c.y < pbeg) & (c.x <= qhi); },
+                              [&](int2 c) { return c.y >= plo; }, see);       // one strip below: sp can only be too low
+        tile_walk_from<T_WIN>(t, sv, sa, root, M, jb, [&](int2 c) { return (c.y < pend2) & (c.x <= qhi); },
+                              [&](int2 c) { return c.y <= phi; }, see);       // one strip above: only too high
+    } else {
+        const int s = strip_of(g, me.y);
+        const int b = strip_start[s], e = strip_start[s + 1];
+        const int tb = s > 0 ? strip_start[s - 1] : b;
+        const int te = s + 1 < g.S ? strip_start[s + 2] : e;
+        if (!v1 && g.minPts <= 128) {
+            const int lb = max(b, i - (g.minPts - 1)), re = min(e, i + g.minPts);
+            const int jl = t.prev_set(i - 1, lb), jr = t.next_set(i + 1, re);
+            const bool hl = jl >= lb, hr = jr < re;
+            const int ql = t.w[hl ? jl : i].x, qr = t.w[hr ? jr : i].x;
+            const int rl = t.x[hl ? jl : i], rr = t.x[hr ? jr : i];
+            if (hl && ql >= qlo) see(jl, rl);
+            if (hr && qr <= qhi) see(jr, rr);
+        } else {
+            tile_visit_own_all(t, sv, root, i, b, e, qlo, qhi, [&](int j, int r) { see(j, r); });
+        }
+        tile_visit_segment<true>(t, sv, sa, root, tb, b, qlo, qhi, [&](int j, int, int pj, int r) {
+            const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.peps) see(j, r); });
+        tile_visit_segment<true>(t, sv, sa, root, e, te, qlo, qhi, [&](int j, int, int pj, int r) {
+            const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.peps) see(j, r); });
     }
     const int o = (v1 && tbest >= 0) ? tbest : best;
     owner[i] = o < 0 ? -1 : (contested ? (o | OWNER_CONTESTED) : o);
@@ -1703,7 +1892,7 @@ k_emit_records(GridParams g, int ntiles, const int* __restrict__ sv, const int* 
                const int* __restrict__ state, const int* __restrict__ owner, Rec* __restrict__ recs, int rec_cap,
                int* __restrict__ counters)
 {
-    __shared__ int2 lw[NT + 2 * HALO];
+    __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
     __shared__ int lx[NT + 2 * HALO];
     __shared__ short l_list[NT];
     __shared__ int l_wcount[NT / 64];
@@ -4098,13 +4287,14 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
 #endif
     const int tile_nt = wide == 1 ? 1024 : TPB;
     int ntiles = 0, tgrid = 0;                          // set once the number of PETs that pass the cut is known
-#define TILE_LAUNCH_H(bighalo, kernel, ...)                                                                          \
+#define TILE_LAUNCH_H(halo, kernel, ...)                                                                             \
     do {                                                                                                             \
         if (wide == 1) hipLaunchKernelGGL((kernel<1024, 512>), dim3(tgrid), dim3(1024), 0, c->stream, __VA_ARGS__);  \
-        else if (bighalo) hipLaunchKernelGGL((kernel<TPB, 512>), dim3(tgrid), dim3(TPB), 0, c->stream, __VA_ARGS__); \
+        else if ((halo) == 512) hipLaunchKernelGGL((kernel<TPB, 512>), dim3(tgrid), dim3(TPB), 0, c->stream, __VA_ARGS__); \
+        else if ((halo) == 256) hipLaunchKernelGGL((kernel<TPB, 256>), dim3(tgrid), dim3(TPB), 0, c->stream, __VA_ARGS__); \
         else hipLaunchKernelGGL((kernel<TPB, 128>), dim3(tgrid), dim3(TPB), 0, c->stream, __VA_ARGS__);              \
     } while (0)
-#define TILE_LAUNCH(kernel, ...) TILE_LAUNCH_H(wide == 2, kernel, __VA_ARGS__)
+#define TILE_LAUNCH(kernel, ...) TILE_LAUNCH_H(wide == 2 ? 512 : (wide == 6 ? 256 : 128), kernel, __VA_ARGS__)
 
     LAUNCH(k_init_flags, n + 1, n, c->flag.as<int>(), counters);
     // row-aligned labels only when somebody reads them: k_final_labels then writes the label (or -1) of every PET that
@@ -4156,14 +4346,14 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
                c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                c->headidx.as<int>(), sv, c->lo.as<int>(), sa, pmax32);   // chain ends live in `lo` until the release fix-up reuses it
     }
-    TILE_LAUNCH_H(wide == 2 || wide == 4, k_union_cores, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
+    TILE_LAUNCH_H((wide == 2 || wide == 4) ? 512 : (wide >= 6 ? 256 : 128), k_union_cores, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
                        pmax32, c->parent.as<int>());
     hipLaunchKernelGGL(k_flatten, dim3(nblocks(nm, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
            c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->chainflag.as<int>() /* root list: the chain ids are dead */, counters);
     int* rootlist = c->chainflag.as<int>();
     ev_record(c, 4);
     // K4
-    TILE_LAUNCH_H(wide >= 2, k_border, g, ntiles, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(),
+    TILE_LAUNCH_H((wide >= 2 && wide <= 4) ? 512 : (wide >= 5 ? 256 : 128), k_border, g, ntiles, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(),
                        c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), cnt);
     if (variant == CL_VARIANT_CDBSCAN2) {
         const int rec_cap = n;
