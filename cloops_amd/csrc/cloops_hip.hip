@@ -4346,7 +4346,10 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
                c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                c->headidx.as<int>(), sv, c->lo.as<int>(), sa, pmax32);   // chain ends live in `lo` until the release fix-up reuses it
     }
-    TILE_LAUNCH_H((wide == 2 || wide == 4) ? 512 : (wide >= 6 ? 256 : 128), k_union_cores, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
+    // the union walk looks one strip back, i.e. about one strip population in front of the PET: a 256-PET halo keeps most of
+    // those windows in LDS on dense data (chr1 of the 200 M genome, eps 5000-10000: -12..-16 %); short strips stay with 128
+    const int union_halo = (long long)n > 40LL * g.S ? 256 : 128;
+    TILE_LAUNCH_H((wide == 2 || wide == 4) ? 512 : union_halo, k_union_cores, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
                        pmax32, c->parent.as<int>());
     hipLaunchKernelGGL(k_flatten, dim3(nblocks(nm, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
            c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->chainflag.as<int>() /* root list: the chain ids are dead */, counters);
