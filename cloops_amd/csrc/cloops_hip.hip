@@ -2049,6 +2049,35 @@ __global__ void k_root_labels_l(GridParams g, const int* __restrict__ rootlist, 
         rlabel[i] = keep ? rankscan[compkey[i]] : -1;
     }
 }
+// The same two steps on a BITMAP of the keys (keys are input rows, 0 .. n-1): one bit per key instead of one int, the
+// ranks come from an exclusive scan over the words' popcounts (n / 32 elements instead of n + 1) plus a popcount
+// inside the key's word -- the per-run clearing and the scan shrink 32-fold.
+struct PopcWord { __host__ __device__ int operator()(unsigned w) const { return __popc(w); } };
+__global__ void k_rank_bits_l(GridParams g, const int* __restrict__ rootlist, const int* __restrict__ counters,
+                              const int* __restrict__ compkey, const int* __restrict__ state, unsigned* __restrict__ bits)
+{
+    const int K = counters[CTR_NROOT];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        const int i = rootlist[k];
+        if (g.variant == CL_VARIANT_CDBSCAN2 && state[i] == ST_DEAD) continue;      // cDBSCAN2.py:183-185 / cDBSCAN.py:136-152
+        const int key = compkey[i];
+        atomicOr(&bits[key >> 5], 1u << (key & 31));
+    }
+}
+__global__ void k_root_labels_bits_l(GridParams g, const int* __restrict__ rootlist, const int* __restrict__ counters,
+                                     const int* __restrict__ compkey, const int* __restrict__ ncore, const int* __restrict__ bsize,
+                                     const int* __restrict__ state, const unsigned* __restrict__ bits, const int* __restrict__ wordrank,
+                                     int* __restrict__ rlabel)
+{
+    const int K = counters[CTR_NROOT];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        const int i = rootlist[k];
+        const bool keep = (g.variant == CL_VARIANT_CDBSCAN2) ? (state[i] != ST_DEAD)
+                                                             : (ncore[i] + bsize[i] >= g.minPts);   // cDBSCAN.py:149-152
+        const int key = compkey[i];
+        rlabel[i] = keep ? wordrank[key >> 5] + __popc(bits[key >> 5] & ((1u << (key & 31)) - 1u)) : -1;
+    }
+}
 __global__ void k_rank_flags(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ root,
                              const int* __restrict__ compkey, const int* __restrict__ state, int* __restrict__ flag)
 {
@@ -2205,11 +2234,13 @@ k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __r
             if (o >= 0) lab = rlabel[o];
             slab[i] = lab;
             if (labels) labels[srow[i]] = lab;
-            // X = (v - a) / 2, Y = (v + a) / 2 exactly (v and a have equal parity)
-            const int spv = sa[i];
-            int pp = ((spv >> g.rbits) + g.s0) * g.eps + (spv & (g.peps - 1)) + g.A0, qq = sv[i] + g.V0;
-            int a = g.swap ? qq : pp, v = g.swap ? pp : qq;
-            x = (v - a) / 2; y = (v + a) / 2;
+            if (lab >= 0) {                              // noise has no box: its coordinates are never loaded
+                // X = (v - a) / 2, Y = (v + a) / 2 exactly (v and a have equal parity)
+                const int spv = sa[i];
+                int pp = ((spv >> g.rbits) + g.s0) * g.eps + (spv & (g.peps - 1)) + g.A0, qq = sv[i] + g.V0;
+                int a = g.swap ? qq : pp, v = g.swap ? pp : qq;
+                x = (v - a) / 2; y = (v + a) / 2;
+            }
         }
         table_accumulate(t, h, lab, x, y);
     }
@@ -3175,6 +3206,7 @@ struct cl_chrom {
     DevBuf bq, bsp, brow, bstrip, btile, sel_tmp;
     struct BaseLayout { bool valid = false; int layout = -1, eps = 0; } base;
     std::vector<long long> dcum;      // dcum[k] = number of PETs with Y - X < k, k = 0 .. 65536 (empty: unknown)
+    const int* k_total = nullptr;     // device: where the run left the number of ids handed out (null: rankscan[n])
     DevBuf dhist;                     // device: number of PETs with Y - X == d, d = 0 .. 65535 (+ one slot for d < 0)
     long long n_neg = 0;              // PETs with Y - X < 0
     int run_m = 0;                    // PETs that enter DBSCAN in the run being enqueued (exact when run_m_exact, else n)
@@ -3849,13 +3881,15 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
         HIP_TRY(hipHostMalloc((void**)&sl.h_boxes, cap * sizeof(cl_box), hipHostMallocDefault));
         sl.h_boxes_cap = cap;
     }
-    hipLaunchKernelGGL(k_pack_header, dim3(1), dim3(64), 0, c->stream, dh, c->rankscan.as<int>() + n, c->counters.as<int>(), d_M);
+    hipLaunchKernelGGL(k_pack_header, dim3(1), dim3(64), 0, c->stream, dh, c->k_total ? c->k_total : c->rankscan.as<int>() + n, c->counters.as<int>(), d_M);
+    c->k_total = nullptr;
     // (without export the kernel still counts the non-empty ids for the header; cap 0 = no row is stored)
-    if (c->export_table || c->pending_step < 0)
-        hipLaunchKernelGGL(k_export_table, dim3(256), dim3(TPB), 0, c->stream, dh, make_table(c), sl.h_boxes,
-                           c->export_table ? (int)std::min<size_t>(sl.h_boxes_cap, 0x7fffffff) : -1);
     // (a sweep step reads neither the rows nor n_clusters / max_label: its header keeps the values of k_pack_header)
-    sl.exported = c->export_table;
+    const bool exported = c->export_table && c->pending_step < 0;
+    if (c->pending_step < 0)
+        hipLaunchKernelGGL(k_export_table, dim3(256), dim3(TPB), 0, c->stream, dh, make_table(c), sl.h_boxes,
+                           exported ? (int)std::min<size_t>(sl.h_boxes_cap, 0x7fffffff) : -1);
+    sl.exported = exported;
     sl.step_valid = false;
     if (c->pending_step >= 0) {
         // sweep-step tail, still inside the run's stream: classify the table (pipe.py:83-97), append the inter-ligation
@@ -4296,7 +4330,8 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     } while (0)
 #define TILE_LAUNCH(kernel, ...) TILE_LAUNCH_H(wide == 2 ? 512 : (wide == 6 ? 256 : 128), kernel, __VA_ARGS__)
 
-    LAUNCH(k_init_flags, n + 1, n, c->flag.as<int>(), counters);
+    const int nw = (n + 31) / 32;                       // words of the key bitmap (K5); one more word takes the scan's total
+    LAUNCH(k_init_flags, nw + 1, nw, c->flag.as<int>(), counters);
     // row-aligned labels only when somebody reads them: k_final_labels then writes the label (or -1) of every PET that
     // entered DBSCAN and only the rows removed by the cut filter need the -1 fill
     const bool rows = labels_out != nullptr || c->device_labels;
@@ -4370,18 +4405,19 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     }
     ev_record(c, 5);
     // K5
-    hipLaunchKernelGGL(k_rank_flags_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, counters, c->compkey.as<int>(), c->state.as<int>(), c->flag.as<int>());
+    hipLaunchKernelGGL(k_rank_bits_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, counters, c->compkey.as<int>(), c->state.as<int>(), c->flag.as<unsigned>());
     {
         size_t tb = c->scan_tmp.bytes;
-        hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, c->flag.as<int>(), c->rankscan.as<int>(), 0, (size_t)n + 1,
-                                               rocprim::plus<int>(), c->stream);
+        hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, rocprim::make_transform_iterator(c->flag.as<unsigned>(), PopcWord()),
+                                               c->rankscan.as<int>(), 0, (size_t)nw + 1, rocprim::plus<int>(), c->stream);
         if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan", hipGetErrorString(e));
     }
+    c->k_total = c->rankscan.as<int>() + nw;
     Table t = make_table(c);
-    LAUNCH(k_init_table, c->slot[c->cur].kmax + 1, t, c->rankscan.as<int>(), n);
+    LAUNCH(k_init_table, c->slot[c->cur].kmax + 1, t, c->rankscan.as<int>(), nw);
     // rlabel reuses the chainhead buffer (free after k_chain_parent)
-    hipLaunchKernelGGL(k_root_labels_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, counters, c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
-                       c->state.as<int>(), c->rankscan.as<int>(), c->chainhead.as<int>());
+    hipLaunchKernelGGL(k_root_labels_bits_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, counters, c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
+                       c->state.as<int>(), c->flag.as<unsigned>(), c->rankscan.as<int>(), c->chainhead.as<int>());
     hipLaunchKernelGGL(k_final_labels, dim3(nblocks(nm, BIGTPB * FINAL_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow, c->owner.as<int>(),
                        c->chainhead.as<int>(), rows ? c->slot[c->cur].labels.as<int>() : (int*)nullptr, c->slot[c->cur].slab.as<int>(), t);
     HIP_TRY(hipGetLastError());
