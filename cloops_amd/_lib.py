@@ -29,7 +29,7 @@ SYMBOLS = [
     "cl_cluster", "cl_get_boxes", "cl_neighbor_counts", "cl_labels_device", "cl_set_profiling",
     "cl_get_timing", "cl_version", "cl_host_alloc", "cl_host_free", "cl_cluster_async", "cl_wait", "cl_boxes_host",
     "cl_dist_summary", "cl_dist_bin_hist", "cl_last_n_in", "cl_sig_counts", "cl_cluster_weighted",
-    "cl_set_layout_reuse", "cl_set_device_labels", "cl_set_table_export", "cl_cand_reset", "cl_cand_append", "cl_cand_finish", "cl_cluster_step_async", "cl_step_result",
+    "cl_set_layout_reuse", "cl_set_sort_index", "cl_set_device_labels", "cl_set_table_export", "cl_cand_reset", "cl_cand_append", "cl_cand_finish", "cl_cluster_step_async", "cl_step_result",
 ]
 
 
@@ -137,6 +137,8 @@ def load():
     lib.cl_set_profiling.argtypes = [vp, ctypes.c_int]
     lib.cl_set_layout_reuse.restype = None
     lib.cl_set_layout_reuse.argtypes = [vp, ctypes.c_int]
+    lib.cl_set_sort_index.restype = None
+    lib.cl_set_sort_index.argtypes = [vp, ctypes.c_int]
     lib.cl_get_timing.restype = ctypes.c_int
     lib.cl_get_timing.argtypes = [vp, ctypes.POINTER(ClTiming)]
     lib.cl_host_alloc.restype = vp

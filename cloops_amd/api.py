@@ -161,6 +161,11 @@ class Chromosome(object):
         _lib.check(self._lib.cl_cand_finish(self._h, int(final_cut), out.ctypes.data_as(ctypes.c_void_p), int(capacity), ctypes.byref(k)))
         return out[: int(k.value)]
 
+    def set_sort_index(self, mode=1):
+        """rows kept sorted by the in-strip coordinate, every eps' layout from a 2-pass strip sort of that order:
+        0 = built at the handle's second sort (default), 1 = at the first, -1 = never (cl_set_sort_index)"""
+        self._lib.cl_set_sort_index(self._h, int(mode))
+
     def set_layout_reuse(self, on=True):
         """keep the sorted arrays of the last eps and start further runs at that eps from a compaction by the cut
         (default on; results identical either way -- cl_set_layout_reuse of include/cloops_hip.h)"""

@@ -314,6 +314,69 @@ __global__ void k_decode_sorted(int n, GridParams g, const u64* __restrict__ ske
     sa[i] = (strip << g.rbits) | (int)(k & ((1ull << g.rbits) - 1ull));
 }
 
+// ------------------------------------------------------------------------------------------
+// K1 through the q index.  The sorted order of a run is (strip, q) with ties in input-row order, and only the strip
+// depends on eps.  A handle that sorts more than once (a sweep: one layout per eps) therefore keeps its rows sorted by q
+// ONCE -- qb_key[i] = q, qb_val[i] = strip coordinate << 32 | row, stable, i.e. ties in row order -- and a layout for
+// some eps is a STABLE sort of that sequence by the strip bits alone: 2 radix passes (9-bit digits, <= 2^18 strips)
+// instead of 5 over (strip, q), the same permutation bit for bit.  The index costs 4 passes once and 12 B/PET.
+// ------------------------------------------------------------------------------------------
+__global__ void k_make_qkeys(const int* __restrict__ X, const int* __restrict__ Y, int n, GridParams g,
+                             u32* __restrict__ keyq, u64* __restrict__ val)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int x = X[r], y = Y[r];
+    const int a = y - x, v = x + y;
+    const u32 prel = (u32)((g.swap ? v : a) - g.A0);      // strip coordinate, >= 0
+    keyq[r] = (u32)((g.swap ? a : v) - g.V0);             // in-strip coordinate, >= 0
+    val[r] = ((u64)prel << 32) | (u32)r;
+}
+// keys of one layout from the q index: key = sp (strip << rbits | p mod eps; rows removed by the cut: strip S),
+// value = q << 32 | row
+__global__ void k_make_spkeys(int n, GridParams g, const u32* __restrict__ keyq, const u64* __restrict__ valq,
+                              u32* __restrict__ key, u64* __restrict__ val)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 q = keyq[i];
+    const u64 pv = valq[i];
+    const int prel = (int)(pv >> 32);
+    const int a = (g.swap ? (int)q + g.V0 : prel + g.A0);  // Y - X
+    const bool valid = (g.cut <= 0) || (a >= g.cut);      // pipe.py:59-62  d >= cut
+    const int sabs = div_eps(g, prel);
+    const u32 rem = (u32)(prel - sabs * g.eps);
+    key[i] = valid ? (((u32)(sabs - g.s0) << g.rbits) | rem) : ((u32)g.S << g.rbits);
+    val[i] = ((u64)q << 32) | (u32)pv;
+}
+__global__ void k_decode_sp(int n, GridParams g, const u32* __restrict__ skey, const u64* __restrict__ sval,
+                            int* __restrict__ sv, int* __restrict__ sa, int* __restrict__ tile_s0, u32* __restrict__ rows_out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 k = skey[i];
+    const u64 v = sval[i];
+    rows_out[i] = (u32)v;
+    const int strip = (int)(k >> g.rbits);
+    if ((i & 255) == 0) tile_s0[i >> 8] = min(strip, g.S);
+    if (strip >= g.S) { sv[i] = INT_MAX; sa[i] = g.S << g.rbits; return; }
+    sv[i] = (int)(v >> 32);
+    sa[i] = (int)k;
+}
+__global__ void k_strip_table32(const u32* __restrict__ skeys, int n, int S, int shift, int* __restrict__ strip_start)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > S + 1) return;
+    if (t == S + 1) { strip_start[t] = n; return; }
+    const u32 target = (u32)t << shift;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+        if (skeys[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    strip_start[t] = lo;
+}
+
 // K1c: strip_start[t] = first sorted index whose strip >= t, t = 0..S+1
 // (strip_start[S] = M = number of rows that entered DBSCAN, strip_start[S+1] = n)
 __global__ void k_strip_table(const u64* __restrict__ skeys, int n, int S, int shift, int* __restrict__ strip_start)
@@ -3190,6 +3253,10 @@ struct cl_chrom {
     Stats st{};
     // workspace
     DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, scan_tmp;
+    DevBuf qb_key, qb_val;            // the q index (k_make_qkeys): rows sorted by q, persistent
+    int qindex_layout = -1;           // layout the q index was built for (-1: none)
+    int sort_index_mode = 0;          // cl_set_sort_index: 0 = build at the second sort, 1 = at the first, -1 = never
+    long long n_sorts = 0;            // layouts sorted on this handle so far
     DevBuf sv, sa, strip, cnt, parent, root, head, headidx, cellfirst, compkey, ncore, bsize, owner, state;
     DevBuf flag, rankscan, ulist, lo, hi, recs, counters, chainflag, chainhead, usize, b_cstart, b_ckey, b_nb, b_cx, b_cy, tile_s0;
     int* h_pinned = nullptr;          // small pinned staging (stats, block scalars)
@@ -3266,7 +3333,7 @@ static void free_chrom(cl_chrom* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->sv, &c->sa,
+    DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->qb_key, &c->qb_val, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->slot[0].d_step, &c->slot[1].d_step, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
                       &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out, &c->dhist};
@@ -3291,6 +3358,7 @@ extern "C" void cl_chrom_destroy(cl_chrom* c) { free_chrom(c); }
 extern "C" int64_t cl_chrom_size(const cl_chrom* c) { return c ? c->n : -1; }
 extern "C" void cl_set_profiling(cl_chrom* c, int enabled) { if (c) c->profiling = enabled != 0; }
 extern "C" void cl_set_layout_reuse(cl_chrom* c, int enabled) { if (c) { c->reuse_layout = enabled != 0; c->base.valid = false; } }
+extern "C" void cl_set_sort_index(cl_chrom* c, int mode) { if (c) c->sort_index_mode = mode > 0 ? 1 : (mode < 0 ? -1 : 0); }
 extern "C" int cl_get_timing(const cl_chrom* c, cl_timing* out)
 {
     if (!c || !out) return fail(CL_ERR_ARG, "cl_get_timing: null argument");
@@ -3504,6 +3572,12 @@ static int ensure_workspace(cl_chrom* c, int S)
     hipError_t e = rocprim::radix_sort_pairs<SortConfig>(nullptr, sort_bytes, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr,
                                              n, 0, 64, c->stream);
     if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs size query", hipGetErrorString(e));
+    {
+        size_t sb2 = 0;
+        e = rocprim::radix_sort_pairs<SortConfig>(nullptr, sb2, (u32*)nullptr, (u32*)nullptr, (u64*)nullptr, (u64*)nullptr, n, 0, 32, c->stream);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs size query (q index)", hipGetErrorString(e));
+        sort_bytes = std::max(sort_bytes, sb2);
+    }
     e = rocprim::inclusive_scan(nullptr, scan_bytes, (int*)nullptr, (int*)nullptr, n, rocprim::maximum<int>(), c->stream);
     if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan size query", hipGetErrorString(e));
     e = rocprim::exclusive_scan(nullptr, scan2, (int*)nullptr, (int*)nullptr, 0, n + 1, rocprim::plus<int>(), c->stream);
@@ -3597,14 +3671,43 @@ static int sort_layout(cl_chrom* c, const GridParams& g, int* dsv, int* dsa, u32
 {
     const int n = (int)c->n;
     const int sh = g.qbits + g.rbits, strip_bits = std::max(1, bits_for((unsigned)g.S));
+    // the q index: built at the handle's second sort (or its first, if the caller announced several: cl_set_sort_index)
+    const int layout = (g.variant == CL_VARIANT_CDBSCAN2 ? 2 : 0) | (g.swap ? 1 : 0);
+    const bool use_index = c->sort_index_mode > 0 || (c->sort_index_mode == 0 && (c->n_sorts >= 1 || c->qindex_layout == layout));
+    ++c->n_sorts;
     // hybrid sort: worth it when it saves at least two radix passes (9-bit digits) and every strip is short
     bool hybrid = false;
     // (a chromosome with more than 64 PETs per strip on average is not measured at all: its longest strip is
     // practically never <= HS_LMAX, and the histogram pass on such data is slow -- many atomics per strip)
-    if (!(g.dbg & 256) && (g.qbits + strip_bits + 8) / 9 - (strip_bits + 8) / 9 >= 2 && (long long)n <= 64LL * g.S) {
+    if (!use_index && !(g.dbg & 256) && (g.qbits + strip_bits + 8) / 9 - (strip_bits + 8) / 9 >= 2 && (long long)n <= 64LL * g.S) {
         int maxlen = 0, rc;
         if ((rc = strip_maxlen(c, g, &maxlen))) return rc;
         hybrid = maxlen <= HS_LMAX;
+    }
+    if (use_index) {
+        int rc;
+        u32* k32_in = c->vals_in.as<u32>(); u32* k32_out = c->vals_out.as<u32>();       // the 4 n / 8 n byte sort buffers swap roles
+        u64* v64_in = c->keys_in.as<u64>(); u64* v64_out = c->keys_out.as<u64>();
+        if (c->qindex_layout != layout) {
+            if ((rc = c->qb_key.ensure((size_t)n * 4)) || (rc = c->qb_val.ensure((size_t)n * 8))) return rc;
+            LAUNCH(k_make_qkeys, n, c->d_x, c->d_y, n, g, k32_in, v64_in);
+            size_t tb = c->sort_tmp.bytes;
+            hipError_t e = rocprim::radix_sort_pairs<SortConfig>(c->sort_tmp.p, tb, k32_in, c->qb_key.as<u32>(), v64_in, c->qb_val.as<u64>(),
+                                                                 (size_t)n, 0, g.qbits, c->stream);
+            if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs(q index)", hipGetErrorString(e));
+            c->qindex_layout = layout;
+        }
+        ev_record(c, 0);
+        LAUNCH(k_make_spkeys, n, n, g, (const u32*)c->qb_key.as<u32>(), (const u64*)c->qb_val.as<u64>(), k32_in, v64_in);
+        ev_record(c, 1);
+        size_t tb = c->sort_tmp.bytes;
+        hipError_t e = rocprim::radix_sort_pairs<SortConfig>(c->sort_tmp.p, tb, k32_in, k32_out, v64_in, v64_out, (size_t)n, g.rbits, g.rbits + strip_bits, c->stream);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs(strips)", hipGetErrorString(e));
+        LAUNCH(k_strip_table32, g.S + 2, (const u32*)k32_out, n, g.S, g.rbits, dstrip);
+        u32* rows = drow ? drow : k32_in;                 // the unsorted keys are dead after the sort
+        LAUNCH(k_decode_sp, n, n, g, (const u32*)k32_out, (const u64*)v64_out, dsv, dsa, dtile, rows);
+        c->srow = rows;
+        return CL_OK;
     }
     ev_record(c, 0);
     LAUNCH(k_make_keys, n, c->d_x, c->d_y, n, g, c->keys_in.as<u64>(), c->vals_in.as<u32>());

@@ -476,6 +476,8 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
     try:
         for f, r in live:
             r.chrom.cand_reset()
+            if len(set(eps)) > 1:
+                r.chrom.set_sort_index(1)                    # several layouts are coming: the q index pays from the first one on
         step_no = 0
         fine_lo = -1                                         # where the summary should look for the next median (see _select_kth)
         for ep in eps:

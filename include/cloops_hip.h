@@ -250,6 +250,14 @@ int cl_get_timing(const cl_chrom* c, cl_timing* out);
  * (eps, minPts) and must pay the whole run every time). */
 void cl_set_layout_reuse(cl_chrom* c, int enabled);
 
+/* The q index.  A run's sorted order is (strip, q) with ties in input-row order, and only the strip depends on eps.
+ * A handle that sorts more than one layout (the eps loop of cLoops/pipe.py:241-281) keeps its rows sorted by q once
+ * (12 B/PET, 4 radix passes) and gets every layout from a stable sort of that sequence by the strip bits alone
+ * (2 passes instead of 5) -- the same permutation.  mode 0 (default): the index is built at the handle's second
+ * sort, so a one-shot run never pays for it; 1: at the first sort (the sweep driver, which knows more eps are
+ * coming); -1: never.  Results are identical in every mode. */
+void cl_set_sort_index(cl_chrom* c, int mode);
+
 /* Page-locked host memory for result buffers (labels_out / boxes_out / counts_out): D2H
  * copies into pinned memory run at PCIe rate instead of through a staging buffer.  Plain
  * malloc'ed memory works everywhere too, only slower. */

@@ -26,6 +26,9 @@ class FakeChromosome(object):
     def set_device_labels(self, on=True):
         pass
 
+    def set_sort_index(self, mode=1):
+        pass
+
     def cluster(self, variant, eps, minPts, cut=0, want_labels=True, want_boxes=True, pinned=False):
         vname = {1: "v1", 2: "v2", 3: "block"}[api.VARIANTS[variant]]
         lab = oracle.single_dbscan(vname, self.X, self.Y, eps, minPts, cut)["labels"]

@@ -64,3 +64,28 @@ def test_neighbor_counts_with_reuse():
         assert np.array_equal(a.neighbor_counts(eps, cut), b.neighbor_counts(eps, cut))
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("variant", ["v2", "v1"])
+@pytest.mark.parametrize("reuse", [True, False])
+def test_sort_index_modes_agree(variant, reuse):
+    """cl_set_sort_index: layouts taken from the q index (a stable strip sort of the rows kept sorted by q) equal the
+    layouts of the full (strip, q) sort -- never / built at the second sort / built at the first -- and the oracle"""
+    X, Y = synth_chrom(300000, 8000000, 11)
+    hs = []
+    for mode in (-1, 0, 1):
+        h = api.Chromosome(X, Y)
+        h.set_sort_index(mode)
+        h.set_layout_reuse(reuse)
+        hs.append(h)
+    seq = [(1500, 5, 0), (1500, 4, 2500), (3000, 6, 2500), (700, 3, 0), (3000, 5, 9000), (1500, 5, 0)]
+    for k, (eps, m, cut) in enumerate(seq):
+        rs = [h.cluster(variant, eps, m, cut) for h in hs]
+        for r in rs[1:]:
+            assert np.array_equal(r.labels, rs[0].labels), (variant, reuse, eps, m, cut)
+            assert np.array_equal(r.boxes, rs[0].boxes)
+        if k in (0, 2, 4):
+            want = oracle.single_dbscan(variant, X, Y, eps, m, cut)["labels"]
+            assert np.array_equal(rs[2].labels, want)
+    for h in hs:
+        h.close()
