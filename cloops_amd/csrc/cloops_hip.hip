@@ -1765,26 +1765,27 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
             if (isroot) myslot = wbase + __builtin_amdgcn_mbcnt_hi((unsigned)(rb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)rb, 0u));
         }
     }
-    unsigned long long pending = __ballot(r >= 0);
-    while (pending) {
+    // a wave of one component (the inside of a large cluster): one reduction, one insertion by its first lane;
+    // anything else: every lane goes to the workgroup's LDS table itself -- lanes that share a root meet on one LDS
+    // address, which the LDS serialises far cheaper than a loop over the wave's distinct roots (or global atomics) would
+    const unsigned long long pending = __ballot(r >= 0);
+    if (pending) {
         const int leader = __ffsll((long long)pending) - 1;
         const int R = __builtin_amdgcn_readlane(r, leader);
         const unsigned long long m = __ballot(r == R);
-        const bool mine = r == R;
-        const int cm = __popcll(m);
-        if (cm >= 4) {
-            int mk = mine ? key : INT_MAX;
+        if (m == pending && __popcll(m) >= 16) {
+            int mk = r == R ? key : INT_MAX;
             mk = dpp_reduce_wave(mk, OpMin());
             if (lane == leader) {
                 const int sl = agg_slot(hkey, R);
-                if (sl >= 0) { atomicMin(&hmin[sl], mk); atomicAdd(&hcnt[sl], cm); }
-                else { atomicMin(&compkey[R], mk); atomicAdd(&ncore[R], cm); }
+                if (sl >= 0) { atomicMin(&hmin[sl], mk); atomicAdd(&hcnt[sl], __popcll(m)); }
+                else { atomicMin(&compkey[R], mk); atomicAdd(&ncore[R], __popcll(m)); }
             }
-        } else if (mine) {
-            atomicMin(&compkey[R], key);
-            atomicAdd(&ncore[R], 1);
+        } else if (r >= 0) {
+            const int sl = agg_slot(hkey, r);
+            if (sl >= 0) { atomicMin(&hmin[sl], key); atomicAdd(&hcnt[sl], 1); }
+            else { atomicMin(&compkey[r], key); atomicAdd(&ncore[r], 1); }
         }
-        pending &= ~m;
     }
     __syncthreads();
     if (threadIdx.x < AGG_H && hkey[threadIdx.x] >= 0) {
@@ -2220,44 +2221,42 @@ __device__ __forceinline__ int tab_slot(int* keys, int key)
 __device__ __forceinline__ void table_accumulate(const Table& t, TableLds& h, int lab, int x, int y)
 {
     const int lane = threadIdx.x & 63;
-    unsigned long long pending = __ballot(lab >= 0);
-    while (pending) {
-        const int leader = __ffsll((long long)pending) - 1;
-        const int L = __builtin_amdgcn_readlane(lab, leader);
-        const unsigned long long m = __ballot(lab == L);
+    const unsigned long long pending = __ballot(lab >= 0);
+    if (!pending) return;
+    const int leader = __ffsll((long long)pending) - 1;
+    const int L = __builtin_amdgcn_readlane(lab, leader);
+    const unsigned long long m = __ballot(lab == L);
+    if (m == pending && __popcll(m) >= 16) {
+        // the wave lies inside one cluster: four reductions, one insertion
         const bool mine = lab == L;
         const int cm = __popcll(m);
-        if (cm >= 6) {
-            int mnx = wave_min_i(mine ? x : INT_MAX), mxx = wave_max_i(mine ? x : INT_MIN);
-            int mny = wave_min_i(mine ? y : INT_MAX), mxy = wave_max_i(mine ? y : INT_MIN);
-            if (lane == leader) {
-                const int sl = tab_slot(h.key, L);
-                if (sl >= 0) {
-                    atomicAdd(&h.cnt[sl], cm);
-                    atomicMin(&h.mnx[sl], mnx); atomicMax(&h.mxx[sl], mxx);
-                    atomicMin(&h.mny[sl], mny); atomicMax(&h.mxy[sl], mxy);
-                } else {
-                    atomicAdd(&t.count[L], cm);
-                    atomicMin(&t.minx[L], mnx); atomicMax(&t.maxx[L], mxx);
-                    atomicMin(&t.miny[L], mny); atomicMax(&t.maxy[L], mxy);
-                }
-            }
-        } else if (mine) {
-            // a handful of lanes share the label: straight into the LDS table (five LDS atomics instead of five
-            // global ones -- clusters are spread over several strips, so most PETs of a wave are in such
-            // small groups and their global atomics used to dominate the kernel)
+        int mnx = wave_min_i(mine ? x : INT_MAX), mxx = wave_max_i(mine ? x : INT_MIN);
+        int mny = wave_min_i(mine ? y : INT_MAX), mxy = wave_max_i(mine ? y : INT_MIN);
+        if (lane == leader) {
             const int sl = tab_slot(h.key, L);
             if (sl >= 0) {
-                atomicAdd(&h.cnt[sl], 1);
-                atomicMin(&h.mnx[sl], x); atomicMax(&h.mxx[sl], x);
-                atomicMin(&h.mny[sl], y); atomicMax(&h.mxy[sl], y);
+                atomicAdd(&h.cnt[sl], cm);
+                atomicMin(&h.mnx[sl], mnx); atomicMax(&h.mxx[sl], mxx);
+                atomicMin(&h.mny[sl], mny); atomicMax(&h.mxy[sl], mxy);
             } else {
-                atomicAdd(&t.count[L], 1);
-                atomicMin(&t.minx[L], x); atomicMax(&t.maxx[L], x);
-                atomicMin(&t.miny[L], y); atomicMax(&t.maxy[L], y);
+                atomicAdd(&t.count[L], cm);
+                atomicMin(&t.minx[L], mnx); atomicMax(&t.maxx[L], mxx);
+                atomicMin(&t.miny[L], mny); atomicMax(&t.maxy[L], mxy);
             }
         }
-        pending &= ~m;
+    } else if (lab >= 0) {
+        // several clusters (and noise) in the wave: every lane straight into the LDS table -- lanes of one cluster meet on
+        // one LDS address, which the LDS unit serialises at a fraction of what a loop over the distinct labels costs
+        const int sl = tab_slot(h.key, lab);
+        if (sl >= 0) {
+            atomicAdd(&h.cnt[sl], 1);
+            atomicMin(&h.mnx[sl], x); atomicMax(&h.mxx[sl], x);
+            atomicMin(&h.mny[sl], y); atomicMax(&h.mxy[sl], y);
+        } else {
+            atomicAdd(&t.count[lab], 1);
+            atomicMin(&t.minx[lab], x); atomicMax(&t.maxx[lab], x);
+            atomicMin(&t.miny[lab], y); atomicMax(&t.maxy[lab], y);
+        }
     }
 }
 // level 2 -> global: one set of atomics per key of the workgroup
