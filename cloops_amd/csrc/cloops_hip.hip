@@ -2852,11 +2852,24 @@ __device__ __forceinline__ void k7_for_each(const K7Src& s, int cut, const signe
         const int M = s.dM ? s.dM[0] : s.M;
         const int per = (M + gridDim.x - 1) / gridDim.x;
         const int i0 = blockIdx.x * per, i1 = min(M, i0 + per);
-        for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        // four PETs per round: the label loads, then the class gathers, of all four are in flight together (the walk is bound
+        // by the dependent label -> class round trips, not by bytes); f() still sees the PETs in ascending order
+        int i = i0 + threadIdx.x;
+        const int bd = blockDim.x;
+        for (; i + 3 * bd < i1; i += 4 * bd) {
+            int lab[4], d[4], g[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { lab[k] = s.slab[i + k * bd]; d[k] = s.sv[i + k * bd] + s.v0; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = lab[k] >= 0 ? (int)cls[lab[k]] : -1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (g[k] >= 0) f(g[k], d[k] < 0 ? -d[k] : d[k], 1);     // ests.py:42-43 np.abs
+        }
+        for (; i < i1; i += bd) {
             const int lab = s.slab[i];
             const int g = lab >= 0 ? (int)cls[lab] : -1;
             const int d = s.sv[i] + s.v0;
-            if (g >= 0) f(g, d < 0 ? -d : d, 1);                   // ests.py:42-43 np.abs
+            if (g >= 0) f(g, d < 0 ? -d : d, 1);
         }
         if (cut > 0 && s.dh) {                                     // pipe.py:63: short PETs go to dss -- all PETs of one distance at once
             for (int d = blockIdx.x * blockDim.x + threadIdx.x; d < cut; d += gridDim.x * blockDim.x) {
