@@ -2128,20 +2128,6 @@ __global__ void k_rank_bits_l(GridParams g, const int* __restrict__ rootlist, co
         atomicOr(&bits[key >> 5], 1u << (key & 31));
     }
 }
-__global__ void k_root_labels_bits_l(GridParams g, const int* __restrict__ rootlist, const int* __restrict__ counters,
-                                     const int* __restrict__ compkey, const int* __restrict__ ncore, const int* __restrict__ bsize,
-                                     const int* __restrict__ state, const unsigned* __restrict__ bits, const int* __restrict__ wordrank,
-                                     int* __restrict__ rlabel)
-{
-    const int K = counters[CTR_NROOT];
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
-        const int i = rootlist[k];
-        const bool keep = (g.variant == CL_VARIANT_CDBSCAN2) ? (state[i] != ST_DEAD)
-                                                             : (ncore[i] + bsize[i] >= g.minPts);   // cDBSCAN.py:149-152
-        const int key = compkey[i];
-        rlabel[i] = keep ? wordrank[key >> 5] + __popc(bits[key >> 5] & ((1u << (key & 31)) - 1u)) : -1;
-    }
-}
 __global__ void k_rank_flags(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ root,
                              const int* __restrict__ compkey, const int* __restrict__ state, int* __restrict__ flag)
 {
@@ -2188,6 +2174,26 @@ __global__ void k_init_table(Table t, const int* __restrict__ rankscan, int n)
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     t.count[k] = 0; t.minx[k] = INT_MAX; t.maxx[k] = INT_MIN; t.miny[k] = INT_MAX; t.maxy[k] = INT_MIN;
+}
+
+__global__ void k_root_labels_bits_l(GridParams g, const int* __restrict__ rootlist, const int* __restrict__ counters,
+                                     const int* __restrict__ compkey, const int* __restrict__ ncore, const int* __restrict__ bsize,
+                                     const int* __restrict__ state, const unsigned* __restrict__ bits, const int* __restrict__ wordrank,
+                                     int* __restrict__ rlabel, Table t, int nw)
+{
+    const int K = counters[CTR_NROOT];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        const int i = rootlist[k];
+        const bool keep = (g.variant == CL_VARIANT_CDBSCAN2) ? (state[i] != ST_DEAD)
+                                                             : (ncore[i] + bsize[i] >= g.minPts);   // cDBSCAN.py:149-152
+        const int key = compkey[i];
+        rlabel[i] = keep ? wordrank[key >> 5] + __popc(bits[key >> 5] & ((1u << (key & 31)) - 1u)) : -1;
+    }
+    // k_init_table rides along: the rows of the ids handed out
+    const int ids = wordrank[nw];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < ids; k += gridDim.x * blockDim.x) {
+        t.count[k] = 0; t.minx[k] = INT_MAX; t.maxx[k] = INT_MIN; t.miny[k] = INT_MAX; t.maxy[k] = INT_MIN;
+    }
 }
 
 __device__ __forceinline__ int je_minus(const int* __restrict__ cstart, int j) { return cstart[j + 1] - cstart[j]; }
@@ -2956,8 +2962,18 @@ k7_summary(K7Src s, int cut, const signed char* __restrict__ cls, K7Part* __rest
 // fixed-order reduction of the workgroup partials into parts[0] (deterministic: thread t sums blocks t, t+256, ... in order,
 // then a fixed tree) -- the host reads 64 bytes instead of K7_BLOCKS partials
 __global__ void __launch_bounds__(256)
-k7_reduce_parts(K7Part* __restrict__ parts, int nparts)
+k7_reduce_parts(K7Part* __restrict__ parts, int nparts, K7Part* __restrict__ out /* or null: parts[0] */,
+                const int* __restrict__ bcount /* or null */, const int* __restrict__ boff, int nb, long long* __restrict__ totals)
 {
+    if (bcount) {                                       // sweep step: the candidate totals of k_cand_totals ride along
+        __shared__ long long redt[4];
+        long long sself = 0;
+        for (int k = threadIdx.x; k < nb; k += 256) sself += bcount[nb + k];
+        for (int o = 32; o > 0; o >>= 1) sself += __shfl_down(sself, o);
+        if ((threadIdx.x & 63) == 0) redt[threadIdx.x >> 6] = sself;
+        __syncthreads();
+        if (threadIdx.x == 0) { totals[0] = (long long)boff[nb - 1] + bcount[nb - 1]; totals[1] = redt[0] + redt[1] + redt[2] + redt[3]; }
+    }
     __shared__ double sd[4][256];
     __shared__ long long sn[4][256];
     double a[4] = {0, 0, 0, 0}; long long c[4] = {0, 0, 0, 0};
@@ -2976,7 +2992,7 @@ k7_reduce_parts(K7Part* __restrict__ parts, int nparts)
         K7Part p;
         p.sx[0] = sd[0][0]; p.sx[1] = sd[1][0]; p.sxx[0] = sd[2][0]; p.sxx[1] = sd[3][0];
         p.n_all[0] = sn[0][0]; p.n_all[1] = sn[1][0]; p.n_pos[0] = sn[2][0]; p.n_pos[1] = sn[3][0];
-        parts[0] = p;
+        if (out) *out = p; else parts[0] = p;
     }
 }
 
@@ -3019,6 +3035,32 @@ k_cand_count(const int* __restrict__ dK, const signed char* __restrict__ cls, in
         const int i = base + k;
         const int c = i < K ? (int)cls[i] : -1;
         ci += c == 0; cs += c == 1;
+    }
+    for (int o = 32; o > 0; o >>= 1) { ci += __shfl_down(ci, o); cs += __shfl_down(cs, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ci; red[1][threadIdx.x >> 6] = cs; }
+    __syncthreads();
+    if (threadIdx.x == 0) { bcount[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3]; bcount[nb + blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3]; }
+}
+// sweep step: k7_classify + k_cand_count in one launch, which also clears the step's histograms (`zero`, nzero 8-byte words)
+__global__ void __launch_bounds__(256)
+k_step_classify_count(const int* __restrict__ dK, Table t, signed char* __restrict__ cls, int* __restrict__ bcount, int nb,
+                      unsigned long long* __restrict__ zero, int nzero)
+{
+    __shared__ int red[2][4];
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < nzero; k += gridDim.x * 256) zero[k] = 0ull;
+    const int K = dK[0];
+    const int base = blockIdx.x * CAND_BLOCK;
+    int ci = 0, cs = 0;
+    for (int k = threadIdx.x; k < CAND_BLOCK; k += 256) {
+        const int i = base + k;
+        if (i < K) {
+            const cl_box b = t.get(i);
+            signed char c = -1;
+            if (b.count > 0 && b.min_x != b.max_x && b.min_y != b.max_y)       // pipe.py:83-85
+                c = (b.max_x < b.min_y) ? 0 : 1;                                // pipe.py:97
+            cls[i] = c;
+            ci += c == 0; cs += c == 1;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) { ci += __shfl_down(ci, o); cs += __shfl_down(cs, o); }
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ci; red[1][threadIdx.x >> 6] = cs; }
@@ -4029,26 +4071,24 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
         int* boff = bcount + 2 * nb;
         Table t = make_table(c);
         signed char* cls = c->k7_cls.as<signed char>();
-        LAUNCH(k7_classify, kmax + 1, dh, t, cls);
-        hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(256), 0, c->stream, (const int*)dh, cls, bcount, nb);
+        char* ds = (char*)sl.d_step.p;
+        unsigned long long* lh = (unsigned long long*)(ds + 16 + sizeof(K7Part));
+        hipLaunchKernelGGL(k_step_classify_count, dim3(nb), dim3(256), 0, c->stream, (const int*)dh, t, cls, bcount, nb,
+                           lh, K7_LOGBINS + K7_FINE);                                       // + log histogram and the fine window behind it cleared
         size_t tb = c->scan_tmp.bytes;
         hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, bcount, boff, 0, (size_t)nb, rocprim::plus<int>(), c->stream);
         if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan(step)", hipGetErrorString(e));
         hipLaunchKernelGGL(k_cand_append, dim3(nb), dim3(256), 0, c->stream, (const int*)dh, cls, t, (const int*)boff, (int)c->cand_n, c->pending_step,
                            (int)std::min<long long>(c->cand_cap, INT_MAX), c->cand_box.as<int4>(), c->cand_step.as<int>());
-        char* ds = (char*)sl.d_step.p;
-        hipLaunchKernelGGL(k_cand_totals, dim3(1), dim3(256), 0, c->stream, (const int*)bcount, (const int*)boff, nb, (long long*)ds);
-        unsigned long long* lh = (unsigned long long*)(ds + 16 + sizeof(K7Part));
         K7Part* parts = (K7Part*)(ds + out_bytes);
-        HIP_TRY(hipMemsetAsync(lh, 0, K7_LOGBINS * 8 + K7_FINE * 8, c->stream));        // log histogram + the fine window behind it
         K7Src src{};
         src.sorted = sl.sorted_src ? 1 : 0; src.n = n; src.M = 0; src.v0 = sl.k7_v0; src.dM = d_M;
         src.X = c->d_x; src.Y = c->d_y; src.labels = sl.labels.as<int>(); src.sv = sl.k7_sv; src.slab = sl.slab.as<int>();
         src.dh = k7_hist_for(c, c->pending_cut);
         hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, src, c->pending_cut, cls, parts, lh,
                            (unsigned)c->pending_fine_lo, c->pending_fine_lo >= 0 ? lh + K7_LOGBINS : (unsigned long long*)nullptr);
-        hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, parts, K7_BLOCKS);
-        HIP_TRY(hipMemcpyAsync(ds + 16, parts, sizeof(K7Part), hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, parts, K7_BLOCKS, (K7Part*)(ds + 16),
+                           (const int*)bcount, (const int*)boff, nb, (long long*)ds);
         sl.fine_lo = c->pending_fine_lo;
         sl.step_valid = true;
     }
@@ -4529,10 +4569,9 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     }
     c->k_total = c->rankscan.as<int>() + nw;
     Table t = make_table(c);
-    LAUNCH(k_init_table, c->slot[c->cur].kmax + 1, t, c->rankscan.as<int>(), nw);
-    // rlabel reuses the chainhead buffer (free after k_chain_parent)
+    // rlabel reuses the chainhead buffer (free after k_chain_parent); the kernel also resets the table rows of the ids handed out
     hipLaunchKernelGGL(k_root_labels_bits_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, counters, c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
-                       c->state.as<int>(), c->flag.as<unsigned>(), c->rankscan.as<int>(), c->chainhead.as<int>());
+                       c->state.as<int>(), c->flag.as<unsigned>(), c->rankscan.as<int>(), c->chainhead.as<int>(), t, nw);
     hipLaunchKernelGGL(k_final_labels, dim3(nblocks(nm, BIGTPB * FINAL_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow, c->owner.as<int>(),
                        c->chainhead.as<int>(), rows ? c->slot[c->cur].labels.as<int>() : (int*)nullptr, c->slot[c->cur].slab.as<int>(), t);
     HIP_TRY(hipGetLastError());
@@ -4581,7 +4620,8 @@ extern "C" int cl_dist_summary(cl_chrom* c, int32_t cut, cl_dsummary* out)
     HIP_TRY(hipMemsetAsync(dh, 0, K7_LOGBINS * 8, c->stream));
     hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, k7_source(c, cut), cut, c->k7_cls.as<signed char>(), c->k7_parts.as<K7Part>(), dh,
                        0u, (unsigned long long*)nullptr);
-    hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->k7_parts.as<K7Part>(), K7_BLOCKS);
+    hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->k7_parts.as<K7Part>(), K7_BLOCKS, (K7Part*)nullptr,
+                       (const int*)nullptr, (const int*)nullptr, 0, (long long*)nullptr);
     K7Part part;
     HIP_TRY(hipMemcpyAsync(&part, c->k7_parts.p, sizeof(K7Part), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(out->loghist, dh, K7_LOGBINS * 8, hipMemcpyDeviceToHost, c->stream));

@@ -145,3 +145,32 @@ def test_sig_counts_kernel_vs_sets():
         assert n == n2
         assert np.array_equal(got, want)
     ch.close()
+
+
+@pytest.mark.parametrize("flip", [False, True])
+def test_dist_stats_cut_sources(jd, flip):
+    """the PETs below the cut come from the upload's distance histogram (cut < 65536, no row with Y < X) or from a pass
+    over the rows (rows with Y < X; a cut beyond the histogram): both against numpy on the reference's lists"""
+    import oracle
+    import golden_util as G
+    from cloops_amd import api
+    X, Y = G.chr21_xy()
+    if flip:                                             # some PETs stored with X > Y: pipe.py:63 keeps them (d < cut), ests.py:42 takes |d|
+        X, Y = X.copy(), Y.copy()
+        sel = np.arange(len(X)) % 17 == 0
+        X[sel], Y[sel] = Y[sel].copy(), X[sel].copy()
+    ch = api.Chromosome(X, Y)
+    ch.set_device_labels(False)
+    for eps, minPts, cut in ((1000, 5, 4601), (1000, 5, 70000), (500, 4, 65535), (500, 4, 65536)):
+        ch.cluster("v1", eps, minPts, cut, want_labels=False)
+        ref = oracle.single_dbscan("v1", X, Y, eps, minPts, cut)
+        st = ch.dist_summary(cut)
+        assert st["n_all"] == [len(ref["dis"]), len(ref["dss"])], (flip, cut)
+        for g, arr in ((0, ref["dis"]), (1, ref["dss"])):
+            a = np.abs(arr)
+            a = a[a > 0]
+            assert st["n_pos"][g] == len(a)
+            if len(a):
+                sumlog = st["sumx"][g] + st["xshift"] * len(a)
+                assert abs(sumlog - np.log2(a).sum()) < 1e-6 * max(1.0, np.log2(a).sum())
+    ch.close()
