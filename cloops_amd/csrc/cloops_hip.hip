@@ -2091,28 +2091,6 @@ __global__ void k_mark_uncertain_l(GridParams g, const int* __restrict__ rootlis
         }
     }
 }
-__global__ void k_rank_flags_l(GridParams g, const int* __restrict__ rootlist, const int* __restrict__ counters,
-                               const int* __restrict__ compkey, const int* __restrict__ state, int* __restrict__ flag)
-{
-    const int K = counters[CTR_NROOT];
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
-        const int i = rootlist[k];
-        if (g.variant == CL_VARIANT_CDBSCAN2 && state[i] == ST_DEAD) continue;      // cDBSCAN2.py:183-185 / cDBSCAN.py:136-152
-        flag[compkey[i]] = 1;
-    }
-}
-__global__ void k_root_labels_l(GridParams g, const int* __restrict__ rootlist, const int* __restrict__ counters,
-                                const int* __restrict__ compkey, const int* __restrict__ ncore, const int* __restrict__ bsize,
-                                const int* __restrict__ state, const int* __restrict__ rankscan, int* __restrict__ rlabel)
-{
-    const int K = counters[CTR_NROOT];
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
-        const int i = rootlist[k];
-        const bool keep = (g.variant == CL_VARIANT_CDBSCAN2) ? (state[i] != ST_DEAD)
-                                                             : (ncore[i] + bsize[i] >= g.minPts);   // cDBSCAN.py:149-152
-        rlabel[i] = keep ? rankscan[compkey[i]] : -1;
-    }
-}
 // The same two steps on a BITMAP of the keys (keys are input rows, 0 .. n-1): one bit per key instead of one int, the
 // ranks come from an exclusive scan over the words' popcounts (n / 32 elements instead of n + 1) plus a popcount
 // inside the key's word -- the per-run clearing and the scan shrink 32-fold.
@@ -2179,8 +2157,11 @@ __global__ void k_init_table(Table t, const int* __restrict__ rankscan, int n)
 __global__ void k_root_labels_bits_l(GridParams g, const int* __restrict__ rootlist, const int* __restrict__ counters,
                                      const int* __restrict__ compkey, const int* __restrict__ ncore, const int* __restrict__ bsize,
                                      const int* __restrict__ state, const unsigned* __restrict__ bits, const int* __restrict__ wordrank,
-                                     int* __restrict__ rlabel, Table t, int nw)
+                                     int* __restrict__ rlabel, Table t, int nw, int* __restrict__ hdr, const int* __restrict__ d_M)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {          // k_pack_header rides along (nothing behind this kernel raises a flag)
+        hdr[0] = wordrank[nw]; hdr[1] = counters[CTR_OVERFLOW]; hdr[2] = d_M[0]; hdr[3] = 0; hdr[4] = -1; hdr[5] = 0;
+    }
     const int K = counters[CTR_NROOT];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
         const int i = rootlist[k];
@@ -2963,16 +2944,16 @@ k7_summary(K7Src s, int cut, const signed char* __restrict__ cls, K7Part* __rest
 // then a fixed tree) -- the host reads 64 bytes instead of K7_BLOCKS partials
 __global__ void __launch_bounds__(256)
 k7_reduce_parts(K7Part* __restrict__ parts, int nparts, K7Part* __restrict__ out /* or null: parts[0] */,
-                const int* __restrict__ bcount /* or null */, const int* __restrict__ boff, int nb, long long* __restrict__ totals)
+                const int* __restrict__ bcount /* or null */, int nb, long long* __restrict__ totals)
 {
     if (bcount) {                                       // sweep step: the candidate totals of k_cand_totals ride along
-        __shared__ long long redt[4];
-        long long sself = 0;
-        for (int k = threadIdx.x; k < nb; k += 256) sself += bcount[nb + k];
-        for (int o = 32; o > 0; o >>= 1) sself += __shfl_down(sself, o);
-        if ((threadIdx.x & 63) == 0) redt[threadIdx.x >> 6] = sself;
+        __shared__ long long redt[2][4];
+        long long sint = 0, sself = 0;
+        for (int k = threadIdx.x; k < nb; k += 256) { sint += bcount[k]; sself += bcount[nb + k]; }
+        for (int o = 32; o > 0; o >>= 1) { sint += __shfl_down(sint, o); sself += __shfl_down(sself, o); }
+        if ((threadIdx.x & 63) == 0) { redt[0][threadIdx.x >> 6] = sint; redt[1][threadIdx.x >> 6] = sself; }
         __syncthreads();
-        if (threadIdx.x == 0) { totals[0] = (long long)boff[nb - 1] + bcount[nb - 1]; totals[1] = redt[0] + redt[1] + redt[2] + redt[3]; }
+        if (threadIdx.x == 0) { totals[0] = redt[0][0] + redt[0][1] + redt[0][2] + redt[0][3]; totals[1] = redt[1][0] + redt[1][1] + redt[1][2] + redt[1][3]; }
     }
     __shared__ double sd[4][256];
     __shared__ long long sn[4][256];
@@ -3069,7 +3050,8 @@ k_step_classify_count(const int* __restrict__ dK, Table t, signed char* __restri
 }
 // ordered scatter of the flagged elements of [0, N): dst = base + boff[block] + rank inside the block (element order)
 template <typename F, typename W>
-__device__ __forceinline__ void ordered_scatter_block(int N, const int* __restrict__ boff, F&& flagged, W&& write)
+__device__ __forceinline__ void ordered_scatter_block(int N, const int* __restrict__ boff /* or null: */, const int* __restrict__ bcount,
+                                                      F&& flagged, W&& write)
 {
     __shared__ int l_cnt[(CAND_BLOCK / 256) * 4];
     const int base = blockIdx.x * CAND_BLOCK;
@@ -3084,7 +3066,18 @@ __device__ __forceinline__ void ordered_scatter_block(int N, const int* __restri
         if (lane == 0) l_cnt[k * 4 + wv] = __popcll(bal);
     }
     __syncthreads();
-    int pre = boff[blockIdx.x];
+    int pre;
+    if (boff) pre = boff[blockIdx.x];
+    else {
+        // no scan over the block counts: a block sums the counts in front of it itself (a few hundred at most: sweep steps)
+        __shared__ int l_pre[4];
+        int sum = 0;
+        for (int k = threadIdx.x; k < (int)blockIdx.x; k += 256) sum += bcount[k];
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+        if (lane == 0) l_pre[wv] = sum;
+        __syncthreads();
+        pre = l_pre[0] + l_pre[1] + l_pre[2] + l_pre[3];
+    }
 #pragma unroll
     for (int k = 0; k < CAND_BLOCK / 256; ++k) {
         int mine = 0;
@@ -3094,22 +3087,11 @@ __device__ __forceinline__ void ordered_scatter_block(int N, const int* __restri
     }
 }
 __global__ void __launch_bounds__(256)
-k_cand_append(const int* __restrict__ dK, const signed char* __restrict__ cls, Table t, const int* __restrict__ boff, int base, int step, int cap,
-              int4* __restrict__ cbox, int* __restrict__ cstep)
+k_cand_append(const int* __restrict__ dK, const signed char* __restrict__ cls, Table t, const int* __restrict__ boff /* or null: */,
+              const int* __restrict__ bcount, int base, int step, int cap, int4* __restrict__ cbox, int* __restrict__ cstep)
 {
-    ordered_scatter_block(dK[0], boff, [&](int i) { return cls[i] == 0; },
+    ordered_scatter_block(dK[0], boff, bcount, [&](int i) { return cls[i] == 0; },
                           [&](int i, int r) { const int d = base + r; if (d < cap) { cbox[d] = make_int4(t.minx[i], t.maxx[i], t.miny[i], t.maxy[i]); cstep[d] = step; } });
-}
-// totals of a run's classification: out[0] = inter-ligation boxes (appended), out[1] = self-ligation boxes
-__global__ void k_cand_totals(const int* __restrict__ bcount, const int* __restrict__ boff, int nb, long long* __restrict__ out)
-{
-    __shared__ long long red[4];
-    long long s = 0;
-    for (int k = threadIdx.x; k < nb; k += blockDim.x) s += bcount[nb + k];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) { out[0] = (long long)boff[nb - 1] + bcount[nb - 1]; out[1] = red[0] + red[1] + red[2] + red[3]; }
 }
 __device__ __forceinline__ u64 box_hash(int4 b, u64 salt)
 {
@@ -3154,7 +3136,7 @@ k_flag_count(int N, const unsigned char* __restrict__ keep, int* __restrict__ bc
 __global__ void __launch_bounds__(256)
 k_cand_emit(int N, const unsigned char* __restrict__ keep, const int4* __restrict__ cbox, const int* __restrict__ boff, int4* __restrict__ out)
 {
-    ordered_scatter_block(N, boff, [&](int i) { return keep[i] != 0; }, [&](int i, int r) { out[r] = cbox[i]; });
+    ordered_scatter_block(N, boff, (const int*)nullptr, [&](int i) { return keep[i] != 0; }, [&](int i, int r) { out[r] = cbox[i]; });
 }
 
 // ==========================================================================================
@@ -3328,6 +3310,7 @@ struct cl_chrom {
     struct BaseLayout { bool valid = false; int layout = -1, eps = 0; } base;
     std::vector<long long> dcum;      // dcum[k] = number of PETs with Y - X < k, k = 0 .. 65536 (empty: unknown)
     const int* k_total = nullptr;     // device: where the run left the number of ids handed out (null: rankscan[n])
+    bool hdr_packed = false;          // the run's own kernels have written the slot header (no k_pack_header)
     DevBuf dhist;                     // device: number of PETs with Y - X == d, d = 0 .. 65535 (+ one slot for d < 0)
     long long n_neg = 0;              // PETs with Y - X < 0
     int run_m = 0;                    // PETs that enter DBSCAN in the run being enqueued (exact when run_m_exact, else n)
@@ -3521,84 +3504,58 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
 
 // ---- cut filter as a stream compaction of the base layout ------------------------------------------------
 // pipe.py:59-62 keeps d = Y - X >= cut; in the strip layout d = q + V0, so the test reads the sorted q alone.
-// Stable compaction in three small steps: per-block counts (4 B/PET read), an exclusive scan over the block
-// counts, then the scatter (12 B/PET read, 12 B per kept PET written); block-local ranks by wave ballots.
 #define CMP_TPB 256
 #define CMP_PER 8                       // elements per thread
 #define CMP_BLOCK (CMP_TPB * CMP_PER)
-__global__ void __launch_bounds__(CMP_TPB)
-k_cut_count(int n, int thr, const int* __restrict__ bq, int* __restrict__ blockcount)
+// Stable compaction of the base layout by STRIPS (its in-strip coordinate is q = Y - X - V0, so the rows a cut removes are
+// a PREFIX of every strip): the kept length of every strip by one bisection per strip, an exclusive scan over the S strips
+// -- which IS the new strip table -- and one copy pass (12 B/PET read, 12 B per kept PET written) that also leaves the tile
+// table, the sentinels behind the last kept PET and M.  (Round 2 first did it by flags: per-block counts over all PETs, a
+// scan over the blocks, a ballot-ranked scatter, then bisections of the compacted array for the strip table -- 5 launches.)
+__global__ void k_cut_strips(int S, int thr, const int* __restrict__ bstrip, const int* __restrict__ bq,
+                             int* __restrict__ kept /* [S+1] */, int* __restrict__ src0 /* [S] first kept source index */)
 {
-    __shared__ int red[CMP_TPB / 64];
-    const int base = blockIdx.x * CMP_BLOCK;
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < CMP_PER; ++k) {
-        const int i = base + k * CMP_TPB + (int)threadIdx.x;
-        c += (i < n && bq[i] >= thr) ? 1 : 0;
-    }
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < CMP_TPB / 64; ++w) t += red[w]; blockcount[blockIdx.x] = t; }
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > S) return;
+    if (s == S) { kept[S] = 0; return; }
+    int lo = bstrip[s];
+    const int e = bstrip[s + 1];
+    int hi = e;
+    while (lo < hi) { const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1); if (bq[mid] < thr) lo = mid + 1; else hi = mid; }
+    kept[s] = e - lo;
+    src0[s] = lo;
 }
 __global__ void __launch_bounds__(CMP_TPB)
-k_cut_scatter(int n, int thr, const int* __restrict__ bq, const int* __restrict__ bsp, const u32* __restrict__ brow,
-              const int* __restrict__ blockoff, const int* __restrict__ blockcount,
-              int* __restrict__ sv, int* __restrict__ sa, u32* __restrict__ srow, int* __restrict__ d_M)
+k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const int* __restrict__ bsp, const u32* __restrict__ brow,
+           const int* __restrict__ src0, int* __restrict__ strip_start /* [0..S] = the scan; [S+1] written here */,
+           int* __restrict__ sv, int* __restrict__ sa, u32* __restrict__ srow, int* __restrict__ tile_s0, int* __restrict__ d_M,
+           int expect_m, int* __restrict__ counters)
 {
-    __shared__ int l_cnt[CMP_PER * (CMP_TPB / 64)];
+    const int M = strip_start[S];
     const int base = blockIdx.x * CMP_BLOCK;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int q[CMP_PER], sp[CMP_PER]; u32 row[CMP_PER]; int before[CMP_PER];
-    bool keep[CMP_PER];
 #pragma unroll
     for (int k = 0; k < CMP_PER; ++k) {
         const int i = base + k * CMP_TPB + (int)threadIdx.x;
-        q[k] = 0; sp[k] = 0; row[k] = 0u;
-        if (i < n) { q[k] = bq[i]; sp[k] = bsp[i]; row[k] = brow[i]; }
-        keep[k] = i < n && q[k] >= thr;
-        const unsigned long long bal = __ballot(keep[k]);
-        before[k] = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-        if (lane == 0) l_cnt[k * (CMP_TPB / 64) + wv] = __popcll(bal);
-    }
-    __syncthreads();
-    // exclusive prefix over the (k, wave) segments, in element order
-    int pre = blockoff[blockIdx.x];
-    int mine[CMP_PER];
-#pragma unroll
-    for (int k = 0; k < CMP_PER; ++k) {
-#pragma unroll
-        for (int w = 0; w < CMP_TPB / 64; ++w) {
-            if (w == wv) mine[k] = pre;
-            pre += l_cnt[k * (CMP_TPB / 64) + w];
+        if (i < n) {
+            const int q = bq[i];
+            if (q >= thr) {
+                const int sp = bsp[i];
+                const int st = sp >> rbits;
+                const int dst = strip_start[st] + (i - src0[st]);
+                sv[dst] = q; sa[dst] = sp; srow[dst] = brow[i];
+                if ((dst & 255) == 0) tile_s0[dst >> 8] = st;
+            }
         }
     }
-#pragma unroll
-    for (int k = 0; k < CMP_PER; ++k) {
-        if (keep[k]) { const int dst = mine[k] + before[k]; sv[dst] = q[k]; sa[dst] = sp[k]; srow[dst] = row[k]; }
+    // what k_after_compact did besides the strip table: tiles behind M, sentinels, M itself
+    const int t = blockIdx.x * CMP_TPB + (int)threadIdx.x;
+    for (int u = t; u <= n / 256; u += gridDim.x * CMP_TPB) if (u * 256 >= M) tile_s0[u] = S;
+    for (int u = t; u < SORT_PAD; u += gridDim.x * CMP_TPB) if (M + u < n) { sv[M + u] = INT_MAX; sa[M + u] = S << rbits; }
+    if (t == 0) {
+        d_M[0] = M;
+        strip_start[S + 1] = n;
+        if (expect_m >= 0 && expect_m != M) counters[CTR_OVERFLOW] = 8;      // the host sized the run by a wrong M: fail loudly
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) d_M[0] = blockoff[blockIdx.x] + blockcount[blockIdx.x];
-}
-
-// after the compaction: strip table by bisection of the compacted sp (strip = sp >> rbits), tile table, and
-// sentinels behind the last kept PET (the tile kernels stage windows a little past M)
-__global__ void k_after_compact(int n, int S, int rbits, const int* __restrict__ d_M, const int* __restrict__ sa,
-                                int* __restrict__ sv_w, int* __restrict__ sa_w, int* __restrict__ strip_start, int* __restrict__ tile_s0,
-                                int expect_m, int* __restrict__ counters)
-{
-    const int M = d_M[0];
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0 && expect_m >= 0 && expect_m != M) counters[CTR_OVERFLOW] = 8;      // the host sized the run by a wrong M: fail loudly
-    if (t <= S + 1) {
-        int lo = 0, hi = M;
-        if (t == S + 1) lo = n;
-        else if (t == S) lo = M;
-        else while (lo < hi) { const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1); if ((sa[mid] >> rbits) < t) lo = mid + 1; else hi = mid; }
-        strip_start[t] = lo;
-    }
-    if (t <= n / 256) { const int idx = t * 256; tile_s0[t] = idx < M ? (sa[idx] >> rbits) : S; }
-    if (t < SORT_PAD && M + t < n) { sv_w[M + t] = INT_MAX; sa_w[M + t] = S << rbits; }
 }
 
 // workspace for a run over n rows
@@ -3829,21 +3786,19 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
             // stable compaction of the base layout by d = q + V0 >= cut (pipe.py:59-62): same order as sorting the
             // filtered rows, one pass over 12 B/PET
             const int nb = nblocks(n, CMP_BLOCK);
-            if ((rc = c->sel_tmp.ensure((size_t)nb * 8 + 64))) return rc;
-            int* bcount = c->sel_tmp.as<int>();
-            int* boff = bcount + nb;
+            if ((rc = c->sel_tmp.ensure(((size_t)g.S + 2) * 8 + 64))) return rc;
+            int* kept = c->sel_tmp.as<int>();
+            int* src0 = kept + g.S + 2;
             int* d_M = c->counters.as<int>() + CTR_M;
             const int thr = g.cut - g.V0;
             const int* bq = c->bq.as<int>() + SORT_PAD;
-            hipLaunchKernelGGL(k_cut_count, dim3(nb), dim3(CMP_TPB), 0, c->stream, n, thr, bq, bcount);
+            LAUNCH(k_cut_strips, g.S + 1, g.S, thr, (const int*)c->bstrip.as<int>(), bq, kept, src0);
             size_t tb = c->scan_tmp.bytes;
-            hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, bcount, boff, 0, (size_t)nb, rocprim::plus<int>(), c->stream);
+            hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, kept, c->strip.as<int>(), 0, (size_t)g.S + 1, rocprim::plus<int>(), c->stream);
             if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan(cut)", hipGetErrorString(e));
-            hipLaunchKernelGGL(k_cut_scatter, dim3(nb), dim3(CMP_TPB), 0, c->stream, n, thr, bq, (const int*)(c->bsp.as<int>() + SORT_PAD),
-                               (const u32*)c->brow.as<u32>(), (const int*)boff, (const int*)bcount, wsv, wsa, c->vals_out.as<u32>(), d_M);
-            const int span = std::max(std::max(g.S + 2, n / 256 + 1), SORT_PAD);
-            LAUNCH(k_after_compact, span, n, g.S, g.rbits, d_M, wsa, wsv, wsa, c->strip.as<int>(), c->tile_s0.as<int>(),
-                   c->run_m_exact ? c->run_m : -1, c->counters.as<int>());
+            hipLaunchKernelGGL(k_cut_copy, dim3(nb), dim3(CMP_TPB), 0, c->stream, n, g.S, g.rbits, thr, bq, (const int*)(c->bsp.as<int>() + SORT_PAD),
+                               (const u32*)c->brow.as<u32>(), (const int*)src0, c->strip.as<int>(), wsv, wsa, c->vals_out.as<u32>(), c->tile_s0.as<int>(),
+                               d_M, c->run_m_exact ? c->run_m : -1, c->counters.as<int>());
             c->w_sv = wsv; c->w_sa = wsa; c->srow = c->vals_out.as<u32>();
             c->w_strip = c->strip.as<int>(); c->w_tile = c->tile_s0.as<int>();
         }
@@ -4038,8 +3993,9 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
         HIP_TRY(hipHostMalloc((void**)&sl.h_boxes, cap * sizeof(cl_box), hipHostMallocDefault));
         sl.h_boxes_cap = cap;
     }
-    hipLaunchKernelGGL(k_pack_header, dim3(1), dim3(64), 0, c->stream, dh, c->k_total ? c->k_total : c->rankscan.as<int>() + n, c->counters.as<int>(), d_M);
-    c->k_total = nullptr;
+    if (!c->hdr_packed)
+        hipLaunchKernelGGL(k_pack_header, dim3(1), dim3(64), 0, c->stream, dh, c->k_total ? c->k_total : c->rankscan.as<int>() + n, c->counters.as<int>(), d_M);
+    c->k_total = nullptr; c->hdr_packed = false;
     // (without export the kernel still counts the non-empty ids for the header; cap 0 = no row is stored)
     // (a sweep step reads neither the rows nor n_clusters / max_label: its header keeps the values of k_pack_header)
     const bool exported = c->export_table && c->pending_step < 0;
@@ -4068,18 +4024,15 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
         const int nb = nblocks(kmax, CAND_BLOCK);
         if ((rc = c->sel_tmp.ensure((size_t)nb * 12 + 64))) return rc;
         int* bcount = c->sel_tmp.as<int>();
-        int* boff = bcount + 2 * nb;
         Table t = make_table(c);
         signed char* cls = c->k7_cls.as<signed char>();
         char* ds = (char*)sl.d_step.p;
         unsigned long long* lh = (unsigned long long*)(ds + 16 + sizeof(K7Part));
         hipLaunchKernelGGL(k_step_classify_count, dim3(nb), dim3(256), 0, c->stream, (const int*)dh, t, cls, bcount, nb,
                            lh, K7_LOGBINS + K7_FINE);                                       // + log histogram and the fine window behind it cleared
-        size_t tb = c->scan_tmp.bytes;
-        hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, bcount, boff, 0, (size_t)nb, rocprim::plus<int>(), c->stream);
-        if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan(step)", hipGetErrorString(e));
-        hipLaunchKernelGGL(k_cand_append, dim3(nb), dim3(256), 0, c->stream, (const int*)dh, cls, t, (const int*)boff, (int)c->cand_n, c->pending_step,
-                           (int)std::min<long long>(c->cand_cap, INT_MAX), c->cand_box.as<int4>(), c->cand_step.as<int>());
+        // (no scan over the nb block counts: every append block sums the few counts in front of it itself)
+        hipLaunchKernelGGL(k_cand_append, dim3(nb), dim3(256), 0, c->stream, (const int*)dh, cls, t, (const int*)nullptr, (const int*)bcount,
+                           (int)c->cand_n, c->pending_step, (int)std::min<long long>(c->cand_cap, INT_MAX), c->cand_box.as<int4>(), c->cand_step.as<int>());
         K7Part* parts = (K7Part*)(ds + out_bytes);
         K7Src src{};
         src.sorted = sl.sorted_src ? 1 : 0; src.n = n; src.M = 0; src.v0 = sl.k7_v0; src.dM = d_M;
@@ -4088,7 +4041,7 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
         hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, src, c->pending_cut, cls, parts, lh,
                            (unsigned)c->pending_fine_lo, c->pending_fine_lo >= 0 ? lh + K7_LOGBINS : (unsigned long long*)nullptr);
         hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, parts, K7_BLOCKS, (K7Part*)(ds + 16),
-                           (const int*)bcount, (const int*)boff, nb, (long long*)ds);
+                           (const int*)bcount, nb, (long long*)ds);
         sl.fine_lo = c->pending_fine_lo;
         sl.step_valid = true;
     }
@@ -4571,7 +4524,9 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     Table t = make_table(c);
     // rlabel reuses the chainhead buffer (free after k_chain_parent); the kernel also resets the table rows of the ids handed out
     hipLaunchKernelGGL(k_root_labels_bits_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, counters, c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
-                       c->state.as<int>(), c->flag.as<unsigned>(), c->rankscan.as<int>(), c->chainhead.as<int>(), t, nw);
+                       c->state.as<int>(), c->flag.as<unsigned>(), c->rankscan.as<int>(), c->chainhead.as<int>(), t, nw,
+                       c->hdr.as<int>() + 16 * c->cur, (const int*)(strip + g.S));
+    c->hdr_packed = true;
     hipLaunchKernelGGL(k_final_labels, dim3(nblocks(nm, BIGTPB * FINAL_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow, c->owner.as<int>(),
                        c->chainhead.as<int>(), rows ? c->slot[c->cur].labels.as<int>() : (int*)nullptr, c->slot[c->cur].slab.as<int>(), t);
     HIP_TRY(hipGetLastError());
@@ -4621,7 +4576,7 @@ extern "C" int cl_dist_summary(cl_chrom* c, int32_t cut, cl_dsummary* out)
     hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, k7_source(c, cut), cut, c->k7_cls.as<signed char>(), c->k7_parts.as<K7Part>(), dh,
                        0u, (unsigned long long*)nullptr);
     hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->k7_parts.as<K7Part>(), K7_BLOCKS, (K7Part*)nullptr,
-                       (const int*)nullptr, (const int*)nullptr, 0, (long long*)nullptr);
+                       (const int*)nullptr, 0, (long long*)nullptr);
     K7Part part;
     HIP_TRY(hipMemcpyAsync(&part, c->k7_parts.p, sizeof(K7Part), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(out->loghist, dh, K7_LOGBINS * 8, hipMemcpyDeviceToHost, c->stream));
@@ -4683,7 +4638,7 @@ extern "C" int cl_cand_append(cl_chrom* c, int32_t step, int64_t* n_inter, int64
     hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, bcount, boff, 0, (size_t)nb, rocprim::plus<int>(), c->stream);
     if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan(cand)", hipGetErrorString(e));
     hipLaunchKernelGGL(k_cand_append, dim3(nb), dim3(256), 0, c->stream, dK, c->k7_cls.as<signed char>(), make_table_slot(c, c->last_slot),
-                       (const int*)boff, (int)c->cand_n, (int)step, (int)std::min<long long>(c->cand_cap, INT_MAX), c->cand_box.as<int4>(), c->cand_step.as<int>());
+                       (const int*)boff, (const int*)bcount, (int)c->cand_n, (int)step, (int)std::min<long long>(c->cand_cap, INT_MAX), c->cand_box.as<int4>(), c->cand_step.as<int>());
     std::vector<int> h(2 * nb);
     HIP_TRY(hipMemcpyAsync(h.data(), bcount, (size_t)2 * nb * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
