@@ -1468,7 +1468,7 @@ template <int NT, int HALO>
 __global__ void __launch_bounds__(NT)
 k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const int* __restrict__ sa,
               const int* __restrict__ strip_start, const int* __restrict__ cnt, int* __restrict__ chainflag,
-              int* __restrict__ chainlast, int* __restrict__ head)
+              int* __restrict__ chainlast, int* __restrict__ head, int* __restrict__ wavelast)
 {
     __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
     __shared__ int lx[NT + 2 * HALO];
@@ -1519,6 +1519,10 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
     }
     chainflag[i] = f;
     chainlast[i] = last;        // 1 = last core of its chain: its q is the chain's upper end
+    // wavelast[w] = the last chain-opening PET (+1) among the 64 PETs [64 w, 64 w + 64), 0 = none: what k_chain_parent needs to
+    // find a core's chain head without a scan over all PETs (the lanes still here are the wave's PETs below M; lane 0 is one)
+    const unsigned long long ob = __ballot(f != 0);
+    if ((threadIdx.x & 63) == 0) wavelast[i >> 6] = ob ? i + (64 - __clzll((long long)ob)) : 0;
 }
 // parent[] = chain head for core points (flat forest to start from); chainid[] = the same for
 // core points and -1 for everything else (what the union kernel stages as its payload)
@@ -1527,7 +1531,7 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
 // pmax32 (optional): the 32-PET block summaries of the union scan (max strip coordinate over the block's CORE PETs, see
 // k_union_cores) come out of the same pass -- every thread already knows whether its PET is a core
 __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const int* __restrict__ cnt, int minPts,
-                               const int* __restrict__ chainhead, int* __restrict__ parent, int* __restrict__ chainid,
+                               const int* __restrict__ wavelast, int* __restrict__ parent, int* chainid /* in: chain flags */,
                                int* __restrict__ compkey, int* __restrict__ ncore, int* __restrict__ bsize,
                                int* __restrict__ usize, int* __restrict__ state, const int* __restrict__ chainlast,
                                const int* __restrict__ sv, int* __restrict__ chain_qend,
@@ -1536,9 +1540,27 @@ __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const
     const int M = strip_start[S];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool core = false;
+    // A core's chain head = the latest chain-opening PET at or before it in sorted order (what an inclusive max-scan of the
+    // flags i + 1 / 0 gives): inside the wave from a ballot, else the nearest earlier 64-PET group that has one
+    // (k_chain_flags left wavelast[]; normally the group right in front -- 64 groups are looked at per round trip).
+    const int lane = threadIdx.x & 63;
+    const int fl = i < M ? chainid[i] : 0;
+    if (i < M) core = cnt[i] >= minPts;
+    const unsigned long long open = __ballot(fl != 0);
+    const unsigned long long upto = open & ((2ull << lane) - 1ull);
+    int head1 = upto ? (i - lane) + (64 - __clzll((long long)upto)) : 0;
+    if (__any(core && !upto)) {
+        int carry = 0;
+        for (int base = ((i - lane) >> 6) - 1; base >= 0; base -= 64) {
+            const int idx = base - lane;
+            const int v = idx >= 0 ? wavelast[idx] : 0;
+            const unsigned long long bal = __ballot(v != 0);
+            if (bal) { carry = __builtin_amdgcn_readlane(v, __ffsll((long long)bal) - 1); break; }
+        }
+        if (!upto) head1 = carry;
+    }
     if (i < M) {
-        core = cnt[i] >= minPts;
-        const int h = core ? chainhead[i] - 1 : -1;
+        const int h = core ? head1 - 1 : -1;
         parent[i] = core ? h : i;
         chainid[i] = h;
         if (h == i) { compkey[i] = INT_MAX; ncore[i] = 0; bsize[i] = 0; usize[i] = 0; state[i] = ST_LIVE; }
@@ -4465,10 +4487,10 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     // K3
     int* pmax32 = nullptr;
     {
-        // own-strip chains by scan; variant 2: the same tile kernel also finds every PET's cell head
+        // own-strip chains; variant 2: the same tile kernel also finds every PET's cell head
         int* head = variant == CL_VARIANT_CDBSCAN2 ? c->head.as<int>() : nullptr;
         TILE_LAUNCH(k_chain_flags, g, ntiles, nm, sv, sa, strip, cnt, c->chainflag.as<int>(),
-                           c->headidx.as<int>(), head);
+                           c->headidx.as<int>(), head, c->chainhead.as<int>() /* wavelast: the buffer is free until the labels */);
         if (head) {
             // cellfirst: segmented suffix-min of the input rows, keyed by the cell's head index, so that
             // cellfirst[head] = smallest row of the whole cell (replaces one atomicMin per PET)
@@ -4479,10 +4501,6 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
                                                rocprim::minimum<int>(), rocprim::equal_to<int>(), c->stream);
             if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan_by_key", hipGetErrorString(e));
         }
-        size_t tb = c->scan_tmp.bytes;
-        hipError_t e = rocprim::inclusive_scan(c->scan_tmp.p, tb, c->chainflag.as<int>(), c->chainhead.as<int>(), (size_t)nm,
-                                               rocprim::maximum<int>(), c->stream);
-        if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan(chain)", hipGetErrorString(e));
         // long strips (dense data at large eps): 32-PET block summaries for the union scan (`hi` is free until K4)
         pmax32 = ((long long)n > 64LL * g.S) ? c->hi.as<int>() : nullptr;
         LAUNCH(k_chain_parent, nm, strip, g.S, cnt, g.minPts, c->chainhead.as<int>(), c->parent.as<int>(), c->chainflag.as<int>(),
