@@ -2118,8 +2118,22 @@ __global__ void k_mark_uncertain_l(GridParams g, const int* __restrict__ rootlis
 // inside the key's word -- the per-run clearing and the scan shrink 32-fold.
 struct PopcWord { __host__ __device__ int operator()(unsigned w) const { return __popc(w); } };
 __global__ void k_rank_bits_l(GridParams g, const int* __restrict__ rootlist, const int* __restrict__ counters,
-                              const int* __restrict__ compkey, const int* __restrict__ state, unsigned* __restrict__ bits)
+                              const int* __restrict__ compkey, const int* __restrict__ state, unsigned* __restrict__ bits,
+                              const Rec* __restrict__ recs /* or null */, int* __restrict__ owner)
 {
+    if (recs) {                                         // variant 2: k_apply_records rides along (both only need the final states)
+        const int nrec = counters[CTR_NREC];
+        for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nrec; q += gridDim.x * blockDim.x) {
+            const Rec rec = recs[q];
+            int o = -1;
+            for (int k = 0; k < 4; ++k) {
+                const int c = rec.r[k];
+                if (c < 0) break;
+                if (state[c] != ST_DEAD) { o = c; break; }
+            }
+            owner[rec.pt] = o;
+        }
+    }
     const int K = counters[CTR_NROOT];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
         const int i = rootlist[k];
@@ -2907,6 +2921,55 @@ __device__ __forceinline__ void k7_for_each(const K7Src& s, int cut, const signe
 
 struct K7Part { double sx[2]; double sxx[2]; long long n_all[2]; long long n_pos[2]; };
 
+// fixed-order reduction of the workgroup partials (deterministic: thread t sums blocks t, t+256, ... in order, then a fixed
+// tree) -- the host reads 64 bytes instead of K7_BLOCKS partials; in a sweep step the candidate totals ride along.  Called by
+// the first 256 threads of ONE workgroup; sd / sn: 4 x 256 doubles / long longs of LDS.
+__device__ __forceinline__ void k7_reduce_block(const K7Part* __restrict__ parts, int nparts, K7Part* __restrict__ out,
+                                                const int* __restrict__ bcount /* or null */, int nb, long long* __restrict__ totals,
+                                                double (*sd)[256], long long (*sn)[256])
+{
+    const int tid = threadIdx.x;
+    double a[4] = {0, 0, 0, 0}; long long c[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = tid; k < nparts; k += 256) {
+        const K7Part p = parts[k];
+        a[0] += p.sx[0]; a[1] += p.sx[1]; a[2] += p.sxx[0]; a[3] += p.sxx[1];
+        c[0] += p.n_all[0]; c[1] += p.n_all[1]; c[2] += p.n_pos[0]; c[3] += p.n_pos[1];
+    }
+    if (bcount) for (int k = tid; k < nb; k += 256) { c[4] += bcount[k]; c[5] += bcount[nb + k]; }      // inter / self boxes of the run
+    for (int q = 0; q < 4; ++q) { sd[q][tid] = a[q]; sn[q][tid] = c[q]; }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) for (int q = 0; q < 4; ++q) { sd[q][tid] += sd[q][tid + o]; sn[q][tid] += sn[q][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        K7Part p;
+        p.sx[0] = sd[0][0]; p.sx[1] = sd[1][0]; p.sxx[0] = sd[2][0]; p.sxx[1] = sd[3][0];
+        p.n_all[0] = sn[0][0]; p.n_all[1] = sn[1][0]; p.n_pos[0] = sn[2][0]; p.n_pos[1] = sn[3][0];
+        *out = p;
+    }
+    if (bcount) {
+        __syncthreads();
+        sn[0][tid] = c[4]; sn[1][tid] = c[5];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) { sn[0][tid] += sn[0][tid + o]; sn[1][tid] += sn[1][tid + o]; }
+            __syncthreads();
+        }
+        if (tid == 0) { totals[0] = sn[0][0]; totals[1] = sn[1][0]; }
+    }
+}
+
+// (a "last workgroup reduces" step inside k7_summary instead of this launch measured 4 % SLOWER on the whole sweep)
+__global__ void __launch_bounds__(256)
+k7_reduce_parts(const K7Part* __restrict__ parts, int nparts, K7Part* __restrict__ out, const int* __restrict__ bcount /* or null */, int nb,
+                long long* __restrict__ totals)
+{
+    __shared__ double sd[4][256];
+    __shared__ long long sn[4][256];
+    k7_reduce_block(parts, nparts, out, bcount, nb, totals, sd, sn);
+}
+
 // one pass: counts, sum x and sum x^2 (x = log2|d| - K7_XSHIFT over d != 0) for both groups, and the log-binned
 // histogram of the self group's |d| (first level of the exact median)
 __global__ void __launch_bounds__(TPB)
@@ -2960,43 +3023,6 @@ k7_summary(K7Src s, int cut, const signed char* __restrict__ cls, K7Part* __rest
     if (want_fine)
         for (int k = threadIdx.x; k < K7_FINE; k += blockDim.x)
             if (hf[k]) atomicAdd(&fine[k], (unsigned long long)hf[k]);
-}
-
-// fixed-order reduction of the workgroup partials into parts[0] (deterministic: thread t sums blocks t, t+256, ... in order,
-// then a fixed tree) -- the host reads 64 bytes instead of K7_BLOCKS partials
-__global__ void __launch_bounds__(256)
-k7_reduce_parts(K7Part* __restrict__ parts, int nparts, K7Part* __restrict__ out /* or null: parts[0] */,
-                const int* __restrict__ bcount /* or null */, int nb, long long* __restrict__ totals)
-{
-    if (bcount) {                                       // sweep step: the candidate totals of k_cand_totals ride along
-        __shared__ long long redt[2][4];
-        long long sint = 0, sself = 0;
-        for (int k = threadIdx.x; k < nb; k += 256) { sint += bcount[k]; sself += bcount[nb + k]; }
-        for (int o = 32; o > 0; o >>= 1) { sint += __shfl_down(sint, o); sself += __shfl_down(sself, o); }
-        if ((threadIdx.x & 63) == 0) { redt[0][threadIdx.x >> 6] = sint; redt[1][threadIdx.x >> 6] = sself; }
-        __syncthreads();
-        if (threadIdx.x == 0) { totals[0] = redt[0][0] + redt[0][1] + redt[0][2] + redt[0][3]; totals[1] = redt[1][0] + redt[1][1] + redt[1][2] + redt[1][3]; }
-    }
-    __shared__ double sd[4][256];
-    __shared__ long long sn[4][256];
-    double a[4] = {0, 0, 0, 0}; long long c[4] = {0, 0, 0, 0};
-    for (int k = threadIdx.x; k < nparts; k += 256) {
-        const K7Part p = parts[k];
-        a[0] += p.sx[0]; a[1] += p.sx[1]; a[2] += p.sxx[0]; a[3] += p.sxx[1];
-        c[0] += p.n_all[0]; c[1] += p.n_all[1]; c[2] += p.n_pos[0]; c[3] += p.n_pos[1];
-    }
-    for (int q = 0; q < 4; ++q) { sd[q][threadIdx.x] = a[q]; sn[q][threadIdx.x] = c[q]; }
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) for (int q = 0; q < 4; ++q) { sd[q][threadIdx.x] += sd[q][threadIdx.x + o]; sn[q][threadIdx.x] += sn[q][threadIdx.x + o]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        K7Part p;
-        p.sx[0] = sd[0][0]; p.sx[1] = sd[1][0]; p.sxx[0] = sd[2][0]; p.sxx[1] = sd[3][0];
-        p.n_all[0] = sn[0][0]; p.n_all[1] = sn[1][0]; p.n_pos[0] = sn[2][0]; p.n_pos[1] = sn[3][0];
-        if (out) *out = p; else parts[0] = p;
-    }
 }
 
 // refinement pass of the exact median: histogram of (|d| - lo) >> shift over the self group's lo <= |d| < hi
@@ -4062,7 +4088,7 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
         src.dh = k7_hist_for(c, c->pending_cut);
         hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, src, c->pending_cut, cls, parts, lh,
                            (unsigned)c->pending_fine_lo, c->pending_fine_lo >= 0 ? lh + K7_LOGBINS : (unsigned long long*)nullptr);
-        hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, parts, K7_BLOCKS, (K7Part*)(ds + 16),
+        hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, (const K7Part*)parts, K7_BLOCKS, (K7Part*)(ds + 16),
                            (const int*)bcount, nb, (long long*)ds);
         sl.fine_lo = c->pending_fine_lo;
         sl.step_valid = true;
@@ -4392,7 +4418,7 @@ extern "C" int cl_step_result(cl_chrom* c, int64_t* n_inter, int64_t* n_self, cl
     if (n_self) *n_self = ((const long long*)h)[1];
     memset(out, 0, sizeof(*out));
     out->xshift = K7_XSHIFT;
-    const K7Part* part = (const K7Part*)(h + 16);           // reduced on the device in a fixed order (k7_reduce_parts)
+    const K7Part* part = (const K7Part*)(h + 16);           // reduced on the device in a fixed order (k7_reduce_block)
     for (int g = 0; g < 2; ++g) { out->sumx[g] = part->sx[g]; out->sumxx[g] = part->sxx[g]; out->n_all[g] = part->n_all[g]; out->n_pos[g] = part->n_pos[g]; }
     memcpy(out->loghist, h + 16 + sizeof(K7Part), K7_LOGBINS * 8);
     out->fine_lo = c->slot[c->last_slot].fine_lo;
@@ -4527,11 +4553,11 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
                            c->compkey.as<int>(), c->state.as<int>(), c->owner.as<int>(), c->recs.as<Rec>(), rec_cap, counters);
         hipLaunchKernelGGL(k_resolve_release, dim3(1), dim3(1024), 0, c->stream, minPts, c->ncore.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                            c->ulist.as<int>(), c->recs.as<Rec>(), c->lo.as<int>(), c->hi.as<int>(), counters);
-        LAUNCH(k_apply_records, nm, c->recs.as<Rec>(), c->state.as<int>(), c->owner.as<int>(), counters);
     }
     ev_record(c, 5);
     // K5
-    hipLaunchKernelGGL(k_rank_bits_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, counters, c->compkey.as<int>(), c->state.as<int>(), c->flag.as<unsigned>());
+    hipLaunchKernelGGL(k_rank_bits_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, counters, c->compkey.as<int>(), c->state.as<int>(), c->flag.as<unsigned>(),
+                       variant == CL_VARIANT_CDBSCAN2 ? (const Rec*)c->recs.as<Rec>() : (const Rec*)nullptr, c->owner.as<int>());
     {
         size_t tb = c->scan_tmp.bytes;
         hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, rocprim::make_transform_iterator(c->flag.as<unsigned>(), PopcWord()),
@@ -4591,12 +4617,13 @@ extern "C" int cl_dist_summary(cl_chrom* c, int32_t cut, cl_dsummary* out)
     if (!c->slot[c->last_slot].sorted_src && !c->slot[c->last_slot].rows_valid) return fail(CL_ERR_ARG, "cl_dist_summary: the last run left no labels");
     unsigned long long* dh = (unsigned long long*)((char*)c->k7_parts.p + K7_BLOCKS * sizeof(K7Part));
     HIP_TRY(hipMemsetAsync(dh, 0, K7_LOGBINS * 8, c->stream));
+    K7Part* dpart = (K7Part*)((char*)dh + K7_LOGBINS * 8);                  // behind the histogram (the buffer's spare 4 KB)
     hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, k7_source(c, cut), cut, c->k7_cls.as<signed char>(), c->k7_parts.as<K7Part>(), dh,
                        0u, (unsigned long long*)nullptr);
-    hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, c->k7_parts.as<K7Part>(), K7_BLOCKS, (K7Part*)nullptr,
+    hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, (const K7Part*)c->k7_parts.as<K7Part>(), K7_BLOCKS, dpart,
                        (const int*)nullptr, 0, (long long*)nullptr);
     K7Part part;
-    HIP_TRY(hipMemcpyAsync(&part, c->k7_parts.p, sizeof(K7Part), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&part, dpart, sizeof(K7Part), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(out->loghist, dh, K7_LOGBINS * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int g = 0; g < 2; ++g) { out->sumx[g] = part.sx[g]; out->sumxx[g] = part.sxx[g]; out->n_all[g] = part.n_all[g]; out->n_pos[g] = part.n_pos[g]; }
