@@ -1,0 +1,14 @@
+"""per-sweep wall clock over many repetitions in ONE process (is the 217 / 231 ms bimodality per process or per sweep?)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from cloops_amd import pipe
+from cloops_amd.synth import synth_genome
+fs = []
+for name, X, Y in synth_genome(200000000, cfg=3):
+    fs.append(pipe.CACHE.put_arrays("%s-%s" % (name, name), X, Y))
+ts = []
+for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
+    t0 = time.perf_counter()
+    pipe.runSweepFast(fs, [5000, 7500, 10000], [50, 40, 30, 20], cut=0)
+    ts.append(time.perf_counter() - t0)
+print(" ".join("%.3f" % t for t in ts))
