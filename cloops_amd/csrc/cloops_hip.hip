@@ -1468,7 +1468,7 @@ template <int NT, int HALO>
 __global__ void __launch_bounds__(NT)
 k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const int* __restrict__ sa,
               const int* __restrict__ strip_start, const int* __restrict__ cnt, int* __restrict__ chainflag,
-              int* __restrict__ chainlast, int* __restrict__ head, int* __restrict__ wavelast)
+              int* __restrict__ head, int* __restrict__ wavelast)
 {
     __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
     __shared__ int lx[NT + 2 * HALO];
@@ -1517,8 +1517,7 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
         tile_visit_own(t, sv, cnt, i, b, e, sat_add(me.x, -g.eps), sat_add(me.x, g.eps), 2,
                        [&](int, int cj) { if (cj >= g.minPts) { last = 0; return true; } return false; });
     }
-    chainflag[i] = f;
-    chainlast[i] = last;        // 1 = last core of its chain: its q is the chain's upper end
+    chainflag[i] = f | (last ? (int)0x80000000u : 0);   // sign bit: last core of its chain (its q is the chain's upper end)
     // wavelast[w] = the last chain-opening PET (+1) among the 64 PETs [64 w, 64 w + 64), 0 = none: what k_chain_parent needs to
     // find a core's chain head without a scan over all PETs (the lanes still here are the wave's PETs below M; lane 0 is one)
     const unsigned long long ob = __ballot(f != 0);
@@ -1533,7 +1532,7 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
 __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const int* __restrict__ cnt, int minPts,
                                const int* __restrict__ wavelast, int* __restrict__ parent, int* chainid /* in: chain flags */,
                                int* __restrict__ compkey, int* __restrict__ ncore, int* __restrict__ bsize,
-                               int* __restrict__ usize, int* __restrict__ state, const int* __restrict__ chainlast,
+                               int* __restrict__ usize, int* __restrict__ state,
                                const int* __restrict__ sv, int* __restrict__ chain_qend,
                                const int* __restrict__ sa, int* __restrict__ pmax32 /* or null */)
 {
@@ -1544,9 +1543,9 @@ __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const
     // flags i + 1 / 0 gives): inside the wave from a ballot, else the nearest earlier 64-PET group that has one
     // (k_chain_flags left wavelast[]; normally the group right in front -- 64 groups are looked at per round trip).
     const int lane = threadIdx.x & 63;
-    const int fl = i < M ? chainid[i] : 0;
+    const int fl = i < M ? chainid[i] : 0;               // i + 1 if the PET opens a chain, sign bit: last core of its chain
     if (i < M) core = cnt[i] >= minPts;
-    const unsigned long long open = __ballot(fl != 0);
+    const unsigned long long open = __ballot((fl & 0x7fffffff) != 0);
     const unsigned long long upto = open & ((2ull << lane) - 1ull);
     int head1 = upto ? (i - lane) + (64 - __clzll((long long)upto)) : 0;
     if (__any(core && !upto)) {
@@ -1561,10 +1560,10 @@ __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const
     }
     if (i < M) {
         const int h = core ? head1 - 1 : -1;
-        parent[i] = core ? h : i;
+        if (core) parent[i] = h;                                // (only cores are ever looked up in the forest)
         chainid[i] = h;
         if (h == i) { compkey[i] = INT_MAX; ncore[i] = 0; bsize[i] = 0; usize[i] = 0; state[i] = ST_LIVE; }
-        if (core && chainlast[i]) chain_qend[h] = sv[i];        // indexed by chain head
+        if (core && fl < 0) chain_qend[h] = sv[i];              // indexed by chain head
     }
     if (pmax32) {                                              // uniform: every lane of the wave takes part in the reduction
         int v = core ? sa[i] : INT_MIN;
@@ -3614,7 +3613,7 @@ static int ensure_workspace(cl_chrom* c, int S)
 #define ENS(buf, bytes) if ((rc = c->buf.ensure(bytes))) return rc
     ENS(keys_in, n * 8); ENS(keys_out, n * 8); ENS(vals_in, n * 4); ENS(vals_out, n * 4);
     ENS(sv, (n + 2 * SORT_PAD) * 4); ENS(sa, (n + 2 * SORT_PAD) * 4); ENS(strip, ((size_t)S + 2) * 4); ENS(cnt, n * 4);
-    ENS(parent, n * 4); ENS(root, n * 4); ENS(head, n * 4); ENS(headidx, n * 4); ENS(cellfirst, n * 4);
+    ENS(parent, n * 4); ENS(root, n * 4); ENS(head, n * 4); ENS(cellfirst, n * 4);
     ENS(compkey, n * 4); ENS(ncore, n * 4); ENS(bsize, n * 4); ENS(owner, n * 4); ENS(state, n * 4);
     ENS(flag, (n + 1) * 4); ENS(rankscan, (n + 1) * 4); ENS(hdr, 256);
     ENS(slot[c->cur].labels, n * 4); ENS(slot[c->cur].table, (n + 1) * sizeof(cl_box)); ENS(slot[c->cur].slab, n * 4);
@@ -4516,7 +4515,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         // own-strip chains; variant 2: the same tile kernel also finds every PET's cell head
         int* head = variant == CL_VARIANT_CDBSCAN2 ? c->head.as<int>() : nullptr;
         TILE_LAUNCH(k_chain_flags, g, ntiles, nm, sv, sa, strip, cnt, c->chainflag.as<int>(),
-                           c->headidx.as<int>(), head, c->chainhead.as<int>() /* wavelast: the buffer is free until the labels */);
+                           head, c->chainhead.as<int>() /* wavelast: the buffer is free until the labels */);
         if (head) {
             // cellfirst: segmented suffix-min of the input rows, keyed by the cell's head index, so that
             // cellfirst[head] = smallest row of the whole cell (replaces one atomicMin per PET)
@@ -4531,7 +4530,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         pmax32 = ((long long)n > 64LL * g.S) ? c->hi.as<int>() : nullptr;
         LAUNCH(k_chain_parent, nm, strip, g.S, cnt, g.minPts, c->chainhead.as<int>(), c->parent.as<int>(), c->chainflag.as<int>(),
                c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
-               c->headidx.as<int>(), sv, c->lo.as<int>(), sa, pmax32);   // chain ends live in `lo` until the release fix-up reuses it
+               sv, c->lo.as<int>(), sa, pmax32);   // chain ends live in `lo` until the release fix-up reuses it
     }
     // the union walk looks one strip back, i.e. about one strip population in front of the PET: a 256-PET halo keeps most of
     // those windows in LDS on dense data (chr1 of the 200 M genome, eps 5000-10000: -12..-16 %); short strips stay with 128
