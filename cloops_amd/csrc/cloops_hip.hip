@@ -2960,13 +2960,23 @@ __device__ __forceinline__ void k7_reduce_block(const K7Part* __restrict__ parts
 }
 
 // (a "last workgroup reduces" step inside k7_summary instead of this launch measured 4 % SLOWER on the whole sweep)
+// host_step / host_hdr (sweep steps): the step's whole output -- totals, statistics, the two histograms -- and the run's header go
+// to pinned host memory from HERE, the last kernel of the step (the host reads them after the stream's completion event): no
+// copy-stream hand-over and no copy packets per run
 __global__ void __launch_bounds__(256)
 k7_reduce_parts(const K7Part* __restrict__ parts, int nparts, K7Part* __restrict__ out, const int* __restrict__ bcount /* or null */, int nb,
-                long long* __restrict__ totals)
+                long long* __restrict__ totals, const unsigned long long* __restrict__ dev_step /* or null */, int step_words,
+                unsigned long long* __restrict__ host_step, const int* __restrict__ dev_hdr, int* __restrict__ host_hdr)
 {
     __shared__ double sd[4][256];
     __shared__ long long sn[4][256];
     k7_reduce_block(parts, nparts, out, bcount, nb, totals, sd, sn);
+    if (dev_step) {
+        __syncthreads();                                // totals and the reduced part are written (same workgroup: visible)
+        __threadfence();
+        for (int k = threadIdx.x; k < step_words; k += 256) host_step[k] = dev_step[k];
+        if (threadIdx.x < 8) host_hdr[threadIdx.x] = dev_hdr[threadIdx.x];
+    }
 }
 
 // one pass: counts, sum x and sum x^2 (x = log2|d| - K7_XSHIFT over d != 0) for both groups, and the log-binned
@@ -3378,6 +3388,8 @@ struct cl_chrom {
         DevBuf slab;                  // labels in sorted order (rotated variants)
         bool exported = true;         // the table rows were stored to h_boxes
         bool step_valid = false;      // the run carried the sweep-step tail (classification, candidate append, distance summary)
+        bool host_written = false;    // ... and its last kernel stored header + step output in pinned host memory itself
+        bool wait_done = false;       // cl_wait waits for ev_done (nothing went through the copy stream)
         long long fine_lo = -1;       // fine window of that tail's summary (-1 = none)
         int kmax = 0;                 // upper bound of the number of cluster ids of the run (host-known; the count itself is on the device)
         DevBuf d_step;                // device: {n_inter, n_self} + K7 partials + log histogram of that tail
@@ -4051,6 +4063,7 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
                            exported ? (int)std::min<size_t>(sl.h_boxes_cap, 0x7fffffff) : -1);
     sl.exported = exported;
     sl.step_valid = false;
+    sl.host_written = false;
     if (c->pending_step >= 0) {
         // sweep-step tail, still inside the run's stream: classify the table (pipe.py:83-97), append the inter-ligation
         // boxes to the chromosome's candidate buffer, reduce the distance statistics -- the host gets everything with
@@ -4087,20 +4100,28 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
         src.dh = k7_hist_for(c, c->pending_cut);
         hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, src, c->pending_cut, cls, parts, lh,
                            (unsigned)c->pending_fine_lo, c->pending_fine_lo >= 0 ? lh + K7_LOGBINS : (unsigned long long*)nullptr);
+        static_assert((16 + sizeof(K7Part)) % 8 == 0, "step output in 8-byte words");
         hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, (const K7Part*)parts, K7_BLOCKS, (K7Part*)(ds + 16),
-                           (const int*)bcount, nb, (long long*)ds);
+                           (const int*)bcount, nb, (long long*)ds, (const unsigned long long*)ds, (int)(out_bytes / 8),
+                           (unsigned long long*)sl.h_step, (const int*)dh, sl.h_hdr);
+        sl.host_written = labels_out == nullptr;        // nothing left for the copy stream
         sl.fine_lo = c->pending_fine_lo;
         sl.step_valid = true;
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sl.ev_done, c->stream));
     ev_record(c, 6);
-    HIP_TRY(hipStreamWaitEvent(c->copy_stream, sl.ev_done, 0));
-    HIP_TRY(hipMemcpyAsync(sl.h_hdr, dh, 32, hipMemcpyDeviceToHost, c->copy_stream));
-    if (sl.step_valid) HIP_TRY(hipMemcpyAsync(sl.h_step, sl.d_step.p, 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8, hipMemcpyDeviceToHost, c->copy_stream));
-    if (labels_out) HIP_TRY(hipMemcpyAsync(labels_out, sl.labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->copy_stream));
-    if (c->profiling) (void)hipEventRecord(sl.ev[7], c->copy_stream);
-    HIP_TRY(hipEventRecord(sl.ev_copied, c->copy_stream));
+    sl.wait_done = sl.host_written && !c->profiling;
+    if (sl.wait_done) {
+        // sweep step: k7_reduce_parts has stored header and step output in pinned host memory; completion = the run's own event
+    } else {
+        HIP_TRY(hipStreamWaitEvent(c->copy_stream, sl.ev_done, 0));
+        HIP_TRY(hipMemcpyAsync(sl.h_hdr, dh, 32, hipMemcpyDeviceToHost, c->copy_stream));
+        if (sl.step_valid) HIP_TRY(hipMemcpyAsync(sl.h_step, sl.d_step.p, 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8, hipMemcpyDeviceToHost, c->copy_stream));
+        if (labels_out) HIP_TRY(hipMemcpyAsync(labels_out, sl.labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        if (c->profiling) (void)hipEventRecord(sl.ev[7], c->copy_stream);
+        HIP_TRY(hipEventRecord(sl.ev_copied, c->copy_stream));
+    }
     sl.pending = true;
     sl.n_strips = n_strips;
     sl.labels_out = labels_out;
@@ -4126,7 +4147,7 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
         fprintf(stderr, "[wait] run %d slot %d: compute_done=%d copied=%d next_done=%d\n", c->deq, w, q1 == hipSuccess, q2 == hipSuccess,
                 (int)(hipEventQuery(c->slot[w ^ 1].ev_done) == hipSuccess));
     }
-    HIP_TRY(hipEventSynchronize(sl.ev_copied));
+    HIP_TRY(hipEventSynchronize(sl.wait_done ? sl.ev_done : sl.ev_copied));
     if (dbg_wait) {
         clock_gettime(CLOCK_MONOTONIC, &ts1);
         fprintf(stderr, "[wait]   ev_copied after %.0f us; next_done=%d\n", (ts1.tv_sec - ts0.tv_sec) * 1e6 + (ts1.tv_nsec - ts0.tv_nsec) / 1e3,
@@ -4620,7 +4641,8 @@ extern "C" int cl_dist_summary(cl_chrom* c, int32_t cut, cl_dsummary* out)
     hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, k7_source(c, cut), cut, c->k7_cls.as<signed char>(), c->k7_parts.as<K7Part>(), dh,
                        0u, (unsigned long long*)nullptr);
     hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, (const K7Part*)c->k7_parts.as<K7Part>(), K7_BLOCKS, dpart,
-                       (const int*)nullptr, 0, (long long*)nullptr);
+                       (const int*)nullptr, 0, (long long*)nullptr, (const unsigned long long*)nullptr, 0, (unsigned long long*)nullptr,
+                       (const int*)nullptr, (int*)nullptr);
     K7Part part;
     HIP_TRY(hipMemcpyAsync(&part, dpart, sizeof(K7Part), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(out->loghist, dh, K7_LOGBINS * 8, hipMemcpyDeviceToHost, c->stream));
