@@ -434,6 +434,10 @@ def _select_kth(chroms, cut, loghist, ranks, allsum=None, pool=None, fine=None):
 
 
 SWEEP_THREADS = 8
+#: enqueue the chromosomes of a sweep step from the pool's threads instead of one after the other from the calling thread.
+#: Measured on the 200 M-PET mode-3 sweep: 0.212 s against 0.208 s -- the serial order (largest chromosome first) is worth more
+#: than the 2 ms of host time the 23 enqueues take, so it stays off.
+PARALLEL_ENQUEUE = False
 
 
 def _lib_logbins():
@@ -489,25 +493,27 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                 # chromosomes are independent inside a step: enqueue them all (each handle has its own
                 # streams), then collect -- the kernels of different chromosomes overlap on the GPU
                 # and the host-side collection runs on the pool
-                enqueued = []
-                try:
-                    for f, r in live:
-                        r.lock.acquire()
-                        try:
-                            r.chrom.step_async(variant, ep, m, step_cut, this_step, fine_lo)
-                        except Exception:
-                            r.lock.release()
-                            raise
-                        enqueued.append(r)
-                except Exception:
-                    # a failed enqueue must not leave the earlier chromosomes locked with a run in flight
-                    for r in enqueued:
-                        try:
-                            r.chrom.wait()
-                        except Exception:
-                            pass
+                def enqueue(fr):
+                    f, r = fr
+                    r.lock.acquire()
+                    try:
+                        r.chrom.step_async(variant, ep, m, step_cut, this_step, fine_lo)
+                    except Exception as e:
                         r.lock.release()
-                    raise
+                        return e
+                    return None
+
+                errs = _pmap(pool if PARALLEL_ENQUEUE else None, enqueue, live)
+                if any(e is not None for e in errs):
+                    # a failed enqueue must not leave the other chromosomes locked with a run in flight
+                    for (f, r), e in zip(live, errs):
+                        if e is None:
+                            try:
+                                r.chrom.wait()
+                            except Exception:
+                                pass
+                            r.lock.release()
+                    raise [e for e in errs if e is not None][0]
 
                 def collect(fr):
                     f, r = fr

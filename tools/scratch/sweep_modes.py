@@ -6,6 +6,8 @@ from cloops_amd.synth import synth_genome
 fs = []
 for name, X, Y in synth_genome(200000000, cfg=3):
     fs.append(pipe.CACHE.put_arrays("%s-%s" % (name, name), X, Y))
+if os.environ.get('SERIAL_ENQUEUE'):
+    pipe.PARALLEL_ENQUEUE = False
 ts = []
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     t0 = time.perf_counter()
