@@ -475,6 +475,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
     cuts = [cut]
     steps = []
     live = [(f, r) for f, r in zip(fs, res_all) if len(r.d)]
+    by_size = sorted(live, key=lambda fr: -len(fr[1].d))   # enqueue order: largest first (results are collected in file order)
     appended = {}                                        # f -> inter-ligation boxes appended on the device so far
     pool = ThreadPoolExecutor(max_workers=SWEEP_THREADS) if len(live) > 1 else None
     try:
@@ -503,10 +504,10 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                         return e
                     return None
 
-                errs = _pmap(pool if PARALLEL_ENQUEUE else None, enqueue, live)
+                errs = _pmap(pool if PARALLEL_ENQUEUE else None, enqueue, by_size)
                 if any(e is not None for e in errs):
                     # a failed enqueue must not leave the other chromosomes locked with a run in flight
-                    for (f, r), e in zip(live, errs):
+                    for (f, r), e in zip(by_size, errs):
                         if e is None:
                             try:
                                 r.chrom.wait()
