@@ -155,9 +155,9 @@ def main(argv=None):
                                                     probe=probe if (log_k2 and rank == 0) else None)
         if use_dist:
             # the path's final exchange (cLoops/pipe.py:119-127 merges its workers' results): all candidate tables
+            # (to rank 0, where the reference's parent process merges them; the other ranks do not copy everybody's rows back)
             rows = [v["boxes"] for v in dataI.values() if len(v["boxes"])]
-            tab = np.concatenate(rows).astype(np.int32) if rows else np.zeros((0, 4), np.int32)
-            ncand = sum(len(t) for t in gather_tables(tab, device=tdev))
+            ncand = sum(len(t) for t in gather_tables(rows if rows else np.zeros((0, 4), np.int32), device=tdev, dst=0, copy=False))
         else:
             ncand = sum(len(v["boxes"]) for v in dataI.values())
         return cut, steps, ncand

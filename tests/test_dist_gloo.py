@@ -35,6 +35,14 @@ def _worker(rank, world, port, q):
         rr = np.random.default_rng(100 + r)
         kk = 0 if r == 1 else 7
         ok = ok and np.array_equal(got[r], rr.integers(0, 1000, (kk, 5)).astype(np.int32))
+    # gather to one rank (what bench.py does: the reference merges in the parent): the others receive nothing
+    got0 = gather_tables(tab, dst=0)
+    ok = ok and len(got0) == world
+    for r in range(world):
+        rr = np.random.default_rng(100 + r)
+        kk = 0 if r == 1 else 7
+        want = rr.integers(0, 1000, (kk, 5)).astype(np.int32) if rank == 0 else np.zeros((0, 5), np.int32)
+        ok = ok and np.array_equal(got0[r], want)
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
