@@ -134,10 +134,17 @@ def main(argv=None):
         X, Y = synth_chrom(n, length, 1000 * CFG + ci)
         fs.append(pipe.CACHE.put_arrays("%s-%s" % (name, name), X, Y, device=device))
     t_gen = time.perf_counter() - t_gen
-    # the per-run exchange of the chained cut is a few KB of host-side statistics: it goes over a gloo group on the host
-    # (no device round trip); RCCL carries the one real exchange of the path, the final gather of the candidate tables
-    stats_group = dist.new_group(backend="gloo") if (use_dist and on_gpu) else None
-    allsum = make_allsum(device=None, group=stats_group) if use_dist else None
+    # the per-run exchange of the chained cut is ONE vector of ~48 KB of statistics per step: over RCCL through a pinned
+    # staging buffer (a ring over xGMI, tens of microseconds; CLOOPS_BENCH_STATS=gloo keeps it on the host over a gloo group:
+    # TCP loopback, hundreds of microseconds per ring at 8 ranks); RCCL also carries the final gather of the candidate tables
+    stats_gloo = os.environ.get("CLOOPS_BENCH_STATS", "rccl") == "gloo"
+    stats_group = dist.new_group(backend="gloo") if (use_dist and on_gpu and stats_gloo) else None
+    if not use_dist:
+        allsum = None
+    elif on_gpu and not stats_gloo:
+        allsum = make_allsum(device=tdev)
+    else:
+        allsum = make_allsum(device=None, group=stats_group)
     eps_list, minpts_list = MODE3
 
     # K2 is timed inside a sweep on the largest local chromosome (chr1 on rank 0): HIP events on the library's stream -- in the

@@ -107,16 +107,32 @@ def gather_tables(table, device=None, group=None, dst=None, copy=True):
 
 def make_allsum(device=None, group=None):
     """-> allsum(np.ndarray) = element-wise sum over all ranks (int64 or float64, any small shape):
-    the only per-step exchange of the chained sweep (cloops_amd.pipe.runSweepFast)."""
+    the only per-step exchange of the chained sweep (cloops_amd.pipe.runSweepFast).
+    device=None: host tensors (a gloo group); a GPU device: the array goes through a cached pinned buffer to the device, is
+    all-reduced over RCCL on torch's current stream and comes back the same way (one stream synchronisation)."""
     import torch
     import torch.distributed as dist
-    dev = torch.device("cpu") if device is None else device
+    on_dev = device is not None and torch.device(device).type != "cpu"
+    dev = torch.device("cpu") if device is None else torch.device(device)
+    cache = {}
 
     def allsum(a):
         a = np.ascontiguousarray(a)
-        t = torch.from_numpy(a.copy()).to(dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        return t.cpu().numpy()
+        if not on_dev:
+            t = torch.from_numpy(a.copy())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return t.numpy()
+        key = (a.dtype.str, a.size)
+        if key not in cache:
+            tdt = torch.from_numpy(np.zeros(1, a.dtype)).dtype
+            cache[key] = (torch.empty(a.size, dtype=tdt, pin_memory=True), torch.empty(a.size, dtype=tdt, device=dev))
+        pin, d = cache[key]
+        pin.numpy()[:] = a.ravel()
+        d.copy_(pin, non_blocking=True)
+        dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
+        pin.copy_(d, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        return pin.numpy().reshape(a.shape).copy()
     return allsum
 
 

@@ -554,8 +554,13 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                     xshift = s1["xshift"]
                 # the genome-wide statistics: everything is additive over chromosomes and ranks -- two small exchanges per
                 # step (one integer vector, one float vector), then the histograms of the median's refinement
-                gi = gsum(np.concatenate([np.asarray([nI_tot, nS, n_in, len(used)] + tot["n_all"] + tot["n_pos"], dtype=np.int64), loghist, fine]))
-                gf = gsum(np.asarray(tot["sumx"] + tot["sumxx"] + [xshift if used else 0.0, 1.0 if used else 0.0], dtype=np.float64))
+                gi = np.concatenate([np.asarray([nI_tot, nS, n_in, len(used)] + tot["n_all"] + tot["n_pos"], dtype=np.int64), loghist, fine])
+                gf = np.asarray(tot["sumx"] + tot["sumxx"] + [xshift if used else 0.0, 1.0 if used else 0.0], dtype=np.float64)
+                if allsum is not None:
+                    # ONE exchange per step: the counts ride as float64 next to the sums (every count and every sum of counts
+                    # stays far below 2^53, so they come back exact)
+                    both = gsum(np.concatenate([gi.astype(np.float64), gf]))
+                    gi, gf = np.rint(both[:len(gi)]).astype(np.int64), both[len(gi):]
                 g, loghist, fine = gi[:4], gi[8:8 + len(loghist)], gi[8 + len(loghist):]
                 st = {"eps": ep, "minPts": m, "cut_in": int(cut), "n_inter": int(g[0]), "n_self": int(g[1]), "n_in": int(g[2])}
                 steps.append(st)
