@@ -47,10 +47,11 @@ def gather_tables(table, device=None, group=None, dst=None, copy=True):
     # pinned staging buffer (one host copy instead of np.concatenate + staging)
     parts = None
     if isinstance(table, (list, tuple)):
-        parts = [np.ascontiguousarray(t, dtype=np.int32) for t in table if len(t)]
-        if any(t.ndim != 2 for t in parts) or len({t.shape[1] for t in parts}) > 1:
-            raise ValueError("tables must be [K, C] with one C")
-        ncols = parts[0].shape[1] if parts else 4
+        alltabs = [np.asarray(t) for t in table]
+        if not alltabs or any(t.ndim != 2 for t in alltabs) or len({t.shape[1] for t in alltabs}) > 1:
+            raise ValueError("tables must be a non-empty list of [K, C] arrays with one C")
+        ncols = alltabs[0].shape[1]
+        parts = [np.ascontiguousarray(t, dtype=np.int32) for t in alltabs if len(t)]
         if device is None or torch.device(device).type == "cpu":
             table = np.concatenate(parts) if parts else np.zeros((0, ncols), np.int32)
             parts = None

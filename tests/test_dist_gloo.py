@@ -43,6 +43,10 @@ def _worker(rank, world, port, q):
         kk = 0 if r == 1 else 7
         want = rr.integers(0, 1000, (kk, 5)).astype(np.int32) if rank == 0 else np.zeros((0, 5), np.int32)
         ok = ok and np.array_equal(got0[r], want)
+    # a list of tables counts as their concatenation (what a rank's per-chromosome tables are)
+    got2 = gather_tables([tab[:3], tab[3:3], tab[3:]])
+    for r in range(world):
+        ok = ok and np.array_equal(got2[r], got[r])
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
