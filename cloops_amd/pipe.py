@@ -537,6 +537,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                 loghist = np.zeros(_lib_logbins(), dtype=np.int64)
                 fine = np.zeros(2048, dtype=np.int64)
                 xshift = 0.0
+                hists, fines = [], []
                 for f, r, nI, ndS, nin, s1 in _pmap(pool, collect, live):
                     nS += ndS
                     n_in += nin
@@ -548,10 +549,15 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                     for gg in (0, 1):
                         for kk in ("n_all", "n_pos", "sumx", "sumxx"):
                             tot[kk][gg] += s1[kk][gg]
-                    loghist += s1["loghist"]
+                    hists.append(s1["loghist"])
                     if s1.get("fine") is not None:
-                        fine += s1["fine"]
+                        fines.append(s1["fine"])
                     xshift = s1["xshift"]
+                # (integer histograms: one reduction over the stack instead of an add per chromosome)
+                if hists:
+                    loghist += np.add.reduce(hists)
+                if fines:
+                    fine += np.add.reduce(fines)
                 # the genome-wide statistics: everything is additive over chromosomes and ranks -- two small exchanges per
                 # step (one integer vector, one float vector), then the histograms of the median's refinement
                 gi = np.concatenate([np.asarray([nI_tot, nS, n_in, len(used)] + tot["n_all"] + tot["n_pos"], dtype=np.int64), loghist, fine])
