@@ -1750,6 +1750,7 @@ __device__ __forceinline__ int agg_slot(int* keys, int key)
 //              (cDBSCAN.py:134-137)
 //   variant 2: key = smallest cellfirst over the cells holding its core points
 //              (cDBSCAN2.py:117-140)
+#define FLAT_PER 2          // PETs per thread
 __global__ void __launch_bounds__(BIGTPB)
 k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ cnt,
           int* parent, const u32* __restrict__ srow,
@@ -1763,49 +1764,83 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
     if (threadIdx.x == 0) l_nroot = 0;
     __syncthreads();
     const int M = strip_start[g.S];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int r = -1, key = INT_MAX;
-    if (i < M) {
-        if (cnt[i] >= g.minPts) {
-            r = uf_find(parent, i);
-            key = (g.variant == CL_VARIANT_CDBSCAN2) ? cellfirst[head[i]] : (int)srow[i];
+    // FLAT_PER PETs per thread: the kernel waits on dependent gathers (forest walk, cell -> first row) 88 % of its time at full
+    // occupancy, so the walks of a thread's PETs advance together -- two independent chains per thread in flight
+    int ii[FLAT_PER], r[FLAT_PER], key[FLAT_PER], x[FLAT_PER], hd[FLAT_PER];
+    bool core[FLAT_PER];
+#pragma unroll
+    for (int e = 0; e < FLAT_PER; ++e) {
+        ii[e] = (blockIdx.x * FLAT_PER + e) * BIGTPB + (int)threadIdx.x;
+        core[e] = ii[e] < M && cnt[ii[e]] >= g.minPts;
+    }
+#pragma unroll
+    for (int e = 0; e < FLAT_PER; ++e) {
+        x[e] = core[e] ? parent[ii[e]] : -1;            // a core's parent is its chain head to start with
+        hd[e] = (core[e] && g.variant == CL_VARIANT_CDBSCAN2) ? head[ii[e]] : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < FLAT_PER; ++e)
+        key[e] = !core[e] ? INT_MAX : ((g.variant == CL_VARIANT_CDBSCAN2) ? cellfirst[hd[e]] : (int)srow[ii[e]]);
+    {
+        // the union kernel has completed (kernel boundary = coherent): plain loads, all chains of the thread step together
+        bool todo = false;
+#pragma unroll
+        for (int e = 0; e < FLAT_PER; ++e) todo |= core[e];
+        while (todo) {
+            int p[FLAT_PER];
+#pragma unroll
+            for (int e = 0; e < FLAT_PER; ++e) p[e] = core[e] ? parent[x[e]] : -1;
+            todo = false;
+#pragma unroll
+            for (int e = 0; e < FLAT_PER; ++e) { todo |= core[e] && p[e] != x[e]; x[e] = core[e] ? p[e] : x[e]; }
         }
-        root[i] = r;
+    }
+#pragma unroll
+    for (int e = 0; e < FLAT_PER; ++e) {
+        r[e] = core[e] ? x[e] : -1;
+        if (ii[e] < M) root[ii[e]] = r[e];
     }
     const int lane = threadIdx.x & 63;
     // the components' roots as a compact list (the per-component kernels that follow walk K entries instead of
     // testing every PET): ranks inside the workgroup through LDS, one global atomic per workgroup
-    int myslot = -1;
-    if (rootlist) {
-        const bool isroot = r == i && r >= 0;
-        const unsigned long long rb = __ballot(isroot);
-        if (rb) {
-            int wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&l_nroot, __popcll(rb));
-            wbase = __builtin_amdgcn_readfirstlane(wbase);
-            if (isroot) myslot = wbase + __builtin_amdgcn_mbcnt_hi((unsigned)(rb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)rb, 0u));
+    int myslot[FLAT_PER];
+#pragma unroll
+    for (int e = 0; e < FLAT_PER; ++e) {
+        myslot[e] = -1;
+        if (rootlist) {
+            const bool isroot = r[e] == ii[e] && r[e] >= 0;
+            const unsigned long long rb = __ballot(isroot);
+            if (rb) {
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&l_nroot, __popcll(rb));
+                wbase = __builtin_amdgcn_readfirstlane(wbase);
+                if (isroot) myslot[e] = wbase + __builtin_amdgcn_mbcnt_hi((unsigned)(rb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)rb, 0u));
+            }
         }
     }
     // a wave of one component (the inside of a large cluster): one reduction, one insertion by its first lane;
     // anything else: every lane goes to the workgroup's LDS table itself -- lanes that share a root meet on one LDS
     // address, which the LDS serialises far cheaper than a loop over the wave's distinct roots (or global atomics) would
-    const unsigned long long pending = __ballot(r >= 0);
-    if (pending) {
-        const int leader = __ffsll((long long)pending) - 1;
-        const int R = __builtin_amdgcn_readlane(r, leader);
-        const unsigned long long m = __ballot(r == R);
-        if (m == pending && __popcll(m) >= 16) {
-            int mk = r == R ? key : INT_MAX;
-            mk = dpp_reduce_wave(mk, OpMin());
-            if (lane == leader) {
-                const int sl = agg_slot(hkey, R);
-                if (sl >= 0) { atomicMin(&hmin[sl], mk); atomicAdd(&hcnt[sl], __popcll(m)); }
-                else { atomicMin(&compkey[R], mk); atomicAdd(&ncore[R], __popcll(m)); }
+#pragma unroll
+    for (int e = 0; e < FLAT_PER; ++e) {
+        const unsigned long long pending = __ballot(r[e] >= 0);
+        if (pending) {
+            const int leader = __ffsll((long long)pending) - 1;
+            const int R = __builtin_amdgcn_readlane(r[e], leader);
+            const unsigned long long m = __ballot(r[e] == R);
+            if (m == pending && __popcll(m) >= 16) {
+                int mk = r[e] == R ? key[e] : INT_MAX;
+                mk = dpp_reduce_wave(mk, OpMin());
+                if (lane == leader) {
+                    const int sl = agg_slot(hkey, R);
+                    if (sl >= 0) { atomicMin(&hmin[sl], mk); atomicAdd(&hcnt[sl], __popcll(m)); }
+                    else { atomicMin(&compkey[R], mk); atomicAdd(&ncore[R], __popcll(m)); }
+                }
+            } else if (r[e] >= 0) {
+                const int sl = agg_slot(hkey, r[e]);
+                if (sl >= 0) { atomicMin(&hmin[sl], key[e]); atomicAdd(&hcnt[sl], 1); }
+                else { atomicMin(&compkey[r[e]], key[e]); atomicAdd(&ncore[r[e]], 1); }
             }
-        } else if (r >= 0) {
-            const int sl = agg_slot(hkey, r);
-            if (sl >= 0) { atomicMin(&hmin[sl], key); atomicAdd(&hcnt[sl], 1); }
-            else { atomicMin(&compkey[r], key); atomicAdd(&ncore[r], 1); }
         }
     }
     __syncthreads();
@@ -1816,7 +1851,8 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
     if (rootlist) {
         if (threadIdx.x == 0) l_rootbase = l_nroot ? atomicAdd(&counters[CTR_NROOT], l_nroot) : 0;
         __syncthreads();
-        if (myslot >= 0) rootlist[l_rootbase + myslot] = i;
+#pragma unroll
+        for (int e = 0; e < FLAT_PER; ++e) if (myslot[e] >= 0) rootlist[l_rootbase + myslot[e]] = ii[e];
     }
 }
 
@@ -2310,24 +2346,34 @@ k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __r
     __shared__ TableLds h;
     table_lds_init(h);
     const int M = strip_start[g.S];
+    // the owner -> label round trips of a thread's FINAL_CHUNKS PETs are all in flight before the first of them is used
+    // (the kernel is bound by those dependent gathers, not by bytes)
+    int idx[FINAL_CHUNKS], own[FINAL_CHUNKS], lab[FINAL_CHUNKS], x[FINAL_CHUNKS], y[FINAL_CHUNKS];
+#pragma unroll
     for (int ch = 0; ch < FINAL_CHUNKS; ++ch) {
-        const int i = (blockIdx.x * FINAL_CHUNKS + ch) * BIGTPB + threadIdx.x;
-        int lab = -1, x = 0, y = 0;
+        idx[ch] = (blockIdx.x * FINAL_CHUNKS + ch) * BIGTPB + threadIdx.x;
+        own[ch] = idx[ch] < M ? owner_root(owner[idx[ch]]) : -1;
+    }
+#pragma unroll
+    for (int ch = 0; ch < FINAL_CHUNKS; ++ch) lab[ch] = own[ch] >= 0 ? rlabel[own[ch]] : -1;
+#pragma unroll
+    for (int ch = 0; ch < FINAL_CHUNKS; ++ch) {
+        const int i = idx[ch];
+        x[ch] = 0; y[ch] = 0;
         if (i < M) {
-            const int o = owner_root(owner[i]);
-            if (o >= 0) lab = rlabel[o];
-            slab[i] = lab;
-            if (labels) labels[srow[i]] = lab;
-            if (lab >= 0) {                              // noise has no box: its coordinates are never loaded
+            slab[i] = lab[ch];
+            if (labels) labels[srow[i]] = lab[ch];
+            if (lab[ch] >= 0) {                          // noise has no box: its coordinates are never loaded
                 // X = (v - a) / 2, Y = (v + a) / 2 exactly (v and a have equal parity)
                 const int spv = sa[i];
                 int pp = ((spv >> g.rbits) + g.s0) * g.eps + (spv & (g.peps - 1)) + g.A0, qq = sv[i] + g.V0;
                 int a = g.swap ? qq : pp, v = g.swap ? pp : qq;
-                x = (v - a) / 2; y = (v + a) / 2;
+                x[ch] = (v - a) / 2; y[ch] = (v + a) / 2;
             }
         }
-        table_accumulate(t, h, lab, x, y);
     }
+#pragma unroll
+    for (int ch = 0; ch < FINAL_CHUNKS; ++ch) table_accumulate(t, h, lab[ch], x[ch], y[ch]);
     table_flush(t, h);
 }
 
@@ -4358,7 +4404,7 @@ static int run_weighted(cl_chrom* c, int eps, int minPts, int wx, int wy, int32_
     LAUNCH(k64_count, n, n, g, sk, p64, strip, cnt);
     ev_record(c, 3);
     LAUNCH(k64_union, n, n, g, sk, p64, strip, cnt, c->parent.as<int>());
-    hipLaunchKernelGGL(k_flatten, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, gi, strip, cnt, c->parent.as<int>(), srow,
+    hipLaunchKernelGGL(k_flatten, dim3(nblocks(n, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, gi, strip, cnt, c->parent.as<int>(), srow,
                        c->head.as<int>(), c->cellfirst.as<int>(), c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), (int*)nullptr, counters);
     ev_record(c, 4);
     LAUNCH(k64_border, n, n, g, sk, p64, strip, c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), srow,
@@ -4558,7 +4604,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     const int union_halo = (long long)n > 40LL * g.S ? 256 : 128;
     TILE_LAUNCH_H((wide == 2 || wide == 4) ? 512 : union_halo, k_union_cores, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
                        pmax32, c->parent.as<int>());
-    hipLaunchKernelGGL(k_flatten, dim3(nblocks(nm, BIGTPB)), dim3(BIGTPB), 0, c->stream, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
+    hipLaunchKernelGGL(k_flatten, dim3(nblocks(nm, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
            c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->chainflag.as<int>() /* root list: the chain ids are dead */, counters);
     int* rootlist = c->chainflag.as<int>();
     ev_record(c, 4);
