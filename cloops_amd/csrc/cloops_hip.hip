@@ -1750,7 +1750,7 @@ __device__ __forceinline__ int agg_slot(int* keys, int key)
 //              (cDBSCAN.py:134-137)
 //   variant 2: key = smallest cellfirst over the cells holding its core points
 //              (cDBSCAN2.py:117-140)
-#define FLAT_PER 2          // PETs per thread
+#define FLAT_PER 4          // PETs per thread
 __global__ void __launch_bounds__(BIGTPB)
 k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ cnt,
           int* parent, const u32* __restrict__ srow,
