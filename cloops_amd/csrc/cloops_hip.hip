@@ -3638,18 +3638,34 @@ k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const i
 {
     const int M = strip_start[S];
     const int base = blockIdx.x * CMP_BLOCK;
+    // stage by stage over the thread's CMP_PER PETs, so that the loads of a stage are all in flight together (q -> sp / row ->
+    // the two per-strip table entries are dependent round trips)
+    int q[CMP_PER], sp[CMP_PER], d0[CMP_PER], s0[CMP_PER]; u32 row[CMP_PER]; bool keep[CMP_PER];
 #pragma unroll
     for (int k = 0; k < CMP_PER; ++k) {
         const int i = base + k * CMP_TPB + (int)threadIdx.x;
-        if (i < n) {
-            const int q = bq[i];
-            if (q >= thr) {
-                const int sp = bsp[i];
-                const int st = sp >> rbits;
-                const int dst = strip_start[st] + (i - src0[st]);
-                sv[dst] = q; sa[dst] = sp; srow[dst] = brow[i];
-                if ((dst & 255) == 0) tile_s0[dst >> 8] = st;
-            }
+        q[k] = i < n ? bq[i] : INT_MIN;
+        keep[k] = i < n && q[k] >= thr;
+    }
+#pragma unroll
+    for (int k = 0; k < CMP_PER; ++k) {
+        const int i = base + k * CMP_TPB + (int)threadIdx.x;
+        sp[k] = keep[k] ? bsp[i] : 0;
+        row[k] = keep[k] ? brow[i] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < CMP_PER; ++k) {
+        const int st = sp[k] >> rbits;
+        d0[k] = keep[k] ? strip_start[st] : 0;
+        s0[k] = keep[k] ? src0[st] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < CMP_PER; ++k) {
+        if (keep[k]) {
+            const int i = base + k * CMP_TPB + (int)threadIdx.x;
+            const int dst = d0[k] + (i - s0[k]);
+            sv[dst] = q[k]; sa[dst] = sp[k]; srow[dst] = row[k];
+            if ((dst & 255) == 0) tile_s0[dst >> 8] = sp[k] >> rbits;
         }
     }
     // what k_after_compact did besides the strip table: tiles behind M, sentinels, M itself
