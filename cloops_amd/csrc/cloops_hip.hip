@@ -1529,6 +1529,7 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
 // heads only, instead of memset-ing five N-sized arrays per run.
 // pmax32 (optional): the 32-PET block summaries of the union scan (max strip coordinate over the block's CORE PETs, see
 // k_union_cores) come out of the same pass -- every thread already knows whether its PET is a core
+#define CP_PER 4
 __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const int* __restrict__ cnt, int minPts,
                                const int* __restrict__ wavelast, int* __restrict__ parent, int* chainid /* in: chain flags */,
                                int* __restrict__ compkey, int* __restrict__ ncore, int* __restrict__ bsize,
@@ -1537,38 +1538,50 @@ __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const
                                const int* __restrict__ sa, int* __restrict__ pmax32 /* or null */)
 {
     const int M = strip_start[S];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool core = false;
     // A core's chain head = the latest chain-opening PET at or before it in sorted order (what an inclusive max-scan of the
     // flags i + 1 / 0 gives): inside the wave from a ballot, else the nearest earlier 64-PET group that has one
     // (k_chain_flags left wavelast[]; normally the group right in front -- 64 groups are looked at per round trip).
+    // CP_PER PETs per thread (a wave handles CP_PER runs of 64 consecutive PETs): all their loads are in flight together.
     const int lane = threadIdx.x & 63;
-    const int fl = i < M ? chainid[i] : 0;               // i + 1 if the PET opens a chain, sign bit: last core of its chain
-    if (i < M) core = cnt[i] >= minPts;
-    const unsigned long long open = __ballot((fl & 0x7fffffff) != 0);
-    const unsigned long long upto = open & ((2ull << lane) - 1ull);
-    int head1 = upto ? (i - lane) + (64 - __clzll((long long)upto)) : 0;
-    if (__any(core && !upto)) {
-        int carry = 0;
-        for (int base = ((i - lane) >> 6) - 1; base >= 0; base -= 64) {
-            const int idx = base - lane;
-            const int v = idx >= 0 ? wavelast[idx] : 0;
-            const unsigned long long bal = __ballot(v != 0);
-            if (bal) { carry = __builtin_amdgcn_readlane(v, __ffsll((long long)bal) - 1); break; }
+    int ii[CP_PER], fl[CP_PER], cn[CP_PER], spv[CP_PER], qv[CP_PER];
+#pragma unroll
+    for (int e = 0; e < CP_PER; ++e) {
+        ii[e] = (blockIdx.x * CP_PER + e) * (int)blockDim.x + (int)threadIdx.x;
+        const bool in = ii[e] < M;
+        fl[e] = in ? chainid[ii[e]] : 0;                 // i + 1 if the PET opens a chain, sign bit: last core of its chain
+        cn[e] = in ? cnt[ii[e]] : INT_MIN;
+        spv[e] = (in && pmax32) ? sa[ii[e]] : INT_MIN;
+        qv[e] = (in && fl[e] < 0) ? sv[ii[e]] : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < CP_PER; ++e) {
+        const int i = ii[e];
+        const bool core = cn[e] >= minPts;
+        const unsigned long long open = __ballot((fl[e] & 0x7fffffff) != 0);
+        const unsigned long long upto = open & ((2ull << lane) - 1ull);
+        int head1 = upto ? (i - lane) + (64 - __clzll((long long)upto)) : 0;
+        if (__any(core && !upto)) {
+            int carry = 0;
+            for (int base = ((i - lane) >> 6) - 1; base >= 0; base -= 64) {
+                const int idx = base - lane;
+                const int v = idx >= 0 ? wavelast[idx] : 0;
+                const unsigned long long bal = __ballot(v != 0);
+                if (bal) { carry = __builtin_amdgcn_readlane(v, __ffsll((long long)bal) - 1); break; }
+            }
+            if (!upto) head1 = carry;
         }
-        if (!upto) head1 = carry;
-    }
-    if (i < M) {
-        const int h = core ? head1 - 1 : -1;
-        if (core) parent[i] = h;                                // (only cores are ever looked up in the forest)
-        chainid[i] = h;
-        if (h == i) { compkey[i] = INT_MAX; ncore[i] = 0; bsize[i] = 0; usize[i] = 0; state[i] = ST_LIVE; }
-        if (core && fl < 0) chain_qend[h] = sv[i];              // indexed by chain head
-    }
-    if (pmax32) {                                              // uniform: every lane of the wave takes part in the reduction
-        int v = core ? sa[i] : INT_MIN;
-        v = dpp_reduce_halves(v, OpMax());                     // lanes 31 and 63 hold the maxima of their 32-PET blocks
-        if ((threadIdx.x & 31) == 31 && (i - 31) < M) pmax32[i >> 5] = v;
+        if (i < M) {
+            const int h = core ? head1 - 1 : -1;
+            if (core) parent[i] = h;                            // (only cores are ever looked up in the forest)
+            chainid[i] = h;
+            if (h == i) { compkey[i] = INT_MAX; ncore[i] = 0; bsize[i] = 0; usize[i] = 0; state[i] = ST_LIVE; }
+            if (core && fl[e] < 0) chain_qend[h] = qv[e];       // indexed by chain head
+        }
+        if (pmax32) {                                          // uniform: every lane of the wave takes part in the reduction
+            int v = core ? spv[e] : INT_MIN;
+            v = dpp_reduce_halves(v, OpMax());                 // lanes 31 and 63 hold the maxima of their 32-PET blocks
+            if ((threadIdx.x & 31) == 31 && (i - 31) < M) pmax32[i >> 5] = v;
+        }
     }
 }
 
@@ -4611,7 +4624,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         }
         // long strips (dense data at large eps): 32-PET block summaries for the union scan (`hi` is free until K4)
         pmax32 = ((long long)n > 64LL * g.S) ? c->hi.as<int>() : nullptr;
-        LAUNCH(k_chain_parent, nm, strip, g.S, cnt, g.minPts, c->chainhead.as<int>(), c->parent.as<int>(), c->chainflag.as<int>(),
+        LAUNCH(k_chain_parent, (nm + CP_PER - 1) / CP_PER, strip, g.S, cnt, g.minPts, c->chainhead.as<int>(), c->parent.as<int>(), c->chainflag.as<int>(),
                c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                sv, c->lo.as<int>(), sa, pmax32);   // chain ends live in `lo` until the release fix-up reuses it
     }
