@@ -1885,8 +1885,11 @@ __global__ void __launch_bounds__(NT)
 k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
          const int* __restrict__ strip_start, const int* __restrict__ root, const int* __restrict__ compkey,
          const int* __restrict__ ncore, const u32* __restrict__ srow, int* __restrict__ owner, int* __restrict__ bsize,
-         int* __restrict__ usize, const int* __restrict__ cnt)
+         int* __restrict__ usize, const int* __restrict__ cnt, int* __restrict__ tileflag)
 {
+    // tileflag[tile] = 1 if the tile holds a CONTESTED border point (one adjacent to more than one component): only such
+    // tiles can have anything for k_emit_records, which then leaves after one load instead of testing 256 PETs
+    if (threadIdx.x == 0) { const int tl = tile_of_block(blockIdx.x); if (tl < ntiles) tileflag[tl] = 0; }
     __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
     __shared__ int lx[NT + 2 * HALO];
     __shared__ short l_list[NT];
@@ -1975,6 +1978,7 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
     }
     const int o = (v1 && tbest >= 0) ? tbest : best;
     owner[i] = o < 0 ? -1 : (contested ? (o | OWNER_CONTESTED) : o);
+    if (o >= 0 && contested) tileflag[t.t0 / NT] = 1;           // (behind the staging barrier: ordered after the reset above)
     // counts per owning component, reduced over the lanes of the wave that share the owner.  Only
     // components that are not already >= minPts on their cores need them (release rule of variant 2,
     // drop rule of variant 1) -- a giant component never sees one of these atomics.
@@ -2024,13 +2028,14 @@ __global__ void __launch_bounds__(NT)
 k_emit_records(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
                const int* __restrict__ strip_start, const int* __restrict__ root, const int* __restrict__ compkey,
                const int* __restrict__ state, const int* __restrict__ owner, Rec* __restrict__ recs, int rec_cap,
-               int* __restrict__ counters)
+               int* __restrict__ counters, const int* __restrict__ tileflag)
 {
     __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
     __shared__ int lx[NT + 2 * HALO];
     __shared__ short l_list[NT];
     __shared__ int l_wcount[NT / 64];
     if (counters[CTR_NU] == 0) return;
+    { const int tl = tile_of_block(blockIdx.x); if (tl >= ntiles || tileflag[tl] == 0) return; }     // (k_border)
     const int M = strip_start[g.S];
     {
         // Only a CONTESTED border point whose first-come owner (its lowest-key adjacent component) is
@@ -3410,6 +3415,7 @@ struct cl_chrom {
     int sort_index_mode = 0;          // cl_set_sort_index: 0 = build at the second sort, 1 = at the first, -1 = never
     long long n_sorts = 0;            // layouts sorted on this handle so far
     DevBuf sv, sa, strip, cnt, parent, root, head, headidx, cellfirst, compkey, ncore, bsize, owner, state;
+    DevBuf tileflag;                  // per 256-PET tile: holds a contested border point (k_border -> k_emit_records)
     DevBuf flag, rankscan, ulist, lo, hi, recs, counters, chainflag, chainhead, usize, b_cstart, b_ckey, b_nb, b_cx, b_cy, tile_s0;
     int* h_pinned = nullptr;          // small pinned staging (stats, block scalars)
     struct StripPlan { int layout, eps, maxlen; };
@@ -3491,7 +3497,7 @@ static void free_chrom(cl_chrom* c)
     DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->qb_key, &c->qb_val, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->slot[0].d_step, &c->slot[1].d_step, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
-                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out, &c->dhist};
+                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->tileflag, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out, &c->dhist};
     for (DevBuf* b : bufs) b->release();
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -3705,7 +3711,7 @@ static int ensure_workspace(cl_chrom* c, int S)
     ENS(flag, (n + 1) * 4); ENS(rankscan, (n + 1) * 4); ENS(hdr, 256);
     ENS(slot[c->cur].labels, n * 4); ENS(slot[c->cur].table, (n + 1) * sizeof(cl_box)); ENS(slot[c->cur].slab, n * 4);
     ENS(ulist, n * 4); ENS(lo, n * 4); ENS(hi, n * 4); ENS(recs, n * sizeof(Rec)); ENS(counters, 256);
-    ENS(chainflag, n * 4); ENS(chainhead, n * 4); ENS(usize, n * 4); ENS(tile_s0, (n / 256 + 2) * 4);
+    ENS(chainflag, n * 4); ENS(chainhead, n * 4); ENS(usize, n * 4); ENS(tile_s0, (n / 256 + 2) * 4); ENS(tileflag, (n / 256 + 2) * 4);
 #undef ENS
     if (c->sv.fresh || c->sa.fresh) {
         // sentinel pads around the sorted arrays (k_region_core stages its windows without bounds checks)
@@ -4639,13 +4645,14 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     ev_record(c, 4);
     // K4
     TILE_LAUNCH_H((wide >= 2 && wide <= 4) ? 512 : (wide >= 5 ? 256 : 128), k_border, g, ntiles, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(),
-                       c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), cnt);
+                       c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), cnt, c->tileflag.as<int>());
     if (variant == CL_VARIANT_CDBSCAN2) {
         const int rec_cap = n;
         hipLaunchKernelGGL(k_mark_uncertain_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, c->ncore.as<int>(), c->bsize.as<int>(), c->state.as<int>(),
                            c->ulist.as<int>(), counters);
         TILE_LAUNCH(k_emit_records, g, ntiles, sv, sa, strip, c->root.as<int>(),
-                           c->compkey.as<int>(), c->state.as<int>(), c->owner.as<int>(), c->recs.as<Rec>(), rec_cap, counters);
+                           c->compkey.as<int>(), c->state.as<int>(), c->owner.as<int>(), c->recs.as<Rec>(), rec_cap, counters,
+                           (const int*)c->tileflag.as<int>());
         hipLaunchKernelGGL(k_resolve_release, dim3(1), dim3(1024), 0, c->stream, minPts, c->ncore.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                            c->ulist.as<int>(), c->recs.as<Rec>(), c->lo.as<int>(), c->hi.as<int>(), counters);
     }
