@@ -1887,9 +1887,10 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
          const int* __restrict__ ncore, const u32* __restrict__ srow, int* __restrict__ owner, int* __restrict__ bsize,
          int* __restrict__ usize, const int* __restrict__ cnt, int* __restrict__ tileflag)
 {
-    // tileflag[tile] = 1 if the tile holds a CONTESTED border point (one adjacent to more than one component): only such
-    // tiles can have anything for k_emit_records, which then leaves after one load instead of testing 256 PETs
-    if (threadIdx.x == 0) { const int tl = tile_of_block(blockIdx.x); if (tl < ntiles) tileflag[tl] = 0; }
+    // tileflag[k] = 1 if the 256 PETs [256 k, 256 k + 256) hold a CONTESTED border point (one adjacent to more than one component)
+    // whose owner is not live on its cores alone: only such tiles can have anything for k_emit_records, which then leaves after
+    // one load instead of testing 256 PETs
+    if (threadIdx.x < NT / 256) { const int tl = tile_of_block(blockIdx.x); if (tl < ntiles) tileflag[tl * (NT / 256) + threadIdx.x] = 0; }
     __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
     __shared__ int lx[NT + 2 * HALO];
     __shared__ short l_list[NT];
@@ -1978,13 +1979,16 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
     }
     const int o = (v1 && tbest >= 0) ? tbest : best;
     owner[i] = o < 0 ? -1 : (contested ? (o | OWNER_CONTESTED) : o);
-    if (o >= 0 && contested) tileflag[t.t0 / NT] = 1;           // (behind the staging barrier: ordered after the reset above)
+
     // counts per owning component, reduced over the lanes of the wave that share the owner.  Only
     // components that are not already >= minPts on their cores need them (release rule of variant 2,
     // drop rule of variant 1) -- a giant component never sees one of these atomics.
     {
         const int lane = threadIdx.x & 63;
         const bool cnt_me = o >= 0 && ncore[o] < g.minPts;
+        // only a component that is not live on its cores alone can end up uncertain (k_mark_uncertain_l): the tiles without a
+        // contested border point of such a component have nothing for k_emit_records
+        if (cnt_me && contested) tileflag[i >> 8] = 1;          // (behind the staging barrier: ordered after the reset above)
         unsigned long long pending = __ballot(cnt_me);
         while (pending) {
             const int leader = __ffsll((long long)pending) - 1;
@@ -2028,14 +2032,23 @@ __global__ void __launch_bounds__(NT)
 k_emit_records(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
                const int* __restrict__ strip_start, const int* __restrict__ root, const int* __restrict__ compkey,
                const int* __restrict__ state, const int* __restrict__ owner, Rec* __restrict__ recs, int rec_cap,
-               int* __restrict__ counters, const int* __restrict__ tileflag)
+               int* __restrict__ counters, const int* __restrict__ tileflag, int nflags)
 {
     __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
     __shared__ int lx[NT + 2 * HALO];
     __shared__ short l_list[NT];
     __shared__ int l_wcount[NT / 64];
     if (counters[CTR_NU] == 0) return;
-    { const int tl = tile_of_block(blockIdx.x); if (tl >= ntiles || tileflag[tl] == 0) return; }     // (k_border)
+    {
+        // (k_border's flags are per 256-PET tile; this kernel may run on larger tiles)
+        const int tl = tile_of_block(blockIdx.x);
+        if (tl >= ntiles) return;
+        constexpr int F = NT / 256;
+        int any = 0;
+#pragma unroll
+        for (int k = 0; k < F; ++k) any |= (tl * F + k < nflags) ? tileflag[tl * F + k] : 0;
+        if (any == 0) return;
+    }
     const int M = strip_start[g.S];
     {
         // Only a CONTESTED border point whose first-come owner (its lowest-key adjacent component) is
@@ -4652,7 +4665,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
                            c->ulist.as<int>(), counters);
         TILE_LAUNCH(k_emit_records, g, ntiles, sv, sa, strip, c->root.as<int>(),
                            c->compkey.as<int>(), c->state.as<int>(), c->owner.as<int>(), c->recs.as<Rec>(), rec_cap, counters,
-                           (const int*)c->tileflag.as<int>());
+                           (const int*)c->tileflag.as<int>(), ntiles);
         hipLaunchKernelGGL(k_resolve_release, dim3(1), dim3(1024), 0, c->stream, minPts, c->ncore.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                            c->ulist.as<int>(), c->recs.as<Rec>(), c->lo.as<int>(), c->hi.as<int>(), counters);
     }
