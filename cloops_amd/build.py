@@ -1,12 +1,21 @@
-"""In-tree build of libcloops_hip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""In-tree build of libcloops_hip.so with hipcc for gfx950 (cross-compiles without a GPU).
+
+The library is several translation units (cloops_amd/csrc/*.hip over the shared header cl_common.h): each is
+compiled to an object on its own (in parallel, only when it or a header changed), then linked -- an edit to one
+kernel family recompiles one file."""
+import glob
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "cloops_hip.hip")
+CSRC = os.path.join(HERE, "csrc")
 HDR = os.path.join(os.path.dirname(HERE), "include", "cloops_hip.h")
 OUT = os.path.join(HERE, "libcloops_hip.so")
+OBJDIR = os.path.join(os.path.dirname(HERE), "build", "obj")
+
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc():
@@ -16,11 +25,26 @@ def hipcc():
     return "hipcc"
 
 
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [HDR]
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(p) > t for p in (SRC, HDR))
+    return any(os.path.getmtime(p) > t for p in sources() + headers())
+
+
+def _compile(src, obj, devel, verbose):
+    cmd = [hipcc()] + FLAGS + (["-DCLOOPS_DEVEL"] if devel else []) + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
 
 
 def build(force=False, verbose=False, devel=False):
@@ -29,10 +53,18 @@ def build(force=False, verbose=False, devel=False):
     out = OUT.replace(".so", "_devel.so") if devel else OUT
     if not devel and not force and not needs_build():
         return OUT
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-Wall", "-Wno-unused-function", SRC, "-o", out]
-    if devel:
-        cmd.insert(1, "-DCLOOPS_DEVEL")
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdr_t = max(os.path.getmtime(p) for p in headers())
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ("_devel" if devel else "") + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append((src, obj))
+    with ThreadPoolExecutor(max_workers=max(1, min(8, len(jobs)))) as pool:
+        for f in [pool.submit(_compile, s, o, devel, verbose) for s, o in jobs]:
+            f.result()
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

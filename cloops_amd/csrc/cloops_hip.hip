@@ -24,48 +24,14 @@
 //   K4 k_border         border ownership per variant rule; v2 release fix-up
 //   K5 k_rank_flags / scan / k_final_labels   reference cluster ids + cluster table
 //   K6 block variant    cell table, links, cell-level union (blockDBSCAN.py)
-#include <cstring>
-#include <cstdlib>
-#include <cstdio>
-#include <climits>
-#include <ctime>
-#include <string>
-#include <vector>
-#include <algorithm>
-#include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
-
-#include "../../include/cloops_hip.h"
-
-#define CL_VERSION_NUM 100   // 0.1.0
-
-typedef unsigned long long u64;
-typedef unsigned int u32;
-
-// rocPRIM onesweep radix sort with 9-bit digits: the 45 significant key bits of a chr1-sized
-// chromosome take 5 passes instead of 6 (measured on MI355X, 5 M pairs: 344 us vs 405 us default)
-typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                   rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<512, 12>, 9,
-                                                                       rocprim::block_radix_rank_algorithm::match>>
-    SortConfig;
+#include "cl_common.h"
 
 // ------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------
-static thread_local std::string g_err;
+thread_local std::string g_err;
 
-static int fail(int code, const char* what, const char* detail = nullptr)
-{
-    g_err = what;
-    if (detail) { g_err += ": "; g_err += detail; }
-    return code;
-}
 
-#define HIP_TRY(expr)                                                              \
-    do {                                                                           \
-        hipError_t e_ = (expr);                                                    \
-        if (e_ != hipSuccess) return fail(CL_ERR_HIP, #expr, hipGetErrorString(e_)); \
-    } while (0)
 
 extern "C" const char* cl_last_error(void) { return g_err.c_str(); }
 extern "C" int cl_version(void) { return CL_VERSION_NUM; }
@@ -84,142 +50,6 @@ extern "C" int cl_device_count(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
-}
-
-// ------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------
-#define TPB 256
-
-enum { ST_LIVE = 0, ST_DEAD = 1, ST_UNKNOWN = 2 };          // variant-2 release state of a component
-enum { CTR_NU = 0, CTR_NREC = 1, CTR_OVERFLOW = 2, CTR_NROOT = 3 };         // device counters
-
-struct GridParams {
-    int eps;      // cell / strip width (cDBSCAN.py:29, cDBSCAN2.py:30: cw = eps)
-    int minPts;
-    int cut;      // pipe.py:59-63 pre-filter, 0 = off
-    int A0;       // offset subtracted from the STRIP coordinate  (0 for variant 2: absolute cells)
-    int V0;       // offset subtracted from the IN-STRIP (sorted) coordinate (0 for variant 2)
-    int swap;     // 0: strips are bands of a = Y-X ordered by v = X+Y;  1: bands of v ordered by a
-    int s0;       // strip index of the first table row
-    int S;        // number of strips in the table; key strip S marks filtered rows
-    int variant;
-    int dbg;      // developer knobs (CLOOPS_DBG env), 0 in production
-    u32 magic;    // strip(a) = a / eps by multiply-shift (Granlund-Montgomery, exact for all u32)
-    int sh1, sh2;
-    int qbits;    // sort key = strip << (qbits+rbits) | q << rbits | (p mod eps): both coordinates ride
-    int rbits;    //   in the key, so the sorted (q,p) arrays are DECODED, not gathered through row ids;
-                  //   the radix sort skips the low rbits (they are payload, not order)
-    int peps;     // 1 << rbits.  The kernels never see p itself but its ORDER-PRESERVING re-encoding
-                  //   sp = strip << rbits | (p mod eps)   (the strip and remainder fields of the sort key):
-                  //   strip(p) = sp >> rbits (no division), and |p_j - p_i| <= eps  <=>  |sp_j - sp_i| <= peps
-                  //   (same strip: always; adjacent strips: both compare the remainders; two or more strips apart: never).
-};
-
-__device__ __forceinline__ int sat_add(int a, int b)
-{
-    long long s = (long long)a + (long long)b;
-    return s > INT_MAX ? INT_MAX : (s < INT_MIN ? INT_MIN : (int)s);
-}
-
-// ---- wave64 reductions on the DPP network (no LDS crossbar traffic, a handful of VALU instructions) ------------
-// quad_perm [1,0,3,2], [2,3,0,1], row_shr:4, row_shr:8 leave every 16-lane row's total in its lane 15; row_bcast:15 then
-// lanes 31 / 63 hold the totals of lanes 0..31 / 32..63; row_bcast:31 completes lane 63.  min / max are idempotent, so
-// lanes that receive nothing combine with their own value.
-#define CL_DPP(v, ctrl, rowmask) __builtin_amdgcn_update_dpp((v), (v), (ctrl), (rowmask), 0xf, false)
-template <typename Op>
-__device__ __forceinline__ int dpp_reduce_halves(int v, Op op)       // result: lane 31 <- lanes 0..31, lane 63 <- lanes 32..63
-{
-    v = op(v, CL_DPP(v, 0xb1, 0xf));
-    v = op(v, CL_DPP(v, 0x4e, 0xf));
-    v = op(v, CL_DPP(v, 0x114, 0xf));
-    v = op(v, CL_DPP(v, 0x118, 0xf));
-    v = op(v, CL_DPP(v, 0x142, 0xa));
-    return v;
-}
-template <typename Op>
-__device__ __forceinline__ int dpp_reduce_wave(int v, Op op)         // wave-uniform result
-{
-    v = dpp_reduce_halves(v, op);
-    v = op(v, CL_DPP(v, 0x143, 0xc));
-    return __builtin_amdgcn_readlane(v, 63);
-}
-struct OpMin { __device__ __forceinline__ int operator()(int a, int b) const { return min(a, b); } };
-struct OpMax { __device__ __forceinline__ int operator()(int a, int b) const { return max(a, b); } };
-
-// first index in [lo,hi) with sv[idx] >= val
-__device__ __forceinline__ int lower_bound_i(const int* __restrict__ sv, int lo, int hi, int val)
-{
-    while (lo < hi) {
-        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
-        if (sv[mid] < val) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-// first index in [lo,hi) with sv[idx] > val
-__device__ __forceinline__ int upper_bound_i(const int* __restrict__ sv, int lo, int hi, int val)
-{
-    while (lo < hi) {
-        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
-        if (sv[mid] <= val) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-__device__ __forceinline__ int div_eps(const GridParams& g, int arel)
-{
-    const u32 n = (u32)arel;                       // arel >= 0 by construction
-    const u32 t1 = __umulhi(g.magic, n);
-    return (int)((t1 + ((n - t1) >> g.sh1)) >> g.sh2);
-}
-__device__ __forceinline__ int strip_of(const GridParams& g, int sp) { return sp >> g.rbits; }      // sp: see GridParams
-
-// ---- lock-free union-find with randomised linking ------------------------------------------
-// Every node has a fixed pseudo-random priority (a bijective hash of its index); a root is only
-// ever hooked under a root of HIGHER priority, so the forest is acyclic whatever the interleaving
-// and its expected depth is logarithmic even for a component that is a 50 000-strip long path
-// (the self-ligation diagonal at large eps: linking by smaller index made that a 50 000-deep list
-// whose first traversal alone cost 8 ms).  Which member ends up as the root is irrelevant -- ids,
-// keys and sizes are all reduced over the members.
-// parent[] is read with PLAIN (L1-cacheable) loads: a stale value is always an earlier parent of
-// the same node, i.e. still an ancestor, so a find that stops early merely returns a non-root
-// ancestor.  Only the hook is an atomic: atomicCAS succeeds only on a true root, and when it fails it
-// returns the true parent, whose priority is strictly higher -- every retry makes progress.
-// (Agent-scope atomic loads here serialise millions of lanes on the one L2 channel holding a giant
-// component's root: 77 ms vs 1 ms on a 16 M-PET chromosome.)
-__device__ __forceinline__ unsigned uf_prio(int x)
-{
-    unsigned h = (unsigned)x;
-    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;      // bijective
-    return h;
-}
-__device__ __forceinline__ int uf_find(int* parent, int x)
-{
-    for (;;) {
-        int p = parent[x];
-        if (p == x) return x;
-        int gp = parent[p];
-        if (gp == p) return p;
-        parent[x] = gp;                             // path halving (benign race: gp is an ancestor)
-        x = gp;
-    }
-}
-__device__ __forceinline__ void uf_unite(int* parent, int a, int b)
-{
-    for (;;) {
-        a = uf_find(parent, a);
-        b = uf_find(parent, b);
-        if (a == b) return;
-        if (uf_prio(a) > uf_prio(b)) { int t = a; a = b; b = t; }      // a = lower priority: it goes under b
-        int old = atomicCAS(parent + a, a, b);
-        if (old == a) return;
-        a = old;                                    // not a root any more: continue from its true parent
-    }
-}
-__device__ __forceinline__ int uf_find_ro(const int* __restrict__ parent, int x)
-{   // after the union kernel has completed (kernel boundary = coherent), plain loads
-    int p = parent[x];
-    while (p != x) { x = p; p = parent[x]; }
-    return x;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -473,649 +303,6 @@ k_strip_sort(int n, GridParams g, const u64* __restrict__ keys, const u32* __res
     if ((dst & 255) == 0) tile_s0[dst >> 8] = strip;
 }
 
-// ------------------------------------------------------------------------------------------
-// K2: region query  (cDBSCAN.py:186-205 regionQuery / cDBSCAN2.py:304-334 neighbour count)
-// ------------------------------------------------------------------------------------------
-// 4-way lower bound: three independent probes per step -- half the dependent memory round
-// trips of a bisect (the global path is latency bound: one L2/HBM round trip per step).
-__device__ __forceinline__ int lower_bound_4(const int* pv, int lo, int hi, int val)
-{
-    while (hi - lo > 4) {
-        const int q = (hi - lo) >> 2;
-        const int m1 = lo + q, m2 = m1 + q, m3 = m2 + q;
-        const int v1 = pv[m1], v2 = pv[m2], v3 = pv[m3];
-        if (v1 >= val) hi = m1;
-        else if (v2 >= val) { lo = m1 + 1; hi = m2; }
-        else if (v3 >= val) { lo = m2 + 1; hi = m3; }
-        else lo = m3 + 1;
-    }
-    while (lo < hi && pv[lo] < val) ++lo;
-    return lo;
-}
-
-struct LdsPairs {       // LDS window of (q = in-strip coord, p = strip coord), addressed by GLOBAL sorted index
-    const int2* a; int base;
-    __device__ __forceinline__ int2 operator[](int j) const { return a[j - base]; }
-    __device__ __forceinline__ int qat(int j) const { return a[j - base].x; }
-};
-struct LdsSoA {         // same window as two int arrays: the searches only read q, and consecutive
-    const int* q; const int* p; int base;          // dwords spread over all LDS banks (pairs: every other bank)
-    __device__ __forceinline__ int2 operator[](int j) const { return make_int2(q[j - base], p[j - base]); }
-    __device__ __forceinline__ int qat(int j) const { return q[j - base]; }
-};
-struct LdsInts {
-    const int* a; int base;
-    __device__ __forceinline__ int operator[](int j) const { return a[j - base]; }
-};
-
-// Branch-free bounded searches on an LDS window of (q,p) pairs: fixed 8 steps, no divergence
-// (a wave pays the LONGEST trip count of its lanes, so data-dependent loops cost far more
-// instructions than the average lane needs).  Valid for hi - lo <= 255.
-// first idx in [lo,hi) with w[idx].x >= val (or hi)
-template <int STEPS = 8, typename W>
-__device__ __forceinline__ int lds_lower_bound8(const W& w, int lo, int hi, int val)
-{
-    int pos = lo;
-#pragma unroll
-    for (int step = 1 << (STEPS - 1); step >= 1; step >>= 1) {
-        const int idx = pos + step - 1;
-        const int v = w.qat(min(idx, hi - 1));
-        pos = (idx < hi && v < val) ? pos + step : pos;
-    }
-    return pos;
-}
-// first idx in [lo,hi) with w[idx].x > val (or hi)
-template <int STEPS = 8, typename W>
-__device__ __forceinline__ int lds_upper_bound8(const W& w, int lo, int hi, int val)
-{
-    int pos = lo;
-#pragma unroll
-    for (int step = 1 << (STEPS - 1); step >= 1; step >>= 1) {
-        const int idx = pos + step - 1;
-        const int v = w.qat(min(idx, hi - 1));
-        pos = (idx < hi && v <= val) ? pos + step : pos;
-    }
-    return pos;
-}
-
-// Count the candidates j of [j,te) with q[j] <= qhi (q ascending) and |p[j]-pi| <= eps, in chunks
-// whose loads are all issued before the first compare (an element-at-a-time `while (q <= qhi)`
-// loop costs one full memory latency per candidate).
-template <bool EXACT, int CH, typename W>
-__device__ __forceinline__ int k2_count_lds(const W& w, int j, int te, int qhi, int pi, int eps, int minPts, int c)
-{
-    while (j < te) {
-        int2 v[CH];
-#pragma unroll
-        for (int k = 0; k < CH; ++k) v[k] = w[min(j + k, te - 1)];
-        bool out = false;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            const bool in = (j + k < te) && (v[k].x <= qhi);
-            out |= !in;
-            const int da = v[k].y - pi;
-            c += (in && (da < 0 ? -da : da) <= eps) ? 1 : 0;
-        }
-        if (out || (!EXACT && c >= minPts)) break;
-        j += CH;
-    }
-    return c;
-}
-template <bool EXACT, int CH>
-__device__ __forceinline__ int k2_count_glb(const int* __restrict__ pq, const int* __restrict__ pp, int j, int te,
-                                            int qhi, int pi, int eps, int minPts, int c)
-{
-    while (j < te) {
-        int v[CH], a[CH];
-#pragma unroll
-        for (int k = 0; k < CH; ++k) { const int idx = min(j + k, te - 1); v[k] = pq[idx]; a[k] = pp[idx]; }
-        bool out = false;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            const bool in = (j + k < te) && (v[k] <= qhi);
-            out |= !in;
-            const int da = a[k] - pi;
-            c += (in && (da < 0 ? -da : da) <= eps) ? 1 : 0;
-        }
-        if (out || (!EXACT && c >= minPts)) break;
-        j += CH;
-    }
-    return c;
-}
-
-// Workgroup compaction: slot list of the threads with `active`; returns their number.  Whole
-// waves fall out of the expensive phase instead of running it at partial lane occupancy.
-template <int NT = TPB>
-__device__ __forceinline__ int block_compact(bool active, short* l_list, int* l_wcount)
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const unsigned long long bal = __ballot(active);
-    if (lane == 0) l_wcount[wv] = __popcll(bal);
-    __syncthreads();
-    int off = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < NT / 64; ++k) { const int c = l_wcount[k]; off += (k < wv) ? c : 0; total += c; }
-    if (active) l_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (short)threadIdx.x;
-    __syncthreads();
-    return total;
-}
-
-// same, with `between()` executed by every thread between the two barriers (stores that may complete late)
-template <int NT, typename F>
-__device__ __forceinline__ int block_compact_with(bool active, short* l_list, int* l_wcount, F&& between)
-{
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const unsigned long long bal = __ballot(active);
-    if (lane == 0) l_wcount[wv] = __popcll(bal);
-    __syncthreads();
-    int off = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < NT / 64; ++k) { const int c = l_wcount[k]; off += (k < wv) ? c : 0; total += c; }
-    if (active) l_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (short)threadIdx.x;
-    between();
-    __syncthreads();
-    return total;
-}
-
-#define UNION_CH 8       // candidates fetched per round trip in the long-strip scan of k_union_cores
-#define K2_TPB 256
-#define K2_HALO 128
-#define K2_WIN (K2_TPB + 2 * K2_HALO)
-#define K2_SPAN 120      // own-strip window searched branch-free within +-K2_SPAN positions
-#define K2_RUN 8         // consecutive tiles given to one XCD (halo reuse in that XCD's L2)
-
-// One workgroup = a tile of 256 consecutive sorted PETs.  The tile plus a halo of K2_HALO PETs
-// on both sides is staged in LDS as (q,p) pairs with coalesced loads.  With strips laid along
-// v (a few tens of PETs per strip, uniformly) the three strips of a query sit next to each
-// other in sorted order, so the whole region query runs out of LDS:
-//   phase 1  own strip: every PET of the in-strip window [q-eps, q+eps] is a neighbour (the
-//            strip coordinate differs by < eps), so that part of the count is an index
-//            difference found by two branch-free 8-step searches -- no candidate is touched;
-//   phase 2  strips s-1 / s+1, only for points not yet known to be core (DBSCAN needs
-//            `count >= minPts`, not the count: EXACT = false saturates; cl_neighbor_counts()
-//            instantiates EXACT = true).  Those points are first COMPACTED inside the
-//            workgroup so that whole waves drop out instead of running at ~45 % lane use.
-// Windows that leave the staged range (pile-ups of hundreds of PETs) continue in global memory.
-// Workgroup b runs on XCD b % 8 (observed placement, used for speed only): each XCD is handed
-// runs of K2_RUN consecutive tiles so that halos are re-read from its own L2.
-template <bool EXACT>
-__global__ void __launch_bounds__(K2_TPB)
-k_region_count(GridParams g, int ntiles, int n, const int* __restrict__ sv, const int* __restrict__ sa,
-               const int* __restrict__ strip_start, int* __restrict__ cnt)
-{
-    __shared__ int lq[K2_WIN], lp[K2_WIN];
-    __shared__ int4 l_sb[K2_TPB];
-    __shared__ short l_list[K2_TPB];
-    __shared__ int l_wcount[K2_TPB / 64];
-    const int xcd = blockIdx.x & 7, kseq = blockIdx.x >> 3;
-    const int tile = ((kseq / K2_RUN) * 8 + xcd) * K2_RUN + (kseq % K2_RUN);
-    const int t0 = tile * K2_TPB;
-    if (tile >= ntiles) return;
-    // M (PETs that passed the cut filter) lives on the device; the staging loads are predicated on the
-    // host-known n instead (rows M..n-1 exist, they carry the sentinel strip), so that the load of M
-    // overlaps the staging round trip instead of preceding it
-    const int M = strip_start[g.S];
-    const int base = t0 - K2_HALO;                 // global index of lq[0] / lp[0]
-    {
-        // all loads of the thread are issued before the first LDS store (a rolled loop waits for
-        // its first round trip before it starts the second)
-        static_assert(K2_WIN <= 2 * K2_TPB, "two staging slots per thread");
-        const int k0 = threadIdx.x, k1 = threadIdx.x + K2_TPB;
-        const int g0 = base + k0, g1 = base + k1;
-        const bool in0 = g0 >= 0 && g0 < n, in1 = k1 < K2_WIN && g1 < n;
-        int q0 = 0, p0v = 0, q1 = 0, p1v = 0;
-        if (in0) { q0 = sv[g0]; p0v = sa[g0]; }
-        if (in1) { q1 = sv[g1]; p1v = sa[g1]; }
-        lq[k0] = q0; lp[k0] = p0v;
-        if (k1 < K2_WIN) { lq[k1] = q1; lp[k1] = p1v; }
-    }
-    __syncthreads();
-    if (t0 >= M) return;
-    LdsSoA w; w.q = lq; w.p = lp; w.base = base;   // w[global sorted index] = (in-strip coord q, strip coord p)
-    const int wbeg = max(base, 0), wend = min(base + K2_WIN, M);
-    const int i = t0 + threadIdx.x;
-    const bool valid = i < M;
-#ifdef CLOOPS_DEVEL
-    if (g.dbg & 32) { if (valid) cnt[i] = w[i].x + w[i].y; return; }        // developer knob: staging only
-#endif
-    // ---- phase 0: one-read core test ----------------------------------------------------------
-    // If the minPts-1 next (or previous) PETs of the own strip are within eps in q, the point is
-    // core: interiors of clusters are settled by one or two LDS reads, without any search.  "Same
-    // strip" is tested on the staged p values, so phase 0 needs no strip bounds: the four bounds of
-    // every PET are requested here (all loads in flight together, L2 hits) but only land in LDS after
-    // the first compaction barrier -- their round trip overlaps phase 0 instead of preceding it.
-    const int m1 = g.minPts - 1;
-    const bool p0 = !EXACT && g.minPts >= 1 && m1 <= K2_SPAN;
-    bool hard = false;
-    int4 sbv = make_int4(0, 0, 0, 0);
-    if (valid) {
-        bool done = false;
-        const int2 me = w[i];
-        const int s = strip_of(g, me.y);
-        sbv.y = strip_start[s]; sbv.z = strip_start[s + 1];
-        sbv.x = strip_start[max(s - 1, 0)];
-        sbv.w = strip_start[min(s + 2, g.S)];           // s + 1 == S: strip_start[S] == e
-        if (p0) {
-            const int jr = i + m1, jl = i - m1;
-            if (jr < wend && w.qat(jr) - me.x <= g.eps && strip_of(g, w.p[jr - base]) == s) done = true;
-            else if (jl >= wbeg && me.x - w.qat(jl) <= g.eps && strip_of(g, w.p[jl - base]) == s) done = true;
-        }
-        if (done) cnt[i] = g.minPts; else hard = true;
-    }
-#ifdef CLOOPS_DEVEL
-    if (g.dbg & 64) { if (valid && hard) cnt[i] = 0; return; }              // developer knob: phase 0 only
-#endif
-    // ---- workgroup compaction: whole waves drop out of the search phases ------------------------
-    const int total = block_compact_with<K2_TPB>(hard, l_list, l_wcount, [&]() { if (hard) l_sb[threadIdx.x] = sbv; });
-    if ((int)threadIdx.x >= total) return;
-    {
-        const int tix = l_list[threadIdx.x];
-        const int ii = t0 + tix;
-        const int2 me = w[ii];
-        const int qi = me.x, pi = me.y;
-        const int qlo = sat_add(qi, -g.eps), qhi = sat_add(qi, g.eps);
-        const int4 sb4 = l_sb[tix];
-        const int tb = sb4.x, b = sb4.y, e = sb4.z, te = sb4.w;
-        // ---- phase 1: own strip, index difference of two branch-free searches -------------------
-        int lo, hi;
-        if (p0) {
-            // phase 0 failed on both sides, so the window ends before the (minPts-1)-th PET on either
-            // side (or at the strip bounds): the searches run over at most minPts-1 positions and never
-            // leave the staged range
-            const int Ls = max(b, ii - m1 + 1), Rs = min(e, ii + m1);
-            if (m1 <= 7) { lo = lds_lower_bound8<3>(w, Ls, ii + 1, qlo); hi = lds_upper_bound8<3>(w, ii + 1, Rs, qhi); }
-            else if (m1 <= 31) { lo = lds_lower_bound8<5>(w, Ls, ii + 1, qlo); hi = lds_upper_bound8<5>(w, ii + 1, Rs, qhi); }
-            else { lo = lds_lower_bound8<7>(w, Ls, ii + 1, qlo); hi = lds_upper_bound8<7>(w, ii + 1, Rs, qhi); }
-        } else {
-            // exact counts: most windows hold < 31 PETs per side: 5 steps; a window that reaches the 31st
-            // position is searched again with 8 steps, one that leaves the staged span continues in global memory
-            const int Ls = max(max(b, wbeg), ii - 31);
-            lo = lds_lower_bound8<5>(w, Ls, ii + 1, qlo);
-            if (lo == Ls && Ls > b) {
-                const int L = max(max(b, wbeg), ii - K2_SPAN);
-                lo = lds_lower_bound8<8>(w, L, Ls + 1, qlo);
-                if (lo == L && L > b) lo = lower_bound_4(sv, b, L, qlo);
-            }
-            const int Rs = min(min(e, wend), ii + 32);
-            hi = lds_upper_bound8<5>(w, ii + 1, Rs, qhi);
-            if (hi == Rs && Rs < e) {
-                const int R = min(min(e, wend), ii + 1 + K2_SPAN);
-                hi = lds_upper_bound8<8>(w, Rs, R, qhi);
-                if (hi == R && R < e) hi = lower_bound_4(sv, R, e, sat_add(qhi, 1));
-            }
-        }
-        int c = hi - lo;
-#ifdef CLOOPS_DEVEL
-        if (g.dbg & 128) { cnt[ii] = c; return; }                             // developer knob: no neighbour strips
-#endif
-        // ---- phase 2: neighbour strips, only while not known to be core -------------------------
-        if (EXACT || c < g.minPts) {
-            // strip s-1 = [tb, b), strip s+1 = [e, te); an EMPTY strip counts as staged (the searches
-            // return at once), so that a wave only leaves the common path for unstaged / very long strips
-            const bool ldsA = tb >= wbeg && b - tb <= 255;
-            const bool ldsB = te <= wend && te - e <= 255;
-            if (ldsA && ldsB) {
-                // both searches advance together (two independent LDS chains in flight); the number of
-                // steps is chosen per WAVE (a per-lane choice makes most waves run every variant)
-                const int longest = max(b - tb, te - e);
-                int ja = tb, jb = e;
-#define K2_PAIR_SEARCH(TOP)                                                                          \
-                _Pragma("unroll") for (int step = TOP; step >= 1; step >>= 1) {                      \
-                    const int ia = ja + step - 1, ib = jb + step - 1;                                \
-                    const int va = w.qat(max(min(ia, b - 1), wbeg)), vb = w.qat(min(ib, te - 1));    \
-                    ja = (ia < b && va < qlo) ? ja + step : ja;                                      \
-                    jb = (ib < te && vb < qlo) ? jb + step : jb;                                     \
-                }
-                if (!__any(longest > 31)) { K2_PAIR_SEARCH(16) }
-                else if (!__any(longest > 63)) { K2_PAIR_SEARCH(32) }
-                else { K2_PAIR_SEARCH(128) }
-#undef K2_PAIR_SEARCH
-                // first four candidates of both strips, all loads in flight before the first compare
-                int2 va[4], vb[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { va[k] = w[max(min(ja + k, b - 1), wbeg)]; vb[k] = w[min(jb + k, te - 1)]; }
-                bool outA = false, outB = false;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool ina = (ja + k < b) && (va[k].x <= qhi), inb = (jb + k < te) && (vb[k].x <= qhi);
-                    outA |= !ina; outB |= !inb;
-                    const int da = va[k].y - pi, db = vb[k].y - pi;
-                    c += (ina && (da < 0 ? -da : da) <= g.peps) ? 1 : 0;
-                    c += (inb && (db < 0 ? -db : db) <= g.peps) ? 1 : 0;
-                }
-                if (EXACT || c < g.minPts) {
-                    if (!outA) c = k2_count_lds<EXACT, 4>(w, ja + 4, b, qhi, pi, g.peps, g.minPts, c);
-                    if (!outB && (EXACT || c < g.minPts)) c = k2_count_lds<EXACT, 4>(w, jb + 4, te, qhi, pi, g.peps, g.minPts, c);
-                }
-            } else {
-                if (tb < b) {
-                    if (ldsA) {
-                        const int j = (b - tb <= 63) ? lds_lower_bound8<6>(w, tb, b, qlo) : lds_lower_bound8<8>(w, tb, b, qlo);
-                        c = k2_count_lds<EXACT, 4>(w, j, b, qhi, pi, g.peps, g.minPts, c);
-                    } else {
-                        const int j = lower_bound_4(sv, tb, b, qlo);
-                        c = k2_count_glb<EXACT, 8>(sv, sa, j, b, qhi, pi, g.peps, g.minPts, c);
-                    }
-                }
-                if ((EXACT || c < g.minPts) && e < te) {
-                    if (ldsB) {
-                        const int j = (te - e <= 63) ? lds_lower_bound8<6>(w, e, te, qlo) : lds_lower_bound8<8>(w, e, te, qlo);
-                        c = k2_count_lds<EXACT, 4>(w, j, te, qhi, pi, g.peps, g.minPts, c);
-                    } else {
-                        const int j = lower_bound_4(sv, e, te, qlo);
-                        c = k2_count_glb<EXACT, 8>(sv, sa, j, te, qhi, pi, g.peps, g.minPts, c);
-                    }
-                }
-            }
-        }
-        cnt[ii] = c;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// K2, clustering form (the roofline kernel).  DBSCAN does not need the neighbour count, only whether it
-// reaches minPts, so this kernel decides "core or not" with as little work per PET as it can:
-//   * a workgroup of 256 threads owns a tile of 256*U consecutive sorted PETs (U per thread) and stages the
-//     tile plus a halo as two int arrays q[], sp[] (sp: GridParams) -- the halo and the two barriers are
-//     amortised over U PETs per thread;
-//   * the strip bounds come from a SLICE of the strip table staged next to the window (the slice starts at
-//     the strip of the tile's first PET, which the sort phase left in tile_s0[]: one scalar load, then one
-//     coalesced load per thread -- no per-PET global loads at all);
-//   * phase 0, every PET: if the (minPts-1)-th next or previous PET lies in the same strip (one compare on
-//     the staged sp: strips are aligned blocks of sp) within eps in q, the PET is core -- two LDS reads per side;
-//   * the undecided PETs are appended to a list in LDS (one LDS atomic per wave) and handled by whole waves:
-//     own strip = an index difference of two bounded branch-free searches; the strips s-1 / s+1 only while
-//     the count is below minPts: both lower bounds by one paired search; where strips are long (dense data)
-//     both upper bounds as well, so that "own + everything in both q windows < minPts" rejects a PET
-//     without touching a candidate; candidates are tested 4 + 4 at a time (|dsp| <= peps is ONE compare
-//     per side: a candidate one strip below can only be too low).
-// Windows that leave the staged range fall back to global memory (pile-ups).  cl_neighbor_counts() (exact
-// counts) and minPts outside 2..128 use k_region_count above.
-// ------------------------------------------------------------------------------------------
-#define K2F_TPB 256
-#define K2F_NS 256        // staged strip-table slice: strips s0-1 .. s0+254 of the tile's first strip s0
-#define K2F_SLACK 128     // LDS entries behind the window that unclamped search probes may touch
-// The sorted arrays sv / sa carry SORT_PAD sentinel entries in front of index 0 and behind index n-1 (left: q = 0,
-// sp = INT_MIN; right: q = sp = INT_MAX -- "in no strip"), written once when the workspace is allocated: a tile
-// window is staged with unpredicated 16-byte loads, no bounds logic at all.
-#define SORT_PAD 4224     // >= largest tile + largest halo + slack
-
-#ifdef CLOOPS_DEVEL
-// developer build: cycle stamps at the phase boundaries of k_region_core, kept in registers and stored once per wave
-// at the very end (a store or atomic in the middle would be waited for by the next s_waitcnt and distort the phases)
-__device__ unsigned int g_k2t[1 << 21];
-#define K2T_INIT unsigned long long t_st[7]; t_st[0] = __builtin_readcyclecounter()
-#define K2T(k) t_st[(k) + 1] = __builtin_readcyclecounter()
-#define K2T_FLUSH do { if ((threadIdx.x & 63) == 0) { const unsigned w_ = (blockIdx.x * (K2F_TPB / 64) + (threadIdx.x >> 6)) & ((1u << 18) - 1u); \
-    for (int k_ = 0; k_ < 6; ++k_) g_k2t[w_ * 8 + k_] = (unsigned)(t_st[k_ + 1] - t_st[k_]); g_k2t[w_ * 8 + 6] = ((unsigned)nh << 16) | (unsigned)n2; g_k2t[w_ * 8 + 7] = 1u; } } while (0)
-#else
-#define K2T(k) do { } while (0)
-#define K2T_INIT do { } while (0)
-#define K2T_FLUSH do { } while (0)
-#endif
-
-// The searches of k_region_core are written on PREDICATES OF THE STAGED PAIRS (q, sp), not on index bounds: sorted
-// order is (strip, q) and strips are aligned blocks of sp, so "j is still before the window" is a monotone predicate
-// of (q_j, sp_j) alone -- a probe is one 8-byte LDS read at an immediate offset, two or three compares and a select;
-// no index compares, no clamps (probes may run a little past a strip: the window carries a halo and K2F_SLACK
-// sentinel entries), no divergent branches.  first_true<K>(w, pos, pred): first index of [pos, pos + 2^K - 1] whose
-// pair satisfies the monotone predicate (pos + 2^K - 1 if none does).
-template <int K, typename P>
-__device__ __forceinline__ int first_true(const int2* __restrict__ w, int pos, P&& pred)
-{
-#pragma unroll
-    for (int step = 1 << (K - 1); step >= 1; step >>= 1) {
-        const int2 v = w[pos + step - 1];
-        pos = pred(v) ? pos : pos + step;
-    }
-    return pos;
-}
-// same with the probe index clamped to `last` (long brackets that may leave the LDS window)
-template <int K, typename P>
-__device__ __forceinline__ int first_true_clamped(const int2* __restrict__ w, int pos, int last, P&& pred)
-{
-#pragma unroll
-    for (int step = 1 << (K - 1); step >= 1; step >>= 1) {
-        const int2 v = w[min(pos + step - 1, last)];
-        pos = pred(v) ? pos : pos + step;
-    }
-    return pos;
-}
-
-// TAIL: the run has a cut, i.e. the sorted arrays end in a filtered tail whose tiles leave right after the scalar load of
-// tile_s0 (before staging anything); without a cut every tile has work and the staging loads are issued BEFORE that load
-// is waited for (its latency hides behind them).
-// hints of k_region_core for the non-core PETs (negative words in cnt[]): bit 30 isolated, bits 0..13 / 14..27 the distance
-// (in sorted positions) back to the start of its window in strip s-1 / forward to the one in strip s+1, all ones = no hints
-#define K2H_BITS 14
-#define K2H_MASK 0x3fffu
-#define K2H_ISOLATED 0x40000000u
-#define K2H_NONE 0x0fffffffu
-template <int U, int HALO, bool TAIL>
-__global__ void __launch_bounds__(K2F_TPB)
-k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
-              const int* __restrict__ strip_start, const int* __restrict__ tile_s0, int* __restrict__ cnt)
-{
-    constexpr int TILE = K2F_TPB * U, WIN = TILE + 2 * HALO, NV = WIN / 4;
-    constexpr int FULL = NV / K2F_TPB, REST = NV % K2F_TPB;              // int4 staging slots: FULL for every thread + a partial one
-    constexpr int RUN = (2048 / TILE) > 0 ? (2048 / TILE) : 1;          // consecutive tiles per XCD (halo reuse in its L2)
-    static_assert(HALO % 4 == 0 && HALO >= 128 && TILE + HALO + K2F_SLACK <= SORT_PAD && TILE % 256 == 0, "window shape");
-    static_assert(WIN + K2F_SLACK < (int)K2H_MASK, "window offsets fit the hint fields");
-    __shared__ __attribute__((aligned(16))) int2 lw[WIN + K2F_SLACK];   // (q, sp) pairs, window index = sorted index - (t0 - HALO)
-    __shared__ int l_st[K2F_NS + 4];
-    __shared__ unsigned int l_list[TILE];                                // undecided PETs, one region of 64*U entries per wave
-    const int xcd = blockIdx.x & 7, kseq = blockIdx.x >> 3;
-    const int tile = ((kseq / RUN) * 8 + xcd) * RUN + (kseq % RUN);
-    if (tile >= ntiles) return;
-    K2T_INIT;
-    const int t0 = tile * TILE;
-    int s0 = 0;                                         // strip of the tile's first PET; S = the tile lies in the filtered tail
-    if (TAIL) { s0 = tile_s0[t0 >> 8]; if (s0 >= g.S) return; }
-    const int M = strip_start[g.S];                     // PETs that passed the cut filter (device-side count)
-    K2T(0);
-    {
-        // stage the window: unpredicated 16-byte loads (the arrays are padded with sentinels), every load of the
-        // thread in flight before the first LDS store; pairs are interleaved on the way into LDS
-        const int4* __restrict__ gq = reinterpret_cast<const int4*>(sv + (t0 - HALO));
-        const int4* __restrict__ gp = reinterpret_cast<const int4*>(sa + (t0 - HALO));
-        int4* l4 = reinterpret_cast<int4*>(lw);
-        static_assert(REST == 0, "the window is a whole number of 16-byte slots per thread");
-        int4 qv[FULL], pv[FULL];
-#pragma unroll
-        for (int u = 0; u < FULL; ++u) { qv[u] = gq[threadIdx.x + u * K2F_TPB]; pv[u] = gp[threadIdx.x + u * K2F_TPB]; }
-        if (!TAIL) { s0 = tile_s0[t0 >> 8]; if (s0 >= g.S) return; }
-        const int st = strip_start[min(max(s0 - 1 + (int)threadIdx.x, 0), g.S)];
-#pragma unroll
-        for (int u = 0; u < FULL; ++u) {
-            const int k = (int)threadIdx.x + u * K2F_TPB;
-            l4[2 * k] = make_int4(qv[u].x, pv[u].x, qv[u].y, pv[u].y);
-            l4[2 * k + 1] = make_int4(qv[u].z, pv[u].z, qv[u].w, pv[u].w);
-        }
-        l_st[threadIdx.x] = st;
-        if (threadIdx.x < 4) l_st[K2F_NS + threadIdx.x] = 0;
-        if (threadIdx.x < K2F_SLACK) lw[WIN + threadIdx.x] = make_int2(INT_MAX, INT_MAX);
-    }
-    K2T(1);
-    __syncthreads();
-    K2T(2);
-    const int m1 = g.minPts - 1;                        // 1 <= m1 <= 127 < HALO (the host guarantees it)
-    const int eps = g.eps, peps = g.peps, minPts = g.minPts;
-    const int nmask = ~(peps - 1);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    unsigned int* my_list = l_list + wv * (64 * U);
-    int nh = 0;                                         // undecided PETs of this wave (wave-uniform)
-    // ---- phase 0: one-read core test, U PETs per thread (all 3 * U LDS reads in flight before the first compare) ------
-    int2 p_me[U], p_rr[U], p_ll[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int li = HALO + (int)threadIdx.x + u * K2F_TPB;
-        p_me[u] = lw[li]; p_rr[u] = lw[li + m1]; p_ll[u] = lw[li - m1];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int tix = (int)threadIdx.x + u * K2F_TPB;
-        const int2 me = p_me[u], rr = p_rr[u], ll = p_ll[u];
-        const int pbeg = me.y & nmask;
-        const bool valid = t0 + tix < M;
-        // the (minPts-1)-th next / previous PET is in the same strip and within eps in q (unsigned add: a sentinel q wraps harmlessly)
-        const bool core = ((rr.y < pbeg + peps) & (rr.x <= (int)((unsigned)me.x + (unsigned)eps))) | ((ll.y >= pbeg) & (ll.x >= me.x - eps));
-        if (valid & core) cnt[t0 + tix] = minPts;
-        const bool hard = valid & !core;
-        const unsigned long long bal = __ballot(hard);
-        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-        if (hard) my_list[nh + before] = (unsigned)tix;
-        nh += __popcll(bal);
-    }
-    K2T(3);
-    // the lists are per wave: a wave only reads what its own lanes wrote, and the LDS executes a wave's operations in order
-    // -- no workgroup barrier, only "all my LDS writes have been issued" and a scheduling fence for the compiler
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    K2T(4);
-    // ---- phase 1: own strip.  Phase 0 failed on both sides, so the q window ends before the (minPts-1)-th PET on
-    // either side (or at the strip ends): lo = first PET of the own strip with q >= qlo, hi = first PET behind the own
-    // strip's PETs with q <= qhi, both inside +-(minPts-1) positions.  PETs still below minPts go on to phase 2
-    // through a second list, written over the first one (a round appends at most as many entries as it has consumed).
-    int n2 = 0;
-    for (int h0 = 0; h0 < nh; h0 += 64) {
-        const int h = h0 + lane;
-        const bool act = h < nh;
-        const int tix = act ? (int)my_list[h] : 0, li = HALO + tix;
-        const int2 me = lw[li];
-        const int qlo = me.x - eps, qhi = me.x + eps;   // q < 2^30, eps < 2^30: no overflow
-        const int pbeg = me.y & nmask, pend = pbeg + peps;
-        int lo, hi;
-        auto inL = [&](int2 v) { return (v.y >= pbeg) & (v.x >= qlo); };            // monotone false -> true up to li
-        auto outR = [&](int2 v) { return !((v.y < pend) & (v.x <= qhi)); };         // monotone false -> true from li + 1
-        if (m1 <= 4) { lo = first_true<2>(lw, li - 3, inL); hi = first_true<2>(lw, li + 1, outR); }
-        else if (m1 <= 8) { lo = first_true<3>(lw, li - 7, inL); hi = first_true<3>(lw, li + 1, outR); }
-        else if (m1 <= 32) { lo = first_true<5>(lw, li - 31, inL); hi = first_true<5>(lw, li + 1, outR); }
-        else { lo = first_true<7>(lw, li - 127, inL); hi = first_true<7>(lw, li + 1, outR); }
-        const int c = hi - lo;
-        const bool need = act & (c < minPts);
-        if (act & !need) cnt[t0 + tix] = c;
-        const unsigned long long bal = __ballot(need);
-        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-        if (need) my_list[n2 + before] = (unsigned)tix | ((unsigned)c << 16);
-        n2 += __popcll(bal);
-    }
-    // ---- phase 2: neighbour strips s-1 = [tb, b) and s+1 = [e, te) -------------------------------------------
-    const int off = HALO - t0;                          // window index = global sorted index + off
-    const int wlo = max(t0 - HALO, 0) + off, whi = min(t0 - HALO + WIN, M) + off;      // staged valid range, window indices
-    for (int h = lane; h < n2; h += 64) {
-        const unsigned ent = my_list[h];
-        const int tix = (int)(ent & 0xffffu), li = HALO + tix;
-        int c = (int)(ent >> 16);
-        const int2 me = lw[li];
-        const int qi = me.x, pi = me.y;
-        const int qlo = qi - eps, qhi = qi + eps;
-        const int pbeg = pi & nmask, pend2 = pbeg + 2 * peps;
-        const int plo = pi - peps, phi = pi + peps;
-        const int kk = (pi >> g.rbits) - s0;            // >= 0: the tile's PETs are in strips >= s0
-        const int kc = min(kk, K2F_NS);                 // beyond the staged slice: dummy slots, fixed up below
-        int tb = l_st[kc], b = l_st[kc + 1], e = l_st[kc + 2], te = l_st[kc + 3];
-        if (kk + 3 >= K2F_NS) {
-            const int s = kk + s0;
-            tb = strip_start[max(s - 1, 0)]; b = strip_start[s]; e = strip_start[s + 1]; te = strip_start[min(s + 2, g.S)];
-        }
-        const int longest = max(b - tb, te - e);
-        tb += off; e += off; te += off;
-        int hja = -1, hjb = -1;                         // window starts in strips s-1 / s+1 (window indices), if found in LDS
-        if ((tb >= wlo) & (te <= whi)) {
-            auto inA = [&](int2 v) { return (v.y >= pbeg) | (v.x >= qlo); };    // from tb on: past the PETs of s-1 below qlo
-            auto inB = [&](int2 v) { return (v.y >= pend2) | (v.x >= qlo); };   // from e on: past the PETs of s+1 below qlo
-            if (!__any(longest > 31)) {
-                // sparse data: 5-step searches, then the first two candidates of both strips at once
-                const int ja = first_true<5>(lw, tb, inA), jb = first_true<5>(lw, e, inB);
-                hja = ja; hjb = jb;
-                int2 va[2], vb[2];
-#pragma unroll
-                for (int k = 0; k < 2; ++k) { va[k] = lw[ja + k]; vb[k] = lw[jb + k]; }
-                bool moreA = true, moreB = true;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const bool ia = (va[k].y < pbeg) & (va[k].x <= qhi), ib = (vb[k].y < pend2) & (vb[k].x <= qhi);
-                    moreA &= ia; moreB &= ib;
-                    c += (ia & (va[k].y >= plo)) ? 1 : 0;           // one strip below: sp can only be too low
-                    c += (ib & (vb[k].y <= phi)) ? 1 : 0;           // one strip above: only too high
-                }
-                if (__any((c < minPts) & (moreA | moreB))) {
-                    for (int j = ja + 2; moreA & (c < minPts); ++j) {
-                        const int2 v = lw[j];
-                        moreA = (v.y < pbeg) & (v.x <= qhi);
-                        c += (moreA & (v.y >= plo)) ? 1 : 0;
-                    }
-                    for (int j = jb + 2; moreB & (c < minPts); ++j) {
-                        const int2 v = lw[j];
-                        moreB = (v.y < pend2) & (v.x <= qhi);
-                        c += (moreB & (v.y <= phi)) ? 1 : 0;
-                    }
-                }
-            } else {
-                // dense data: both q windows [ja, ka), [jb, kb) first -- if even all of their PETs cannot lift the
-                // count to minPts the PET is not core and no candidate is read
-                auto outA = [&](int2 v) { return (v.y >= pbeg) | (v.x > qhi); };
-                auto outB = [&](int2 v) { return (v.y >= pend2) | (v.x > qhi); };
-                const int last = WIN + K2F_SLACK - 1;
-                int ja, jb, ka, kb;
-                if (!__any(longest > 127)) {
-                    ja = first_true<7>(lw, tb, inA); jb = first_true<7>(lw, e, inB);
-                    ka = first_true<7>(lw, ja, outA); kb = first_true<7>(lw, jb, outB);
-                } else if (!__any(longest > 511)) {
-                    ja = first_true_clamped<9>(lw, tb, last, inA); jb = first_true_clamped<9>(lw, e, last, inB);
-                    ka = first_true_clamped<9>(lw, ja, last, outA); kb = first_true_clamped<9>(lw, jb, last, outB);
-                } else {
-                    ja = first_true_clamped<12>(lw, tb, last, inA); jb = first_true_clamped<12>(lw, e, last, inB);
-                    ka = first_true_clamped<12>(lw, ja, last, outA); kb = first_true_clamped<12>(lw, jb, last, outB);
-                }
-                hja = ja; hjb = jb;
-                const int ub = c + (ka - ja) + (kb - jb);
-                if (ub < minPts) c = ub;                // not core; what is stored is an upper bound of the count (k_border: <= 1 = isolated)
-                else {
-                    for (int j = ja; (j < ka) & (c < minPts); j += 4) {
-                        int2 v[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = lw[j + k];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) c += ((j + k < ka) & (v[k].y >= plo)) ? 1 : 0;
-                    }
-                    for (int j = jb; (j < kb) & (c < minPts); j += 4) {
-                        int2 v[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = lw[j + k];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) c += ((j + k < kb) & (v[k].y <= phi)) ? 1 : 0;
-                    }
-                }
-            }
-        } else {
-            // a neighbour strip reaches outside the staged window (pile-up): global memory, sorted index space
-            const int gtb = tb - off, ge = e - off, gte = te - off;
-            if (gtb < b) {
-                const int j = lower_bound_4(sv, gtb, b, qlo);
-                c = k2_count_glb<false, 8>(sv, sa, j, b, qhi, pi, peps, minPts, c);
-            }
-            if (c < minPts && ge < gte) {
-                const int j = lower_bound_4(sv, ge, gte, qlo);
-                c = k2_count_glb<false, 8>(sv, sa, j, gte, qhi, pi, peps, minPts, c);
-            }
-        }
-        // a non-core PET leaves a NEGATIVE word (every consumer tests cnt >= minPts): K2H_ISOLATED if nothing can be within
-        // eps of it, and where its windows in the neighbour strips start, relative to itself -- k_border walks them without
-        // searching again (and without the strip table)
-        int outv = c;
-        if (c < minPts) {
-            unsigned enc = 0x80000000u | (c <= 1 ? K2H_ISOLATED : 0u);
-            enc |= (hja >= 0) ? ((unsigned)(li - hja) | ((unsigned)(hjb - li) << K2H_BITS)) : K2H_NONE;
-            outv = (int)enc;
-        }
-        cnt[t0 + tix] = outv;
-    }
-    K2T(5);
-    K2T_FLUSH;
-}
 
 // ------------------------------------------------------------------------------------------
 // LDS tile framework shared by the traversal kernels K3 (chains, union) and K4 (border, records)
@@ -3546,7 +2733,6 @@ extern "C" const int32_t* cl_labels_device(const cl_chrom* c)
 extern "C" void cl_set_device_labels(cl_chrom* c, int enabled) { if (c) c->device_labels = enabled != 0; }
 extern "C" void cl_set_table_export(cl_chrom* c, int enabled) { if (c) c->export_table = enabled != 0; }
 
-static inline int nblocks(long long n, int tpb = TPB) { return (int)((n + tpb - 1) / tpb); }
 
 __global__ void k_init_pads(int* __restrict__ svbuf, int* __restrict__ sabuf, long long n)
 {
@@ -3957,60 +3143,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
         }
     }
     ev_record(c, 2);
-    {
-        const int m1 = g.minPts - 1;
-        if (!exact && m1 >= 1 && m1 <= 127) {
-            // clustering form: tile / halo picked from the mean strip population (long strips need a wide window)
-            const long long avg = (long long)n / std::max(1, g.S);
-            int shape = avg <= 40 ? 0 : (avg <= 400 ? 1 : 2);
-#ifdef CLOOPS_DEVEL
-            if (const char* e = getenv("CLOOPS_K2_SHAPE")) shape = atoi(e);
-#endif
-#define K2F_LAUNCH(UU, HH)                                                                                              \
-            {                                                                                                           \
-                const int tile = K2F_TPB * UU, ntiles = nblocks(std::max(1, c->run_m), tile), run = std::max(1, 2048 / tile); \
-                const int grid = ((ntiles + 8 * run - 1) / (8 * run)) * (8 * run);                                      \
-                if (g.cut > 0) hipLaunchKernelGGL((k_region_core<UU, HH, true>), dim3(grid), dim3(K2F_TPB), 0, c->stream, g, ntiles, \
-                                   c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->cnt.as<int>());                            \
-                else hipLaunchKernelGGL((k_region_core<UU, HH, false>), dim3(grid), dim3(K2F_TPB), 0, c->stream, g, ntiles, \
-                                   c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->cnt.as<int>()); \
-            }
-            // window = tile + 2 * halo entries; shapes keep it a multiple of 1024 (every thread stages whole 16-byte slots)
-            switch (shape) {
-            case 0: K2F_LAUNCH(3, 128) break;
-            case 1: K2F_LAUNCH(4, 512) break;
-            case 2: K2F_LAUNCH(4, 1024) break;
-#ifdef CLOOPS_DEVEL
-            case 3: K2F_LAUNCH(2, 256) break;
-            case 4: K2F_LAUNCH(6, 256) break;
-            case 5: K2F_LAUNCH(2, 768) break;
-            case 6: K2F_LAUNCH(1, 384) break;
-            case 7: K2F_LAUNCH(8, 1024) break;
-#endif
-            default: K2F_LAUNCH(4, 1024) break;
-            }
-#undef K2F_LAUNCH
-#ifdef CLOOPS_DEVEL
-            if (getenv("CLOOPS_K2_CLOCK")) {
-                static std::vector<unsigned> h(1 << 21);
-                (void)hipStreamSynchronize(c->stream);
-                (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_k2t), h.size() * 4);
-                double sum[6] = {0, 0, 0, 0, 0, 0}; long long nw = 0, s1 = 0, s2 = 0;
-                for (size_t w = 0; w < (1u << 18); ++w) if (h[w * 8 + 7]) { ++nw; for (int k = 0; k < 6; ++k) sum[k] += h[w * 8 + k]; s1 += h[w * 8 + 6] >> 16; s2 += h[w * 8 + 6] & 0xffff; }
-                fprintf(stderr, "[k2 clock] undecided after phase 0: %lld, after the own strip: %lld (of %d rows)\n", s1, s2, n);
-                fprintf(stderr, "[k2 clock] %lld waves; mean cycles per wave: scalar %.0f | stage %.0f | barrier1 %.0f | phase0 %.0f | barrier2 %.0f | hard %.0f\n",
-                        nw, sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw, sum[5] / nw);
-                std::fill(h.begin(), h.end(), 0u);
-                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k2t), h.data(), h.size() * 4);
-            }
-#endif
-        } else {
-            const int ntiles = nblocks(n, K2_TPB);
-            const int grid = ((ntiles + 8 * K2_RUN - 1) / (8 * K2_RUN)) * (8 * K2_RUN);
-            if (exact) hipLaunchKernelGGL(k_region_count<true>, dim3(grid), dim3(K2_TPB), 0, c->stream, g, ntiles, n, c->w_sv, c->w_sa, c->w_strip, c->cnt.as<int>());
-            else hipLaunchKernelGGL(k_region_count<false>, dim3(grid), dim3(K2_TPB), 0, c->stream, g, ntiles, n, c->w_sv, c->w_sa, c->w_strip, c->cnt.as<int>());
-        }
-    }
+    if ((rc = cl_launch_region(c->stream, g, n, c->run_m, exact, c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->cnt.as<int>()))) return rc;
     ev_record(c, 3);
     HIP_TRY(hipGetLastError());
     return CL_OK;

@@ -619,7 +619,10 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                 b = r.chrom.cand_finish(final_cut, appended[f])
             return r.key, {"f": f, "boxes": b}                # int32 [k, 4] rows (minX, maxX, minY, maxY), append order
 
-        dataI = dict(_pmap(pool, finish, [(f, r) for f, r in live if appended.get(f, 0) > 0]))
+        # key order = first appearance over the steps, file order inside a step: what combineTwice's dict inserts
+        # (pipe.py:155-174) and runStat later walks -- `appended` was filled in exactly that order
+        res_of = dict(live)
+        dataI = dict(_pmap(pool, finish, [(f, res_of[f]) for f in appended]))
     finally:
         if pool is not None:
             pool.shutdown(wait=True)

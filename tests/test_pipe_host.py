@@ -188,3 +188,31 @@ def test_cut_on_an_integer_boundary_is_settled_from_the_lists(cpu_pipe, monkeypa
     assert [s.get("cut_out") for s in steps] == [s.get("cut_out") for s in meta["v2"]["steps"]]
     assert [s.get("frags") for s in steps] == [s.get("frags") for s in meta["v2"]["steps"]]
     assert np.array_equal(dataI[("chr21", "chr21")]["boxes"], z["v2_filtered"])
+
+
+def test_sweep_fast_key_order_is_first_appearance(monkeypatch):
+    """combineTwice (cLoops/pipe.py:155-174) inserts a chromosome's key when it FIRST yields an inter-ligation box;
+    runStat walks the dict, so the key order fixes the row order of the .loop file.  A chromosome that comes first in
+    file order but gets its first box only in the second step must come second -- in runSweep and runSweepFast alike."""
+    monkeypatch.setattr(api, "Chromosome", fake_backend.FakeChromosome)
+    monkeypatch.setattr(api, "device_count", lambda: 1)
+    pipe.CACHE.clear()
+    rng = np.random.RandomState(5)
+
+    def blob(x, y, k):
+        return x + rng.randint(0, 300, k), y + rng.randint(0, 300, k)
+
+    ax, ay = blob(100000, 600000, 5)                      # chrA: one inter-ligation cluster of 5 PETs (only minPts 4 sees it)
+    sx = 300000 + rng.randint(0, 300, 12)
+    bx, by = [np.concatenate(t) for t in zip(blob(150000, 700000, 12), (sx, sx + rng.randint(20, 200, 12)))]   # chrB: inter + self, 12 each
+    fa = pipe.CACHE.put_arrays("chrA-chrA", ax, ay)
+    fb = pipe.CACHE.put_arrays("chrB-chrB", bx, by)
+    try:
+        slow = pipe.runSweep([fa, fb], [1000], [8, 4], cut=0)
+        fast = pipe.runSweepFast([fa, fb], [1000], [8, 4], cut=0)
+        assert [s["n_inter"] for s in slow[3]] == [1, 2] and slow[1] > 0
+        assert list(slow[0]) == [("chrB", "chrB"), ("chrA", "chrA")]
+        assert list(fast[0]) == list(slow[0])
+        assert fast[1] == slow[1] and fast[2] == slow[2]
+    finally:
+        pipe.CACHE.clear()
