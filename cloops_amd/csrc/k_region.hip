@@ -216,6 +216,11 @@ k_region_count(GridParams g, int ntiles, int n, const int* __restrict__ sv, cons
 // window is staged with unpredicated 16-byte loads, no bounds logic at all.
 
 #ifdef CLOOPS_DEVEL
+#define K2_ABL(bit) do { if (g.dbg & (bit)) return; } while (0)      // developer ablation: stop after a phase (results invalid)
+#else
+#define K2_ABL(bit) do { } while (0)
+#endif
+#ifdef CLOOPS_DEVEL
 // developer build: cycle stamps at the phase boundaries of k_region_core, kept in registers and stored once per wave
 // at the very end (a store or atomic in the middle would be waited for by the next s_waitcnt and distort the phases)
 __device__ unsigned int g_k2t[1 << 21];
@@ -309,6 +314,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     K2T(1);
     __syncthreads();
     K2T(2);
+    K2_ABL(32);
     const int m1 = g.minPts - 1;                        // 1 <= m1 <= 127 < HALO (the host guarantees it)
     const int eps = g.eps, peps = g.peps, minPts = g.minPts;
     const int nmask = ~(peps - 1);
@@ -345,6 +351,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     K2T(4);
+    K2_ABL(64);
     // ---- phase 1: own strip.  Phase 0 failed on both sides, so the q window ends before the (minPts-1)-th PET on
     // either side (or at the strip ends): lo = first PET of the own strip with q >= qlo, hi = first PET behind the own
     // strip's PETs with q <= qhi, both inside +-(minPts-1) positions.  PETs still below minPts go on to phase 2
@@ -372,9 +379,56 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         if (need) my_list[n2 + before] = (unsigned)tix | ((unsigned)c << 16);
         n2 += __popcll(bal);
     }
+    K2_ABL(128);
     // ---- phase 2: neighbour strips s-1 = [tb, b) and s+1 = [e, te) -------------------------------------------
     const int off = HALO - t0;                          // window index = global sorted index + off
     const int wlo = max(t0 - HALO, 0) + off, whi = min(t0 - HALO + WIN, M) + off;      // staged valid range, window indices
+    // A PET whose q windows in the neighbour strips hold enough PETs to reach minPts needs its candidates tested one by
+    // one (|dp| <= eps) -- a loop whose trip count differs from lane to lane, and a wave pays the longest of its lanes.
+    // Those PETs (one in seven on chr1 of the 200 M genome) go to a THIRD list and are counted by full waves afterwards
+    // (phase 3) instead of stalling every round of phase 2: (tix | c << 16, ja | jb << 16) in the part of the wave's list
+    // that phase 2 has already consumed.
+    auto emit = [&](int tix, int li, int c, int hja, int hjb) {
+        // a non-core PET leaves a NEGATIVE word (every consumer tests cnt >= minPts): K2H_ISOLATED if nothing can be within
+        // eps of it, and where its windows in the neighbour strips start, relative to itself -- k_border walks them without
+        // searching again (and without the strip table)
+        int outv = c;
+        if (c < minPts) {
+            unsigned enc = 0x80000000u | (c <= 1 ? K2H_ISOLATED : 0u);
+            enc |= (hja >= 0) ? ((unsigned)(li - hja) | ((unsigned)(hjb - li) << K2H_BITS)) : K2H_NONE;
+            outv = (int)enc;
+        }
+        cnt[t0 + tix] = outv;
+    };
+    const int cap3 = minPts <= 32 ? 31 : (minPts <= 64 ? 63 : 127);           // depth of the upper-bound searches
+    auto count_candidates = [&](int c, int ja, int jb, int qhi, int pbeg, int pend2, int plo, int phi) {
+        bool more = true;
+        for (int j = ja; more & (c < minPts); j += 4) {
+            int2 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = lw[j + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool in = (v[k].y < pbeg) & (v[k].x <= qhi);          // still a PET of strip s-1 inside the q window
+                more &= in;
+                c += (in & (v[k].y >= plo)) ? 1 : 0;                         // one strip below: sp can only be too low
+            }
+        }
+        more = true;
+        for (int j = jb; more & (c < minPts); j += 4) {
+            int2 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = lw[j + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool in = (v[k].y < pend2) & (v[k].x <= qhi);
+                more &= in;
+                c += (in & (v[k].y <= phi)) ? 1 : 0;                         // one strip above: only too high
+            }
+        }
+        return c;
+    };
+    int n3 = 0;
     for (int h = lane; h < n2; h += 64) {
         const unsigned ent = my_list[h];
         const int tix = (int)(ent & 0xffffu), li = HALO + tix;
@@ -391,10 +445,27 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
             const int s = kk + s0;
             tb = strip_start[max(s - 1, 0)]; b = strip_start[s]; e = strip_start[s + 1]; te = strip_start[min(s + 2, g.S)];
         }
-        const int longest = max(b - tb, te - e);
+        const int gtb0 = tb, gte0 = te;                 // global sorted indices, for the global-memory path
         tb += off; e += off; te += off;
+        // A neighbour strip that sticks out of the staged range is CLIPPED to it when the staged part provably holds the
+        // PET's q window (sorted by q: the first staged PET belongs to strip s-1 and lies below qlo / the last one to strip
+        // s+1 above qhi) -- only a q window that itself leaves the staged range goes to global memory.  (Without this a few
+        // per cent of the lanes -- strips of 150 .. 300 PETs against a 512-PET halo -- sent nearly every wave through
+        // the global path as well.)
+        bool okA = tb >= wlo, okB = te <= whi;
+        if (__any(!(okA & okB))) {
+            const int2 f = lw[wlo], l = lw[whi - 1];
+            if (!okA) { okA = (f.y >= pbeg - peps) & (f.y < pbeg) & (f.x < qlo); tb = wlo; }
+            if (!okB) { okB = (l.y >= pbeg + peps) & (l.y < pend2) & (l.x > qhi); te = whi; }
+        }
+        const int longest = max(b + off - tb, te - e);
+#ifdef CLOOPS_DEVEL
+        if (g.dbg & 1024) { cnt[t0 + tix] = c + longest; continue; }
+        if (g.dbg & 256) { okA = okB = true; }
+#endif
         int hja = -1, hjb = -1;                         // window starts in strips s-1 / s+1 (window indices), if found in LDS
-        if ((tb >= wlo) & (te <= whi)) {
+        bool deferred = false;
+        if (okA & okB) {
             auto inA = [&](int2 v) { return (v.y >= pbeg) | (v.x >= qlo); };    // from tb on: past the PETs of s-1 below qlo
             auto inB = [&](int2 v) { return (v.y >= pend2) | (v.x >= qlo); };   // from e on: past the PETs of s+1 below qlo
             if (!__any(longest > 31)) {
@@ -431,39 +502,36 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
                 auto outB = [&](int2 v) { return (v.y >= pend2) | (v.x > qhi); };
                 const int last = WIN + K2F_SLACK - 1;
                 int ja, jb, ka, kb;
-                if (!__any(longest > 127)) {
-                    ja = first_true<7>(lw, tb, inA); jb = first_true<7>(lw, e, inB);
-                    ka = first_true<7>(lw, ja, outA); kb = first_true<7>(lw, jb, outB);
-                } else if (!__any(longest > 511)) {
-                    ja = first_true_clamped<9>(lw, tb, last, inA); jb = first_true_clamped<9>(lw, e, last, inB);
-                    ka = first_true_clamped<9>(lw, ja, last, outA); kb = first_true_clamped<9>(lw, jb, last, outB);
-                } else {
-                    ja = first_true_clamped<12>(lw, tb, last, inA); jb = first_true_clamped<12>(lw, e, last, inB);
-                    ka = first_true_clamped<12>(lw, ja, last, outA); kb = first_true_clamped<12>(lw, jb, last, outB);
-                }
+                if (!__any(longest > 127)) { ja = first_true<7>(lw, tb, inA); jb = first_true<7>(lw, e, inB); }
+                else if (!__any(longest > 255)) { ja = first_true_clamped<8>(lw, tb, last, inA); jb = first_true_clamped<8>(lw, e, last, inB); }
+                else if (!__any(longest > 511)) { ja = first_true_clamped<9>(lw, tb, last, inA); jb = first_true_clamped<9>(lw, e, last, inB); }
+                else if (!__any(longest > 1023)) { ja = first_true_clamped<10>(lw, tb, last, inA); jb = first_true_clamped<10>(lw, e, last, inB); }
+                else { ja = first_true_clamped<12>(lw, tb, last, inA); jb = first_true_clamped<12>(lw, e, last, inB); }
+                // the upper bounds only 2^K - 1 >= minPts - 1 positions deep: "do at least r = minPts - c more PETs follow in the
+                // two windows" is all the rejection test needs (a search that runs out of steps reports 2^K - 1 >= r)
+                if (cap3 == 31) { ka = first_true_clamped<5>(lw, ja, last, outA); kb = first_true_clamped<5>(lw, jb, last, outB); }
+                else if (cap3 == 63) { ka = first_true_clamped<6>(lw, ja, last, outA); kb = first_true_clamped<6>(lw, jb, last, outB); }
+                else { ka = first_true_clamped<7>(lw, ja, last, outA); kb = first_true_clamped<7>(lw, jb, last, outB); }
                 hja = ja; hjb = jb;
+#ifdef CLOOPS_DEVEL
+                if (g.dbg & 512) { cnt[t0 + tix] = c + ja + jb + ka + kb; continue; }
+#endif
                 const int ub = c + (ka - ja) + (kb - jb);
                 if (ub < minPts) c = ub;                // not core; what is stored is an upper bound of the count (k_border: <= 1 = isolated)
                 else {
-                    for (int j = ja; (j < ka) & (c < minPts); j += 4) {
-                        int2 v[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = lw[j + k];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) c += ((j + k < ka) & (v[k].y >= plo)) ? 1 : 0;
-                    }
-                    for (int j = jb; (j < kb) & (c < minPts); j += 4) {
-                        int2 v[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = lw[j + k];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) c += ((j + k < kb) & (v[k].y <= phi)) ? 1 : 0;
-                    }
+                    // candidates to test: phase 3 (all lanes of this round have read their entries; what the round
+                    // has consumed so far, 64 entries per round, is free -- an entry that would not fit is counted here)
+                    const unsigned long long bal = __ballot(true);
+                    const int slot = n3 + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    if (2 * slot + 1 < (h - lane) + 64) {
+                        my_list[2 * slot] = ent; my_list[2 * slot + 1] = (unsigned)ja | ((unsigned)jb << 16);
+                        deferred = true;
+                    } else c = count_candidates(c, ja, jb, qhi, pbeg, pend2, plo, phi);
                 }
             }
         } else {
             // a neighbour strip reaches outside the staged window (pile-up): global memory, sorted index space
-            const int gtb = tb - off, ge = e - off, gte = te - off;
+            const int gtb = gtb0, ge = e - off, gte = gte0;
             if (gtb < b) {
                 const int j = lower_bound_4(sv, gtb, b, qlo);
                 c = k2_count_glb<false, 8>(sv, sa, j, b, qhi, pi, peps, minPts, c);
@@ -473,16 +541,33 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
                 c = k2_count_glb<false, 8>(sv, sa, j, gte, qhi, pi, peps, minPts, c);
             }
         }
-        // a non-core PET leaves a NEGATIVE word (every consumer tests cnt >= minPts): K2H_ISOLATED if nothing can be within
-        // eps of it, and where its windows in the neighbour strips start, relative to itself -- k_border walks them without
-        // searching again (and without the strip table)
-        int outv = c;
-        if (c < minPts) {
-            unsigned enc = 0x80000000u | (c <= 1 ? K2H_ISOLATED : 0u);
-            enc |= (hja >= 0) ? ((unsigned)(li - hja) | ((unsigned)(hjb - li) << K2H_BITS)) : K2H_NONE;
-            outv = (int)enc;
-        }
-        cnt[t0 + tix] = outv;
+        // the number of deferred PETs of this round, seen by every lane that is still in the loop (wave-uniform count)
+        n3 += __popcll(__ballot(deferred));
+        if (!deferred) emit(tix, li, c, hja, hjb);
+    }
+    // every lane needs the final n3: lanes that left the loop early missed the later rounds
+    n3 = __builtin_amdgcn_readfirstlane(dpp_reduce_wave(n3, OpMax()));
+    // ---- phase 3: the candidates of the deferred PETs.  A wave defers a few tens of PETs of its 64 U -- a quarter of a
+    // wave on chr1 of the 200 M genome, and the candidate loops run as long as the longest window of the wave -- so the four
+    // lists are walked as ONE by the whole workgroup (one barrier): full waves first, the remainder in the last one.
+    if (lane == 0) l_st[K2F_NS + wv] = n3;               // (the four dummy slots behind the strip-table slice: only phase 2 read them)
+    __syncthreads();
+    const int c0 = l_st[K2F_NS], c1 = c0 + l_st[K2F_NS + 1], c2 = c1 + l_st[K2F_NS + 2];
+    int ntot = c2 + l_st[K2F_NS + 3];
+#ifdef CLOOPS_DEVEL
+    if (g.dbg & 2048) ntot = 0;
+#endif
+    for (int gi = (int)threadIdx.x; gi < ntot; gi += K2F_TPB) {
+        const int w = (gi >= c0) + (gi >= c1) + (gi >= c2);
+        const int h = gi - (w == 0 ? 0 : (w == 1 ? c0 : (w == 2 ? c1 : c2)));
+        const unsigned int* wl = l_list + w * (64 * U);
+        const unsigned ent = wl[2 * h], jj = wl[2 * h + 1];
+        const int tix = (int)(ent & 0xffffu), li = HALO + tix;
+        const int ja = (int)(jj & 0xffffu), jb = (int)(jj >> 16);
+        const int2 me = lw[li];
+        const int pbeg = me.y & nmask;
+        const int c = count_candidates((int)(ent >> 16), ja, jb, me.x + eps, pbeg, pbeg + 2 * peps, me.y - peps, me.y + peps);
+        emit(tix, li, c, ja, jb);
     }
     K2T(5);
     K2T_FLUSH;
@@ -502,13 +587,17 @@ int cl_launch_region(hipStream_t stream, const GridParams& g, int n, int run_m, 
 #ifdef CLOOPS_DEVEL
             if (const char* e = getenv("CLOOPS_K2_SHAPE")) shape = atoi(e);
 #endif
+            int padlds = 0;                                 // developer knob: dynamic LDS on top of the static arrays (occupancy experiments)
+#ifdef CLOOPS_DEVEL
+            if (const char* e = getenv("CLOOPS_K2_PADLDS")) padlds = atoi(e);
+#endif
 #define K2F_LAUNCH(UU, HH)                                                                                              \
             {                                                                                                           \
                 const int tile = K2F_TPB * UU, ntiles = nblocks(std::max(1, run_m), tile), run = std::max(1, 2048 / tile); \
                 const int grid = ((ntiles + 8 * run - 1) / (8 * run)) * (8 * run);                                      \
-                if (g.cut > 0) hipLaunchKernelGGL((k_region_core<UU, HH, true>), dim3(grid), dim3(K2F_TPB), 0, stream, g, ntiles, \
+                if (g.cut > 0) hipLaunchKernelGGL((k_region_core<UU, HH, true>), dim3(grid), dim3(K2F_TPB), padlds, stream, g, ntiles, \
                                    sv, sa, strip_start, tile_s0, cnt);                            \
-                else hipLaunchKernelGGL((k_region_core<UU, HH, false>), dim3(grid), dim3(K2F_TPB), 0, stream, g, ntiles, \
+                else hipLaunchKernelGGL((k_region_core<UU, HH, false>), dim3(grid), dim3(K2F_TPB), padlds, stream, g, ntiles, \
                                    sv, sa, strip_start, tile_s0, cnt); \
             }
             // window = tile + 2 * halo entries; shapes keep it a multiple of 1024 (every thread stages whole 16-byte slots)

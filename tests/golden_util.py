@@ -61,3 +61,17 @@ def regenerate_family(family, ncase=60):
     rng = np.random.default_rng(FAMILY_SEEDS[family])
     gen = getattr(cases, family + "_case")
     return [gen(rng, k) for k in range(ncase)]
+
+
+_MIX = np.array([0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F, 0x165667B19E3779F9, 0x27D4EB2F165667C5], dtype=np.uint64)
+
+
+def box_checksum(boxes):
+    """order-independent checksum of int rows (minX, maxX, minY, maxY): sum over rows of a 64-bit mix, mod 2^64"""
+    b = np.asarray(boxes, dtype=np.int64).reshape(-1, 4).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        h = (b * _MIX[None, :]).sum(axis=1, dtype=np.uint64)
+        h ^= h >> np.uint64(29)
+        h *= np.uint64(0xBF58476D1CE4E5B9)
+        h ^= h >> np.uint64(32)
+        return int(h.sum(dtype=np.uint64))

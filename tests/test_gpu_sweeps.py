@@ -2,14 +2,20 @@
 
   configs[2]  40 M PETs, 23 chromosomes, HiChIP mode -m 4  (eps 2500..10000 x minPts 30, 20; cLoops/pipe.py:341-344)
   configs[3]  200 M PETs, 23 chromosomes, Hi-C mode -m 3   (eps 5000, 7500, 10000 x minPts 50..20; pipe.py:337-340)
-  configs[4]  500 M-PET genome, dense user sweep eps 1000..10000 x minPts 50, 30, 20, 10, 5 (50 runs): run on three of
-              its chromosomes (chr1 = 41 M PETs, chr2, chr21 -- 87 M PETs; generating all 500 M takes longer than the
-              sweep itself, and chromosomes are independent units)
+  configs[4]  500 M PETs, 23 chromosomes, dense user sweep eps 1000..10000 x minPts 50, 30, 20, 10, 5 (50 runs)
 
-Size-independent properties: (i) run-to-run determinism of cuts and candidate tables, with the chained cut of
-cLoops/pipe.py:247-275; (ii) runSweepFast (statistics on the GPU) == runSweep (labels and distance lists on the host,
-the reference's data flow) on a scaled genome; (iii) equality with the C oracle's chain on one chromosome of the
-200 M genome at the mode-3 / mode-4 parameters, chained cut included."""
+Checks: (i) run-to-run determinism of cuts and candidate tables, with the chained cut of cLoops/pipe.py:247-275;
+(ii) configs[3] against the chain of the SEQUENTIAL C oracle over the whole 200 M genome (tests/golden/
+synth200M_mode3_oracle_chain.json, made by tests/golden/make_golden_synth200M_chain.py: every step's PET / box counts and
+cut, the final cut, per chromosome the number and a checksum of the surviving candidate boxes); (iii) runSweepFast
+(statistics on the GPU) == runSweep (labels and distance lists on the host, the reference's data flow) on a scaled
+genome; (iv) equality with the C oracle's chain, run by run, on one chromosome of the 200 M genome at the mode-3 /
+mode-4 parameters and on one chromosome of the 500 M genome at configs[4]'s parameters (eps 1000 / 4000 / 10000 x minPts
+50, 30, 20, 10, 5 in the reference's order, pipe.py:310-324), chained cut included."""
+import json
+import multiprocessing as mp
+import os
+
 import numpy as np
 import pytest
 
@@ -48,10 +54,27 @@ def _same(a, b):
         assert np.array_equal(a[4][k], b[4][k]), k
 
 
+def _check_against_oracle_chain(snap, path):
+    """the whole-genome chain of the sequential C oracle (one process per chromosome, the reference's estimator on the
+    concatenated distance lists): every step and the final candidate tables"""
+    from golden_util import box_checksum
+    want = json.load(open(path))
+    cut, cuts_out, n_in, n_inter, boxes = snap
+    assert cuts_out == [s.get("cut_out") for s in want["steps"]]
+    assert n_in == [s["n_in"] for s in want["steps"]]
+    assert n_inter == [s["n_inter"] for s in want["steps"]]
+    assert cut == want["final_cut"]
+    assert sum(len(v) for v in boxes.values()) == want["candidates"]
+    for name, w in want["chromosomes"].items():
+        got = boxes.get(name, np.zeros((0, 4), np.int32))
+        assert len(got) == w["candidates"], name
+        assert box_checksum(got) == w["checksum"], name
+
+
 @pytest.mark.parametrize("name,n_total,cfg,mode,only", [
     ("configs[2]", 40000000, 4, MODE4, None),
     ("configs[3]", 200000000, 3, MODE3, None),
-    ("configs[4]", 500000000, 5, DENSE, ("chr1", "chr2", "chr21")),
+    ("configs[4]", 500000000, 5, DENSE, None),
 ])
 def test_full_size_sweep_is_deterministic(name, n_total, cfg, mode, only):
     fs = _load(n_total, cfg, only)
@@ -63,9 +86,7 @@ def test_full_size_sweep_is_deterministic(name, n_total, cfg, mode, only):
         assert a[2][0] == sum(len(pipe.CACHE.get(f).d) for f in fs)           # the first run sees every PET (cut 0)
         assert all(x <= a[2][0] for x in a[2]) and sum(len(v) for v in a[4].values()) > 0
         if name == "configs[3]":
-            # the chain this genome has produced since round 1 (profiles/r1/sweeps_one_gpu.txt)
-            assert a[1] == [4536, 6098, 6306, 5711, 3871, 5004, 5256, 5517, 4896, 5977, 6250, 6428]
-            assert a[0] == 3871 and sum(len(v) for v in a[4].values()) == 3651369
+            _check_against_oracle_chain(a, os.path.join(os.path.dirname(__file__), "golden", "synth200M_mode3_oracle_chain.json"))
     finally:
         pipe.CACHE.clear()
 
@@ -92,35 +113,51 @@ def test_sweep_fast_equals_sweep_on_scaled_genome(mode):
         pipe.CACHE.clear()
 
 
-@pytest.mark.parametrize("mode,ci", [(MODE3, 20), (MODE4, 18)], ids=["mode3-chr21", "mode4-chr19"])
-def test_chain_equals_oracle_on_one_chromosome(mode, ci):
-    """one chromosome of the 200 M genome (3.1 M / 3.9 M PETs): every run of the chained sweep against the sequential
-    C oracle -- candidate boxes of every step, the distance lists' statistics through the reference's estimator, the
-    cut handed to the next step"""
-    name, length, n = chrom_sizes(200000000)[ci]
-    X, Y = synth_chrom(n, length, 1000 * 3 + ci)
+_ORACLE_XY = None          # the chromosome of the running test: the forked oracle workers inherit it
+
+
+def _oracle_run(job):
+    ep, m, cut = job
+    X, Y = _ORACLE_XY
+    ref = oracle.single_dbscan("v2", X, Y, ep, m, cut)
+    return ref["dataI"], len(ref["dataS"]), ref["dis"], ref["dss"]
+
+
+@pytest.mark.parametrize("n_total,cfg,mode,ci", [
+    (200000000, 3, MODE3, 20), (200000000, 3, MODE4, 18),
+    (500000000, 5, ([1000, 4000, 10000], DENSE[1]), 20),
+], ids=["mode3-chr21", "mode4-chr19", "configs4-chr21"])
+def test_chain_equals_oracle_on_one_chromosome(n_total, cfg, mode, ci):
+    """one chromosome of the 200 M genome (3.1 M / 3.9 M PETs) or of the 500 M genome (7.7 M PETs): every run of the
+    chained sweep against the sequential C oracle -- candidate boxes of every step, the distance lists' statistics through
+    the reference's estimator, the cut handed to the next step.  The oracle's runs are independent once each is given the
+    cut the GPU chain handed in (which the previous run's check has just pinned), so they run side by side."""
+    name, length, n = chrom_sizes(n_total)[ci]
+    X, Y = synth_chrom(n, length, 1000 * cfg + ci)
     pipe.CACHE.clear()
     f = pipe.CACHE.put_arrays("%s-%s" % (name, name), X, Y)
     try:
         dataI, final_cut, cuts, steps = pipe.runSweepFast([f], mode[0], mode[1], cut=0)
+        settings = [(ep, m) for ep in mode[0] for m in mode[1]]
+        assert len(steps) == len(settings)
+        global _ORACLE_XY
+        _ORACLE_XY = (X, Y)
+        jobs = [(ep, m, st["cut_in"]) for (ep, m), st in zip(settings, steps)]
+        with mp.get_context("fork").Pool(min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as pool:
+            refs = pool.map(_oracle_run, jobs, chunksize=1)
         cut = 0
         seen, want_rows, want_cuts = set(), [], []
-        k = 0
-        for ep in mode[0]:
-            for m in mode[1]:
-                ref = oracle.single_dbscan("v2", X, Y, ep, m, cut)
-                st = steps[k]
-                k += 1
-                assert st["cut_in"] == cut and st["n_inter"] == len(ref["dataI"]) and st["n_self"] == len(ref["dataS"])
-                assert st["n_in"] == int(((Y.astype(np.int64) - X) >= cut).sum())
-                for b in ref["dataI"]:                      # combineTwice: first appearance of an exact box wins
-                    if tuple(b) not in seen:
-                        want_rows.append(b)
-                seen.update(tuple(b) for b in ref["dataI"])
-                cut2, frags = ests.estIntSelCutFrag(ref["dis"], ref["dss"])
-                assert (st["cut_out"], st["frags"]) == (cut2, frags), (ep, m)
-                want_cuts.append(cut2)
-                cut = cut2
+        for (ep, m), st, (rI, nS, dis, dss) in zip(settings, steps, refs):
+            assert st["cut_in"] == cut and st["n_inter"] == len(rI) and st["n_self"] == nS, (ep, m)
+            assert st["n_in"] == int(((Y.astype(np.int64) - X) >= cut).sum())
+            for b in rI:                                # combineTwice: first appearance of an exact box wins
+                if tuple(b) not in seen:
+                    want_rows.append(b)
+            seen.update(tuple(b) for b in rI)
+            cut2, frags = ests.estIntSelCutFrag(dis, dss)
+            assert (st["cut_out"], st["frags"]) == (cut2, frags), (ep, m)
+            want_cuts.append(cut2)
+            cut = cut2
         assert final_cut == min(want_cuts)
         want = np.asarray(want_rows, dtype=np.int64).reshape(-1, 4)
         want = want[((want[:, 2] + want[:, 3]) // 2 - (want[:, 0] + want[:, 1]) // 2) >= final_cut]      # filterClusterByDis
