@@ -7,6 +7,19 @@ operations in the same order as the reference (abs, drop NaN, drop <= 0, log2, m
 import numpy as np
 
 
+def estFragSize(ds, top=500):
+    """cLoops/ests.py:23-33: the fragment size behind `eps = 0` (pipe.py:237-239: eps = [2 * frags]) -- the median of the
+    `top` most frequent distances between PETs mapped to different strands.  Same pandas calls as the reference (a
+    Series of the distance counts, `sort_values(ascending=False)` with its default sort, the first `top` index values):
+    which of several equally frequent distances make the cut is whatever pandas' sort does, here as there."""
+    from collections import Counter
+    import pandas as pd
+    ds = pd.Series(Counter(ds))
+    ds.sort_values(inplace=True, ascending=False)
+    ds = ds[:top]
+    return int(np.median(ds.index))
+
+
 def estIntSelCutFrag(di, ds, log=1):
     """di: distances of PETs in inter-ligation clusters; ds: of self-ligation PETs.
     Returns (rcut, rfrags) as Python ints (ests.py:57,60)."""

@@ -1,7 +1,7 @@
 """Input side of the hot path: BEDPE -> per-chromosome PET arrays -> `.jd` / HBM.
 
-Restates cLoops/io.py:30-59 (class PET), :132-189 (parseRawBedpe2), :192-203 (txt2jd) and
-:206-217 (parseJd) with the reference's PYTHON-2 semantics:
+Restates cLoops/io.py:30-59 (class PET), :62-129 (parseRawBedpe, the `eps = 0` input path), :132-189
+(parseRawBedpe2), :192-203 (txt2jd) and :206-217 (parseJd) with the reference's PYTHON-2 semantics:
 
   * cis PETs only (chromA == chromB, io.py:168), optional chromosome filter (:171);
   * lines holding both a "*" and a "-1" field, or fewer than 6 fields, or non-integer
@@ -24,10 +24,15 @@ def _open(f):
     return gzip.open(f, "rt") if f.endswith(".gz") else open(f)
 
 
-def parse_bedpe(fs, cs=(), cut=0):
-    """-> (OrderedDict-like dict chrom -> int64 [n,3] rows [id, X, Y] in file order, n_lines, n_cis)."""
+def parse_bedpe(fs, cs=(), cut=0, unique=False, strand_distances=None):
+    """-> (OrderedDict-like dict chrom -> int64 [n,3] rows [id, X, Y] in file order, n_lines, n_cis).
+
+    `unique` / `strand_distances` are the two extras of the reference's `eps = 0` parser (cLoops/io.py:62-129):
+    a PET whose (cA, cB) was already seen on its chromosome is dropped (:113-114), and the distances of the kept
+    PETs whose two ends map to different strands are appended to the list `strand_distances` (:122-123).  That
+    parser also tests only chromA against the wanted chromosomes (:98; the PETs are cis anyway)."""
     cs = set(cs) if cs else set()
-    xs, ys = {}, {}
+    xs, ys, seen = {}, {}, {}
     i = j = 0
     for f in fs:
         with _open(f) as fh:
@@ -56,7 +61,13 @@ def parse_bedpe(fs, cs=(), cut=0):
                 if cut > 0 and cB - cA < cut:
                     continue
                 if chromA not in xs:
-                    xs[chromA], ys[chromA] = [], []
+                    xs[chromA], ys[chromA], seen[chromA] = [], [], set()
+                if unique:
+                    if (cA, cB) in seen[chromA]:
+                        continue
+                    seen[chromA].add((cA, cB))
+                if strand_distances is not None and line[8] != line[9]:
+                    strand_distances.append(cB - cA)
                 xs[chromA].append(cA)
                 ys[chromA].append(cB)
                 j += 1
@@ -69,6 +80,26 @@ def parse_bedpe(fs, cs=(), cut=0):
         m[:, 2] = ys[c]
         out[c] = m
     return out, i, j
+
+
+def parseRawBedpe(fs, fout, cs, cut, logger=None):
+    """cLoops/io.py:62-129, the parser of the `eps = 0` path (pipe.py:231-232): like parseRawBedpe2 but duplicates
+    (same two mid-points on a chromosome) are removed and the distances of the PETs mapped to different strands come
+    back as the second value -- `ests.estFragSize` turns them into eps (pipe.py:237-239)."""
+    import joblib
+    for f in fs:
+        if logger is not None:
+            logger.info("Parsing PETs from %s, requiring initial distance cutoff > %s" % (f, cut))
+    ds = []
+    mats, i, j = parse_bedpe(fs, cs, cut, unique=True, strand_distances=ds)
+    cfs = []
+    for c, m in mats.items():
+        cf = os.path.join(fout, "%s-%s" % (c, c) + ".jd")
+        joblib.dump(m, cf)
+        cfs.append(cf)
+    if logger is not None:
+        logger.info("Totaly %s PETs from %s, in which %s cis PETs" % (i, ",".join(fs), j))
+    return cfs, ds
 
 
 def parseRawBedpe2(fs, fout, cs, cut, logger=None):

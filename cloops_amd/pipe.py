@@ -695,8 +695,8 @@ def pipe(fs, fout, eps, minPts, chroms="", cpu=1, tmp=0, hic=0, washU=0, juice=0
     distance cutoff on the GPU(s) -> candidate loops -> significance -> `<fout>.loop`.
 
     Differences to the reference, all outside the hot path: no washU / juicebox conversion and no
-    plots (`washU`, `juice`, `plot` are accepted and ignored), `eps == 0` (auto-eps from the strand
-    distances, io.py:62-129) is not supported."""
+    plots (`washU`, `juice`, `plot` are accepted and ignored).  `eps == 0` estimates eps from the distances of the
+    PETs mapped to different strands (io.py:62-129, ests.py:23-33)."""
     import shutil
     from . import io as cio
     from . import cModel
@@ -708,10 +708,14 @@ def pipe(fs, fout, eps, minPts, chroms="", cpu=1, tmp=0, hic=0, washU=0, juice=0
         if log:
             log("working directory %s exists, return." % fout)
         return
-    if eps == 0 or eps == [0]:
-        raise NotImplementedError("eps = 0 (auto-estimated eps, cLoops/io.py:62-129) is outside the ported path")
     os.mkdir(fout)
-    cfs = [cio.txt2jd(f) for f in cio.parseRawBedpe2(fs, fout, chroms, cut)]
+    if eps == 0 or eps == [0]:                                # pipe.py:231-239: eps from the data
+        from .ests import estFragSize
+        cfs, ds = cio.parseRawBedpe(fs, fout, chroms, cut)
+        cfs = [cio.txt2jd(f) for f in cfs]
+        eps = [estFragSize(ds) * 2]
+    else:
+        cfs = [cio.txt2jd(f) for f in cio.parseRawBedpe2(fs, fout, chroms, cut)]
     dataI, cut, cuts, steps = runSweepFast(cfs, eps, minPts, cut=cut, max_cut=max_cut, log=log)
     records = {key: {"f": v["f"], "records": _records(key, v["boxes"])} for key, v in dataI.items()}
     e = cModel.runStat(records, minPts, 0, cpu, fout, hic)    # pipe.py:284 passes cut = 0

@@ -129,6 +129,38 @@ def test_end_to_end_bedpe_to_loop_file(tmp_path):
     assert not os.path.isdir(fout)                         # pipe.py:294-295 removes the working directory
 
 
+def test_end_to_end_auto_eps(tmp_path):
+    """`-eps 0` (cLoops/pipe.py:231-239): eps = 2 x the fragment size estimated from the PETs mapped to different strands
+    (io.py:62-129 also drops duplicate PETs); the run then equals a run with that eps given on the de-duplicated file."""
+    import gzip
+    import os
+    from cloops_amd import io as cio, ests
+    X, Y = G.chr21_xy()
+    bed = os.path.join(str(tmp_path), "in.bedpe.gz")
+    with gzip.open(bed, "wt") as fh:                       # mid-points (X, Y); two of three PETs on different strands; 500 duplicates
+        rows = list(zip(X.tolist(), Y.tolist()))
+        for k, (x, y) in enumerate(rows + rows[:500]):
+            fh.write("chr21\t%d\t%d\tchr21\t%d\t%d\tid\t1\t+\t%s\n" % (x, x, y, y, "-" if k % 3 else "+"))
+    d = os.path.join(str(tmp_path), "p")
+    os.mkdir(d)
+    cfs, ds = cio.parseRawBedpe([bed], d, [], 0)
+    eps = ests.estFragSize(ds) * 2
+    assert eps > 0 and len(ds) > 1000
+    uniq = os.path.join(str(tmp_path), "uniq.bedpe.gz")     # the same PETs without the duplicates, for the run with eps given
+    import joblib
+    m = joblib.load(cfs[0])
+    with gzip.open(uniq, "wt") as fh:
+        for _, x, y in m.tolist():
+            fh.write("chr21\t%d\t%d\tchr21\t%d\t%d\tid\t1\t+\t-\n" % (x, x, y, y))
+    pipe.CACHE.clear()
+    a = pipe.pipe([bed], os.path.join(str(tmp_path), "auto"), 0, [5], tmp=0, hic=0)
+    pipe.CACHE.clear()
+    b = pipe.pipe([uniq], os.path.join(str(tmp_path), "given"), [eps], [5], tmp=0, hic=0)
+    pipe.CACHE.clear()
+    assert [s["eps"] for s in a] == [eps] and a == b
+    assert open(os.path.join(str(tmp_path), "auto.loop")).read() == open(os.path.join(str(tmp_path), "given.loop")).read()
+
+
 def test_sig_counts_kernel_vs_sets():
     """K8 interval counts == the set-based host restatement (cModel.CoverageModel), incl. a cut filter"""
     import fake_backend

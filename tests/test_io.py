@@ -83,3 +83,50 @@ def test_against_reference_parser_with_py2_semantics(tmp_path):
     ref = np.loadtxt(cfs[0], dtype=np.int64)
     mats, _, _ = cio.parse_bedpe([BEDPE])
     assert np.array_equal(ref, mats["chr21"])
+
+
+@pytest.mark.skipif(not refload.available(), reason="reference checkout not present")
+def test_auto_eps_path_against_the_reference(tmp_path):
+    """`eps = 0` (cLoops/pipe.py:231-239): the reference's parseRawBedpe (duplicate removal, distances of the PETs mapped to
+    different strands; sliced out of the py2-only io.py with the same two py2 -> py3 patches as above) and its own
+    estFragSize (ests.py:23-33) on the example file, against cloops_amd.io.parseRawBedpe / cloops_amd.ests.estFragSize."""
+    import joblib
+    from cloops_amd import ests
+    with open(os.path.join(refload.REF_ROOT, "cLoops", "io.py")) as fh:
+        lines = fh.read().split("\n")
+
+    def block(start_pat):
+        s = [i for i, l in enumerate(lines) if l.startswith(start_pat)][0]
+        e = [i for i, l in enumerate(lines) if i > s and (l.startswith("def ") or l.startswith("class "))][0]
+        return "\n".join(lines[s:e])
+    src = block("class PET") + "\n" + block("def parseRawBedpe(")
+    src = src.replace(") / 2", ") // 2").replace('"rb"', '"rt"')
+
+    class L(object):
+        def info(self, *a):
+            pass
+    ns = {"gzip": gzip, "os": os, "cFlush": lambda *a: None}
+    exec(compile(src, "io.py:slice", "exec"), ns)
+    # the example file, and a file with duplicated PETs (the example holds none): the first 3000 lines followed by the
+    # first 1000 again
+    dup = str(tmp_path / "dup.bedpe")
+    with gzip.open(BEDPE, "rt") as fh:
+        head = [next(fh) for _ in range(3000)]
+    with open(dup, "w") as fh:
+        fh.writelines(head + head[:1000])
+    for k, f in enumerate((BEDPE, dup)):
+        out = tmp_path / ("ref%d" % k)
+        out.mkdir()
+        cfs, ds = ns["parseRawBedpe"]([f], str(out), [], 0, L())
+        ref = np.loadtxt(cfs[0], dtype=np.int64)
+        mine = tmp_path / ("mine%d" % k)
+        mine.mkdir()
+        cfs2, ds2 = cio.parseRawBedpe([f], str(mine), [], 0)
+        assert len(cfs) == len(cfs2) == 1
+        assert np.array_equal(ref, joblib.load(cfs2[0]))
+        assert ds == ds2 and len(ds) > 100 and len(ds) < len(ref)
+        want = refload.ref_ests().estFragSize(ds)
+        assert ests.estFragSize(ds2) == want and want > 0
+        if k == 1:
+            mats, _, _ = cio.parse_bedpe([f])
+            assert len(ref) < len(mats["chr21"])            # the duplicate filter really dropped PETs
