@@ -44,8 +44,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# two hardware queues serve the per-chromosome streams best (cloops_amd/_lib.py has the measurements); set here as well because
-# with --gpus N torch initialises the HIP runtime before libcloops_hip.so is loaded
+# two hardware queues serve the 23 per-chromosome streams best (1 queue 0.378 s, 2 -> 0.311, 4 -> 0.35 for
+# the sweep of round 2); an application-level choice -- the library itself touches no environment variable -- that has to be
+# made before the first HIP call of the process (with --gpus N that is torch's); an explicit setting wins
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 N_TOTAL = 200000000
@@ -65,6 +66,8 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU ranks (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-with-labels", action="store_true", help="skip the label-inclusive sweep (labels + tables on the host every run)")
+    ap.add_argument("--proxy-ranks", type=int, default=8, help="single-GPU scaling proxy: time every rank's LPT share of N alone (0 = off)")
     return ap.parse_args(argv)
 
 
@@ -232,6 +235,12 @@ def main(argv=None):
             if k2_log:
                 line["roofline"]["in_sweep_avg_launch_ms"] = sum(max(t[3]["ms_region"] - t[3]["ms_bracket"], 1e-6) for t in k2_log) / len(k2_log)
                 line["roofline"]["in_sweep_source"] = "HIP events around K2 on chr1's stream during the last warm-up sweep (same work as a timed one; the event records between the kernels cost a sweep ~7 %, so the timed sweeps run without them)"
+    # single-GPU legs behind the timed region: the label-inclusive form of the same sweep, the scaling proxy
+    if rank == 0 and world == 1 and on_gpu:
+        if not args.no_with_labels:
+            line["with_labels"] = with_labels_sweep(pipe, fs, steps, pets // max(1, args.steps))
+        if args.proxy_ranks > 1:
+            line["scaling_proxy"] = scaling_proxy(pipe, lpt_assign, fs, sizes, steps, args.proxy_ranks, elapsed / max(1, args.steps))
     # the secondary single-eps figure and the CPU baseline: rank 0, single GPU only
     if rank == 0 and world == 1 and on_gpu:
         pipe.CACHE.clear()
@@ -296,6 +305,66 @@ def roofline_block(k2_log, n_probe):
             "algorithmic_bytes_per_launch": b // len(k2_log), "avg_launch_ms": net / len(k2_log),
             "avg_event_bracket_ms": raw / len(k2_log), "empty_kernel_bracket_ms": float(k2_log[0][3]["ms_bracket"]),
             "per_eps": per_eps}
+
+
+def with_labels_sweep(pipe, fs, steps, pets_per_sweep, reps=2):
+    """SURVEY.md 8d(1)'s end point on the headline workload: the same 12 runs (the chain's own eps, minPts, cut) over the same
+    23 resident chromosomes, every run landing ROW-ALIGNED labels and its cluster table in pinned host memory (what
+    cLoops/pipe.py:70-102 consumes) -- the row-order label scatter and 0.8 GB of labels over PCIe per run that the sweep's
+    own form (statistics and candidates on the device) never pays.  All chromosomes of a run are enqueued, then collected."""
+    res = [pipe.CACHE.get(f) for f in fs]
+    res.sort(key=lambda r: -len(r.d))
+    for r in res:
+        r.chrom.set_device_labels(True)
+
+    def sweep():
+        nlab = 0
+        for st in steps:
+            for r in res:
+                r.chrom.cluster_async(VARIANT, st["eps"], st["minPts"], st["cut_in"], want_labels=True, want_boxes=True)
+            for r in res:
+                out = r.chrom.wait()
+                nlab += int(out.labels.shape[0])
+        return nlab
+    sweep()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        nlab = sweep()
+    dt = (time.perf_counter() - t0) / reps
+    for r in res:
+        r.chrom.set_device_labels(False)
+    return {"sweep_wall_s": dt, "value": pets_per_sweep / dt, "unit": "PETs/s", "runs": len(steps), "labels_to_host_per_sweep": nlab,
+            "end_point": "row-aligned int32 labels of every PET + the cluster table of every run in pinned host memory "
+                         "(SURVEY.md 8d(1)); cuts = the chain of the timed sweeps; no statistics / candidate work on the device"}
+
+
+def scaling_proxy(pipe, lpt_assign, fs, sizes, steps, nranks, one_gpu_sweep_s, reps=2):
+    """Single-GPU evidence for the N-GPU claim: the sweep time of EVERY rank's LPT share of `nranks`, each share alone on
+    this GPU, replaying the genome-wide chain (the cuts a real run all-reduces) -- the makespan over the ranks is what an
+    N-GPU run cannot beat; the per-run statistics all-reduce and the final table gather come on top."""
+    shares = lpt_assign([n for _, _, n in sizes], nranks)
+    forced = [s.get("cut_out") for s in steps]
+    eps = sorted({s["eps"] for s in steps})
+    mps = sorted({s["minPts"] for s in steps}, reverse=True)
+    per = []
+    for r, share in enumerate(shares):
+        fr = [fs[ci] for ci in sorted(share)]
+        if not fr:
+            per.append({"rank": r, "chromosomes": [], "pets": 0, "sweep_wall_s": 0.0})
+            continue
+        pipe.runSweepFast(fr, eps, mps, cut=0, variant=VARIANT, forced_cuts=forced)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pipe.runSweepFast(fr, eps, mps, cut=0, variant=VARIANT, forced_cuts=forced)
+        dt = (time.perf_counter() - t0) / reps
+        per.append({"rank": r, "chromosomes": [sizes[ci][0] for ci in sorted(share)], "pets": int(sum(sizes[ci][2] for ci in share)),
+                    "sweep_wall_s": dt})
+    mk = max(p["sweep_wall_s"] for p in per)
+    return {"ranks": nranks, "per_rank": per, "makespan_s": mk, "one_gpu_sweep_s": one_gpu_sweep_s,
+            "implied_speedup": one_gpu_sweep_s / mk if mk > 0 else None, "implied_efficiency": one_gpu_sweep_s / mk / nranks if mk > 0 else None,
+            "lpt_balance": max(p["pets"] for p in per) / (sum(p["pets"] for p in per) / float(nranks)),
+            "note": "each rank's share timed ALONE on one MI355X with the genome-wide cut chain forced (runSweepFast(forced_cuts)); "
+                    "excludes the per-run all-reduce of ~48 KB of statistics and the final RCCL gather of the candidate tables"}
 
 
 def secondary_5m(api, synth_chrom, steps=20, warmup=3):

@@ -1,7 +1,12 @@
 """`python -m cloops_amd ...` (see cloops_amd.pipe.main)."""
+import os
 import sys
 
-from .pipe import main
+# the sweep keeps one stream per chromosome busy: two hardware queues serve them best; an
+# explicit setting of the user wins.  Must be in the environment before the first HIP call of the process.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
+from .pipe import main  # noqa: E402
 
 if __name__ == "__main__":
     sys.exit(main())

@@ -68,12 +68,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    # The sweep driver keeps one stream per chromosome (23 of them, plus their copy streams) busy at once.  The HIP runtime
-    # multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); measured on MI355X / ROCm 7.2 with the 200 M-PET
-    # mode-3 sweep: 1 queue 0.378 s, 2 queues 0.311 s, 3 queues 0.400 s, 4 queues 0.345-0.365 s, 8 queues 5.0 s, 16 queues 3.1 s
-    # (the kernels each fill the chip; more queues only add arbitration).  The runtime reads the variable when it initialises,
-    # so it has to be in the environment before the first HIP call of the process; an explicit setting wins.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+    # (The library reads and writes no environment variable.  An APPLICATION that keeps many chromosome handles busy at
+    # once -- the sweep driver keeps one stream per chromosome -- may want GPU_MAX_HW_QUEUES=2 in the environment before the
+    # first HIP call of the process: the HIP runtime multiplexes streams onto that many hardware queues (default 4), and two
+    # serve this pipeline best; bench.py and `python -m cloops_amd` set it unless the user has)
     path = SO_PATH
     if os.environ.get("CLOOPS_DEVEL_LIB") == "1":          # developer build with ablation knobs (cloops_amd/build.py --devel)
         path = SO_PATH.replace(".so", "_devel.so")

@@ -428,6 +428,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         }
         return c;
     };
+    constexpr bool DEFER = HALO >= 512;                 // dense shapes
     int n3 = 0;
     for (int h = lane; h < n2; h += 64) {
         const unsigned ent = my_list[h];
@@ -523,7 +524,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
                     // has consumed so far, 64 entries per round, is free -- an entry that would not fit is counted here)
                     const unsigned long long bal = __ballot(true);
                     const int slot = n3 + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                    if (2 * slot + 1 < (h - lane) + 64) {
+                    if (DEFER && 2 * slot + 1 < (h - lane) + 64) {
                         my_list[2 * slot] = ent; my_list[2 * slot + 1] = (unsigned)ja | ((unsigned)jb << 16);
                         deferred = true;
                     } else c = count_candidates(c, ja, jb, qhi, pbeg, pend2, plo, phi);
@@ -542,9 +543,12 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
             }
         }
         // the number of deferred PETs of this round, seen by every lane that is still in the loop (wave-uniform count)
-        n3 += __popcll(__ballot(deferred));
+        if (DEFER) n3 += __popcll(__ballot(deferred));
         if (!deferred) emit(tix, li, c, hja, hjb);
     }
+    // (the sparse shape never defers -- DEFER is a compile-time property of the tile shape: its strips are short, the few
+    // candidate loops run in place and the tile ends here without the extra barrier)
+    if (!DEFER) { K2T(5); K2T_FLUSH; return; }
     // every lane needs the final n3: lanes that left the loop early missed the later rounds
     n3 = __builtin_amdgcn_readfirstlane(dpp_reduce_wave(n3, OpMax()));
     // ---- phase 3: the candidates of the deferred PETs.  A wave defers a few tens of PETs of its 64 U -- a quarter of a

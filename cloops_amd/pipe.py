@@ -448,7 +448,7 @@ def _lib_logbins():
 CUT_RECHECK_MARGIN = 1e-6
 
 
-def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, allsum=None, probe=None):
+def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, allsum=None, probe=None, forced_cuts=None):
     """runSweep with the per-step statistics reduced on the GPUs: neither labels nor distance
     lists come back to the host -- per chromosome only the K-row cluster table, a few sums, and
     the 256-bin histograms of an exact radix select for the median (all additive over chromosomes
@@ -463,15 +463,19 @@ def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, 
     `probe` (optional): called as probe(f, eps, minPts, cut_in, result) for every completed run (bench.py reads
     the HIP-event kernel timings of profiled handles through it).
 
+    `forced_cuts` (optional): one cut per step that REPLACES the cut estimated by that step (every step still does all
+    of its work, the estimate included) -- bench.py replays the genome-wide chain on one emulated rank's share of the
+    chromosomes with it.
+
     returns (dataI {key: {"f": f, "boxes": int32[k,4]}} of the local chromosomes, cut, cuts, steps)."""
     variant = variant or DBSCAN_VARIANT
     gsum = allsum if allsum is not None else (lambda a: a)
     devs = _devices()
     with CACHE.pinned(fs, devs) as res_all:
-        return _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gsum, probe)
+        return _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gsum, probe, forced_cuts)
 
 
-def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gsum, probe=None):
+def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gsum, probe=None, forced_cuts=None):
     cuts = [cut]
     steps = []
     live = [(f, r) for f, r in zip(fs, res_all) if len(r.d)]
@@ -573,6 +577,10 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                 if int(g[3]) == 0:                            # pipe.py:251-255
                     if log:
                         log("ERROR: no inter-ligation PETs detected for eps %s minPts %s,can't model the distance cutoff,continue anyway" % (ep, m))
+                    if forced_cuts is not None and forced_cuts[this_step] is not None:
+                        cut = int(forced_cuts[this_step])
+                        cuts.append(cut)
+                        st["cut_out"] = cut
                     continue
                 xshift = float(gf[4]) / max(float(gf[5]), 1.0)            # the library constant (ranks without a chromosome report 0)
                 tot = {"n_all": [int(gi[4]), int(gi[5])], "n_pos": [int(gi[6]), int(gi[7])]}
@@ -600,10 +608,16 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                         st["cut_rechecked"] = True
                     if log:
                         log("Estimated inter-ligation and self-ligation distance cutoff as %s for eps=%s,minPts=%s" % (cut_2, ep, m))
+                    if forced_cuts is not None and forced_cuts[this_step] is not None:
+                        cut_2 = int(forced_cuts[this_step])
                     st["cut_out"] = int(cut_2)
                     st["frags"] = int(frags)
                     cuts.append(cut_2)
                     cut = cut_2                               # pipe.py:274
+                elif forced_cuts is not None and forced_cuts[this_step] is not None:
+                    cut = int(forced_cuts[this_step])
+                    cuts.append(cut)
+                    st["cut_out"] = cut
         pos = [c for c in cuts if c > 0]
         if pos:
             cut = int(np.max(pos)) if max_cut else int(np.min(pos))     # pipe.py:276-280
