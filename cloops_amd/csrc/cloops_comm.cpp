@@ -1,0 +1,136 @@
+// cloops_comm.cpp -- libcloops_comm.so: RCCL collectives of the multi-GPU path behind the C ABI of include/cloops_comm.h
+// (one process per GPU, no PyTorch in the process).  Host buffers are staged through one pinned buffer and one device
+// buffer per communicator, both grown on demand; every call returns with its result on the host.
+#include <cstring>
+#include <string>
+#include <algorithm>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include "../../include/cloops_comm.h"
+
+static thread_local std::string g_cerr;
+static int cfail(const char* what, const char* detail)
+{
+    g_cerr = what;
+    if (detail) { g_cerr += ": "; g_cerr += detail; }
+    return -2;
+}
+#define HIPC(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return cfail(#expr, hipGetErrorString(e_)); } while (0)
+#define NCC(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) return cfail(#expr, ncclGetErrorString(r_)); } while (0)
+
+struct cl_comm {
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    int rank = 0, world = 1, device = 0;
+    void* pin = nullptr; size_t pin_bytes = 0;
+    void* dev = nullptr; size_t dev_bytes = 0;
+};
+
+extern "C" const char* cl_comm_last_error(void) { return g_cerr.c_str(); }
+
+extern "C" int cl_comm_unique_id(void* id_out)
+{
+    if (!id_out) return cfail("cl_comm_unique_id", "null argument");
+    static_assert(sizeof(ncclUniqueId) == CL_COMM_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    NCC(ncclGetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+
+extern "C" int cl_comm_init(const void* idp, int rank, int world, int device, cl_comm** out)
+{
+    if (!idp || !out || world < 1 || rank < 0 || rank >= world) return cfail("cl_comm_init", "bad arguments");
+    *out = nullptr;
+    HIPC(hipSetDevice(device));
+    cl_comm* c = new cl_comm();
+    c->rank = rank; c->world = world; c->device = device;
+    ncclUniqueId id;
+    memcpy(&id, idp, sizeof(id));
+    hipError_t he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) { delete c; return cfail("hipStreamCreateWithFlags", hipGetErrorString(he)); }
+    ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) { (void)hipStreamDestroy(c->stream); delete c; return cfail("ncclCommInitRank", ncclGetErrorString(r)); }
+    *out = c;
+    return 0;
+}
+
+extern "C" void cl_comm_destroy(cl_comm* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->pin) (void)hipHostFree(c->pin);
+    if (c->dev) (void)hipFree(c->dev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int cl_comm_rank(const cl_comm* c) { return c ? c->rank : -1; }
+extern "C" int cl_comm_world(const cl_comm* c) { return c ? c->world : -1; }
+
+static int ensure(cl_comm* c, size_t pin_bytes, size_t dev_bytes)
+{
+    HIPC(hipSetDevice(c->device));
+    if (pin_bytes > c->pin_bytes) {
+        if (c->pin) (void)hipHostFree(c->pin);
+        c->pin = nullptr; c->pin_bytes = 0;
+        const size_t want = pin_bytes + pin_bytes / 4 + 4096;
+        HIPC(hipHostMalloc(&c->pin, want, hipHostMallocDefault));
+        c->pin_bytes = want;
+    }
+    if (dev_bytes > c->dev_bytes) {
+        if (c->dev) (void)hipFree(c->dev);
+        c->dev = nullptr; c->dev_bytes = 0;
+        const size_t want = dev_bytes + dev_bytes / 4 + 4096;
+        HIPC(hipMalloc(&c->dev, want));
+        c->dev_bytes = want;
+    }
+    return 0;
+}
+
+static int allreduce_f64(cl_comm* c, double* h, int64_t n, ncclRedOp_t op)
+{
+    if (!c || (n > 0 && !h) || n < 0) return cfail("cl_comm_allreduce", "bad arguments");
+    if (n == 0) return 0;
+    const size_t bytes = (size_t)n * 8;
+    int rc = ensure(c, bytes, bytes);
+    if (rc) return rc;
+    memcpy(c->pin, h, bytes);
+    HIPC(hipMemcpyAsync(c->dev, c->pin, bytes, hipMemcpyHostToDevice, c->stream));
+    NCC(ncclAllReduce(c->dev, c->dev, (size_t)n, ncclDouble, op, c->comm, c->stream));
+    HIPC(hipMemcpyAsync(c->pin, c->dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    memcpy(h, c->pin, bytes);
+    return 0;
+}
+
+extern "C" int cl_comm_allreduce_f64(cl_comm* c, double* h, int64_t n) { return allreduce_f64(c, h, n, ncclSum); }
+extern "C" int cl_comm_allreduce_max_f64(cl_comm* c, double* h, int64_t n) { return allreduce_f64(c, h, n, ncclMax); }
+
+extern "C" int cl_comm_allgather_i32(cl_comm* c, const int32_t* hin, int64_t n, int32_t* hout)
+{
+    if (!c || n < 0 || (n > 0 && (!hin || !hout))) return cfail("cl_comm_allgather_i32", "bad arguments");
+    if (n == 0) return 0;
+    const size_t in_bytes = (size_t)n * 4, out_bytes = in_bytes * (size_t)c->world;
+    int rc = ensure(c, out_bytes, in_bytes + out_bytes);
+    if (rc) return rc;
+    char* dsend = (char*)c->dev;
+    char* drecv = dsend + ((in_bytes + 255) / 256) * 256;
+    if ((size_t)(drecv - dsend) + out_bytes > c->dev_bytes) { rc = ensure(c, out_bytes, (size_t)(drecv - dsend) + out_bytes); if (rc) return rc; dsend = (char*)c->dev; drecv = dsend + ((in_bytes + 255) / 256) * 256; }
+    memcpy(c->pin, hin, in_bytes);
+    HIPC(hipMemcpyAsync(dsend, c->pin, in_bytes, hipMemcpyHostToDevice, c->stream));
+    NCC(ncclAllGather(dsend, drecv, (size_t)n, ncclInt32, c->comm, c->stream));
+    HIPC(hipMemcpyAsync(c->pin, drecv, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    memcpy(hout, c->pin, out_bytes);
+    return 0;
+}
+
+extern "C" int cl_comm_barrier(cl_comm* c)
+{
+    double one = 1.0;
+    return allreduce_f64(c, &one, 1, ncclSum);
+}

@@ -2228,16 +2228,18 @@ __device__ __forceinline__ void k7_reduce_block(const K7Part* __restrict__ parts
 // to pinned host memory from HERE, the last kernel of the step (the host reads them after the stream's completion event): no
 // copy-stream hand-over and no copy packets per run
 __global__ void __launch_bounds__(256)
-k7_reduce_parts(const K7Part* __restrict__ parts, int nparts, K7Part* __restrict__ out, const int* __restrict__ bcount /* or null */, int nb,
-                long long* __restrict__ totals, const unsigned long long* __restrict__ dev_step /* or null */, int step_words,
+k7_reduce_parts(const K7Part* __restrict__ parts, int nparts, K7Part* out, const int* __restrict__ bcount /* or null */, int nb,
+                long long* totals, const volatile unsigned long long* dev_step /* or null */, int step_words,
                 unsigned long long* __restrict__ host_step, const int* __restrict__ dev_hdr, int* __restrict__ host_hdr)
 {
+    // `out`, `totals` and `dev_step` are views of ONE device buffer (the step output: totals | reduced part | histograms):
+    // no restrict on them, and the copy to the host re-reads what thread 0 has just stored (volatile loads behind the fence)
     __shared__ double sd[4][256];
     __shared__ long long sn[4][256];
     k7_reduce_block(parts, nparts, out, bcount, nb, totals, sd, sn);
     if (dev_step) {
-        __syncthreads();                                // totals and the reduced part are written (same workgroup: visible)
         __threadfence();
+        __syncthreads();                                // totals and the reduced part are written (same workgroup: visible)
         for (int k = threadIdx.x; k < step_words; k += 256) host_step[k] = dev_step[k];
         if (threadIdx.x < 8) host_hdr[threadIdx.x] = dev_hdr[threadIdx.x];
     }
@@ -2689,6 +2691,26 @@ struct cl_chrom {
     bool ev_ready = false;
     float ev_bracket_ms = 0.f;        // event bracket around an empty kernel (calibration, see cl_timing)
 };
+
+// The candidate buffer of a sweep (K10) holds every inter-ligation box of every step: it grows on demand (contents kept) --
+// before a step is enqueued it has room for all the boxes the step can produce (one per cluster id, at most n / minPts).
+static int ensure_cand_capacity(cl_chrom* c, long long need)
+{
+    if (need <= c->cand_cap) return CL_OK;
+    const long long cap = std::max<long long>(std::max<long long>(need, 2 * c->cand_cap), 1 << 20);
+    DevBuf nb, ns;
+    int rc;
+    if ((rc = nb.ensure((size_t)cap * 16)) || (rc = ns.ensure((size_t)cap * 4))) { nb.release(); ns.release(); return rc; }
+    if (c->cand_n > 0) {
+        HIP_TRY(hipMemcpyAsync(nb.p, c->cand_box.p, (size_t)c->cand_n * 16, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(ns.p, c->cand_step.p, (size_t)c->cand_n * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    c->cand_box.release(); c->cand_step.release();
+    c->cand_box = nb; c->cand_step = ns;
+    c->cand_cap = cap;
+    return CL_OK;
+}
 
 static void free_chrom(cl_chrom* c)
 {
@@ -3297,17 +3319,13 @@ static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* la
         // the run's own completion (one wait per chromosome and step)
         int rc;
         if ((rc = c->k7_cls.ensure((size_t)n + 16))) return rc;
-        if (c->cand_cap == 0) {
-            const long long cap = std::max<long long>(c->n / 2, 1 << 20);
-            if ((rc = c->cand_box.ensure((size_t)cap * 16)) || (rc = c->cand_step.ensure((size_t)cap * 4))) return rc;
-            c->cand_cap = cap;
-        }
+        const int kmax = std::max(1, std::min(sl.kmax, n));     // the number of ids K is only known on the device: K <= kmax
+        if ((rc = ensure_cand_capacity(c, c->cand_n + kmax))) return rc;
         // step output (device and pinned host): 16 B box totals | the reduced statistics (one K7Part) | log histogram | fine window;
         // the workgroup partials live behind it on the device only
         const size_t out_bytes = 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8;
         if ((rc = sl.d_step.ensure(out_bytes + K7_BLOCKS * sizeof(K7Part)))) return rc;
         if (!sl.h_step) HIP_TRY(hipHostMalloc((void**)&sl.h_step, out_bytes, hipHostMallocDefault));
-        const int kmax = std::max(1, std::min(sl.kmax, n));     // the number of ids K is only known on the device: K <= kmax
         const int nb = nblocks(kmax, CAND_BLOCK);
         if ((rc = c->sel_tmp.ensure((size_t)nb * 12 + 64))) return rc;
         int* bcount = c->sel_tmp.as<int>();
@@ -3413,7 +3431,7 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
     c->k7_classified = sl.step_valid;                    // the step tail has classified this run's table already
     if (sl.step_valid) {
         const long long ni = ((const long long*)sl.h_step)[0];
-        if (c->cand_n + ni > c->cand_cap) return fail(CL_ERR_GRID, "candidate buffer full (more inter-ligation boxes over the sweep than n / 2)");
+        if (c->cand_n + ni > c->cand_cap) return fail(CL_ERR_GRID, "internal: candidate buffer overrun");
         c->cand_n += ni;
     }
     if (c->profiling) {
@@ -3917,11 +3935,7 @@ extern "C" int cl_cand_append(cl_chrom* c, int32_t step, int64_t* n_inter, int64
     cl_chrom::Slot& sl = c->slot[c->last_slot];
     const int K = sl.h_hdr[0];
     if (K <= 0) return CL_OK;
-    if (c->cand_cap == 0) {
-        const long long cap = std::max<long long>(c->n / 2, 1 << 20);
-        if ((rc = c->cand_box.ensure((size_t)cap * 16)) || (rc = c->cand_step.ensure((size_t)cap * 4))) return rc;
-        c->cand_cap = cap;
-    }
+    if ((rc = ensure_cand_capacity(c, c->cand_n + K))) return rc;
     const int nb = nblocks(K, CAND_BLOCK);
     if ((rc = c->sel_tmp.ensure((size_t)nb * 12 + 64))) return rc;
     int* bcount = c->sel_tmp.as<int>();
@@ -3938,7 +3952,7 @@ extern "C" int cl_cand_append(cl_chrom* c, int32_t step, int64_t* n_inter, int64
     HIP_TRY(hipStreamSynchronize(c->stream));
     long long ni = 0, ns = 0;
     for (int k = 0; k < nb; ++k) { ni += h[k]; ns += h[nb + k]; }
-    if (c->cand_n + ni > c->cand_cap) return fail(CL_ERR_GRID, "candidate buffer full (more inter-ligation boxes over the sweep than n / 2)");
+    if (c->cand_n + ni > c->cand_cap) return fail(CL_ERR_GRID, "internal: candidate buffer overrun");
     c->cand_n += ni;
     if (n_inter) *n_inter = ni;
     if (n_self) *n_self = ns;
@@ -3952,24 +3966,40 @@ extern "C" int cl_cand_finish(cl_chrom* c, int32_t final_cut, int32_t* boxes_out
     const long long N = c->cand_n;
     if (N == 0) return CL_OK;
     if (c->enq != c->deq) return fail(CL_ERR_ARG, "cl_cand_finish: asynchronous runs still in flight");
-    if (N > c->n) return fail(CL_ERR_GRID, "cl_cand_finish: more candidates than PETs");      // (the sort workspace is sized for n pairs)
+    if (N > INT_MAX - 1024) return fail(CL_ERR_GRID, "cl_cand_finish: more than 2^31 candidates");
     HIP_TRY(hipSetDevice(c->device));
     int rc;
     if ((rc = ensure_workspace(c, 1))) return rc;
     if ((rc = c->cand_keep.ensure((size_t)N + 64)) || (rc = c->cand_out.ensure((size_t)N * 16))) return rc;
     const int n = (int)N;
+    // the sort buffers of the handle are sized for its PETs; a sweep of many steps on a strongly clustered chromosome can
+    // leave more candidates than that: then the dedup sorts in buffers of its own (released at the end), and rocPRIM's
+    // temporary storage is sized from N with the configuration the sort below uses
+    struct Tmp { DevBuf kin, kout, vin, vout; ~Tmp() { kin.release(); kout.release(); vin.release(); vout.release(); } } tmp;
+    u64 *kin = c->keys_in.as<u64>(), *kout = c->keys_out.as<u64>();
+    u32 *vin = c->vals_in.as<u32>(), *vout = c->vals_out.as<u32>();
+    if (N > c->n) {
+        if ((rc = tmp.kin.ensure((size_t)N * 8)) || (rc = tmp.kout.ensure((size_t)N * 8)) || (rc = tmp.vin.ensure((size_t)N * 4)) ||
+            (rc = tmp.vout.ensure((size_t)N * 4))) return rc;
+        kin = tmp.kin.as<u64>(); kout = tmp.kout.as<u64>(); vin = tmp.vin.as<u32>(); vout = tmp.vout.as<u32>();
+    }
+    {
+        size_t need = 0;
+        hipError_t e0 = rocprim::radix_sort_pairs(nullptr, need, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, (size_t)n, 0, 64, c->stream);
+        if (e0 != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs size query (cand)", hipGetErrorString(e0));
+        if ((rc = c->sort_tmp.ensure(std::max<size_t>(need, 16)))) return rc;
+    }
     int* flags = c->counters.as<int>() + 60;
     // two different boxes sharing a 64-bit hash would be merged: the exact compare inside k_cand_mark notices, and the
     // pass is redone under another salt (a collision under four independent hashes does not happen)
     int hflag = 0;
     for (int attempt = 0; attempt < 4; ++attempt) {
         HIP_TRY(hipMemsetAsync(flags, 0, 4, c->stream));
-        LAUNCH(k_cand_hash, n, n, c->cand_box.as<int4>(), (u64)attempt * 0x9FB21C651E98DF25ull, c->keys_in.as<u64>(), c->vals_in.as<u32>());
+        LAUNCH(k_cand_hash, n, n, c->cand_box.as<int4>(), (u64)attempt * 0x9FB21C651E98DF25ull, kin, vin);
         size_t tmp_bytes = c->sort_tmp.bytes;
-        hipError_t e = rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->keys_in.as<u64>(), c->keys_out.as<u64>(), c->vals_in.as<u32>(), c->vals_out.as<u32>(),
-                                                 (size_t)n, 0, 64, c->stream);
+        hipError_t e = rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0, 64, c->stream);
         if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs(cand)", hipGetErrorString(e));
-        LAUNCH(k_cand_mark, n, n, c->keys_out.as<u64>(), c->vals_out.as<u32>(), c->cand_box.as<int4>(), c->cand_step.as<int>(), (int)final_cut,
+        LAUNCH(k_cand_mark, n, n, (const u64*)kout, (const u32*)vout, c->cand_box.as<int4>(), c->cand_step.as<int>(), (int)final_cut,
                c->cand_keep.as<unsigned char>(), flags);
         HIP_TRY(hipMemcpyAsync(&hflag, flags, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));

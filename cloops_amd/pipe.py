@@ -47,7 +47,7 @@ def parseJd(f, cut=0):
 # resident chromosomes
 # ---------------------------------------------------------------------------------------
 class _Resident(object):
-    __slots__ = ("key", "ids", "X", "Y", "d", "chrom", "device", "stamp", "lock", "pins")
+    __slots__ = ("key", "ids", "X", "Y", "d", "chrom", "device", "stamp", "lock", "pins", "sweep_lock", "replaced")
 
 
 class ChromCache(object):
@@ -98,6 +98,10 @@ class ChromCache(object):
                     for r in self_inner.rs:
                         r.pins -= 1
                     victims = cache._evict_idle()
+                    # a resident that was replaced in the cache while a sweep held it is closed by its last user
+                    victims += [r for r in self_inner.rs if r.replaced and r.pins == 0]
+                    for r in victims:
+                        r.replaced = False
                 for v in victims:
                     v.chrom.close()
                 return False
@@ -111,6 +115,8 @@ class ChromCache(object):
         r.key = tuple(name.split("-")) if "-" in name else (name, name)
         r.stamp, r.device = ("mem", len(X)), device
         r.lock = threading.Lock()
+        r.sweep_lock = threading.Lock()
+        r.replaced = False
         r.pins = 0
         r.X = np.ascontiguousarray(X)
         r.Y = np.ascontiguousarray(Y)
@@ -121,6 +127,8 @@ class ChromCache(object):
         with self._lock:
             old = self._items.pop(f, None)
             self._items[f] = r
+            if old is not None and old.pins > 0:
+                old.replaced, old = True, None            # still held by a sweep: its last user closes it
         if old is not None:
             old.chrom.close()
         return f
@@ -147,6 +155,8 @@ class ChromCache(object):
         r = _Resident()
         r.key, r.stamp, r.device = key, stamp, device
         r.lock = threading.Lock()
+        r.sweep_lock = threading.Lock()
+        r.replaced = False
         r.pins = 1 if _pin else 0
         if len(mat):
             r.ids = mat[:, 0]
@@ -161,9 +171,11 @@ class ChromCache(object):
             old = self._items.pop(f, None)
             self._items[f] = r
             victims = self._evict_idle()
+            if old is not None and old.pins > 0:
+                old.replaced, old = True, None            # still held by a sweep: its last user closes it
         for v in victims:
             v.chrom.close()
-        if old is not None and old.pins == 0:
+        if old is not None:
             old.chrom.close()
         return r
 
@@ -482,6 +494,11 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
     by_size = sorted(live, key=lambda fr: -len(fr[1].d))   # enqueue order: largest first (results are collected in file order)
     appended = {}                                        # f -> inter-ligation boxes appended on the device so far
     pool = ThreadPoolExecutor(max_workers=SWEEP_THREADS) if len(live) > 1 else None
+    # the candidate buffer, the layout and the sort index of a handle are state of ONE sweep: a second sweep over the same
+    # residents waits (locks taken in one global order, so two sweeps over overlapping sets cannot deadlock)
+    held = sorted({id(r): r for _, r in live}.values(), key=id)
+    for r in held:
+        r.sweep_lock.acquire()
     try:
         for f, r in live:
             r.chrom.cand_reset()
@@ -640,6 +657,8 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
     finally:
         if pool is not None:
             pool.shutdown(wait=True)
+        for r in held:
+            r.sweep_lock.release()
     return dataI, cut, cuts, steps
 
 

@@ -1,0 +1,56 @@
+/*
+ * cloops_comm.h -- C ABI of libcloops_comm.so: the few RCCL collectives of the multi-GPU path of the cDBSCAN hot path,
+ * one process per GPU, no PyTorch in the process.
+ *
+ * The reference runs its per-chromosome workers as joblib processes and merges their pickled results in the parent
+ * (cLoops/pipe.py:113-127); between the steps of the sweep the parent estimates ONE distance cut from the concatenated
+ * distance lists of all chromosomes (cLoops/pipe.py:247-275).  Here the ranks own chromosomes, so the path has exactly two
+ * exchanges: the per-step sum of a small vector of statistics (cl_comm_allreduce_f64: counts ride as float64, exact below
+ * 2^53) and, once per sweep, the gather of the candidate tables (cl_comm_allgather_i32 of the row counts, then of the
+ * padded rows).  Both run over RCCL (xGMI inside a node) on a stream of the library's own.
+ *
+ * The 128-byte ncclUniqueId is made by rank 0 (cl_comm_unique_id) and handed to the other ranks by the HOST program
+ * (cloops_amd/comm.py: a file in /tmp keyed by the launcher's pid; any other channel works as well).
+ */
+#ifndef CLOOPS_COMM_H
+#define CLOOPS_COMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CL_COMM_ID_BYTES 128
+
+typedef struct cl_comm cl_comm;
+
+/* last error text of the calling thread */
+const char* cl_comm_last_error(void);
+
+/* rank 0: a fresh unique id (CL_COMM_ID_BYTES bytes) for cl_comm_init of all ranks */
+int cl_comm_unique_id(void* id_out);
+
+/* every rank: join the communicator on HIP device `device` (blocks until all `world` ranks have called it) */
+int cl_comm_init(const void* id, int rank, int world, int device, cl_comm** out);
+void cl_comm_destroy(cl_comm* c);
+int cl_comm_rank(const cl_comm* c);
+int cl_comm_world(const cl_comm* c);
+
+/* element-wise sum over all ranks, in place, of n float64 in HOST memory (staged through a pinned buffer and the device;
+ * returns when the result is in `host_inout`) -- the per-step statistics of the chained sweep (replaces the parent's
+ * np.concatenate over its workers' lists, cLoops/pipe.py:119-127, 247-259) */
+int cl_comm_allreduce_f64(cl_comm* c, double* host_inout, int64_t n);
+/* same with max (bench.py: the slowest rank's wall time) */
+int cl_comm_allreduce_max_f64(cl_comm* c, double* host_inout, int64_t n);
+
+/* all-gather of `n` int32 per rank from HOST memory: host_out receives world * n values in rank order */
+int cl_comm_allgather_i32(cl_comm* c, const int32_t* host_in, int64_t n, int32_t* host_out);
+
+/* barrier over all ranks (an all-reduce of one element) */
+int cl_comm_barrier(cl_comm* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

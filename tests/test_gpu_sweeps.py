@@ -166,3 +166,26 @@ def test_chain_equals_oracle_on_one_chromosome(n_total, cfg, mode, ci):
         assert np.array_equal(order(got), order(want))
     finally:
         pipe.CACHE.clear()
+
+
+def test_candidate_buffer_grows_beyond_n():
+    """a strongly clustered chromosome swept with many steps appends more candidate boxes than it has PETs (the same 120 000
+    three-PET clusters come back in every one of 12 steps: 1.44 M appended rows for 366 000 PETs): the device buffer grows
+    and the dedup sorts in buffers sized from the candidate count -- same boxes as the list-shaped host path"""
+    k = 120000
+    cx = np.arange(k, dtype=np.int64) * 1000 + 5000
+    j = np.arange(3, dtype=np.int64)
+    X = np.concatenate([(cx[:, None] + j[None, :]).ravel(), (np.arange(2000, dtype=np.int64)[:, None] * 700 + 100 + j[None, :]).ravel()])
+    Y = np.concatenate([(cx[:, None] + 50000 + 2 * j[None, :]).ravel(), (np.arange(2000, dtype=np.int64)[:, None] * 700 + 101 + j[None, :]).ravel()])
+    pipe.CACHE.clear()
+    f = pipe.CACHE.put_arrays("chrC-chrC", X.astype(np.int32), Y.astype(np.int32))
+    try:
+        eps, mps = [10, 20, 30, 40, 50, 60], [3, 2]
+        fast = pipe.runSweepFast([f], eps, mps, cut=0)
+        assert sum(s["n_inter"] for s in fast[3]) > len(X) and sum(s["n_inter"] for s in fast[3]) > (1 << 20)
+        slow = pipe.runSweep([f], eps, mps, cut=0)
+        assert fast[1] == slow[1] and fast[2] == slow[2]
+        want = np.asarray([[r[1], r[2], r[4], r[5]] for r in slow[0][("chrC", "chrC")]["records"]], dtype=np.int64).reshape(-1, 4)
+        assert len(want) == k and np.array_equal(fast[0][("chrC", "chrC")]["boxes"], want)
+    finally:
+        pipe.CACHE.clear()

@@ -216,3 +216,44 @@ def test_sweep_fast_key_order_is_first_appearance(monkeypatch):
         assert fast[1] == slow[1] and fast[2] == slow[2]
     finally:
         pipe.CACHE.clear()
+
+
+def test_two_sweeps_over_the_same_residents_do_not_interleave(monkeypatch, tmp_path):
+    """the candidate buffer / layout of a handle belong to one sweep at a time: two threads sweeping the same files get
+    the same result as one after the other"""
+    import threading
+    monkeypatch.setattr(api, "Chromosome", fake_backend.FakeChromosome)
+    monkeypatch.setattr(api, "device_count", lambda: 1)
+    pipe.CACHE.clear()
+    fs = _write_many_jd(tmp_path, 3, n=600)
+    try:
+        want = pipe.runSweepFast(fs, [800, 1200], [4, 3], cut=0)
+        got = [None, None]
+
+        def run(k):
+            got[k] = pipe.runSweepFast(fs, [800, 1200], [4, 3], cut=0)
+        ts = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for g in got:
+            assert g[1] == want[1] and g[2] == want[2] and g[0].keys() == want[0].keys()
+            for k in g[0]:
+                assert np.array_equal(g[0][k]["boxes"], want[0][k]["boxes"])
+    finally:
+        pipe.CACHE.clear()
+
+
+def test_replaced_resident_is_closed_by_its_last_user(monkeypatch, tmp_path):
+    monkeypatch.setattr(api, "Chromosome", _ClosableFake)
+    monkeypatch.setattr(api, "device_count", lambda: 1)
+    pipe.CACHE.clear()
+    X = np.arange(10, dtype=np.int64) * 100
+    f = pipe.CACHE.put_arrays("c-c", X, X + 50)
+    with pipe.CACHE.pinned([f]) as rs:
+        old = rs[0]
+        pipe.CACHE.put_arrays("c-c", X, X + 60)          # replaces the resident a sweep still holds
+        assert not getattr(old.chrom, "dead", False) and old.replaced
+    assert getattr(old.chrom, "dead", False)              # closed when the pin dropped
+    pipe.CACHE.clear()
