@@ -18,11 +18,12 @@ that layout by their cut (cl_set_layout_reuse; the layout of the previous sweep'
 sweep's first) -- and region query, components, borders, cluster table and distance statistics for every run.  The
 first sweep of the process (allocations) is reported separately as `first_sweep_s`.
 
-With N > 1 (`--gpus N` spawns N ranks through torch.distributed.run when not already launched by it) the 23
-chromosomes are LPT-sharded over the ranks (cloops_amd.dist.shard_chromosomes; chromosomes are independent units,
-cLoops/pipe.py:117), every run exchanges a few hundred bytes of statistics (all-reduce: the chained cut is a
-genome-wide estimate) and the final candidate tables are all-gathered once per sweep over RCCL -- the path's only
-exchanges.  Total work is fixed (the same 200 M PETs): "scaling": "strong".
+With N > 1 (`--gpus N` spawns N ranks through torch.distributed.run -- only the launcher -- when not already launched by
+it) the 23 chromosomes are LPT-sharded over the ranks (cloops_amd.dist.lpt_assign; chromosomes are independent units,
+cLoops/pipe.py:117), every run exchanges ~48 KB of statistics (all-reduce: the chained cut is a genome-wide estimate) and
+the final candidate tables are gathered once per sweep -- the path's only exchanges, both over RCCL through
+libcloops_comm.so (cloops_amd/comm.py; no PyTorch in the GPU processes).  Total work is fixed (the same 200 M PETs):
+"scaling": "strong".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   "roofline"      K2 region-query kernel on chr1 (16.4 M PETs) at the sweep's own 12 (eps, minPts, cut) settings, timed
@@ -102,8 +103,15 @@ def main(argv=None):
         # test hook: a module imported before anything else (the CPU tests install their stand-in GPU backend here)
         importlib.import_module(os.environ["CLOOPS_BENCH_PRELOAD"])
     import numpy as np
-    torch = dist = tdev = None
-    if use_dist:
+    torch = dist = tdev = comm = None
+    # GPU ranks talk over RCCL through libcloops_comm.so -- no PyTorch in the process (torch.distributed.run is only the
+    # launcher): with torch imported its bundled HIP runtime serves libcloops_hip.so as well and a sweep runs ~6 % slower.
+    # CLOOPS_BENCH_COMM=torch keeps the torch.distributed path; the CPU tests (--backend gloo) always use it.
+    direct = use_dist and on_gpu and os.environ.get("CLOOPS_BENCH_COMM", "rccl") != "torch"
+    if direct:
+        from cloops_amd.comm import Comm
+        comm = Comm(rank, world, local_rank)
+    elif use_dist:
         # torch first: its bundled HIP runtime then also serves libcloops_hip.so (same SONAME; the other order aborts
         # at the first RCCL call)
         import torch
@@ -120,7 +128,9 @@ def main(argv=None):
     from cloops_amd.dist import gather_tables, make_allsum, lpt_assign
 
     def sync_all():
-        if use_dist:
+        if comm is not None:
+            comm.barrier()                              # hipDeviceSynchronize + a barrier over the ranks
+        elif use_dist:
             dist.barrier()
             if on_gpu:
                 torch.cuda.synchronize()
@@ -141,9 +151,11 @@ def main(argv=None):
     # staging buffer (a ring over xGMI, tens of microseconds; CLOOPS_BENCH_STATS=gloo keeps it on the host over a gloo group:
     # TCP loopback, hundreds of microseconds per ring at 8 ranks); RCCL also carries the final gather of the candidate tables
     stats_gloo = os.environ.get("CLOOPS_BENCH_STATS", "rccl") == "gloo"
-    stats_group = dist.new_group(backend="gloo") if (use_dist and on_gpu and stats_gloo) else None
+    stats_group = dist.new_group(backend="gloo") if (use_dist and comm is None and on_gpu and stats_gloo) else None
     if not use_dist:
         allsum = None
+    elif comm is not None:
+        allsum = comm.make_allsum()
     elif on_gpu and not stats_gloo:
         allsum = make_allsum(device=tdev)
     else:
@@ -167,7 +179,9 @@ def main(argv=None):
             # the path's final exchange (cLoops/pipe.py:119-127 merges its workers' results): all candidate tables
             # (to rank 0, where the reference's parent process merges them; the other ranks do not copy everybody's rows back)
             rows = [v["boxes"] for v in dataI.values() if len(v["boxes"])]
-            ncand = sum(len(t) for t in gather_tables(rows if rows else np.zeros((0, 4), np.int32), device=tdev, dst=0, copy=False))
+            rows = rows if rows else np.zeros((0, 4), np.int32)
+            tabs = comm.gather_tables(rows, dst=0, copy=False) if comm is not None else gather_tables(rows, device=tdev, dst=0, copy=False)
+            ncand = sum(len(t) for t in tabs)
         else:
             ncand = sum(len(v["boxes"]) for v in dataI.values())
         return cut, steps, ncand
@@ -191,7 +205,9 @@ def main(argv=None):
         pets += sum(s["n_in"] for s in steps)          # genome-wide (all-reduced inside runSweepFast)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if use_dist:
+    if comm is not None:
+        elapsed = comm.allmax(elapsed)
+    elif use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=tdev if on_gpu else None)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -213,6 +229,7 @@ def main(argv=None):
             "data": "synthetic",
             "sweep_wall_s": elapsed / max(1, args.steps),
             "first_sweep_s": first_sweep_s,
+            "comm": ("rccl (libcloops_comm.so, no torch in the process)" if comm is not None else ("torch.distributed/%s" % args.backend if use_dist else None)),
             "config": {"workload": "synthetic-%s-23chr-mode3 (BASELINE.json configs[3])" % _human(n_total),
                        "variant": "cDBSCAN2", "pets": n_total, "chromosomes": len(sizes), "eps": eps_list, "minPts": minpts_list,
                        "runs_per_sweep": len(steps), "chained_cut": True, "cuts": [s.get("cut_out") for s in steps],
@@ -249,7 +266,10 @@ def main(argv=None):
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(api, sizes, steps)
     pipe.CACHE.clear()
-    if use_dist:
+    if comm is not None:
+        comm.barrier()
+        comm.close()
+    elif use_dist:
         dist.barrier()
         dist.destroy_process_group()
     # everything written to fd 1 during the run (RCCL's banner comes through C stdio) went to stderr: give stdout

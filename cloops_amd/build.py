@@ -13,6 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HDR = os.path.join(os.path.dirname(HERE), "include", "cloops_hip.h")
 OUT = os.path.join(HERE, "libcloops_hip.so")
+COMM_SRC = os.path.join(CSRC, "cloops_comm.cpp")
+COMM_HDR = os.path.join(os.path.dirname(HERE), "include", "cloops_comm.h")
+COMM_OUT = os.path.join(HERE, "libcloops_comm.so")
 OBJDIR = os.path.join(os.path.dirname(HERE), "build", "obj")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
@@ -47,10 +50,25 @@ def _compile(src, obj, devel, verbose):
     subprocess.check_call(cmd)
 
 
+def build_comm(force=False, verbose=False):
+    """libcloops_comm.so: the RCCL collectives of the multi-GPU path (include/cloops_comm.h), linked against librccl."""
+    if not force and os.path.exists(COMM_OUT) and os.path.getmtime(COMM_OUT) >= max(os.path.getmtime(COMM_SRC), os.path.getmtime(COMM_HDR)):
+        return COMM_OUT
+    rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-x", "hip", COMM_SRC, "-o", COMM_OUT,
+           "-L" + rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return COMM_OUT
+
+
 def build(force=False, verbose=False, devel=False):
     """`devel=True` builds libcloops_hip_devel.so with -DCLOOPS_DEVEL (ablation / shape knobs read from the
     environment; loaded only when CLOOPS_DEVEL_LIB=1) -- the shipped library has none of them."""
     out = OUT.replace(".so", "_devel.so") if devel else OUT
+    if not devel:
+        build_comm(force, verbose)
     if not devel and not force and not needs_build():
         return OUT
     os.makedirs(OBJDIR, exist_ok=True)

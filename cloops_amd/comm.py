@@ -1,0 +1,174 @@
+"""RCCL without PyTorch: the multi-GPU exchanges of the sweep over libcloops_comm.so (include/cloops_comm.h).
+
+One process per GPU, launched by anything that sets RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run does; it is only
+the launcher -- this module imports no torch).  The ncclUniqueId travels from rank 0 to the others through a file in /tmp
+keyed by the launcher's pid and MASTER_PORT (one node, which is what the path is specified for).
+
+    comm = Comm.from_env()
+    allsum = comm.make_allsum()          # for cloops_amd.pipe.runSweepFast(..., allsum=allsum)
+    tables = comm.gather_tables(rows, dst=0)
+
+The reference shape: joblib workers + merge in the parent (cLoops/pipe.py:113-127), the cut estimated from all chromosomes'
+distance lists between the steps (pipe.py:247-275)."""
+import ctypes
+import os
+import time
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libcloops_comm.so")
+SYMBOLS = ("cl_comm_last_error", "cl_comm_unique_id", "cl_comm_init", "cl_comm_destroy", "cl_comm_rank", "cl_comm_world",
+           "cl_comm_allreduce_f64", "cl_comm_allreduce_max_f64", "cl_comm_allgather_i32", "cl_comm_gather_i32", "cl_comm_barrier")
+ID_BYTES = 128
+_lib = None
+
+
+class CommError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError("libcloops_comm.so is missing (%s): build it with `python -m cloops_amd.build`" % SO_PATH)
+    lib = ctypes.CDLL(SO_PATH)
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    lib.cl_comm_last_error.restype = ctypes.c_char_p
+    lib.cl_comm_unique_id.argtypes = [vp]
+    lib.cl_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.cl_comm_destroy.argtypes = [vp]
+    lib.cl_comm_destroy.restype = None
+    lib.cl_comm_rank.argtypes = [vp]
+    lib.cl_comm_world.argtypes = [vp]
+    lib.cl_comm_allreduce_f64.argtypes = [vp, vp, i64]
+    lib.cl_comm_allreduce_max_f64.argtypes = [vp, vp, i64]
+    lib.cl_comm_allgather_i32.argtypes = [vp, vp, i64, vp]
+    lib.cl_comm_gather_i32.argtypes = [vp, vp, i64, ctypes.c_int, vp]
+    lib.cl_comm_barrier.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise CommError((load().cl_comm_last_error() or b"").decode("utf-8", "replace"))
+
+
+def exchange_id(rank, world, make_id, tag=None, timeout=300.0, directory="/tmp"):
+    """rank 0 makes the id (make_id() -> bytes) and publishes it; every rank returns the same bytes.  The file name carries
+    the launcher's pid (all local ranks share the parent) and MASTER_PORT, so concurrent launches do not meet."""
+    if world == 1:
+        return make_id()
+    tag = tag or "%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+    path = os.path.join(directory, "cloops_comm_id_%s" % tag)
+    if rank == 0:
+        blob = make_id()
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as fh:
+            fh.write(blob)
+        os.replace(tmp, path)                              # atomic: readers see nothing or all of it
+        return blob
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as fh:
+                blob = fh.read()
+            if len(blob) == ID_BYTES and time.time() - os.path.getmtime(path) < timeout:
+                return blob
+        except (IOError, OSError):
+            pass
+        if time.time() - t0 > timeout:
+            raise CommError("no unique id from rank 0 within %.0f s (%s)" % (timeout, path))
+        time.sleep(0.01)
+
+
+class Comm(object):
+    def __init__(self, rank, world, device, tag=None):
+        lib = load()
+        self._lib = lib
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+
+        def make_id():
+            buf = ctypes.create_string_buffer(ID_BYTES)
+            _check(lib.cl_comm_unique_id(buf))
+            return buf.raw
+        self._id_path = None
+        blob = exchange_id(self.rank, self.world, make_id, tag)
+        h = ctypes.c_void_p()
+        _check(lib.cl_comm_init(ctypes.c_char_p(blob), self.rank, self.world, self.device, ctypes.byref(h)))
+        self._h = h
+        if self.world > 1:
+            self.barrier()
+            if self.rank == 0:                             # everyone has joined: the id file has done its job
+                try:
+                    os.remove(os.path.join("/tmp", "cloops_comm_id_%s" % (tag or "%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))))
+                except OSError:
+                    pass
+
+    @classmethod
+    def from_env(cls, device=None):
+        rank = int(os.environ.get("RANK", "0"))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        return cls(rank, world, local if device is None else device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cl_comm_destroy(self._h)
+            self._h = None
+
+    def barrier(self):
+        _check(self._lib.cl_comm_barrier(self._h))
+
+    def allmax(self, x):
+        a = np.asarray([x], dtype=np.float64)
+        _check(self._lib.cl_comm_allreduce_max_f64(self._h, a.ctypes.data_as(ctypes.c_void_p), 1))
+        return float(a[0])
+
+    def allsum(self, a):
+        """element-wise sum over the ranks of a small int64 / float64 array (counts ride as float64: exact below 2^53)"""
+        a = np.asarray(a)
+        f = np.ascontiguousarray(a, dtype=np.float64).ravel().copy()
+        _check(self._lib.cl_comm_allreduce_f64(self._h, f.ctypes.data_as(ctypes.c_void_p), f.size))
+        f = f.reshape(a.shape)
+        return np.rint(f).astype(a.dtype) if a.dtype.kind in "iu" else f.astype(a.dtype, copy=False)
+
+    def make_allsum(self):
+        return self.allsum
+
+    def gather_tables(self, table, dst=None, copy=True):
+        """variable-length int32 [K_r, C] tables from every rank -> list of per-rank arrays (on `dst` only when given; the
+        other ranks get empty tables).  `table` may be a list of tables (their concatenation).  Two collectives: the row
+        counts, then the rows padded to the longest table."""
+        if isinstance(table, (list, tuple)):
+            tabs = [np.asarray(t) for t in table]
+            if not tabs or any(t.ndim != 2 for t in tabs) or len({t.shape[1] for t in tabs}) > 1:
+                raise ValueError("tables must be a non-empty list of [K, C] arrays with one C")
+            parts = [np.ascontiguousarray(t, dtype=np.int32) for t in tabs if len(t)]
+            table = np.concatenate(parts) if parts else np.zeros((0, tabs[0].shape[1]), np.int32)
+        table = np.ascontiguousarray(table, dtype=np.int32)
+        if table.ndim != 2:
+            raise ValueError("table must be [K, C]")
+        k, c = table.shape
+        mine = np.asarray([k, c], dtype=np.int32)
+        ks = np.zeros(2 * self.world, dtype=np.int32)
+        _check(self._lib.cl_comm_allgather_i32(self._h, mine.ctypes.data_as(ctypes.c_void_p), 2, ks.ctypes.data_as(ctypes.c_void_p)))
+        ks = ks.reshape(self.world, 2)
+        if len({int(x) for x in ks[:, 1]}) != 1:
+            raise ValueError("the ranks' tables differ in their number of columns")
+        kmax = max(int(ks[:, 0].max()), 1)
+        pad = np.zeros((kmax, c), dtype=np.int32)
+        pad[:k] = table
+        recv = dst is None or dst == self.rank
+        out = np.empty((self.world, kmax, c), dtype=np.int32) if recv else None
+        outp = out.ctypes.data_as(ctypes.c_void_p) if recv else None
+        if dst is None:
+            _check(self._lib.cl_comm_allgather_i32(self._h, pad.ctypes.data_as(ctypes.c_void_p), kmax * c, outp))
+        else:
+            _check(self._lib.cl_comm_gather_i32(self._h, pad.ctypes.data_as(ctypes.c_void_p), kmax * c, int(dst), outp))
+        if not recv:
+            return [np.zeros((0, c), np.int32) for _ in range(self.world)]
+        return [out[r, : int(ks[r, 0])].copy() if copy else out[r, : int(ks[r, 0])] for r in range(self.world)]

@@ -110,27 +110,42 @@ static int allreduce_f64(cl_comm* c, double* h, int64_t n, ncclRedOp_t op)
 extern "C" int cl_comm_allreduce_f64(cl_comm* c, double* h, int64_t n) { return allreduce_f64(c, h, n, ncclSum); }
 extern "C" int cl_comm_allreduce_max_f64(cl_comm* c, double* h, int64_t n) { return allreduce_f64(c, h, n, ncclMax); }
 
-extern "C" int cl_comm_allgather_i32(cl_comm* c, const int32_t* hin, int64_t n, int32_t* hout)
+// n int32 per rank from host memory; ROOT < 0: all-gather (every rank receives world * n values in rank order), else only
+// rank ROOT receives (the others neither copy back nor need host_out)
+static int gather_i32(cl_comm* c, const int32_t* hin, int64_t n, int root, int32_t* hout)
 {
-    if (!c || n < 0 || (n > 0 && (!hin || !hout))) return cfail("cl_comm_allgather_i32", "bad arguments");
+    if (!c || n < 0 || root >= c->world || (n > 0 && !hin)) return cfail("cl_comm_gather_i32", "bad arguments");
+    const bool recv = root < 0 || root == c->rank;
+    if (n > 0 && recv && !hout) return cfail("cl_comm_gather_i32", "null receive buffer");
     if (n == 0) return 0;
-    const size_t in_bytes = (size_t)n * 4, out_bytes = in_bytes * (size_t)c->world;
-    int rc = ensure(c, out_bytes, in_bytes + out_bytes);
+    const size_t in_bytes = (size_t)n * 4, out_bytes = in_bytes * (size_t)c->world, pad = ((in_bytes + 255) / 256) * 256;
+    int rc = ensure(c, std::max(in_bytes, recv ? out_bytes : (size_t)0), pad + (recv ? out_bytes : (size_t)0));
     if (rc) return rc;
     char* dsend = (char*)c->dev;
-    char* drecv = dsend + ((in_bytes + 255) / 256) * 256;
-    if ((size_t)(drecv - dsend) + out_bytes > c->dev_bytes) { rc = ensure(c, out_bytes, (size_t)(drecv - dsend) + out_bytes); if (rc) return rc; dsend = (char*)c->dev; drecv = dsend + ((in_bytes + 255) / 256) * 256; }
+    char* drecv = dsend + pad;
     memcpy(c->pin, hin, in_bytes);
     HIPC(hipMemcpyAsync(dsend, c->pin, in_bytes, hipMemcpyHostToDevice, c->stream));
-    NCC(ncclAllGather(dsend, drecv, (size_t)n, ncclInt32, c->comm, c->stream));
-    HIPC(hipMemcpyAsync(c->pin, drecv, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (root < 0) NCC(ncclAllGather(dsend, drecv, (size_t)n, ncclInt32, c->comm, c->stream));
+    else NCC(ncclGather(dsend, recv ? drecv : nullptr, (size_t)n, ncclInt32, root, c->comm, c->stream));
+    if (recv) HIPC(hipMemcpyAsync(c->pin, drecv, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
-    memcpy(hout, c->pin, out_bytes);
+    if (recv) memcpy(hout, c->pin, out_bytes);
     return 0;
+}
+
+extern "C" int cl_comm_allgather_i32(cl_comm* c, const int32_t* hin, int64_t n, int32_t* hout) { return gather_i32(c, hin, n, -1, hout); }
+extern "C" int cl_comm_gather_i32(cl_comm* c, const int32_t* hin, int64_t n, int root, int32_t* hout)
+{
+    if (root < 0) return cfail("cl_comm_gather_i32", "bad root");
+    return gather_i32(c, hin, n, root, hout);
 }
 
 extern "C" int cl_comm_barrier(cl_comm* c)
 {
+    // everything this process has enqueued on the device is done, then all ranks meet
+    if (!c) return cfail("cl_comm_barrier", "null communicator");
+    HIPC(hipSetDevice(c->device));
+    HIPC(hipDeviceSynchronize());
     double one = 1.0;
     return allreduce_f64(c, &one, 1, ncclSum);
 }

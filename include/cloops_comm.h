@@ -47,7 +47,11 @@ int cl_comm_allreduce_max_f64(cl_comm* c, double* host_inout, int64_t n);
 /* all-gather of `n` int32 per rank from HOST memory: host_out receives world * n values in rank order */
 int cl_comm_allgather_i32(cl_comm* c, const int32_t* host_in, int64_t n, int32_t* host_out);
 
-/* barrier over all ranks (an all-reduce of one element) */
+/* gather to one rank: only `root` receives world * n values (host_out may be null elsewhere) -- the candidate tables of a
+ * sweep go to the rank that writes the result, like the reference's parent process (cLoops/pipe.py:119-127) */
+int cl_comm_gather_i32(cl_comm* c, const int32_t* host_in, int64_t n, int root, int32_t* host_out);
+
+/* hipDeviceSynchronize() of this rank's device, then a barrier over all ranks (an all-reduce of one element) */
 int cl_comm_barrier(cl_comm* c);
 
 #ifdef __cplusplus
