@@ -1,0 +1,204 @@
+// cl_chrom.h -- host side shared by the translation units: the chromosome handle (device buffers, result slots, sweep
+// state), the structures the step tail exchanges with the K7 / K10 kernels, and the functions / kernels one unit uses
+// from another.  A __global__ function may be launched from a unit that only sees its declaration: the launch goes
+// through the defining unit's host stub.
+#pragma once
+#include "cl_common.h"
+#include "cl_table.h"
+
+#define BIGTPB 1024
+#define AGG_H 512
+// slot of `key` in a workgroup's LDS hash table of AGG_H keys (-1 = table crowded: the caller goes to global memory)
+__device__ __forceinline__ int agg_slot(int* keys, int key)
+{
+    unsigned h = ((unsigned)key * 2654435761u) >> 23;            // 9 bits
+    for (int probe = 0; probe < 24; ++probe) {
+        const int old = atomicCAS(&keys[h], -1, key);
+        if (old == -1 || old == key) return (int)h;
+        h = (h + 1) & (AGG_H - 1);
+    }
+    return -1;                                                    // table crowded: caller goes to global memory
+}
+#define FLAT_PER 4          // PETs per thread
+struct Stats { int amin, amax, vmin, vmax, xmin, xmax, ymin, ymax; };
+__device__ __forceinline__ int je_minus(const int* __restrict__ cstart, int j) { return cstart[j + 1] - cstart[j]; }
+static inline int bits_for(unsigned v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
+
+
+#define K7_BLOCKS 2048           // workgroups (= fixed partial sums) of the K7 reductions: 8 waves per SIMD (512 left the loads
+#define K7_LOGBINS 3840          // 30 octaves x 128: bin = floor(log2 d) * 128 + the next 7 bits of d (monotone in d)
+#define K7_FINE 2048
+#define K7_XSHIFT 11.0           // sums are taken over x = log2|d| - K7_XSHIFT (less cancellation in sum x^2 - (sum x)^2 / n)
+#define CAND_BLOCK 2048
+
+struct K7Src {
+    int sorted; int n; int M; int v0;
+    const int* dM;                                      // if set: M is read from the device (the run has not been waited for yet)
+    const int* X; const int* Y; const int* labels;      // input rows (+ row-order labels)
+    const int* sv; const int* slab;                     // sorted q and sorted-order labels of [0, M)
+    const int* dh;                                      // if set: dh[d] = number of input rows with Y - X == d for 0 <= d < cut, and no row has
+                                                        // Y - X < 0: the PETs dropped by the cut come from it, not from a pass over the rows
+};
+
+struct K7Part { double sx[2]; double sxx[2]; long long n_all[2]; long long n_pos[2]; };
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    bool fresh = false;               // (re)allocated since the flag was last cleared
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return CL_OK;
+        fresh = true;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        size_t want = need + need / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "hipMalloc", hipGetErrorString(e));
+        bytes = want;
+        return CL_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <typename T> T* as() { return (T*)p; }
+};
+
+struct cl_chrom {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t n = 0;
+    int *d_x = nullptr, *d_y = nullptr;
+    bool own_xy = false;
+    Stats st{};
+    // workspace
+    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, scan_tmp;
+    DevBuf qb_key, qb_val;            // the q index (k_make_qkeys): rows sorted by q, persistent
+    int qindex_layout = -1;           // layout the q index was built for (-1: none)
+    int sort_index_mode = 0;          // cl_set_sort_index: 0 = build at the second sort, 1 = at the first, -1 = never
+    long long n_sorts = 0;            // layouts sorted on this handle so far
+    DevBuf sv, sa, strip, cnt, parent, root, head, headidx, cellfirst, compkey, ncore, bsize, owner, state;
+    DevBuf tileflag;                  // per 256-PET tile: holds a contested border point (k_border -> k_emit_records)
+    DevBuf flag, rankscan, ulist, lo, hi, recs, counters, chainflag, chainhead, usize, b_cstart, b_ckey, b_nb, b_cx, b_cy, tile_s0;
+    int* h_pinned = nullptr;          // small pinned staging (stats, block scalars)
+    struct StripPlan { int layout, eps, maxlen; };
+    std::vector<StripPlan> plans;     // longest strip over all rows per (layout, eps): picks the sort path
+    u32* srow = nullptr;              // sorted position -> input row of the run being enqueued
+    // working set of the run being enqueued: sorted (q, sp), strip table, tile table.  They alias either the
+    // workspace buffers (sv, sa, strip, tile_s0) or, for a run without cut filter, the base layout itself.
+    int *w_sv = nullptr, *w_sa = nullptr, *w_strip = nullptr, *w_tile = nullptr;
+    // Base layout: the sorted arrays of ALL rows (cut = 0) for one (variant layout, eps), kept until eps changes.
+    // The sort order does not depend on minPts and a cut only REMOVES rows, so every further run of a sweep at this
+    // eps is one stable stream compaction of the base layout instead of five radix passes (cLoops/pipe.py:241-281
+    // walks eps in the outer loop).  Nothing of a result is kept: neighbour counts, components, labels are redone.
+    DevBuf bq, bsp, brow, bstrip, btile, sel_tmp;
+    struct BaseLayout { bool valid = false; int layout = -1, eps = 0; } base;
+    std::vector<long long> dcum;      // dcum[k] = number of PETs with Y - X < k, k = 0 .. 65536 (empty: unknown)
+    const int* k_total = nullptr;     // device: where the run left the number of ids handed out (null: rankscan[n])
+    bool hdr_packed = false;          // the run's own kernels have written the slot header (no k_pack_header)
+    DevBuf dhist;                     // device: number of PETs with Y - X == d, d = 0 .. 65535 (+ one slot for d < 0)
+    long long n_neg = 0;              // PETs with Y - X < 0
+    int run_m = 0;                    // PETs that enter DBSCAN in the run being enqueued (exact when run_m_exact, else n)
+    bool run_m_exact = false;
+    bool reuse_layout = true;
+    // Result slots: two runs may be in flight (cl_cluster_async) -- the labels / table / header of
+    // run k live in slot k & 1, so the D2H copy of run k (copy stream) overlaps the kernels of run k+1.
+    struct Slot {
+        DevBuf labels, table;
+        bool pending = false;
+        int n_strips = 0;
+        hipEvent_t ev_done = nullptr, ev_copied = nullptr;
+        hipEvent_t ev[8]{};           // profiling marks of the run that used this slot
+        int* h_hdr = nullptr;         // pinned: {K, overflow, M}
+        cl_box* h_boxes = nullptr;    // pinned host copy of the cluster table
+        size_t h_boxes_cap = 0;
+        int32_t* labels_out = nullptr;
+        DevBuf slab;                  // labels in sorted order (rotated variants)
+        bool exported = true;         // the table rows were stored to h_boxes
+        bool step_valid = false;      // the run carried the sweep-step tail (classification, candidate append, distance summary)
+        bool host_written = false;    // ... and its last kernel stored header + step output in pinned host memory itself
+        bool wait_done = false;       // cl_wait waits for ev_done (nothing went through the copy stream)
+        long long fine_lo = -1;       // fine window of that tail's summary (-1 = none)
+        int kmax = 0;                 // upper bound of the number of cluster ids of the run (host-known; the count itself is on the device)
+        DevBuf d_step;                // device: {n_inter, n_self} + K7 partials + log histogram of that tail
+        char* h_step = nullptr;       // pinned host copy
+        bool rows_valid = false;      // `labels` (row order) was produced by the run
+        bool sorted_src = false;      // the run left sorted (q, label) arrays for the distance statistics
+        const int* k7_sv = nullptr;   // sorted q of the run
+        int k7_v0 = 0;                // d = q + k7_v0
+    } slot[2];
+    bool device_labels = true;        // produce row-order device labels even without a host destination (cl_set_device_labels)
+    bool export_table = true;         // copy the cluster table to pinned host memory at the end of a run (cl_set_table_export)
+    int pending_step = -1;            // >= 0: the run being enqueued is step `pending_step` of a sweep (cl_cluster_step_async)
+    int pending_cut = 0;
+    long long pending_fine_lo = -1;   // >= 0: the step's summary also histograms the self group's [fine_lo, fine_lo + 2048) exactly
+    DevBuf cand_box, cand_step, cand_keep, cand_out;   // K10: candidate loops of the running sweep
+    long long cand_n = 0, cand_cap = 0;
+    DevBuf hdr;                       // device result headers, 16 ints per slot
+    DevBuf k7_cls, k7_parts;          // K7: class per cluster id, per-workgroup partials
+    DevBuf sig_tx, sig_ty, sig_tmp, sig_sorttmp, sig_m, sig_win, sig_out;   // K8: sorted PET tables, windows, counts
+    bool sig_ready = false; int sig_cut = 0;
+    bool k7_classified = false;       // k7_cls matches the last completed run
+    hipStream_t copy_stream = nullptr, aux_stream = nullptr;
+    int enq = 0, deq = 0;             // runs enqueued / completed
+    int cur = 0;                      // slot of the run being enqueued
+    // last completed result
+    int last_slot = -1;
+    int last_K = 0;                   // max_label + 1
+    bool have_result = false;
+    // profiling
+    bool profiling = false;
+    cl_timing timing{};
+    bool ev_ready = false;
+    float ev_bracket_ms = 0.f;        // event bracket around an empty kernel (calibration, see cl_timing)
+};
+
+
+#define LAUNCH(kernel, nthreads, ...) \
+    hipLaunchKernelGGL(kernel, dim3(nblocks(nthreads)), dim3(TPB), 0, c->stream, __VA_ARGS__)
+
+// cloops_hip.hip
+int ensure_workspace(cl_chrom* c, int S);
+int ensure_events(cl_chrom* c);
+void ev_record(cl_chrom* c, int k);
+int ensure_cand_capacity(cl_chrom* c, long long need);
+Table make_table_slot(cl_chrom* c, int slot);
+Table make_table(cl_chrom* c);
+const int* k7_hist_for(cl_chrom* c, int cut);
+int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* labels_out);
+// k_block.hip, k_weighted.hip
+int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_out);
+int run_weighted(cl_chrom* c, int eps, int minPts, int wx, int wy, int32_t* labels_out);
+
+// kernels of cloops_hip.hip that k_block.hip / k_weighted.hip launch
+__global__ void k_init_table(Table t, const int* __restrict__ rankscan, int n);
+__global__ void k_init_arrays(int n, int* __restrict__ parent, int* __restrict__ compkey, int* __restrict__ ncore,
+                              int* __restrict__ bsize, int* __restrict__ usize, int* __restrict__ cellfirst,
+                              int* __restrict__ flag, int* __restrict__ state, int* __restrict__ counters);
+__global__ void k_strip_table(const u64* __restrict__ skeys, int n, int S, int shift, int* __restrict__ strip_start);
+__global__ void k_root_labels(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ root,
+                              const int* __restrict__ compkey, const int* __restrict__ ncore, const int* __restrict__ bsize,
+                              const int* __restrict__ state, const int* __restrict__ rankscan, int* __restrict__ rlabel);
+__global__ void k_rank_flags(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ root,
+                             const int* __restrict__ compkey, const int* __restrict__ state, int* __restrict__ flag);
+__global__ void __launch_bounds__(BIGTPB)
+k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ cnt,
+          int* parent, const u32* __restrict__ srow,
+          const int* __restrict__ head, const int* __restrict__ cellfirst,
+          int* __restrict__ root, int* __restrict__ compkey, int* __restrict__ ncore,
+          int* __restrict__ rootlist , int* __restrict__ counters);
+
+// kernels of k_sweep.hip that the step tail (finish_enqueue) launches
+__global__ void __launch_bounds__(256)
+k_step_classify_count(const int* __restrict__ dK, Table t, signed char* __restrict__ cls, int* __restrict__ bcount, int nb,
+                      unsigned long long* __restrict__ zero, int nzero);
+__global__ void __launch_bounds__(256)
+k_cand_append(const int* __restrict__ dK, const signed char* __restrict__ cls, Table t, const int* __restrict__ boff ,
+              const int* __restrict__ bcount, int base, int step, int cap, int4* __restrict__ cbox, int* __restrict__ cstep);
+__global__ void __launch_bounds__(TPB)
+k7_summary(K7Src s, int cut, const signed char* __restrict__ cls, K7Part* __restrict__ parts, unsigned long long* __restrict__ loghist,
+           unsigned fine_lo, unsigned long long* __restrict__ fine );
+__global__ void __launch_bounds__(256)
+k7_reduce_parts(const K7Part* __restrict__ parts, int nparts, K7Part* out, const int* __restrict__ bcount , int nb,
+                long long* totals, const volatile unsigned long long* dev_step , int step_words,
+                unsigned long long* __restrict__ host_step, const int* __restrict__ dev_hdr, int* __restrict__ host_hdr);

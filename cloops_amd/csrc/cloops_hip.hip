@@ -24,7 +24,7 @@
 //   K4 k_border         border ownership per variant rule; v2 release fix-up
 //   K5 k_rank_flags / scan / k_final_labels   reference cluster ids + cluster table
 //   K6 block variant    cell table, links, cell-level union (blockDBSCAN.py)
-#include "cl_common.h"
+#include "cl_chrom.h"
 
 // ------------------------------------------------------------------------------------------
 // error plumbing
@@ -55,7 +55,6 @@ extern "C" int cl_device_count(void)
 // ------------------------------------------------------------------------------------------
 // chromosome statistics (once per upload)
 // ------------------------------------------------------------------------------------------
-struct Stats { int amin, amax, vmin, vmax, xmin, xmax, ymin, ymax; };
 
 __global__ void k_stats(const int* __restrict__ X, const int* __restrict__ Y, long long n, Stats* out)
 {
@@ -932,25 +931,12 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
 // shuffles.  Level 2: the per-wave results of a 1024-thread workgroup meet in a small LDS hash
 // table; one global atomic per key per WORKGROUP remains.
 // ------------------------------------------------------------------------------------------
-#define BIGTPB 1024
-#define AGG_H 512
-__device__ __forceinline__ int agg_slot(int* keys, int key)
-{
-    unsigned h = ((unsigned)key * 2654435761u) >> 23;            // 9 bits
-    for (int probe = 0; probe < 24; ++probe) {
-        const int old = atomicCAS(&keys[h], -1, key);
-        if (old == -1 || old == key) return (int)h;
-        h = (h + 1) & (AGG_H - 1);
-    }
-    return -1;                                                    // table crowded: caller goes to global memory
-}
 
 // K3b: root per core point, component keys and core counts.
 //   variant 1: key = smallest input row of a core point = the component's start point
 //              (cDBSCAN.py:134-137)
 //   variant 2: key = smallest cellfirst over the cells holding its core points
 //              (cDBSCAN2.py:117-140)
-#define FLAT_PER 4          // PETs per thread
 __global__ void __launch_bounds__(BIGTPB)
 k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ cnt,
           int* parent, const u32* __restrict__ srow,
@@ -1408,17 +1394,6 @@ __global__ void k_rank_flags(GridParams g, const int* __restrict__ strip_start, 
     flag[compkey[i]] = 1;
 }
 
-// Device cluster table, struct-of-arrays: the five accumulators of one id live in five different cache
-// lines, so the atomics of a hot id (a giant component) spread over five L2 channels instead of
-// queueing on one line (AoS measured 3x slower on the 16 M-PET giant-component case).
-struct Table {
-    int* count; int* minx; int* maxx; int* miny; int* maxy;
-    __device__ __forceinline__ cl_box get(int k) const
-    {
-        cl_box b; b.min_x = minx[k]; b.max_x = maxx[k]; b.min_y = miny[k]; b.max_y = maxy[k]; b.count = count[k];
-        return b;
-    }
-};
 
 // label of every component root (-1 = not kept), so that k_final_labels needs ONE gather per PET
 // instead of the chain owner -> compkey -> rank (+ state / sizes)
@@ -1465,89 +1440,6 @@ __global__ void k_root_labels_bits_l(GridParams g, const int* __restrict__ rootl
         t.count[k] = 0; t.minx[k] = INT_MAX; t.maxx[k] = INT_MIN; t.miny[k] = INT_MAX; t.maxy[k] = INT_MIN;
     }
 }
-
-__device__ __forceinline__ int je_minus(const int* __restrict__ cstart, int j) { return cstart[j + 1] - cstart[j]; }
-__device__ __forceinline__ int wave_min_i(int v) { return dpp_reduce_wave(v, OpMin()); }
-__device__ __forceinline__ int wave_max_i(int v) { return dpp_reduce_wave(v, OpMax()); }
-
-// Cluster table (pipe.py:78-102) by the two-level reduce-by-key above; called by all threads
-// of a BIGTPB workgroup (sorted order keeps a cluster's PETs in neighbouring lanes, so a wave
-// usually carries a handful of labels).
-#define TAB_H 512
-struct TableLds { int key[TAB_H], cnt[TAB_H], mnx[TAB_H], mxx[TAB_H], mny[TAB_H], mxy[TAB_H]; };
-
-__device__ __forceinline__ void table_lds_init(TableLds& h)
-{
-    for (int k = threadIdx.x; k < TAB_H; k += blockDim.x) {
-        h.key[k] = -1; h.cnt[k] = 0; h.mnx[k] = INT_MAX; h.mxx[k] = INT_MIN; h.mny[k] = INT_MAX; h.mxy[k] = INT_MIN;
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ int tab_slot(int* keys, int key)
-{
-    unsigned h = ((unsigned)key * 2654435761u) >> 23;            // 9 bits = log2(TAB_H)
-    for (int probe = 0; probe < 16; ++probe) {
-        const int old = atomicCAS(&keys[h], -1, key);
-        if (old == -1 || old == key) return (int)h;
-        h = (h + 1) & (TAB_H - 1);
-    }
-    return -1;
-}
-// level 1 + insertion into the workgroup's LDS table (no barrier inside: may be called repeatedly)
-__device__ __forceinline__ void table_accumulate(const Table& t, TableLds& h, int lab, int x, int y)
-{
-    const int lane = threadIdx.x & 63;
-    const unsigned long long pending = __ballot(lab >= 0);
-    if (!pending) return;
-    const int leader = __ffsll((long long)pending) - 1;
-    const int L = __builtin_amdgcn_readlane(lab, leader);
-    const unsigned long long m = __ballot(lab == L);
-    if (m == pending && __popcll(m) >= 16) {
-        // the wave lies inside one cluster: four reductions, one insertion
-        const bool mine = lab == L;
-        const int cm = __popcll(m);
-        int mnx = wave_min_i(mine ? x : INT_MAX), mxx = wave_max_i(mine ? x : INT_MIN);
-        int mny = wave_min_i(mine ? y : INT_MAX), mxy = wave_max_i(mine ? y : INT_MIN);
-        if (lane == leader) {
-            const int sl = tab_slot(h.key, L);
-            if (sl >= 0) {
-                atomicAdd(&h.cnt[sl], cm);
-                atomicMin(&h.mnx[sl], mnx); atomicMax(&h.mxx[sl], mxx);
-                atomicMin(&h.mny[sl], mny); atomicMax(&h.mxy[sl], mxy);
-            } else {
-                atomicAdd(&t.count[L], cm);
-                atomicMin(&t.minx[L], mnx); atomicMax(&t.maxx[L], mxx);
-                atomicMin(&t.miny[L], mny); atomicMax(&t.maxy[L], mxy);
-            }
-        }
-    } else if (lab >= 0) {
-        // several clusters (and noise) in the wave: every lane straight into the LDS table -- lanes of one cluster meet on
-        // one LDS address, which the LDS unit serialises at a fraction of what a loop over the distinct labels costs
-        const int sl = tab_slot(h.key, lab);
-        if (sl >= 0) {
-            atomicAdd(&h.cnt[sl], 1);
-            atomicMin(&h.mnx[sl], x); atomicMax(&h.mxx[sl], x);
-            atomicMin(&h.mny[sl], y); atomicMax(&h.mxy[sl], y);
-        } else {
-            atomicAdd(&t.count[lab], 1);
-            atomicMin(&t.minx[lab], x); atomicMax(&t.maxx[lab], x);
-            atomicMin(&t.miny[lab], y); atomicMax(&t.maxy[lab], y);
-        }
-    }
-}
-// level 2 -> global: one set of atomics per key of the workgroup
-__device__ __forceinline__ void table_flush(const Table& t, TableLds& h)
-{
-    __syncthreads();
-    for (int k = threadIdx.x; k < TAB_H; k += blockDim.x) {
-        if (h.key[k] < 0) continue;
-        const int L = h.key[k];
-        atomicAdd(&t.count[L], h.cnt[k]);
-        atomicMin(&t.minx[L], h.mnx[k]); atomicMax(&t.maxx[L], h.mxx[k]);
-        atomicMin(&t.miny[L], h.mny[k]); atomicMax(&t.maxy[L], h.mxy[k]);
-    }
-}
-
 
 // Labels are scattered to input-row order; the cluster table (pipe.py:78-102) is reduced
 // per wave first: sorted order keeps a cluster's PETs in neighbouring lanes, so a wave
@@ -1596,1105 +1488,9 @@ k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __r
 }
 
 
-// ==========================================================================================
-// K9: variant 1 under an axis-weighted city-block metric  wx*|dX| + wy*|dY| <= eps
-// ==========================================================================================
-// scripts/callStripes:37-72 (singleStripDBSCAN) multiplies the X or the Y column by `ext` (50) and runs
-// cDBSCAN (variant 1) on the scaled matrix.  Scaled coordinates reach 1.25e10, so the rotated pair
-// U = wx*X + wy*Y (strip coordinate), W = wy*Y - wx*X (in-strip coordinate) is 64-bit here and the sort key
-// is  strip << qbits | (W - W0)  (<= 64 bits; U rides in a separate array, gathered after the sort).
-// This second caller is not a throughput path: the kernels are the plain global-memory form of rule R1
-// (searches on the sorted keys, one thread per PET), sharing sort, strip table, union-find, flatten,
-// ranks and the cluster table with the main path.  Results: the ids of cDBSCAN(mat * [1, wx, wy], eps, minPts).
-struct G64 { int eps, minPts, S, qbits, wx, wy; long long U0, W0; };
-
-__global__ void k64_keys(const int* __restrict__ X, const int* __restrict__ Y, int n, G64 g, u64* __restrict__ keys, u32* __restrict__ vals)
-{
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const long long x = X[r], y = Y[r];
-    const long long U = g.wx * x + g.wy * y - g.U0, W = g.wy * y - g.wx * x - g.W0;
-    keys[r] = ((u64)((unsigned long long)U / (unsigned)g.eps) << g.qbits) | (u64)W;
-    vals[r] = (u32)r;
-}
-__global__ void k64_p(int n, G64 g, const int* __restrict__ X, const int* __restrict__ Y, const u32* __restrict__ srow,
-                      long long* __restrict__ p64)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u32 r = srow[i];
-    p64[i] = (long long)g.wx * X[r] + (long long)g.wy * Y[r] - g.U0;
-}
-__device__ __forceinline__ int lb_keys(const u64* __restrict__ k, int lo, int hi, u64 target)
-{
-    while (lo < hi) { const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1); if (k[mid] < target) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-// window of strip t = [sb, se) with q in [qi - eps, qi + eps]  ->  [*w0, *w1)
-__device__ __forceinline__ void win64(const G64& g, const u64* __restrict__ k, int t, int sb, int se, long long qi, int* w0, int* w1)
-{
-    const u64 base = (u64)(u32)t << g.qbits, qmask = (1ull << g.qbits) - 1ull;
-    const long long lo = qi - g.eps, hi = qi + g.eps;
-    *w0 = lb_keys(k, sb, se, base + (u64)(lo < 0 ? 0 : lo));
-    *w1 = lb_keys(k, *w0, se, base + ((u64)hi > qmask ? qmask : (u64)hi) + 1ull);
-}
-__global__ void k64_count(int n, G64 g, const u64* __restrict__ k, const long long* __restrict__ p64,
-                          const int* __restrict__ strip_start, int* __restrict__ cnt)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u64 qmask = (1ull << g.qbits) - 1ull;
-    const int s = (int)(k[i] >> g.qbits);
-    const long long qi = (long long)(k[i] & qmask), pi = p64[i];
-    int w0, w1;
-    win64(g, k, s, strip_start[s], strip_start[s + 1], qi, &w0, &w1);
-    int c = w1 - w0;                                     // own strip: |dU| < eps is implied
-    for (int d = -1; d <= 1 && c < g.minPts; d += 2) {
-        const int t = s + d;
-        if (t < 0 || t >= g.S) continue;
-        win64(g, k, t, strip_start[t], strip_start[t + 1], qi, &w0, &w1);
-        for (int j = w0; j < w1 && c < g.minPts; ++j) {
-            const long long dp = p64[j] - pi;
-            c += ((dp < 0 ? -dp : dp) <= g.eps) ? 1 : 0;
-        }
-    }
-    cnt[i] = c;                                          // saturated at minPts
-}
-__global__ void k64_union(int n, G64 g, const u64* __restrict__ k, const long long* __restrict__ p64,
-                          const int* __restrict__ strip_start, const int* __restrict__ cnt, int* parent)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || cnt[i] < g.minPts) return;
-    const u64 qmask = (1ull << g.qbits) - 1ull;
-    const int s = (int)(k[i] >> g.qbits);
-    const long long qi = (long long)(k[i] & qmask), pi = p64[i];
-    // own strip: the next core within eps (consecutive cores within eps chain the whole window together)
-    const int e = strip_start[s + 1];
-    for (int j = i + 1; j < e && (long long)(k[j] & qmask) - qi <= g.eps; ++j)
-        if (cnt[j] >= g.minPts) { uf_unite(parent, i, j); break; }
-    if (s > 0) {
-        int w0, w1;
-        win64(g, k, s - 1, strip_start[s - 1], strip_start[s], qi, &w0, &w1);
-        int last = -1;
-        for (int j = w0; j < w1; ++j) {
-            if (cnt[j] < g.minPts) continue;
-            const long long dp = p64[j] - pi;
-            if ((dp < 0 ? -dp : dp) > g.eps) continue;
-            const int rj = parent[j];                     // any ancestor: only used to skip repeated work
-            if (rj != last) { uf_unite(parent, i, j); last = rj; }
-        }
-    }
-}
-// border points by rule R1 (cDBSCAN.py:172-173, 179-182): see k_border
-__global__ void k64_border(int n, G64 g, const u64* __restrict__ k, const long long* __restrict__ p64,
-                           const int* __restrict__ strip_start, const int* __restrict__ root, const int* __restrict__ compkey,
-                           const int* __restrict__ ncore, const u32* __restrict__ srow, int* __restrict__ owner, int* __restrict__ bsize)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int ri = root[i];
-    if (ri >= 0) { owner[i] = ri; return; }
-    const u64 qmask = (1ull << g.qbits) - 1ull;
-    const int s = (int)(k[i] >> g.qbits);
-    const long long qi = (long long)(k[i] & qmask), pi = p64[i];
-    int bestk = INT_MAX, best = -1, tk = -1, tbest = -1, lastr = -1, lastk = 0;
-    for (int d = -1; d <= 1; ++d) {
-        const int t = s + d;
-        if (t < 0 || t >= g.S) continue;
-        int w0, w1;
-        win64(g, k, t, strip_start[t], strip_start[t + 1], qi, &w0, &w1);
-        for (int j = w0; j < w1; ++j) {
-            const int r = root[j];
-            if (r < 0) continue;
-            if (d != 0) { const long long dp = p64[j] - pi; if ((dp < 0 ? -dp : dp) > g.eps) continue; }
-            int kk;
-            if (r == lastr) kk = lastk; else { kk = compkey[r]; lastr = r; lastk = kk; }
-            if (kk < bestk) { bestk = kk; best = r; }
-            if ((int)srow[j] == kk && kk > tk) { tk = kk; tbest = r; }     // j is its component's start point
-        }
-    }
-    const int o = tbest >= 0 ? tbest : best;
-    owner[i] = o;
-    if (o >= 0 && ncore[o] < g.minPts) atomicAdd(&bsize[o], 1);
-}
-__global__ void __launch_bounds__(BIGTPB)
-k64_final(int n, const int* __restrict__ X, const int* __restrict__ Y, const u32* __restrict__ srow, const int* __restrict__ owner,
-          const int* __restrict__ rlabel, int* __restrict__ labels, Table t)
-{
-    __shared__ TableLds h;
-    table_lds_init(h);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int lab = -1, x = 0, y = 0;
-    if (i < n) {
-        const int o = owner[i];
-        if (o >= 0) lab = rlabel[o];
-        const u32 r = srow[i];
-        labels[r] = lab;
-        x = X[r]; y = Y[r];
-    }
-    table_accumulate(t, h, lab, x, y);
-    table_flush(t, h);
-}
-
-// ==========================================================================================
-// K6: blockDBSCAN (cLoops/blockDBSCAN.py) -- DBSCAN over grid CELLS
-// ==========================================================================================
-// Closed form: unrotated eps-grid anchored at the filtered set's (minX,minY)
-// (:74-82); cells whose 9-cell population is < minPts and whose existing neighbours are all
-// like that are deleted (:101-122); two surviving 8-adjacent cells are LINKED iff their
-// float64 centroids are within eps (city block) or some point pair is (:204-239); a cell is
-// CORE iff own + linked population >= minPts (:181,191); components of core cells are ranked
-// by their first cell in insertion order (= smallest input row of the cell's first point,
-// :148-152); a non-core cell linked to core cells takes the LARGEST adjacent rank
-// (unconditional overwrite, :195-198); points inherit their cell's label (:154-168).
-struct BlkParams {
-    int eps, minPts, cut;
-    int R;            // rows of the cell-row table; key row R marks filtered PETs
-    int n;
-    int nyb, rb;      // sort key = ((nx << nyb | ny) << 2*rb) | rx << rb | ry ; only the cell bits are sorted
-    u32 magic; int sh1, sh2;      // v / eps by multiply-shift (same constants as GridParams)
-};
-__device__ __forceinline__ u32 blk_div(const BlkParams& p, u32 n)
-{
-    const u32 t1 = __umulhi(p.magic, n);
-    return (t1 + ((n - t1) >> p.sh1)) >> p.sh2;
-}
-struct BlkScalars { int minx, miny, M, C; };
-
-__global__ void k_blk_init_scalars(BlkScalars* sc, int minx, int miny)
-{
-    sc->minx = minx; sc->miny = miny; sc->M = 0; sc->C = 0;
-}
-
-__global__ void k_blk_minmax(const int* __restrict__ X, const int* __restrict__ Y, int n, int cut, BlkScalars* sc)
-{
-    __shared__ int red[2][TPB / 64];
-    int mx = INT_MAX, my = INT_MAX;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        int x = X[i], y = Y[i];
-        if (y - x < cut) continue;
-        mx = min(mx, x); my = min(my, y);
-    }
-    for (int o = 32; o > 0; o >>= 1) { mx = min(mx, __shfl_down(mx, o)); my = min(my, __shfl_down(my, o)); }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = mx; red[1][threadIdx.x >> 6] = my; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < TPB / 64; ++w) { mx = min(mx, red[0][w]); my = min(my, red[1][w]); }
-        if (mx != INT_MAX) { atomicMin(&sc->minx, mx); atomicMin(&sc->miny, my); }
-    }
-}
-
-__global__ void k_blk_keys(const int* __restrict__ X, const int* __restrict__ Y, BlkParams p, const BlkScalars* __restrict__ sc,
-                           u64* __restrict__ keys, u32* __restrict__ vals)
-{
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= p.n) return;
-    int x = X[r], y = Y[r];
-    bool valid = (p.cut <= 0) || (y - x >= p.cut);
-    // nx = int((X - minX) / cw) + 1 (:81-82); the +1 is dropped (cells are only compared)
-    u64 key = (u64)(u32)p.R << (p.nyb + 2 * p.rb);
-    if (valid) {
-        const u32 ux = (u32)(x - sc->minx), uy = (u32)(y - sc->miny);
-        const u32 nx = blk_div(p, ux), ny = blk_div(p, uy);
-        const u32 rx = ux - nx * (u32)p.eps, ry = uy - ny * (u32)p.eps;
-        key = ((((u64)nx << p.nyb) | ny) << (2 * p.rb)) | ((u64)rx << p.rb) | ry;
-    }
-    keys[r] = key;
-    vals[r] = (u32)r;
-}
-
-// decode the sorted keys back into coordinates (no gather), mark cell heads
-__global__ void k_blk_gather(BlkParams p, const u64* __restrict__ skeys,
-                             int* __restrict__ sx, int* __restrict__ sy, int* __restrict__ headflag, BlkScalars* sc)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
-    const int cb = 2 * p.rb;
-    const u64 k = skeys[i];
-    const u64 cell = k >> cb;
-    const u32 nx = (u32)(cell >> p.nyb), ny = (u32)(cell & ((1ull << p.nyb) - 1));
-    const bool valid = nx < (u32)p.R;
-    const u32 rmask = (1u << p.rb) - 1;
-    sx[i] = sc->minx + (int)(nx * (u32)p.eps + ((u32)(k >> p.rb) & rmask));
-    sy[i] = sc->miny + (int)(ny * (u32)p.eps + ((u32)k & rmask));
-    const u64 prev = i ? (skeys[i - 1] >> cb) : ~0ull;
-    headflag[i] = (valid && prev != cell) ? 1 : 0;
-    if (!valid && (i == 0 || (u32)(prev >> p.nyb) < (u32)p.R)) sc->M = i;   // first filtered row
-    if (valid && i == p.n - 1) sc->M = p.n;
-}
-
-// cid[i] = (inclusive prefix sum of headflag)[i] - 1 ; per-cell arrays
-__global__ void k_blk_cells(BlkParams p, const u64* __restrict__ skeys, const int* __restrict__ headflag,
-                            const int* __restrict__ cidp1, const u32* __restrict__ srow, BlkScalars* sc,
-                            int* __restrict__ cstart, u64* __restrict__ ckey, int* __restrict__ cfirst)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int M = sc->M;
-    if (i >= M) return;
-    if (headflag[i]) {
-        int c = cidp1[i] - 1;
-        cstart[c] = i;
-        ckey[c] = skeys[i] >> (2 * p.rb);
-        cfirst[c] = (int)srow[i];       // stable sort: first of the run = smallest input row
-    }
-    if (i == M - 1) { int C = cidp1[i]; sc->C = C; cstart[C] = M; }
-}
-
-// rowcell[r] = first cell index whose row >= r, r = 0..R
-__global__ void k_blk_rowtable(BlkParams p, const BlkScalars* __restrict__ sc, const u64* __restrict__ ckey,
-                               int* __restrict__ rowcell)
-{
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > p.R) return;
-    const int C = sc->C;
-    u64 target = (u64)(u32)r << p.nyb;
-    int lo = 0, hi = C;
-    while (lo < hi) { int mid = (lo + hi) >> 1; if (ckey[mid] < target) lo = mid + 1; else hi = mid; }
-    rowcell[r] = lo;
-}
-
-// neighbour indices (8 per cell, order (dx,dy) = (-1,-1),(-1,0),(-1,1),(0,-1),(0,1),(1,-1),(1,0),(1,1); the
-// reverse of direction q is 7-q), 9-cell population test, centroids.  Cells of one row are consecutive in
-// the cell table, so each neighbouring row costs ONE binary search (for ny-1) plus a walk over <= 3 cells.
-__global__ void k_blk_neighbors(BlkParams p, const BlkScalars* __restrict__ sc, const u64* __restrict__ ckey,
-                                const int* __restrict__ rowcell, const int* __restrict__ cstart,
-                                const int* __restrict__ sx, const int* __restrict__ sy,
-                                int* __restrict__ nb, int* __restrict__ low, double* __restrict__ cx, double* __restrict__ cy)
-{
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int C = sc->C;
-    if (c >= C) return;
-    const u64 k = ckey[c];
-    const long long nx = (long long)(k >> p.nyb), ny = (long long)(k & ((1ull << p.nyb) - 1));
-    const int cb = cstart[c], ce = cstart[c + 1];
-    int tot = ce - cb;
-    int res[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) res[q] = -1;
-    // same row: the neighbours are c-1 / c+1 when their keys are k-1 / k+1 (ny-1 >= 0 checked: k-1 would borrow)
-    if (ny > 0 && c > 0 && ckey[c - 1] == k - 1) res[3] = c - 1;
-    if (c + 1 < C && ckey[c + 1] == k + 1 && ny + 1 < (1ll << p.nyb)) res[4] = c + 1;
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        const long long rx = nx + (side ? 1 : -1);
-        if (rx < 0 || rx >= p.R) continue;
-        const int rlo = rowcell[rx], rhi = rowcell[rx + 1];
-        const long long y0 = ny > 0 ? ny - 1 : 0;
-        const u64 target = ((u64)rx << p.nyb) | (u64)y0;
-        int lo = rlo, hi = rhi;
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (ckey[mid] < target) lo = mid + 1; else hi = mid; }
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            if (lo >= rhi) break;
-            const long long yy = (long long)(ckey[lo] & ((1ull << p.nyb) - 1));
-            const long long d = yy - ny;
-            if (d > 1) break;
-            if (d == -1) res[side * 5 + 0] = lo;       // side 0 -> q 0..2, side 1 -> q 5..7
-            if (d == 0) res[side * 5 + 1] = lo;
-            if (d == 1) res[side * 5 + 2] = lo;
-            ++lo;
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) if (res[q] >= 0) tot += cstart[res[q] + 1] - cstart[res[q]];
-    int4* o = reinterpret_cast<int4*>(nb + (size_t)c * 8);
-    o[0] = make_int4(res[0], res[1], res[2], res[3]);
-    o[1] = make_int4(res[4], res[5], res[6], res[7]);
-    low[c] = tot < p.minPts ? 1 : 0;
-    long long sumx = 0, sumy = 0;
-    for (int t = cb; t < ce; ++t) { sumx += sx[t]; sumy += sy[t]; }
-    double m = (double)(ce - cb);
-    cx[c] = (double)sumx / m;          // true division of Python ints (:136-137)
-    cy[c] = (double)sumy / m;
-}
-
-// alive[c] = population of the cell if it survives the 9-cell test (:215-228), else 0
-__global__ void k_blk_alive(const BlkScalars* __restrict__ sc, const int* __restrict__ nb, const int* __restrict__ low,
-                            const int* __restrict__ cstart, int* __restrict__ alive, int* __restrict__ linkbits)
-{
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= sc->C) return;
-    int a = 1;
-    if (low[c]) {
-        a = 0;
-        for (int q = 0; q < 8; ++q) { int j = nb[(size_t)c * 8 + q]; if (j >= 0 && !low[j]) { a = 1; break; } }
-    }
-    alive[c] = a ? cstart[c + 1] - cstart[c] : 0;
-    linkbits[c] = 0;
-}
-
-// link bits: one thread per (cell, forward direction q = 4..7); the link test is symmetric (same centroid
-// distance, same point pairs), so the thread sets bit q of its cell and bit 7-q of the neighbour.
-// (A work list + 16 lanes per undecided cell pair was measured slower: the list append costs more
-// than the pair loops it spreads.)
-__global__ void k_blk_links(BlkParams p, const BlkScalars* __restrict__ sc, const int* __restrict__ nb,
-                            const int* __restrict__ alive, const int* __restrict__ cstart,
-                            const int* __restrict__ sx, const int* __restrict__ sy,
-                            const double* __restrict__ cx, const double* __restrict__ cy,
-                            int* __restrict__ linkbits)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = t >> 2, q = 4 + (t & 3);
-    if (c >= sc->C) return;
-    const int j = nb[(size_t)c * 8 + q];
-    if (j < 0) return;
-    const int na = alive[c], nbj = alive[j];
-    if (!na || !nbj) return;
-    bool linked = (fabs(cx[c] - cx[j]) + fabs(cy[c] - cy[j])) <= (double)p.eps;        // :232
-    // two single-PET cells: the centroids ARE the PETs, the pair test below cannot differ
-    if (!linked && (na > 1 || nbj > 1)) {                                              // getGridDist :204-213
-        int ab = cstart[c], ae = ab + na, bb = cstart[j], be = bb + nbj;
-        if (na > nbj) { int x0 = ab, x1 = ae; ab = bb; ae = be; bb = x0; be = x1; }    // walk the larger cell inside
-        for (int s = ab; s < ae && !linked; ++s) {
-            const int x = sx[s], y = sy[s];
-            int u = bb;
-            for (; u + 4 <= be && !linked; u += 4) {
-                int d[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    int dx = x - sx[u + k], dy = y - sy[u + k];
-                    d[k] = (dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy);
-                }
-                linked = min(min(d[0], d[1]), min(d[2], d[3])) <= p.eps;
-            }
-            for (; u < be && !linked; ++u) {
-                int dx = x - sx[u], dy = y - sy[u];
-                linked = (dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy) <= p.eps;
-            }
-        }
-    }
-    if (linked) { atomicOr(&linkbits[c], 1 << q); atomicOr(&linkbits[j], 1 << (7 - q)); }
-}
-
-// population over the linked cells + core flag (:236-240)
-__global__ void k_blk_core(BlkParams p, const BlkScalars* __restrict__ sc, const int* __restrict__ nb,
-                           const int* __restrict__ alive, const int* __restrict__ cstart,
-                           const int* __restrict__ linkbits, int* __restrict__ corec)
-{
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= sc->C) return;
-    int core = 0;
-    if (alive[c]) {
-        const int bits = linkbits[c];
-        int psum = cstart[c + 1] - cstart[c];
-        for (int q = 0; q < 8; ++q)
-            if (bits & (1 << q)) psum += je_minus(cstart, nb[(size_t)c * 8 + q]);
-        core = psum >= p.minPts ? 1 : 0;
-    }
-    corec[c] = core;
-}
-
-__global__ void k_blk_union(const BlkScalars* __restrict__ sc, const int* __restrict__ nb, const int* __restrict__ linkbits,
-                            const int* __restrict__ corec, int* parent)
-{
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= sc->C) return;
-    if (!corec[c]) return;
-    int bits = linkbits[c];
-    for (int q = 0; q < 8; ++q) {
-        if (!(bits & (1 << q))) continue;
-        int j = nb[(size_t)c * 8 + q];
-        if (j < c && corec[j]) uf_unite(parent, c, j);
-    }
-}
-
-// root per core cell + component key = smallest cfirst (two-level reduce-by-key like k_flatten: a giant
-// component would otherwise serialise millions of atomicMin on one address)
-__global__ void __launch_bounds__(BIGTPB)
-k_blk_flatten(const BlkScalars* __restrict__ sc, const int* __restrict__ corec, int* parent,
-              const int* __restrict__ cfirst, int* __restrict__ root, int* __restrict__ compkey)
-{
-    __shared__ int hkey[AGG_H], hmin[AGG_H];
-    if (threadIdx.x < AGG_H) { hkey[threadIdx.x] = -1; hmin[threadIdx.x] = INT_MAX; }
-    __syncthreads();
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    int r = -1, key = INT_MAX;
-    if (c < sc->C) {
-        if (corec[c]) { r = uf_find(parent, c); key = cfirst[c]; }
-        root[c] = r;
-    }
-    const int lane = threadIdx.x & 63;
-    unsigned long long pending = __ballot(r >= 0);
-    while (pending) {
-        const int leader = __ffsll((long long)pending) - 1;
-        const int R = __builtin_amdgcn_readlane(r, leader);
-        const unsigned long long m = __ballot(r == R);
-        const bool mine = r == R;
-        if (__popcll(m) >= 4) {
-            int mk = mine ? key : INT_MAX;
-            mk = dpp_reduce_wave(mk, OpMin());
-            if (lane == leader) {
-                const int sl = agg_slot(hkey, R);
-                if (sl >= 0) atomicMin(&hmin[sl], mk); else atomicMin(&compkey[R], mk);
-            }
-        } else if (mine) {
-            atomicMin(&compkey[R], key);
-        }
-        pending &= ~m;
-    }
-    __syncthreads();
-    if (threadIdx.x < AGG_H && hkey[threadIdx.x] >= 0) atomicMin(&compkey[hkey[threadIdx.x]], hmin[threadIdx.x]);
-}
-
-__global__ void k_blk_rank_flags(const BlkScalars* __restrict__ sc, const int* __restrict__ root,
-                                 const int* __restrict__ compkey, int* __restrict__ flag)
-{
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= sc->C) return;
-    if (root[c] == c) flag[compkey[c]] = 1;
-}
-
-__global__ void k_blk_cell_labels(const BlkScalars* __restrict__ sc, const int* __restrict__ nb,
-                                  const int* __restrict__ linkbits, const int* __restrict__ alive,
-                                  const int* __restrict__ root, const int* __restrict__ compkey,
-                                  const int* __restrict__ rankscan, int* __restrict__ clab)
-{
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= sc->C) return;
-    int lab = -1;
-    if (root[c] >= 0) lab = rankscan[compkey[root[c]]];
-    else if (alive[c]) {
-        int bits = linkbits[c];
-        for (int q = 0; q < 8; ++q) {
-            if (!(bits & (1 << q))) continue;
-            int j = nb[(size_t)c * 8 + q];
-            if (root[j] >= 0) lab = max(lab, rankscan[compkey[root[j]]]);     // :195-198 last writer = highest rank
-        }
-    }
-    clab[c] = lab;
-}
-
-__global__ void __launch_bounds__(BIGTPB)
-k_blk_point_labels(BlkParams p, const BlkScalars* __restrict__ sc, const int* __restrict__ cidp1,
-                   const int* __restrict__ clab, const u32* __restrict__ srow, const int* __restrict__ sx,
-                   const int* __restrict__ sy, int* __restrict__ labels, Table t)
-{
-    __shared__ TableLds h;
-    table_lds_init(h);
-    const int M = sc->M;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int lab = -1, x = 0, y = 0;
-    if (i < M) {
-        lab = clab[cidp1[i] - 1];
-        labels[srow[i]] = lab;
-        x = sx[i]; y = sy[i];
-    }
-    table_accumulate(t, h, lab, x, y);
-    table_flush(t, h);
-}
-
-// ==========================================================================================
-// K7: distance statistics of one step (the inputs of cLoops/ests.py:36-61, estIntSelCutFrag)
-// ==========================================================================================
-// pipe.py:106-109 collects `dis` = Y-X of the PETs in inter-ligation clusters and `dss` = Y-X of
-// the PETs in self-ligation clusters plus the PETs dropped by the cut (pipe.py:63); ests.py then
-// needs counts, mean / std of log2(|d|) over d > 0 for both groups and the median of the self
-// group.  At tens of millions of PETs per step the host-side masks, log2 and np.median cost
-// ~20x the clustering itself, so the sums are reduced here (fixed order: deterministic) and the
-// median comes from an exact 4-pass radix select on the integer distances.
-// group 0 = inter, group 1 = self (+ short), -1 = in no group
-__global__ void k7_classify(const int* __restrict__ hdr, Table t, signed char* __restrict__ cls)
-{
-    const int K = hdr[0];
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
-    const cl_box b = t.get(k);
-    signed char c = -1;
-    if (b.count > 0 && b.min_x != b.max_x && b.min_y != b.max_y)           // pipe.py:83-85
-        c = (b.max_x < b.min_y) ? 0 : 1;                                    // pipe.py:97
-    cls[k] = c;
-}
-
-// Source of the per-PET (distance, label) pairs of the last completed run:
-//   sorted  the run's sorted arrays: d = q + V0 and the label of sorted position i (rotated variants; the PETs
-//           removed by the cut are not in them and come from the input rows: d = Y - X < cut)
-//   rows    input-row order (variants that only produce row-order labels)
-struct K7Src {
-    int sorted; int n; int M; int v0;
-    const int* dM;                                      // if set: M is read from the device (the run has not been waited for yet)
-    const int* X; const int* Y; const int* labels;      // input rows (+ row-order labels)
-    const int* sv; const int* slab;                     // sorted q and sorted-order labels of [0, M)
-    const int* dh;                                      // if set: dh[d] = number of input rows with Y - X == d for 0 <= d < cut, and no row has
-                                                        // Y - X < 0: the PETs dropped by the cut come from it, not from a pass over the rows
-};
-#define K7_BLOCKS 2048           // workgroups (= fixed partial sums) of the K7 reductions: 8 waves per SIMD (512 left the loads
-                                 // of a 66-element sequential loop per thread uncovered: 177 us -> see DESIGN.md)
-#define K7_LOGBINS 3840          // 30 octaves x 128: bin = floor(log2 d) * 128 + the next 7 bits of d (monotone in d)
-#define K7_FINE 2048
-#define K7_XSHIFT 11.0           // sums are taken over x = log2|d| - K7_XSHIFT (less cancellation in sum x^2 - (sum x)^2 / n)
-
-__device__ __forceinline__ int k7_logbin(unsigned d)      // d >= 1
-{
-    const int e = 31 - __clz((int)d);
-    const unsigned m = e >= 7 ? ((d >> (e - 7)) & 127u) : ((d << (7 - e)) & 127u);
-    return e * 128 + (int)m;
-}
-// f(group, |d|) for every PET of a group, in a fixed order per thread (deterministic partial sums): the block works
-// on fixed contiguous ranges of the sources
-template <typename F>
-__device__ __forceinline__ void k7_for_each(const K7Src& s, int cut, const signed char* __restrict__ cls, F&& f)
-{
-    if (s.sorted) {
-        const int M = s.dM ? s.dM[0] : s.M;
-        const int per = (M + gridDim.x - 1) / gridDim.x;
-        const int i0 = blockIdx.x * per, i1 = min(M, i0 + per);
-        // four PETs per round: the label loads, then the class gathers, of all four are in flight together (the walk is bound
-        // by the dependent label -> class round trips, not by bytes); f() still sees the PETs in ascending order
-        int i = i0 + threadIdx.x;
-        const int bd = blockDim.x;
-        for (; i + 3 * bd < i1; i += 4 * bd) {
-            int lab[4], d[4], g[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { lab[k] = s.slab[i + k * bd]; d[k] = s.sv[i + k * bd] + s.v0; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) g[k] = lab[k] >= 0 ? (int)cls[lab[k]] : -1;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (g[k] >= 0) f(g[k], d[k] < 0 ? -d[k] : d[k], 1);     // ests.py:42-43 np.abs
-        }
-        for (; i < i1; i += bd) {
-            const int lab = s.slab[i];
-            const int g = lab >= 0 ? (int)cls[lab] : -1;
-            const int d = s.sv[i] + s.v0;
-            if (g >= 0) f(g, d < 0 ? -d : d, 1);
-        }
-        if (cut > 0 && s.dh) {                                     // pipe.py:63: short PETs go to dss -- all PETs of one distance at once
-            for (int d = blockIdx.x * blockDim.x + threadIdx.x; d < cut; d += gridDim.x * blockDim.x) {
-                const int w = s.dh[d];
-                if (w) f(1, d, w);
-            }
-        } else if (cut > 0) {
-            const int perr = (s.n + gridDim.x - 1) / gridDim.x;
-            const int r0 = blockIdx.x * perr, r1 = min(s.n, r0 + perr);
-            for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
-                const int d = s.Y[r] - s.X[r];
-                if (d < cut) f(1, d < 0 ? -d : d, 1);
-            }
-        }
-    } else {
-        const int perr = (s.n + gridDim.x - 1) / gridDim.x;
-        const int r0 = blockIdx.x * perr, r1 = min(s.n, r0 + perr);
-        for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
-            const int d = s.Y[r] - s.X[r];
-            int g = 1;
-            if (!(cut > 0 && d < cut)) { const int lab = s.labels[r]; g = lab >= 0 ? (int)cls[lab] : -1; }
-            if (g >= 0) f(g, d < 0 ? -d : d, 1);
-        }
-    }
-}
-
-struct K7Part { double sx[2]; double sxx[2]; long long n_all[2]; long long n_pos[2]; };
-
-// fixed-order reduction of the workgroup partials (deterministic: thread t sums blocks t, t+256, ... in order, then a fixed
-// tree) -- the host reads 64 bytes instead of K7_BLOCKS partials; in a sweep step the candidate totals ride along.  Called by
-// the first 256 threads of ONE workgroup; sd / sn: 4 x 256 doubles / long longs of LDS.
-__device__ __forceinline__ void k7_reduce_block(const K7Part* __restrict__ parts, int nparts, K7Part* __restrict__ out,
-                                                const int* __restrict__ bcount /* or null */, int nb, long long* __restrict__ totals,
-                                                double (*sd)[256], long long (*sn)[256])
-{
-    const int tid = threadIdx.x;
-    double a[4] = {0, 0, 0, 0}; long long c[6] = {0, 0, 0, 0, 0, 0};
-    for (int k = tid; k < nparts; k += 256) {
-        const K7Part p = parts[k];
-        a[0] += p.sx[0]; a[1] += p.sx[1]; a[2] += p.sxx[0]; a[3] += p.sxx[1];
-        c[0] += p.n_all[0]; c[1] += p.n_all[1]; c[2] += p.n_pos[0]; c[3] += p.n_pos[1];
-    }
-    if (bcount) for (int k = tid; k < nb; k += 256) { c[4] += bcount[k]; c[5] += bcount[nb + k]; }      // inter / self boxes of the run
-    for (int q = 0; q < 4; ++q) { sd[q][tid] = a[q]; sn[q][tid] = c[q]; }
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) for (int q = 0; q < 4; ++q) { sd[q][tid] += sd[q][tid + o]; sn[q][tid] += sn[q][tid + o]; }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        K7Part p;
-        p.sx[0] = sd[0][0]; p.sx[1] = sd[1][0]; p.sxx[0] = sd[2][0]; p.sxx[1] = sd[3][0];
-        p.n_all[0] = sn[0][0]; p.n_all[1] = sn[1][0]; p.n_pos[0] = sn[2][0]; p.n_pos[1] = sn[3][0];
-        *out = p;
-    }
-    if (bcount) {
-        __syncthreads();
-        sn[0][tid] = c[4]; sn[1][tid] = c[5];
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o) { sn[0][tid] += sn[0][tid + o]; sn[1][tid] += sn[1][tid + o]; }
-            __syncthreads();
-        }
-        if (tid == 0) { totals[0] = sn[0][0]; totals[1] = sn[1][0]; }
-    }
-}
-
-// (a "last workgroup reduces" step inside k7_summary instead of this launch measured 4 % SLOWER on the whole sweep)
-// host_step / host_hdr (sweep steps): the step's whole output -- totals, statistics, the two histograms -- and the run's header go
-// to pinned host memory from HERE, the last kernel of the step (the host reads them after the stream's completion event): no
-// copy-stream hand-over and no copy packets per run
-__global__ void __launch_bounds__(256)
-k7_reduce_parts(const K7Part* __restrict__ parts, int nparts, K7Part* out, const int* __restrict__ bcount /* or null */, int nb,
-                long long* totals, const volatile unsigned long long* dev_step /* or null */, int step_words,
-                unsigned long long* __restrict__ host_step, const int* __restrict__ dev_hdr, int* __restrict__ host_hdr)
-{
-    // `out`, `totals` and `dev_step` are views of ONE device buffer (the step output: totals | reduced part | histograms):
-    // no restrict on them, and the copy to the host re-reads what thread 0 has just stored (volatile loads behind the fence)
-    __shared__ double sd[4][256];
-    __shared__ long long sn[4][256];
-    k7_reduce_block(parts, nparts, out, bcount, nb, totals, sd, sn);
-    if (dev_step) {
-        __threadfence();
-        __syncthreads();                                // totals and the reduced part are written (same workgroup: visible)
-        for (int k = threadIdx.x; k < step_words; k += 256) host_step[k] = dev_step[k];
-        if (threadIdx.x < 8) host_hdr[threadIdx.x] = dev_hdr[threadIdx.x];
-    }
-}
-
-// one pass: counts, sum x and sum x^2 (x = log2|d| - K7_XSHIFT over d != 0) for both groups, and the log-binned
-// histogram of the self group's |d| (first level of the exact median)
-__global__ void __launch_bounds__(TPB)
-k7_summary(K7Src s, int cut, const signed char* __restrict__ cls, K7Part* __restrict__ parts, unsigned long long* __restrict__ loghist,
-           unsigned fine_lo, unsigned long long* __restrict__ fine /* or null: exact histogram of the self group's fine_lo <= |d| < fine_lo + 2048 */)
-{
-    __shared__ unsigned int h[K7_LOGBINS];
-    __shared__ unsigned int hf[K7_FINE];
-    for (int k = threadIdx.x; k < K7_LOGBINS; k += blockDim.x) h[k] = 0u;
-    for (int k = threadIdx.x; k < K7_FINE; k += blockDim.x) hf[k] = 0u;
-    __syncthreads();
-    double sx[2] = {0.0, 0.0}, sxx[2] = {0.0, 0.0};
-    long long na[2] = {0, 0}, np_[2] = {0, 0};
-    const bool want_fine = fine != nullptr;
-    k7_for_each(s, cut, cls, [&](int g, int ad, int w) {                  // w PETs of this group and distance
-        na[g] += w;
-        if (ad > 0) {
-            const double x = log2((double)ad) - K7_XSHIFT, wx = (double)w * x;
-            np_[g] += w; sx[g] += wx; sxx[g] += wx * x;
-            if (g == 1) {
-                atomicAdd(&h[k7_logbin((unsigned)ad)], (unsigned)w);
-                const unsigned off = (unsigned)ad - fine_lo;                  // wraps for ad < fine_lo: out of range
-                if (want_fine && off < (unsigned)K7_FINE) atomicAdd(&hf[off], (unsigned)w);
-            }
-        }
-    });
-    __shared__ double s_d[4][TPB / 64];
-    __shared__ long long s_n[4][TPB / 64];
-    for (int g = 0; g < 2; ++g)
-        for (int o = 32; o > 0; o >>= 1) {
-            sx[g] += __shfl_down(sx[g], o); sxx[g] += __shfl_down(sxx[g], o);
-            na[g] += __shfl_down(na[g], o); np_[g] += __shfl_down(np_[g], o);
-        }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) {
-        s_d[0][wv] = sx[0]; s_d[1][wv] = sx[1]; s_d[2][wv] = sxx[0]; s_d[3][wv] = sxx[1];
-        s_n[0][wv] = na[0]; s_n[1][wv] = na[1]; s_n[2][wv] = np_[0]; s_n[3][wv] = np_[1];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        K7Part p;
-        for (int g = 0; g < 2; ++g) {
-            double a = 0, b = 0; long long c = 0, d = 0;
-            for (int w = 0; w < TPB / 64; ++w) { a += s_d[g][w]; b += s_d[2 + g][w]; c += s_n[g][w]; d += s_n[2 + g][w]; }
-            p.sx[g] = a; p.sxx[g] = b; p.n_all[g] = c; p.n_pos[g] = d;
-        }
-        parts[blockIdx.x] = p;
-    }
-    for (int k = threadIdx.x; k < K7_LOGBINS; k += blockDim.x)
-        if (h[k]) atomicAdd(&loghist[k], (unsigned long long)h[k]);
-    if (want_fine)
-        for (int k = threadIdx.x; k < K7_FINE; k += blockDim.x)
-            if (hf[k]) atomicAdd(&fine[k], (unsigned long long)hf[k]);
-}
-
-// refinement pass of the exact median: histogram of (|d| - lo) >> shift over the self group's lo <= |d| < hi
-__global__ void __launch_bounds__(TPB)
-k7_bin_hist(K7Src s, int cut, const signed char* __restrict__ cls, unsigned lo, unsigned hi, int shift, unsigned long long* __restrict__ hist)
-{
-    __shared__ unsigned int h[K7_FINE];
-    for (int k = threadIdx.x; k < K7_FINE; k += blockDim.x) h[k] = 0u;
-    __syncthreads();
-    k7_for_each(s, cut, cls, [&](int g, int ad, int w) {
-        const unsigned u = (unsigned)ad;
-        if (g == 1 && u >= lo && u < hi) atomicAdd(&h[min((u - lo) >> shift, (unsigned)(K7_FINE - 1))], (unsigned)w);
-    });
-    __syncthreads();
-    for (int k = threadIdx.x; k < K7_FINE; k += blockDim.x)
-        if (h[k]) atomicAdd(&hist[k], (unsigned long long)h[k]);
-}
-
-// ==========================================================================================
-// K10: the candidate loops of a sweep, kept on the device
-// ==========================================================================================
-// The sweep driver used to pull every run's cluster table over PCIe, classify it with numpy and, at the end, dedup
-// the concatenation of all steps on the host (combineTwice, cLoops/pipe.py:155-174: a box is kept in the step where
-// it FIRST appears; duplicates inside one step all stay) and filter it by the final cut (filterClusterByDis,
-// pipe.py:130-143, Python-2 floor mid-points).  Here a run's inter-ligation boxes (pipe.py:83-97) are appended, in
-// ascending cluster id, to a per-chromosome device buffer together with their step number; at the end of the sweep
-// one 64-bit-hash radix sort groups equal boxes (stable: the first of a group is its first appearance), the exact
-// boxes are compared inside a group, and the survivors are compacted in append order -- the order the reference's
-// record lists have.  Only the final table crosses PCIe.
-#define CAND_BLOCK 2048
-__global__ void __launch_bounds__(256)
-k_cand_count(const int* __restrict__ dK, const signed char* __restrict__ cls, int* __restrict__ bcount /* [nb] inter, [nb] self */, int nb)
-{
-    __shared__ int red[2][4];
-    const int K = dK[0];
-    const int base = blockIdx.x * CAND_BLOCK;
-    int ci = 0, cs = 0;
-    for (int k = threadIdx.x; k < CAND_BLOCK; k += 256) {
-        const int i = base + k;
-        const int c = i < K ? (int)cls[i] : -1;
-        ci += c == 0; cs += c == 1;
-    }
-    for (int o = 32; o > 0; o >>= 1) { ci += __shfl_down(ci, o); cs += __shfl_down(cs, o); }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ci; red[1][threadIdx.x >> 6] = cs; }
-    __syncthreads();
-    if (threadIdx.x == 0) { bcount[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3]; bcount[nb + blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3]; }
-}
-// sweep step: k7_classify + k_cand_count in one launch, which also clears the step's histograms (`zero`, nzero 8-byte words)
-__global__ void __launch_bounds__(256)
-k_step_classify_count(const int* __restrict__ dK, Table t, signed char* __restrict__ cls, int* __restrict__ bcount, int nb,
-                      unsigned long long* __restrict__ zero, int nzero)
-{
-    __shared__ int red[2][4];
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < nzero; k += gridDim.x * 256) zero[k] = 0ull;
-    const int K = dK[0];
-    const int base = blockIdx.x * CAND_BLOCK;
-    int ci = 0, cs = 0;
-    for (int k = threadIdx.x; k < CAND_BLOCK; k += 256) {
-        const int i = base + k;
-        if (i < K) {
-            const cl_box b = t.get(i);
-            signed char c = -1;
-            if (b.count > 0 && b.min_x != b.max_x && b.min_y != b.max_y)       // pipe.py:83-85
-                c = (b.max_x < b.min_y) ? 0 : 1;                                // pipe.py:97
-            cls[i] = c;
-            ci += c == 0; cs += c == 1;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) { ci += __shfl_down(ci, o); cs += __shfl_down(cs, o); }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ci; red[1][threadIdx.x >> 6] = cs; }
-    __syncthreads();
-    if (threadIdx.x == 0) { bcount[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3]; bcount[nb + blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3]; }
-}
-// ordered scatter of the flagged elements of [0, N): dst = base + boff[block] + rank inside the block (element order)
-template <typename F, typename W>
-__device__ __forceinline__ void ordered_scatter_block(int N, const int* __restrict__ boff /* or null: */, const int* __restrict__ bcount,
-                                                      F&& flagged, W&& write)
-{
-    __shared__ int l_cnt[(CAND_BLOCK / 256) * 4];
-    const int base = blockIdx.x * CAND_BLOCK;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    bool keep[CAND_BLOCK / 256]; int before[CAND_BLOCK / 256];
-#pragma unroll
-    for (int k = 0; k < CAND_BLOCK / 256; ++k) {
-        const int i = base + k * 256 + (int)threadIdx.x;
-        keep[k] = i < N && flagged(i);
-        const unsigned long long bal = __ballot(keep[k]);
-        before[k] = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-        if (lane == 0) l_cnt[k * 4 + wv] = __popcll(bal);
-    }
-    __syncthreads();
-    int pre;
-    if (boff) pre = boff[blockIdx.x];
-    else {
-        // no scan over the block counts: a block sums the counts in front of it itself (a few hundred at most: sweep steps)
-        __shared__ int l_pre[4];
-        int sum = 0;
-        for (int k = threadIdx.x; k < (int)blockIdx.x; k += 256) sum += bcount[k];
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
-        if (lane == 0) l_pre[wv] = sum;
-        __syncthreads();
-        pre = l_pre[0] + l_pre[1] + l_pre[2] + l_pre[3];
-    }
-#pragma unroll
-    for (int k = 0; k < CAND_BLOCK / 256; ++k) {
-        int mine = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { if (w == wv) mine = pre; pre += l_cnt[k * 4 + w]; }
-        if (keep[k]) write(base + k * 256 + (int)threadIdx.x, mine + before[k]);
-    }
-}
-__global__ void __launch_bounds__(256)
-k_cand_append(const int* __restrict__ dK, const signed char* __restrict__ cls, Table t, const int* __restrict__ boff /* or null: */,
-              const int* __restrict__ bcount, int base, int step, int cap, int4* __restrict__ cbox, int* __restrict__ cstep)
-{
-    ordered_scatter_block(dK[0], boff, bcount, [&](int i) { return cls[i] == 0; },
-                          [&](int i, int r) { const int d = base + r; if (d < cap) { cbox[d] = make_int4(t.minx[i], t.maxx[i], t.miny[i], t.maxy[i]); cstep[d] = step; } });
-}
-__device__ __forceinline__ u64 box_hash(int4 b, u64 salt)
-{
-    u64 h = salt ^ ((u64)(u32)b.x * 0x9E3779B97F4A7C15ull) ^ ((u64)(u32)b.y * 0xC2B2AE3D27D4EB4Full) ^ ((u64)(u32)b.z * 0x165667B19E3779F9ull) ^ ((u64)(u32)b.w * 0xD6E8FEB86659FD93ull);
-    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
-    return h;
-}
-__global__ void k_cand_hash(int N, const int4* __restrict__ cbox, u64 salt, u64* __restrict__ keys, u32* __restrict__ vals)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) { keys[i] = box_hash(cbox[i], salt); vals[i] = (u32)i; }
-}
-__device__ __forceinline__ long long floordiv2(long long a) { return a >> 1; }      // floor(a / 2) for any sign (pipe.py:138 on Python-2 ints)
-__global__ void k_cand_mark(int N, const u64* __restrict__ skeys, const u32* __restrict__ svals, const int4* __restrict__ cbox,
-                            const int* __restrict__ cstep, int final_cut, unsigned char* __restrict__ keep, int* __restrict__ flags)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
-    const u64 key = skeys[j];
-    int j0 = j, guard = 0;
-    while (j0 > 0 && skeys[j0 - 1] == key && guard < 65536) { --j0; ++guard; }
-    if (guard >= 65536) atomicExch(&flags[0], 2);
-    const u32 p = svals[j], hp = svals[j0];              // stable sort: the head of a group is its first appearance
-    const int4 b = cbox[p], hb = cbox[hp];
-    const bool same = b.x == hb.x && b.y == hb.y && b.z == hb.z && b.w == hb.w;
-    if (!same) atomicExch(&flags[0], 1);                 // two different boxes share a 64-bit hash: the caller redoes this chromosome exactly
-    const long long d = floordiv2((long long)b.z + b.w) - floordiv2((long long)b.x + b.y);
-    keep[p] = (same && cstep[p] == cstep[hp] && d >= (long long)final_cut) ? 1 : 0;
-}
-__global__ void __launch_bounds__(256)
-k_flag_count(int N, const unsigned char* __restrict__ keep, int* __restrict__ bcount)
-{
-    __shared__ int red[4];
-    const int base = blockIdx.x * CAND_BLOCK;
-    int c = 0;
-    for (int k = threadIdx.x; k < CAND_BLOCK; k += 256) { const int i = base + k; c += (i < N && keep[i]) ? 1 : 0; }
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) bcount[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-__global__ void __launch_bounds__(256)
-k_cand_emit(int N, const unsigned char* __restrict__ keep, const int4* __restrict__ cbox, const int* __restrict__ boff, int4* __restrict__ out)
-{
-    ordered_scatter_block(N, boff, (const int*)nullptr, [&](int i) { return keep[i] != 0; }, [&](int i, int r) { out[r] = cbox[i]; });
-}
-
-// ==========================================================================================
-// K8: interval counting for the significance test (cLoops/cModel.py:60-80, 108-143)
-// ==========================================================================================
-// For a candidate loop with anchors iva, ivb the reference builds Python sets of the PETs that have
-// an end inside a window, S(W) = {i : X_i in W} | {i : Y_i in W}, for the two anchors and for 10 + 10
-// shifted windows, and needs |S(A_k)|, |S(B_l)|, |S(A_k) & S(B_l)| and rab = |{X in iva} & {Y in ivb}|.
-// One workgroup per candidate: the PETs with an end inside the span of the A windows (resp. B windows)
-// are two contiguous slices of the X-sorted and Y-sorted PET tables; every PET gets an 11-bit
-// membership mask per side and bumps the counters in LDS.  Pure integer work; the p-values stay on
-// the host (scipy), fed with exactly the reference's counts.
-#define SIG_W 11                       // window 0 = the anchor itself, 1..10 = cModel.getNearbyPairRegions
-#define SIG_OUT (2 * SIG_W + 1 + SIG_W * SIG_W)
-
-__global__ void k8_split(const int* __restrict__ X, const int* __restrict__ Y, int n, int cut,
-                         u64* __restrict__ kx, u64* __restrict__ ky)
-{
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const int x = X[r], y = Y[r];
-    const bool valid = cut <= 0 || (y - x) >= cut;            // parseJd(f, cut), io.py:213-216
-    // sort key = coordinate (biased to be non-negative), payload = the other coordinate
-    kx[r] = valid ? (((u64)(u32)(x + (1 << 30)) << 32) | (u32)(y + (1 << 30))) : ~0ull;
-    ky[r] = valid ? (((u64)(u32)(y + (1 << 30)) << 32) | (u32)(x + (1 << 30))) : ~0ull;
-}
-
-// first index with (key >> 32) >= v   /   > v   in a sorted u64 table of m valid entries
-__device__ __forceinline__ int k8_lb(const u64* __restrict__ t, int m, long long v)
-{
-    const u64 target = v <= -(1ll << 30) ? 0ull : ((u64)(u32)(v + (1 << 30)) << 32);
-    int lo = 0, hi = m;
-    while (lo < hi) { int mid = (lo + hi) >> 1; if (t[mid] < target) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-__device__ __forceinline__ int k8_ub(const u64* __restrict__ t, int m, long long v)
-{
-    return k8_lb(t, m, v + 1);
-}
-
-struct SigWin { int lo[2 * SIG_W]; int hi[2 * SIG_W]; };      // [0..10] = A windows, [11..21] = B windows
-
-__global__ void __launch_bounds__(TPB)
-k8_counts(const u64* __restrict__ tx, const u64* __restrict__ ty, const int* __restrict__ d_m, int nrec,
-          const SigWin* __restrict__ wins, int* __restrict__ out)
-{
-    __shared__ int wlo[2 * SIG_W], whi[2 * SIG_W];
-    __shared__ int c_a[SIG_W], c_b[SIG_W], c_ab[SIG_W * SIG_W], c_rab;
-    __shared__ int rng[8];
-    const int rec = blockIdx.x;
-    if (rec >= nrec) return;
-    const int m = d_m[0];
-    if (threadIdx.x < 2 * SIG_W) { wlo[threadIdx.x] = wins[rec].lo[threadIdx.x]; whi[threadIdx.x] = wins[rec].hi[threadIdx.x]; }
-    if (threadIdx.x < SIG_W) { c_a[threadIdx.x] = 0; c_b[threadIdx.x] = 0; }
-    for (int k = threadIdx.x; k < SIG_W * SIG_W; k += blockDim.x) c_ab[k] = 0;
-    if (threadIdx.x == 0) c_rab = 0;
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        // spans of the A and of the B windows; slices of the X-sorted (0,2) and Y-sorted (1,3) tables
-        const int side = threadIdx.x >> 1, off = side * SIG_W;
-        int lo = wlo[off], hi = whi[off];
-        for (int k = 1; k < SIG_W; ++k) { lo = min(lo, wlo[off + k]); hi = max(hi, whi[off + k]); }
-        const u64* t = (threadIdx.x & 1) ? ty : tx;
-        rng[threadIdx.x * 2] = k8_lb(t, m, lo);
-        rng[threadIdx.x * 2 + 1] = k8_ub(t, m, hi);
-        if ((threadIdx.x & 1) == 0) { /* keep spans for the dedupe test */ }
-    }
-    __syncthreads();
-    int spanlo[2], spanhi[2];
-    for (int side = 0; side < 2; ++side) {
-        int lo = wlo[side * SIG_W], hi = whi[side * SIG_W];
-        for (int k = 1; k < SIG_W; ++k) { lo = min(lo, wlo[side * SIG_W + k]); hi = max(hi, whi[side * SIG_W + k]); }
-        spanlo[side] = lo; spanhi[side] = hi;
-    }
-    for (int side = 0; side < 2; ++side) {
-        for (int tab = 0; tab < 2; ++tab) {
-            const u64* t = tab ? ty : tx;
-            const int b = rng[(side * 2 + tab) * 2], e = rng[(side * 2 + tab) * 2 + 1];
-            for (int j = b + (int)threadIdx.x; j < e; j += blockDim.x) {
-                const u64 kv = t[j];
-                const int first = (int)(u32)(kv >> 32) - (1 << 30), second = (int)(u32)(kv & 0xffffffffu) - (1 << 30);
-                const int x = tab ? second : first, y = tab ? first : second;
-                // a PET with both ends inside the span is in both slices: count it from the X table only
-                if (tab == 1 && x >= spanlo[side] && x <= spanhi[side]) continue;
-                unsigned ma = 0, mb = 0;
-#pragma unroll
-                for (int k = 0; k < SIG_W; ++k) {
-                    ma |= (unsigned)(((x >= wlo[k]) & (x <= whi[k])) | ((y >= wlo[k]) & (y <= whi[k]))) << k;
-                    mb |= (unsigned)(((x >= wlo[SIG_W + k]) & (x <= whi[SIG_W + k])) | ((y >= wlo[SIG_W + k]) & (y <= whi[SIG_W + k]))) << k;
-                }
-                if (side == 0) {
-                    for (unsigned a = ma; a; a &= a - 1) {
-                        const int k = __ffs(a) - 1;
-                        atomicAdd(&c_a[k], 1);
-                        for (unsigned bb = mb; bb; bb &= bb - 1) atomicAdd(&c_ab[k * SIG_W + (__ffs(bb) - 1)], 1);
-                    }
-                    // rab = |{X in iva} & {Y in ivb}|  (cModel.py:79): needs x in A_0, found in the X table
-                    if (tab == 0 && x >= wlo[0] && x <= whi[0] && y >= wlo[SIG_W] && y <= whi[SIG_W]) atomicAdd(&c_rab, 1);
-                } else {
-                    for (unsigned bb = mb; bb; bb &= bb - 1) atomicAdd(&c_b[__ffs(bb) - 1], 1);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    int* o = out + (size_t)rec * SIG_OUT;
-    if (threadIdx.x < SIG_W) { o[threadIdx.x] = c_a[threadIdx.x]; o[SIG_W + threadIdx.x] = c_b[threadIdx.x]; }
-    if (threadIdx.x == 0) o[2 * SIG_W] = c_rab;
-    for (int k = threadIdx.x; k < SIG_W * SIG_W; k += blockDim.x) o[2 * SIG_W + 1 + k] = c_ab[k];
-}
-
-__global__ void k8_count_valid(const u64* __restrict__ t, int n, int* __restrict__ d_m)
-{
-    // number of valid (non-sentinel) entries of the sorted table = lower bound of the sentinel
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int lo = 0, hi = n;
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (t[mid] != ~0ull) lo = mid + 1; else hi = mid; }
-        d_m[0] = lo;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// host side
-// ------------------------------------------------------------------------------------------
-struct DevBuf {
-    void* p = nullptr; size_t bytes = 0;
-    bool fresh = false;               // (re)allocated since the flag was last cleared
-    int ensure(size_t need)
-    {
-        if (need <= bytes) return CL_OK;
-        fresh = true;
-        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-        size_t want = need + need / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) return fail(CL_ERR_HIP, "hipMalloc", hipGetErrorString(e));
-        bytes = want;
-        return CL_OK;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
-    template <typename T> T* as() { return (T*)p; }
-};
-
-struct cl_chrom {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int64_t n = 0;
-    int *d_x = nullptr, *d_y = nullptr;
-    bool own_xy = false;
-    Stats st{};
-    // workspace
-    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, scan_tmp;
-    DevBuf qb_key, qb_val;            // the q index (k_make_qkeys): rows sorted by q, persistent
-    int qindex_layout = -1;           // layout the q index was built for (-1: none)
-    int sort_index_mode = 0;          // cl_set_sort_index: 0 = build at the second sort, 1 = at the first, -1 = never
-    long long n_sorts = 0;            // layouts sorted on this handle so far
-    DevBuf sv, sa, strip, cnt, parent, root, head, headidx, cellfirst, compkey, ncore, bsize, owner, state;
-    DevBuf tileflag;                  // per 256-PET tile: holds a contested border point (k_border -> k_emit_records)
-    DevBuf flag, rankscan, ulist, lo, hi, recs, counters, chainflag, chainhead, usize, b_cstart, b_ckey, b_nb, b_cx, b_cy, tile_s0;
-    int* h_pinned = nullptr;          // small pinned staging (stats, block scalars)
-    struct StripPlan { int layout, eps, maxlen; };
-    std::vector<StripPlan> plans;     // longest strip over all rows per (layout, eps): picks the sort path
-    u32* srow = nullptr;              // sorted position -> input row of the run being enqueued
-    // working set of the run being enqueued: sorted (q, sp), strip table, tile table.  They alias either the
-    // workspace buffers (sv, sa, strip, tile_s0) or, for a run without cut filter, the base layout itself.
-    int *w_sv = nullptr, *w_sa = nullptr, *w_strip = nullptr, *w_tile = nullptr;
-    // Base layout: the sorted arrays of ALL rows (cut = 0) for one (variant layout, eps), kept until eps changes.
-    // The sort order does not depend on minPts and a cut only REMOVES rows, so every further run of a sweep at this
-    // eps is one stable stream compaction of the base layout instead of five radix passes (cLoops/pipe.py:241-281
-    // walks eps in the outer loop).  Nothing of a result is kept: neighbour counts, components, labels are redone.
-    DevBuf bq, bsp, brow, bstrip, btile, sel_tmp;
-    struct BaseLayout { bool valid = false; int layout = -1, eps = 0; } base;
-    std::vector<long long> dcum;      // dcum[k] = number of PETs with Y - X < k, k = 0 .. 65536 (empty: unknown)
-    const int* k_total = nullptr;     // device: where the run left the number of ids handed out (null: rankscan[n])
-    bool hdr_packed = false;          // the run's own kernels have written the slot header (no k_pack_header)
-    DevBuf dhist;                     // device: number of PETs with Y - X == d, d = 0 .. 65535 (+ one slot for d < 0)
-    long long n_neg = 0;              // PETs with Y - X < 0
-    int run_m = 0;                    // PETs that enter DBSCAN in the run being enqueued (exact when run_m_exact, else n)
-    bool run_m_exact = false;
-    bool reuse_layout = true;
-    // Result slots: two runs may be in flight (cl_cluster_async) -- the labels / table / header of
-    // run k live in slot k & 1, so the D2H copy of run k (copy stream) overlaps the kernels of run k+1.
-    struct Slot {
-        DevBuf labels, table;
-        bool pending = false;
-        int n_strips = 0;
-        hipEvent_t ev_done = nullptr, ev_copied = nullptr;
-        hipEvent_t ev[8]{};           // profiling marks of the run that used this slot
-        int* h_hdr = nullptr;         // pinned: {K, overflow, M}
-        cl_box* h_boxes = nullptr;    // pinned host copy of the cluster table
-        size_t h_boxes_cap = 0;
-        int32_t* labels_out = nullptr;
-        DevBuf slab;                  // labels in sorted order (rotated variants)
-        bool exported = true;         // the table rows were stored to h_boxes
-        bool step_valid = false;      // the run carried the sweep-step tail (classification, candidate append, distance summary)
-        bool host_written = false;    // ... and its last kernel stored header + step output in pinned host memory itself
-        bool wait_done = false;       // cl_wait waits for ev_done (nothing went through the copy stream)
-        long long fine_lo = -1;       // fine window of that tail's summary (-1 = none)
-        int kmax = 0;                 // upper bound of the number of cluster ids of the run (host-known; the count itself is on the device)
-        DevBuf d_step;                // device: {n_inter, n_self} + K7 partials + log histogram of that tail
-        char* h_step = nullptr;       // pinned host copy
-        bool rows_valid = false;      // `labels` (row order) was produced by the run
-        bool sorted_src = false;      // the run left sorted (q, label) arrays for the distance statistics
-        const int* k7_sv = nullptr;   // sorted q of the run
-        int k7_v0 = 0;                // d = q + k7_v0
-    } slot[2];
-    bool device_labels = true;        // produce row-order device labels even without a host destination (cl_set_device_labels)
-    bool export_table = true;         // copy the cluster table to pinned host memory at the end of a run (cl_set_table_export)
-    int pending_step = -1;            // >= 0: the run being enqueued is step `pending_step` of a sweep (cl_cluster_step_async)
-    int pending_cut = 0;
-    long long pending_fine_lo = -1;   // >= 0: the step's summary also histograms the self group's [fine_lo, fine_lo + 2048) exactly
-    DevBuf cand_box, cand_step, cand_keep, cand_out;   // K10: candidate loops of the running sweep
-    long long cand_n = 0, cand_cap = 0;
-    DevBuf hdr;                       // device result headers, 16 ints per slot
-    DevBuf k7_cls, k7_parts;          // K7: class per cluster id, per-workgroup partials
-    DevBuf sig_tx, sig_ty, sig_tmp, sig_sorttmp, sig_m, sig_win, sig_out;   // K8: sorted PET tables, windows, counts
-    bool sig_ready = false; int sig_cut = 0;
-    bool k7_classified = false;       // k7_cls matches the last completed run
-    hipStream_t copy_stream = nullptr, aux_stream = nullptr;
-    int enq = 0, deq = 0;             // runs enqueued / completed
-    int cur = 0;                      // slot of the run being enqueued
-    // last completed result
-    int last_slot = -1;
-    int last_K = 0;                   // max_label + 1
-    bool have_result = false;
-    // profiling
-    bool profiling = false;
-    cl_timing timing{};
-    bool ev_ready = false;
-    float ev_bracket_ms = 0.f;        // event bracket around an empty kernel (calibration, see cl_timing)
-};
-
 // The candidate buffer of a sweep (K10) holds every inter-ligation box of every step: it grows on demand (contents kept) --
 // before a step is enqueued it has room for all the boxes the step can produce (one per cluster id, at most n / minPts).
-static int ensure_cand_capacity(cl_chrom* c, long long need)
+int ensure_cand_capacity(cl_chrom* c, long long need)
 {
     if (need <= c->cand_cap) return CL_OK;
     const long long cap = std::max<long long>(std::max<long long>(need, 2 * c->cand_cap), 1 << 20);
@@ -2920,7 +1716,7 @@ k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const i
 }
 
 // workspace for a run over n rows
-static int ensure_workspace(cl_chrom* c, int S)
+int ensure_workspace(cl_chrom* c, int S)
 {
     const size_t n = (size_t)c->n;
     int rc;
@@ -2963,7 +1759,6 @@ static int ensure_workspace(cl_chrom* c, int S)
     return CL_OK;
 }
 
-static int bits_for(unsigned v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 
 // Build GridParams for the rotated-strip layout (variants 1 and 2)
 static int make_grid(cl_chrom* c, int variant, int eps, int minPts, int cut, GridParams* g)
@@ -3005,10 +1800,8 @@ static int make_grid(cl_chrom* c, int variant, int eps, int minPts, int cut, Gri
     return CL_OK;
 }
 
-#define LAUNCH(kernel, nthreads, ...) \
-    hipLaunchKernelGGL(kernel, dim3(nblocks(nthreads)), dim3(TPB), 0, c->stream, __VA_ARGS__)
 
-static void ev_record(cl_chrom* c, int k)
+void ev_record(cl_chrom* c, int k)
 {
     if (c->profiling) (void)hipEventRecord(c->slot[c->cur].ev[k], c->stream);
 }
@@ -3173,7 +1966,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
 
 __global__ void k_nop() {}
 
-static int ensure_events(cl_chrom* c)
+int ensure_events(cl_chrom* c)
 {
     if (c->profiling && !c->ev_ready) {
         for (auto& sl : c->slot) for (auto& e : sl.ev) HIP_TRY(hipEventCreate(&e));
@@ -3275,7 +2068,7 @@ __global__ void k_export_table(int* __restrict__ hdr, Table t, cl_box* __restric
     if (blockIdx.x == 0 && threadIdx.x == 0 && store && K > cap) hdr[5] = 1;
 }
 
-static Table make_table_slot(cl_chrom* c, int slot)
+Table make_table_slot(cl_chrom* c, int slot)
 {
     Table t;
     int* base = c->slot[slot].table.as<int>();
@@ -3283,15 +2076,15 @@ static Table make_table_slot(cl_chrom* c, int slot)
     t.count = base; t.minx = base + stride; t.maxx = base + 2 * stride; t.miny = base + 3 * stride; t.maxy = base + 4 * stride;
     return t;
 }
-static Table make_table(cl_chrom* c) { return make_table_slot(c, c->cur); }
+Table make_table(cl_chrom* c) { return make_table_slot(c, c->cur); }
 
 // the upload's distance histogram, when it covers every PET a cut of `cut` drops (K7Src::dh)
-static const int* k7_hist_for(cl_chrom* c, int cut)
+const int* k7_hist_for(cl_chrom* c, int cut)
 {
     return (cut > 0 && cut < DCUM_BINS && c->n_neg == 0 && !c->dcum.empty() && c->dhist.p) ? c->dhist.as<int>() : (const int*)nullptr;
 }
 
-static int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* labels_out)
+int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* labels_out)
 {
     const int n = (int)c->n;
     cl_chrom::Slot& sl = c->slot[c->cur];
@@ -3456,176 +2249,8 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
 
 static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, int32_t* labels_out);
 
-// ---- variant 3 host driver -----------------------------------------------------------------
-static int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_out)
-{
-    int rc;
-    const int n = (int)c->n;
-    long long R = ((long long)c->st.xmax - c->st.xmin) / eps + 1;
-    if (R > (1LL << 28)) return fail(CL_ERR_GRID, "eps too small for the coordinate extent (cell-row table > 2^28 rows)");
-    if ((rc = ensure_workspace(c, (int)R))) return rc;
-    if ((rc = ensure_events(c))) return rc;
-#define ENSB(buf, bytes) if ((rc = c->buf.ensure(bytes))) return rc
-    ENSB(b_cstart, ((size_t)n + 1) * 4); ENSB(b_ckey, (size_t)n * 8); ENSB(b_nb, (size_t)n * 32);
-    ENSB(b_cx, (size_t)n * 8); ENSB(b_cy, (size_t)n * 8);
-#undef ENSB
-    BlkParams p; p.eps = eps; p.minPts = minPts; p.cut = cut; p.R = (int)R; p.n = n;
-    p.nyb = std::max(1, bits_for((unsigned)(((long long)c->st.ymax - c->st.ymin) / eps)));
-    p.rb = bits_for((unsigned)(eps - 1));
-    {
-        const unsigned d = (unsigned)eps;
-        int l = 0; while ((1ull << l) < d) ++l;
-        p.magic = (u32)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
-        p.sh1 = l < 1 ? l : 1; p.sh2 = l > 1 ? l - 1 : 0;
-    }
-    int* counters = c->counters.as<int>();
-    BlkScalars* sc = (BlkScalars*)(counters + 32);
-    LAUNCH(k_init_arrays, n + 1, n, c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
-           c->usize.as<int>(), c->cellfirst.as<int>(), c->flag.as<int>(), c->state.as<int>(), counters);
-    HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
-    // minX / minY of the (filtered) mat (blockDBSCAN.py:74-80): known from the upload statistics when
-    // nothing is filtered, one reduction pass otherwise
-    hipLaunchKernelGGL(k_blk_init_scalars, dim3(1), dim3(1), 0, c->stream, sc, cut > 0 ? INT_MAX : c->st.xmin,
-                       cut > 0 ? INT_MAX : c->st.ymin);
-    ev_record(c, 0);
-    if (cut > 0)
-        hipLaunchKernelGGL(k_blk_minmax, dim3(std::min(nblocks(n), 2048)), dim3(TPB), 0, c->stream, c->d_x, c->d_y, n, cut, sc);
-    LAUNCH(k_blk_keys, n, c->d_x, c->d_y, p, sc, c->keys_in.as<u64>(), c->vals_in.as<u32>());
-    ev_record(c, 1);
-    {
-        size_t tmp_bytes = c->sort_tmp.bytes;
-        const int begin_bit = 2 * p.rb;
-        const int end_bit = begin_bit + p.nyb + std::max(1, bits_for((unsigned)p.R));
-        hipError_t e = rocprim::radix_sort_pairs<SortConfig>(c->sort_tmp.p, tmp_bytes, c->keys_in.as<u64>(), c->keys_out.as<u64>(),
-                                                 c->vals_in.as<u32>(), c->vals_out.as<u32>(), (size_t)n, begin_bit, end_bit, c->stream);
-        if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs", hipGetErrorString(e));
-    }
-    u64* skeys = c->keys_out.as<u64>();
-    u32* srow = c->vals_out.as<u32>();
-    int* sx = (c->sv.as<int>() + SORT_PAD);
-    int* sy = (c->sa.as<int>() + SORT_PAD);
-    int* headflag = c->chainflag.as<int>();
-    int* cidp1 = c->chainhead.as<int>();
-    LAUNCH(k_blk_gather, n, p, skeys, sx, sy, headflag, sc);
-    {
-        size_t tb = c->scan_tmp.bytes;
-        hipError_t e = rocprim::inclusive_scan(c->scan_tmp.p, tb, headflag, cidp1, (size_t)n, rocprim::plus<int>(), c->stream);
-        if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan(cells)", hipGetErrorString(e));
-    }
-    int* cstart = c->b_cstart.as<int>();
-    u64* ckey = c->b_ckey.as<u64>();
-    int* cfirst = c->cellfirst.as<int>();
-    int* rowcell = c->strip.as<int>();
-    LAUNCH(k_blk_cells, n, p, skeys, headflag, cidp1, srow, sc, cstart, ckey, cfirst);
-    LAUNCH(k_blk_rowtable, p.R + 1, p, sc, ckey, rowcell);
-    ev_record(c, 2);
-    int* nb = c->b_nb.as<int>();
-    int* low = c->ncore.as<int>();
-    int* alive = c->bsize.as<int>();
-    double* cx = c->b_cx.as<double>();
-    double* cy = c->b_cy.as<double>();
-    int* linkbits = c->owner.as<int>();
-    int* corec = c->state.as<int>();
-    LAUNCH(k_blk_neighbors, n, p, sc, ckey, rowcell, cstart, sx, sy, nb, low, cx, cy);
-    LAUNCH(k_blk_alive, n, sc, nb, low, cstart, alive, linkbits);
-    hipLaunchKernelGGL(k_blk_links, dim3((unsigned)(((size_t)n * 4 + TPB - 1) / TPB)), dim3(TPB), 0, c->stream,
-                       p, sc, nb, alive, cstart, sx, sy, cx, cy, linkbits);
-    LAUNCH(k_blk_core, n, p, sc, nb, alive, cstart, linkbits, corec);
-    ev_record(c, 3);
-    LAUNCH(k_blk_union, n, sc, nb, linkbits, corec, c->parent.as<int>());
-    hipLaunchKernelGGL(k_blk_flatten, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, sc, corec, c->parent.as<int>(), cfirst,
-                       c->root.as<int>(), c->compkey.as<int>());
-    ev_record(c, 4);
-    LAUNCH(k_blk_rank_flags, n, sc, c->root.as<int>(), c->compkey.as<int>(), c->flag.as<int>());
-    {
-        size_t tb = c->scan_tmp.bytes;
-        hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, c->flag.as<int>(), c->rankscan.as<int>(), 0, (size_t)n + 1,
-                                               rocprim::plus<int>(), c->stream);
-        if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan", hipGetErrorString(e));
-    }
-    ev_record(c, 5);
-    Table t = make_table(c);
-    LAUNCH(k_init_table, n + 1, t, c->rankscan.as<int>(), n);
-    int* clab = c->cnt.as<int>();
-    LAUNCH(k_blk_cell_labels, n, sc, nb, linkbits, alive, c->root.as<int>(), c->compkey.as<int>(), c->rankscan.as<int>(), clab);
-    hipLaunchKernelGGL(k_blk_point_labels, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, p, sc, cidp1, clab, srow, sx, sy, c->slot[c->cur].labels.as<int>(), t);
-    HIP_TRY(hipGetLastError());
-    // blockDBSCAN.py:74: an empty (fully filtered) mat raises only when the class is called
-    // on it; pipe.py:64-65 returns before that, so cut > 0 with no survivors is just empty.
-    { cl_chrom::Slot& sl = c->slot[c->cur]; sl.rows_valid = true; sl.sorted_src = false; }
-    return finish_enqueue(c, p.R + 1, &sc->M, labels_out);
-}
 
 
-// ---- variant 1 under the weighted metric (K9) ------------------------------------------------
-static int run_weighted(cl_chrom* c, int eps, int minPts, int wx, int wy, int32_t* labels_out)
-{
-    int rc;
-    const int n = (int)c->n;
-    G64 g; g.eps = eps; g.minPts = minPts; g.wx = wx; g.wy = wy;
-    // bounds of U = wx*X + wy*Y and W = wy*Y - wx*X from the upload statistics
-    const long long umin = (long long)wx * c->st.xmin + (long long)wy * c->st.ymin, umax = (long long)wx * c->st.xmax + (long long)wy * c->st.ymax;
-    const long long wmin = (long long)wy * c->st.ymin - (long long)wx * c->st.xmax, wmax = (long long)wy * c->st.ymax - (long long)wx * c->st.xmin;
-    g.U0 = umin; g.W0 = wmin;
-    const long long S = (umax - umin) / eps + 1;
-    if (S > (1LL << 28)) return fail(CL_ERR_GRID, "eps too small for the scaled coordinate extent (strip table > 2^28 rows)");
-    g.S = (int)S;
-    int qbits = 1; while (qbits < 63 && ((wmax - wmin) >> qbits) != 0) ++qbits;
-    g.qbits = qbits;
-    const int strip_bits = std::max(1, bits_for((unsigned)g.S));
-    if (qbits + strip_bits > 64) return fail(CL_ERR_GRID, "scaled coordinates need more than 64 key bits");
-    if ((rc = ensure_workspace(c, g.S))) return rc;
-    if ((rc = ensure_events(c))) return rc;
-    int* strip = c->strip.as<int>();
-    int* cnt = c->cnt.as<int>();
-    int* counters = c->counters.as<int>();
-    GridParams gi{};                                     // what the shared kernels read: S, minPts, variant
-    gi.eps = eps; gi.minPts = minPts; gi.variant = CL_VARIANT_CDBSCAN1; gi.S = g.S;
-    LAUNCH(k_init_arrays, n + 1, n, c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
-           c->usize.as<int>(), c->cellfirst.as<int>(), c->flag.as<int>(), c->state.as<int>(), counters);
-    HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
-    ev_record(c, 0);
-    LAUNCH(k64_keys, n, c->d_x, c->d_y, n, g, c->keys_in.as<u64>(), c->vals_in.as<u32>());
-    ev_record(c, 1);
-    {
-        size_t tmp_bytes = c->sort_tmp.bytes;
-        hipError_t e = rocprim::radix_sort_pairs<SortConfig>(c->sort_tmp.p, tmp_bytes, c->keys_in.as<u64>(), c->keys_out.as<u64>(),
-                                                 c->vals_in.as<u32>(), c->vals_out.as<u32>(), (size_t)n, 0, qbits + strip_bits, c->stream);
-        if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs", hipGetErrorString(e));
-    }
-    const u64* sk = c->keys_out.as<u64>();
-    const u32* srow = c->vals_out.as<u32>();
-    c->srow = c->vals_out.as<u32>();
-    long long* p64 = c->keys_in.as<long long>();         // the unsorted keys are dead after the sort
-    LAUNCH(k_strip_table, g.S + 2, sk, n, g.S, qbits, strip);
-    LAUNCH(k64_p, n, n, g, c->d_x, c->d_y, srow, p64);
-    ev_record(c, 2);
-    LAUNCH(k64_count, n, n, g, sk, p64, strip, cnt);
-    ev_record(c, 3);
-    LAUNCH(k64_union, n, n, g, sk, p64, strip, cnt, c->parent.as<int>());
-    hipLaunchKernelGGL(k_flatten, dim3(nblocks(n, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, gi, strip, cnt, c->parent.as<int>(), srow,
-                       c->head.as<int>(), c->cellfirst.as<int>(), c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), (int*)nullptr, counters);
-    ev_record(c, 4);
-    LAUNCH(k64_border, n, n, g, sk, p64, strip, c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), srow,
-           c->owner.as<int>(), c->bsize.as<int>());
-    ev_record(c, 5);
-    LAUNCH(k_rank_flags, n, gi, strip, c->root.as<int>(), c->compkey.as<int>(), c->state.as<int>(), c->flag.as<int>());
-    {
-        size_t tb = c->scan_tmp.bytes;
-        hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, c->flag.as<int>(), c->rankscan.as<int>(), 0, (size_t)n + 1,
-                                               rocprim::plus<int>(), c->stream);
-        if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan", hipGetErrorString(e));
-    }
-    Table t = make_table(c);
-    LAUNCH(k_init_table, n + 1, t, c->rankscan.as<int>(), n);
-    LAUNCH(k_root_labels, n, gi, strip, c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
-           c->state.as<int>(), c->rankscan.as<int>(), c->chainhead.as<int>());
-    hipLaunchKernelGGL(k64_final, dim3(nblocks(n, BIGTPB)), dim3(BIGTPB), 0, c->stream, n, c->d_x, c->d_y, srow, c->owner.as<int>(),
-                       c->chainhead.as<int>(), c->slot[c->cur].labels.as<int>(), t);
-    HIP_TRY(hipGetLastError());
-    { cl_chrom::Slot& sl = c->slot[c->cur]; sl.rows_valid = true; sl.sorted_src = false; }
-    return finish_enqueue(c, g.S + 2, strip + g.S, labels_out);
-}
 
 extern "C" int cl_cluster_weighted(cl_chrom* c, int32_t eps, int32_t min_pts, int32_t wx, int32_t wy, int32_t* labels_out,
                                    int32_t* n_clusters, int32_t* max_label)
@@ -3843,239 +2468,6 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     return finish_enqueue(c, g.S + 2, strip + g.S, labels_out);
 }
 
-
-// ---- K7 host entry points --------------------------------------------------------------------
-static int k7_prepare(cl_chrom* c)
-{
-    if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
-    if (!c->have_result || c->last_slot < 0) return fail(CL_ERR_ARG, "distance statistics need a completed clustering run");
-    if (c->enq != c->deq) return fail(CL_ERR_ARG, "distance statistics: asynchronous runs still in flight");
-    HIP_TRY(hipSetDevice(c->device));
-    int rc;
-    if ((rc = c->k7_cls.ensure((size_t)c->n + 16))) return rc;
-    if ((rc = c->k7_parts.ensure(K7_BLOCKS * sizeof(K7Part) + K7_LOGBINS * 8 + 4096))) return rc;
-    if (!c->k7_classified) {
-        int* dh = c->hdr.as<int>() + 16 * c->last_slot;
-        LAUNCH(k7_classify, c->n + 1, dh, make_table_slot(c, c->last_slot), c->k7_cls.as<signed char>());
-        c->k7_classified = true;
-    }
-    return CL_OK;
-}
-
-static K7Src k7_source(cl_chrom* c, int cut)
-{
-    cl_chrom::Slot& sl = c->slot[c->last_slot];
-    K7Src s{};
-    s.dh = k7_hist_for(c, cut);
-    s.sorted = sl.sorted_src ? 1 : 0; s.n = (int)c->n; s.M = sl.h_hdr[2]; s.v0 = sl.k7_v0;
-    s.X = c->d_x; s.Y = c->d_y; s.labels = sl.labels.as<int>(); s.sv = sl.k7_sv; s.slab = sl.slab.as<int>();
-    return s;
-}
-
-extern "C" int cl_dist_summary(cl_chrom* c, int32_t cut, cl_dsummary* out)
-{
-    if (!out) return fail(CL_ERR_ARG, "cl_dist_summary: out is null");
-    memset(out, 0, sizeof(*out));
-    out->xshift = K7_XSHIFT;
-    if (c && c->n == 0) return CL_OK;
-    int rc = k7_prepare(c);
-    if (rc) return rc;
-    if (!c->slot[c->last_slot].sorted_src && !c->slot[c->last_slot].rows_valid) return fail(CL_ERR_ARG, "cl_dist_summary: the last run left no labels");
-    unsigned long long* dh = (unsigned long long*)((char*)c->k7_parts.p + K7_BLOCKS * sizeof(K7Part));
-    HIP_TRY(hipMemsetAsync(dh, 0, K7_LOGBINS * 8, c->stream));
-    K7Part* dpart = (K7Part*)((char*)dh + K7_LOGBINS * 8);                  // behind the histogram (the buffer's spare 4 KB)
-    hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, k7_source(c, cut), cut, c->k7_cls.as<signed char>(), c->k7_parts.as<K7Part>(), dh,
-                       0u, (unsigned long long*)nullptr);
-    hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, (const K7Part*)c->k7_parts.as<K7Part>(), K7_BLOCKS, dpart,
-                       (const int*)nullptr, 0, (long long*)nullptr, (const unsigned long long*)nullptr, 0, (unsigned long long*)nullptr,
-                       (const int*)nullptr, (int*)nullptr);
-    K7Part part;
-    HIP_TRY(hipMemcpyAsync(&part, dpart, sizeof(K7Part), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(out->loghist, dh, K7_LOGBINS * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int g = 0; g < 2; ++g) { out->sumx[g] = part.sx[g]; out->sumxx[g] = part.sxx[g]; out->n_all[g] = part.n_all[g]; out->n_pos[g] = part.n_pos[g]; }
-    out->fine_lo = -1;
-    return CL_OK;
-}
-
-extern "C" int cl_dist_bin_hist(cl_chrom* c, int32_t cut, uint32_t lo, uint32_t hi, int shift, uint64_t* hist2048)
-{
-    if (!hist2048) return fail(CL_ERR_ARG, "cl_dist_bin_hist: out is null");
-    memset(hist2048, 0, K7_FINE * sizeof(uint64_t));
-    if (shift < 0 || shift > 31 || hi < lo || (((uint64_t)hi - lo + ((1ull << shift) - 1)) >> shift) > K7_FINE)
-        return fail(CL_ERR_ARG, "cl_dist_bin_hist: (hi - lo) >> shift must fit 2048 bins");
-    if (c && c->n == 0) return CL_OK;
-    int rc = k7_prepare(c);
-    if (rc) return rc;
-    unsigned long long* dh = (unsigned long long*)c->k7_parts.p;
-    HIP_TRY(hipMemsetAsync(dh, 0, K7_FINE * 8, c->stream));
-    const int n = (int)c->n;
-    hipLaunchKernelGGL(k7_bin_hist, dim3(std::min(nblocks(n), K7_BLOCKS)), dim3(TPB), 0, c->stream, k7_source(c, cut), cut, c->k7_cls.as<signed char>(),
-                       (unsigned)lo, (unsigned)hi, shift, dh);
-    HIP_TRY(hipMemcpyAsync(hist2048, dh, K7_FINE * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return CL_OK;
-}
-
-// ---- K10 host entry points -----------------------------------------------------------------------
-extern "C" int cl_cand_reset(cl_chrom* c)
-{
-    if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
-    c->cand_n = 0;
-    return CL_OK;
-}
-
-extern "C" int cl_cand_append(cl_chrom* c, int32_t step, int64_t* n_inter, int64_t* n_self)
-{
-    if (n_inter) *n_inter = 0;
-    if (n_self) *n_self = 0;
-    if (c && c->n == 0) return CL_OK;
-    int rc = k7_prepare(c);                              // classifies the table of the last completed run (pipe.py:83-97)
-    if (rc) return rc;
-    cl_chrom::Slot& sl = c->slot[c->last_slot];
-    const int K = sl.h_hdr[0];
-    if (K <= 0) return CL_OK;
-    if ((rc = ensure_cand_capacity(c, c->cand_n + K))) return rc;
-    const int nb = nblocks(K, CAND_BLOCK);
-    if ((rc = c->sel_tmp.ensure((size_t)nb * 12 + 64))) return rc;
-    int* bcount = c->sel_tmp.as<int>();
-    int* boff = bcount + 2 * nb;
-    const int* dK = c->hdr.as<int>() + 16 * c->last_slot;
-    hipLaunchKernelGGL(k_cand_count, dim3(nb), dim3(256), 0, c->stream, dK, c->k7_cls.as<signed char>(), bcount, nb);
-    size_t tb = c->scan_tmp.bytes;
-    hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, bcount, boff, 0, (size_t)nb, rocprim::plus<int>(), c->stream);
-    if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan(cand)", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_cand_append, dim3(nb), dim3(256), 0, c->stream, dK, c->k7_cls.as<signed char>(), make_table_slot(c, c->last_slot),
-                       (const int*)boff, (const int*)bcount, (int)c->cand_n, (int)step, (int)std::min<long long>(c->cand_cap, INT_MAX), c->cand_box.as<int4>(), c->cand_step.as<int>());
-    std::vector<int> h(2 * nb);
-    HIP_TRY(hipMemcpyAsync(h.data(), bcount, (size_t)2 * nb * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    long long ni = 0, ns = 0;
-    for (int k = 0; k < nb; ++k) { ni += h[k]; ns += h[nb + k]; }
-    if (c->cand_n + ni > c->cand_cap) return fail(CL_ERR_GRID, "internal: candidate buffer overrun");
-    c->cand_n += ni;
-    if (n_inter) *n_inter = ni;
-    if (n_self) *n_self = ns;
-    return CL_OK;
-}
-
-extern "C" int cl_cand_finish(cl_chrom* c, int32_t final_cut, int32_t* boxes_out, int64_t capacity, int64_t* n_out)
-{
-    if (!c || !n_out) return fail(CL_ERR_ARG, "cl_cand_finish: null argument");
-    *n_out = 0;
-    const long long N = c->cand_n;
-    if (N == 0) return CL_OK;
-    if (c->enq != c->deq) return fail(CL_ERR_ARG, "cl_cand_finish: asynchronous runs still in flight");
-    if (N > INT_MAX - 1024) return fail(CL_ERR_GRID, "cl_cand_finish: more than 2^31 candidates");
-    HIP_TRY(hipSetDevice(c->device));
-    int rc;
-    if ((rc = ensure_workspace(c, 1))) return rc;
-    if ((rc = c->cand_keep.ensure((size_t)N + 64)) || (rc = c->cand_out.ensure((size_t)N * 16))) return rc;
-    const int n = (int)N;
-    // the sort buffers of the handle are sized for its PETs; a sweep of many steps on a strongly clustered chromosome can
-    // leave more candidates than that: then the dedup sorts in buffers of its own (released at the end), and rocPRIM's
-    // temporary storage is sized from N with the configuration the sort below uses
-    struct Tmp { DevBuf kin, kout, vin, vout; ~Tmp() { kin.release(); kout.release(); vin.release(); vout.release(); } } tmp;
-    u64 *kin = c->keys_in.as<u64>(), *kout = c->keys_out.as<u64>();
-    u32 *vin = c->vals_in.as<u32>(), *vout = c->vals_out.as<u32>();
-    if (N > c->n) {
-        if ((rc = tmp.kin.ensure((size_t)N * 8)) || (rc = tmp.kout.ensure((size_t)N * 8)) || (rc = tmp.vin.ensure((size_t)N * 4)) ||
-            (rc = tmp.vout.ensure((size_t)N * 4))) return rc;
-        kin = tmp.kin.as<u64>(); kout = tmp.kout.as<u64>(); vin = tmp.vin.as<u32>(); vout = tmp.vout.as<u32>();
-    }
-    {
-        size_t need = 0;
-        hipError_t e0 = rocprim::radix_sort_pairs(nullptr, need, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr, (size_t)n, 0, 64, c->stream);
-        if (e0 != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs size query (cand)", hipGetErrorString(e0));
-        if ((rc = c->sort_tmp.ensure(std::max<size_t>(need, 16)))) return rc;
-    }
-    int* flags = c->counters.as<int>() + 60;
-    // two different boxes sharing a 64-bit hash would be merged: the exact compare inside k_cand_mark notices, and the
-    // pass is redone under another salt (a collision under four independent hashes does not happen)
-    int hflag = 0;
-    for (int attempt = 0; attempt < 4; ++attempt) {
-        HIP_TRY(hipMemsetAsync(flags, 0, 4, c->stream));
-        LAUNCH(k_cand_hash, n, n, c->cand_box.as<int4>(), (u64)attempt * 0x9FB21C651E98DF25ull, kin, vin);
-        size_t tmp_bytes = c->sort_tmp.bytes;
-        hipError_t e = rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0, 64, c->stream);
-        if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs(cand)", hipGetErrorString(e));
-        LAUNCH(k_cand_mark, n, n, (const u64*)kout, (const u32*)vout, c->cand_box.as<int4>(), c->cand_step.as<int>(), (int)final_cut,
-               c->cand_keep.as<unsigned char>(), flags);
-        HIP_TRY(hipMemcpyAsync(&hflag, flags, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (hflag == 0) break;
-    }
-    if (hflag != 0) return fail(CL_ERR_HASH, "candidate dedup: hash collisions under four salts");
-    hipError_t e;
-    const int nb = nblocks(n, CAND_BLOCK);
-    if ((rc = c->sel_tmp.ensure((size_t)nb * 8 + 64))) return rc;
-    int* bcount = c->sel_tmp.as<int>();
-    int* boff = bcount + nb;
-    hipLaunchKernelGGL(k_flag_count, dim3(nb), dim3(256), 0, c->stream, n, c->cand_keep.as<unsigned char>(), bcount);
-    size_t tb = c->scan_tmp.bytes;
-    e = rocprim::exclusive_scan(c->scan_tmp.p, tb, bcount, boff, 0, (size_t)nb, rocprim::plus<int>(), c->stream);
-    if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan(cand out)", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_cand_emit, dim3(nb), dim3(256), 0, c->stream, n, c->cand_keep.as<unsigned char>(), c->cand_box.as<int4>(), (const int*)boff, c->cand_out.as<int4>());
-    int tail[2];
-    HIP_TRY(hipMemcpyAsync(&tail[0], boff + nb - 1, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&tail[1], bcount + nb - 1, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    const long long kept = (long long)tail[0] + tail[1];
-    *n_out = kept;
-    if (kept > capacity) return fail(CL_ERR_ARG, "cl_cand_finish: boxes_out too small");
-    if (kept > 0) {
-        if (!boxes_out) return fail(CL_ERR_ARG, "cl_cand_finish: boxes_out is null");
-        HIP_TRY(hipMemcpyAsync(boxes_out, c->cand_out.p, (size_t)kept * 16, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    return CL_OK;
-}
-
-// ---- K8 host entry point ------------------------------------------------------------------------
-extern "C" int cl_sig_counts(cl_chrom* c, int32_t cut, int32_t n_records, const int32_t* windows, int32_t* out,
-                             int64_t* n_pets)
-{
-    if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
-    if (n_pets) *n_pets = 0;
-    if (n_records < 0 || (n_records > 0 && (!windows || !out))) return fail(CL_ERR_ARG, "cl_sig_counts: bad arguments");
-    if (c->enq != c->deq) return fail(CL_ERR_ARG, "cl_sig_counts: asynchronous runs still in flight");
-    if (c->n == 0) { if (n_records) memset(out, 0, (size_t)n_records * SIG_OUT * 4); return CL_OK; }
-    HIP_TRY(hipSetDevice(c->device));
-    const int n = (int)c->n;
-    int rc;
-    if (!c->sig_ready || c->sig_cut != cut) {
-        // X-sorted and Y-sorted tables of the PETs that pass parseJd(f, cut); built once per (chromosome, cut)
-        if ((rc = c->sig_tx.ensure((size_t)n * 8)) || (rc = c->sig_ty.ensure((size_t)n * 8)) ||
-            (rc = c->sig_tmp.ensure((size_t)n * 8)) || (rc = c->sig_m.ensure(64))) return rc;
-        LAUNCH(k8_split, n, c->d_x, c->d_y, n, cut, c->sig_tmp.as<u64>(), c->sig_ty.as<u64>());
-        size_t bytes = 0;
-        hipError_t e = rocprim::radix_sort_keys(nullptr, bytes, (u64*)nullptr, (u64*)nullptr, (size_t)n, 0, 64, c->stream);
-        if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_keys size query", hipGetErrorString(e));
-        if ((rc = c->sig_sorttmp.ensure(std::max<size_t>(bytes, 16)))) return rc;
-        bytes = c->sig_sorttmp.bytes;
-        e = rocprim::radix_sort_keys(c->sig_sorttmp.p, bytes, c->sig_tmp.as<u64>(), c->sig_tx.as<u64>(), (size_t)n, 0, 64, c->stream);
-        if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_keys(X)", hipGetErrorString(e));
-        HIP_TRY(hipMemcpyAsync(c->sig_tmp.p, c->sig_ty.p, (size_t)n * 8, hipMemcpyDeviceToDevice, c->stream));
-        bytes = c->sig_sorttmp.bytes;
-        e = rocprim::radix_sort_keys(c->sig_sorttmp.p, bytes, c->sig_tmp.as<u64>(), c->sig_ty.as<u64>(), (size_t)n, 0, 64, c->stream);
-        if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_keys(Y)", hipGetErrorString(e));
-        hipLaunchKernelGGL(k8_count_valid, dim3(1), dim3(64), 0, c->stream, c->sig_tx.as<u64>(), n, c->sig_m.as<int>());
-        c->sig_ready = true; c->sig_cut = cut;
-    }
-    int hm = 0;
-    HIP_TRY(hipMemcpyAsync(&hm, c->sig_m.p, 4, hipMemcpyDeviceToHost, c->stream));
-    if (n_records > 0) {
-        if ((rc = c->sig_win.ensure((size_t)n_records * sizeof(SigWin))) || (rc = c->sig_out.ensure((size_t)n_records * SIG_OUT * 4))) return rc;
-        HIP_TRY(hipMemcpyAsync(c->sig_win.p, windows, (size_t)n_records * sizeof(SigWin), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k8_counts, dim3(n_records), dim3(TPB), 0, c->stream, c->sig_tx.as<u64>(), c->sig_ty.as<u64>(), c->sig_m.as<int>(),
-                           n_records, c->sig_win.as<SigWin>(), c->sig_out.as<int>());
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(out, c->sig_out.p, (size_t)n_records * SIG_OUT * 4, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (n_pets) *n_pets = hm;
-    return CL_OK;
-}
 
 extern "C" int cl_get_boxes(cl_chrom* c, cl_box* boxes_out)
 {
