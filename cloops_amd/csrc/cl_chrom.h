@@ -48,22 +48,28 @@ struct K7Part { double sx[2]; double sxx[2]; long long n_all[2]; long long n_pos
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
     bool fresh = false;               // (re)allocated since the flag was last cleared
+    bool owned = true;                // false: a slice of the handle's arena (never freed on its own)
     int ensure(size_t need)
     {
         if (need <= bytes) return CL_OK;
         fresh = true;
-        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        if (p && owned) (void)hipFree(p);
+        p = nullptr; bytes = 0; owned = true;
         size_t want = need + need / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) return fail(CL_ERR_HIP, "hipMalloc", hipGetErrorString(e));
         bytes = want;
         return CL_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    void adopt(void* slice, size_t n) { if (p && owned) (void)hipFree(p); p = slice; bytes = n; owned = false; fresh = true; }
+    void release() { if (p && owned) (void)hipFree(p); p = nullptr; bytes = 0; owned = true; }
     template <typename T> T* as() { return (T*)p; }
 };
 
 struct cl_chrom {
+    long long tmp_n = -1;             // n the rocPRIM temporary storage was last sized for
+    DevBuf arena;                     // ONE allocation behind the per-PET workspace of the handle (ensure_workspace): the first
+                                      // run of a handle pays one hipMalloc instead of forty
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;

@@ -1181,20 +1181,6 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
 // A component is surely live if cores + first-come borders >= minPts (its share can only grow
 // when lower components die).  The rest form the small uncertain set U, resolved in key order.
 
-__global__ void k_mark_uncertain(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ root,
-                                 const int* __restrict__ ncore, const int* __restrict__ bsize,
-                                 int* __restrict__ state, int* __restrict__ ulist, int* __restrict__ counters)
-{
-    const int M = strip_start[g.S];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    if (root[i] != i) return;
-    if (ncore[i] + bsize[i] < g.minPts) {
-        state[i] = ST_UNKNOWN;
-        int k = atomicAdd(&counters[CTR_NU], 1);
-        ulist[k] = i;
-    }
-}
 
 // records: for every border point adjacent to an uncertain component, its (<= 4, geometric
 // bound) distinct adjacent components in ascending key order
@@ -1517,12 +1503,11 @@ static void free_chrom(cl_chrom* c)
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->slot[0].d_step, &c->slot[1].d_step, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
                       &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->tileflag, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out, &c->dhist};
     for (DevBuf* b : bufs) b->release();
+    c->arena.release();                                  // (after its slices have been dropped)
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (auto& sl : c->slot) {
         if (sl.h_boxes) (void)hipHostFree(sl.h_boxes);
-        if (sl.h_hdr) (void)hipHostFree(sl.h_hdr);
-        if (sl.h_step) (void)hipHostFree(sl.h_step);
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
         if (sl.ev_copied) (void)hipEventDestroy(sl.ev_copied);
         if (c->ev_ready) for (auto& e : sl.ev) (void)hipEventDestroy(e);
@@ -1562,6 +1547,8 @@ __global__ void k_init_pads(int* __restrict__ svbuf, int* __restrict__ sabuf, lo
     sabuf[idx] = left ? INT_MIN : INT_MAX;
 }
 
+static int reserve_workspace(cl_chrom* c);
+
 extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const int32_t* y, int64_t n,
                                int on_device, cl_chrom** out)
 {
@@ -1583,7 +1570,10 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
             if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipStreamCreate"); break; }
             c->own_stream = true;
         }
-        if (hipHostMalloc((void**)&c->h_pinned, 4096, hipHostMallocDefault) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipHostMalloc"); break; }
+        // ONE pinned block per handle: 4 KB of scratch, then per result slot the 64-byte header and the step output of a sweep
+        // step (hipHostMalloc costs about a millisecond a call: two per slot and handle were half of the first sweep's overhead)
+        const size_t step_bytes = ((16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8 + 255) / 256) * 256;
+        if (hipHostMalloc((void**)&c->h_pinned, 4096 + 2 * (256 + step_bytes), hipHostMallocDefault) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipHostMalloc"); break; }
         {
             // copies must not queue up behind the next run's kernels: give their streams the highest priority
             int prio_lo = 0, prio_hi = 0;
@@ -1592,10 +1582,14 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
                 hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipStreamCreate(copy)"); break; }
         }
         bool okslots = true;
+        int kslot = 0;
         for (auto& sl : c->slot) {
             okslots = okslots && hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) == hipSuccess;
             okslots = okslots && hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming) == hipSuccess;
-            okslots = okslots && hipHostMalloc((void**)&sl.h_hdr, 64, hipHostMallocDefault) == hipSuccess;
+            char* base = (char*)c->h_pinned + 4096 + (size_t)kslot * (256 + step_bytes);
+            sl.h_hdr = (int*)base;
+            sl.h_step = base + 256;
+            ++kslot;
         }
         if (!okslots) { rc = fail(CL_ERR_HIP, "result slot setup"); break; }
         if (on_device) { c->d_x = (int*)x; c->d_y = (int*)y; }
@@ -1639,6 +1633,7 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
         }
     } while (0);
     if (rc != CL_OK) { std::string keep = g_err; free_chrom(c); g_err = keep; return rc; }
+    (void)reserve_workspace(c);                          // best effort: without it the buffers are allocated one by one at the first run
     *out = c;
     return CL_OK;
 }
@@ -1716,46 +1711,102 @@ k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const i
 }
 
 // workspace for a run over n rows
+// (buffer, bytes) of the per-PET workspace of a handle; the last two rows are the base layout of the current eps, the q index
+// and the class array of the step tail (sweeps)
+#define WORKSPACE_WANTS(c, n) \
+    struct Want { DevBuf* b; size_t bytes; }; \
+    const Want wants[] = { \
+        {&c->keys_in, n * 8}, {&c->keys_out, n * 8}, {&c->vals_in, n * 4}, {&c->vals_out, n * 4}, \
+        {&c->sv, (n + 2 * SORT_PAD) * 4}, {&c->sa, (n + 2 * SORT_PAD) * 4}, {&c->cnt, n * 4}, \
+        {&c->parent, n * 4}, {&c->root, n * 4}, {&c->head, n * 4}, {&c->cellfirst, n * 4}, \
+        {&c->compkey, n * 4}, {&c->ncore, n * 4}, {&c->bsize, n * 4}, {&c->owner, n * 4}, {&c->state, n * 4}, \
+        {&c->flag, (n + 1) * 4}, {&c->rankscan, (n + 1) * 4}, {&c->hdr, 256}, \
+        {&c->slot[0].labels, n * 4}, {&c->slot[0].table, (n + 1) * sizeof(cl_box)}, {&c->slot[0].slab, n * 4}, \
+        {&c->slot[1].labels, n * 4}, {&c->slot[1].table, (n + 1) * sizeof(cl_box)}, {&c->slot[1].slab, n * 4}, \
+        {&c->ulist, n * 4}, {&c->lo, n * 4}, {&c->hi, n * 4}, {&c->recs, n * sizeof(Rec)}, \
+        {&c->chainflag, n * 4}, {&c->chainhead, n * 4}, {&c->usize, n * 4}, {&c->tile_s0, (n / 256 + 2) * 4}, {&c->tileflag, (n / 256 + 2) * 4}, \
+        {&c->bq, (n + 2 * SORT_PAD) * 4}, {&c->bsp, (n + 2 * SORT_PAD) * 4}, {&c->brow, n * 4}, {&c->btile, (n / 256 + 2) * 4}, \
+        {&c->qb_key, n * 4}, {&c->qb_val, n * 8}, {&c->k7_cls, n + 16}, \
+        {&c->slot[0].d_step, 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8 + K7_BLOCKS * sizeof(K7Part)}, \
+        {&c->slot[1].d_step, 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8 + K7_BLOCKS * sizeof(K7Part)}, \
+    };
+
+// The per-PET workspace of a handle comes out of ONE allocation, reserved when the chromosome is uploaded: mapping the
+// ~225 B/PET of device memory is what the first run of a handle used to pay for (a third of the first sweep of a process:
+// 0.28 s against 0.20 s), and forty hipMalloc calls per chromosome on top.  A buffer that has to grow later (it does not for a
+// fixed chromosome) falls back to an allocation of its own.
+// rocPRIM temporary storage for the sorts / scans of a handle with n rows
+static int workspace_tmp_sizes(cl_chrom* c, size_t* sort_out, size_t* scan_out)
+{
+    const size_t n = (size_t)c->n;
+    size_t sort_bytes = 0, scan_bytes = 0, scan2 = 0, scan3 = 0, sb2 = 0;
+    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(nullptr, sort_bytes, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr,
+                                                         n, 0, 64, c->stream);
+    if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs size query", hipGetErrorString(e));
+    e = rocprim::radix_sort_pairs<SortConfig>(nullptr, sb2, (u32*)nullptr, (u32*)nullptr, (u64*)nullptr, (u64*)nullptr, n, 0, 32, c->stream);
+    if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs size query (q index)", hipGetErrorString(e));
+    e = rocprim::inclusive_scan(nullptr, scan_bytes, (int*)nullptr, (int*)nullptr, n, rocprim::maximum<int>(), c->stream);
+    if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan size query", hipGetErrorString(e));
+    e = rocprim::exclusive_scan(nullptr, scan2, (int*)nullptr, (int*)nullptr, 0, n + 1, rocprim::plus<int>(), c->stream);
+    if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan size query", hipGetErrorString(e));
+    e = rocprim::inclusive_scan_by_key(nullptr, scan3, rocprim::make_reverse_iterator((int*)nullptr), rocprim::make_reverse_iterator((int*)nullptr),
+                                       rocprim::make_reverse_iterator((int*)nullptr), n, rocprim::minimum<int>(), rocprim::equal_to<int>(), c->stream);
+    if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan_by_key size query", hipGetErrorString(e));
+    *sort_out = std::max<size_t>(std::max(sort_bytes, sb2), 16);
+    *scan_out = std::max<size_t>(std::max(std::max(scan_bytes, scan2), scan3), 16);
+    return CL_OK;
+}
+
+static int reserve_workspace(cl_chrom* c)
+{
+    const size_t n = (size_t)c->n;
+    WORKSPACE_WANTS(c, n);
+    if (!c->arena.p && n > 0) {
+        // + what a first run would otherwise allocate piece by piece on the host's critical path: rocPRIM's temporary
+        // storage, the strip tables and the compaction scratch for eps >= 1000 (a smaller eps grows them), a first
+        // candidate buffer of max(n / 8, 2^20) boxes (it grows on demand)
+        size_t sort_bytes = 16, scan_bytes = 16;
+        if (workspace_tmp_sizes(c, &sort_bytes, &scan_bytes) != CL_OK) return CL_OK;
+        const size_t s_guess = (size_t)(((long long)c->st.vmax - c->st.vmin) / 1000 + 64);
+        const long long cand0 = std::max<long long>((long long)n / 8, 1 << 20);
+        std::vector<Want> all(std::begin(wants), std::end(wants));
+        all.push_back({&c->sort_tmp, sort_bytes}); all.push_back({&c->scan_tmp, scan_bytes});
+        all.push_back({&c->strip, (s_guess + 2) * 4}); all.push_back({&c->bstrip, (s_guess + 2) * 4}); all.push_back({&c->sel_tmp, (s_guess + 2) * 8 + 64});
+        all.push_back({&c->cand_box, (size_t)cand0 * 16}); all.push_back({&c->cand_step, (size_t)cand0 * 4});
+        bool untouched = true;
+        size_t total = 0;
+        for (const Want& w : all) { untouched = untouched && w.b->p == nullptr; total += ((w.bytes + 255) / 256) * 256 + 256; }
+        if (untouched && c->arena.ensure(total) == CL_OK) {
+            char* at = (char*)c->arena.p;
+            for (const Want& w : all) { const size_t sz = ((w.bytes + 255) / 256) * 256 + 256; w.b->adopt(at, sz); at += sz; }
+            c->cand_cap = cand0;
+        }
+    }
+    return CL_OK;
+}
+
 int ensure_workspace(cl_chrom* c, int S)
 {
     const size_t n = (size_t)c->n;
     int rc;
-#define ENS(buf, bytes) if ((rc = c->buf.ensure(bytes))) return rc
-    ENS(keys_in, n * 8); ENS(keys_out, n * 8); ENS(vals_in, n * 4); ENS(vals_out, n * 4);
-    ENS(sv, (n + 2 * SORT_PAD) * 4); ENS(sa, (n + 2 * SORT_PAD) * 4); ENS(strip, ((size_t)S + 2) * 4); ENS(cnt, n * 4);
-    ENS(parent, n * 4); ENS(root, n * 4); ENS(head, n * 4); ENS(cellfirst, n * 4);
-    ENS(compkey, n * 4); ENS(ncore, n * 4); ENS(bsize, n * 4); ENS(owner, n * 4); ENS(state, n * 4);
-    ENS(flag, (n + 1) * 4); ENS(rankscan, (n + 1) * 4); ENS(hdr, 256);
-    ENS(slot[c->cur].labels, n * 4); ENS(slot[c->cur].table, (n + 1) * sizeof(cl_box)); ENS(slot[c->cur].slab, n * 4);
-    ENS(ulist, n * 4); ENS(lo, n * 4); ENS(hi, n * 4); ENS(recs, n * sizeof(Rec)); ENS(counters, 256);
-    ENS(chainflag, n * 4); ENS(chainhead, n * 4); ENS(usize, n * 4); ENS(tile_s0, (n / 256 + 2) * 4); ENS(tileflag, (n / 256 + 2) * 4);
-#undef ENS
+    WORKSPACE_WANTS(c, n);
+    if (!c->arena.p) (void)reserve_workspace(c);
+    const cl_chrom::Slot* other = &c->slot[1 - c->cur];
+    for (const Want& w : wants) if (w.b != &other->labels && w.b != &other->table && w.b != &other->slab && w.b != &c->slot[0].d_step && w.b != &c->slot[1].d_step && w.b != &c->bq && w.b != &c->bsp && w.b != &c->brow && w.b != &c->btile && w.b != &c->qb_key &&
+                                    w.b != &c->qb_val && w.b != &c->k7_cls && (rc = w.b->ensure(w.bytes))) return rc;
+    if ((rc = c->strip.ensure(((size_t)S + 2) * 4)) || (rc = c->counters.ensure(256))) return rc;      // (counters: allocated at upload)
     if (c->sv.fresh || c->sa.fresh) {
         // sentinel pads around the sorted arrays (k_region_core stages its windows without bounds checks)
         hipLaunchKernelGGL(k_init_pads, dim3(nblocks(2 * SORT_PAD)), dim3(TPB), 0, c->stream, c->sv.as<int>(), c->sa.as<int>(), (long long)n);
         c->sv.fresh = c->sa.fresh = false;
     }
-    // rocPRIM temporary storage
-    size_t sort_bytes = 0, scan_bytes = 0, scan2 = 0;
-    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(nullptr, sort_bytes, (u64*)nullptr, (u64*)nullptr, (u32*)nullptr, (u32*)nullptr,
-                                             n, 0, 64, c->stream);
-    if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs size query", hipGetErrorString(e));
-    {
-        size_t sb2 = 0;
-        e = rocprim::radix_sort_pairs<SortConfig>(nullptr, sb2, (u32*)nullptr, (u32*)nullptr, (u64*)nullptr, (u64*)nullptr, n, 0, 32, c->stream);
-        if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs size query (q index)", hipGetErrorString(e));
-        sort_bytes = std::max(sort_bytes, sb2);
+    // rocPRIM temporary storage (part of the arena when the handle has one)
+    size_t sort_bytes = 16, scan_bytes = 16;
+    if (c->sort_tmp.bytes < 16 || c->scan_tmp.bytes < 16 || c->tmp_n != c->n) {
+        if ((rc = workspace_tmp_sizes(c, &sort_bytes, &scan_bytes))) return rc;
+        if ((rc = c->sort_tmp.ensure(sort_bytes)) || (rc = c->scan_tmp.ensure(scan_bytes))) return rc;
+        c->tmp_n = c->n;
     }
-    e = rocprim::inclusive_scan(nullptr, scan_bytes, (int*)nullptr, (int*)nullptr, n, rocprim::maximum<int>(), c->stream);
-    if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan size query", hipGetErrorString(e));
-    e = rocprim::exclusive_scan(nullptr, scan2, (int*)nullptr, (int*)nullptr, 0, n + 1, rocprim::plus<int>(), c->stream);
-    if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan size query", hipGetErrorString(e));
-    if ((rc = c->sort_tmp.ensure(std::max<size_t>(sort_bytes, 16)))) return rc;
-    size_t scan3 = 0;
-    e = rocprim::inclusive_scan_by_key(nullptr, scan3, rocprim::make_reverse_iterator((int*)nullptr), rocprim::make_reverse_iterator((int*)nullptr),
-                                       rocprim::make_reverse_iterator((int*)nullptr), n, rocprim::minimum<int>(), rocprim::equal_to<int>(), c->stream);
-    if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan_by_key size query", hipGetErrorString(e));
-    if ((rc = c->scan_tmp.ensure(std::max<size_t>(std::max(std::max(scan_bytes, scan2), scan3), 16)))) return rc;
     return CL_OK;
 }
 
@@ -2089,7 +2140,9 @@ int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* labels_ou
     const int n = (int)c->n;
     cl_chrom::Slot& sl = c->slot[c->cur];
     int* dh = c->hdr.as<int>() + 16 * c->cur;
-    if (sl.h_boxes_cap == 0) {
+    // the pinned host rows of the cluster table: only a run that exports its table needs them (a sweep step does not, and
+    // page-locking (n / 16 + 65 536) rows per result slot was most of the first sweep's overhead: 1 .. 10 ms per handle and slot)
+    if (sl.h_boxes_cap == 0 && c->export_table && c->pending_step < 0) {
         const size_t cap = (size_t)n / 16 + 65536;
         HIP_TRY(hipHostMalloc((void**)&sl.h_boxes, cap * sizeof(cl_box), hipHostMallocDefault));
         sl.h_boxes_cap = cap;
@@ -2118,7 +2171,6 @@ int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* labels_ou
         // the workgroup partials live behind it on the device only
         const size_t out_bytes = 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8;
         if ((rc = sl.d_step.ensure(out_bytes + K7_BLOCKS * sizeof(K7Part)))) return rc;
-        if (!sl.h_step) HIP_TRY(hipHostMalloc((void**)&sl.h_step, out_bytes, hipHostMallocDefault));
         const int nb = nblocks(kmax, CAND_BLOCK);
         if ((rc = c->sel_tmp.ensure((size_t)nb * 12 + 64))) return rc;
         int* bcount = c->sel_tmp.as<int>();
@@ -2352,9 +2404,23 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
 {
     int rc;
     GridParams g;
+#ifdef CLOOPS_DEVEL
+    // developer build: host time of the enqueue, by section (CLOOPS_TRACE_ENQ=<ms> prints the calls above that)
+    static const double trace_ms = getenv("CLOOPS_TRACE_ENQ") ? atof(getenv("CLOOPS_TRACE_ENQ")) : -1.0;
+    struct EnqTrace {
+        double t[4]; int k = 0; double lim; long long n;
+        static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+        void mark() { if (k < 4) t[k++] = now(); }
+        ~EnqTrace() { mark(); if (lim >= 0 && k == 4 && t[3] - t[0] > lim) fprintf(stderr, "[enq n=%lld] grid+workspace %.2f ms | sort+K2 %.2f ms | rest %.2f ms\n", n, t[1] - t[0], t[2] - t[1], t[3] - t[2]); }
+    } tr; tr.lim = trace_ms; tr.n = c->n; tr.mark();
+#define ENQ_MARK() tr.mark()
+#else
+#define ENQ_MARK() do { } while (0)
+#endif
     if ((rc = make_grid(c, variant, eps, minPts, cut, &g))) return rc;
     if ((rc = ensure_workspace(c, g.S))) return rc;
     if ((rc = ensure_events(c))) return rc;
+    ENQ_MARK();
     const int n = (int)c->n;
     int* cnt = c->cnt.as<int>();
     int* counters = c->counters.as<int>();
@@ -2383,6 +2449,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     const bool rows = labels_out != nullptr || c->device_labels;
     if (rows && cut > 0) HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
     if ((rc = run_sort_and_count(c, g, false))) return rc;
+    ENQ_MARK();
     {
         cl_chrom::Slot& sl = c->slot[c->cur];
         sl.rows_valid = rows; sl.sorted_src = g.swap != 0; sl.k7_sv = c->w_sv; sl.k7_v0 = g.V0;
