@@ -356,7 +356,8 @@ static inline int tile_grid(int ntiles) { return ((ntiles + 8 * K2_RUN - 1) / (8
 // The (q, p) arrays are the padded sorted arrays (SORT_PAD sentinels on both sides): unpredicated 16-byte loads, pairs
 // interleaved on the way into LDS (lw must be 16-byte aligned).  The payload array is not padded: predicated dwords.
 // lmask (optional, (NT + 2 * HALO) / 64 words): Tile::m, built from the payload loads with one ballot per wave and pass.
-template <int NT, int HALO>
+// NT = PETs of the tile, NTH = threads of the workgroup (NT / NTH PETs per thread).
+template <int NT, int HALO, int NTH = NT>
 __device__ __forceinline__ bool tile_stage(Tile& t, int2* lw, int* lx, int ntiles, int M,
                                            const int* __restrict__ gq, const int* __restrict__ gp,
                                            const int* __restrict__ gx, unsigned long long* lmask = nullptr)
@@ -371,13 +372,13 @@ __device__ __forceinline__ bool tile_stage(Tile& t, int2* lw, int* lx, int ntile
         const int4* __restrict__ gq4 = reinterpret_cast<const int4*>(gq + base);
         const int4* __restrict__ gp4 = reinterpret_cast<const int4*>(gp + base);
         int4* l4 = reinterpret_cast<int4*>(lw);
-        for (int c = threadIdx.x; c < NV; c += NT) {
+        for (int c = threadIdx.x; c < NV; c += NTH) {
             const int4 q = gq4[c], p = gp4[c];
             l4[2 * c] = make_int4(q.x, p.x, q.y, p.y);
             l4[2 * c + 1] = make_int4(q.z, p.z, q.w, p.w);
         }
     }
-    for (int k = threadIdx.x; k < T_WIN; k += NT) {
+    for (int k = threadIdx.x; k < T_WIN; k += NTH) {
         const int gi = base + k;
         const bool in = gi >= 0 && gi < M;
         const int x = in ? gx[gi] : -1;                  // every payload test is `>= (something >= 0)`
@@ -1053,8 +1054,11 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
 #define OWNER_CONTESTED 0x40000000
 __device__ __forceinline__ int owner_root(int o) { return o < 0 ? -1 : (o & (OWNER_CONTESTED - 1)); }
 
-template <int NT, int HALO>
-__global__ void __launch_bounds__(NT)
+// NT PETs per tile, NTH threads: NT / NTH PETs per thread in the first pass (staging and its barrier amortised: a halo of 128 on
+// both sides is 1.25 x the tile at NT = 1024 instead of 2 x at 256), then the border points that have to walk are compacted over the
+// WHOLE tile and walked in rounds of NTH -- a 256-PET tile left its one walking wave (or its second) half empty.
+template <int NT, int HALO, int NTH = NT>
+__global__ void __launch_bounds__(NTH)
 k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
          const int* __restrict__ strip_start, const int* __restrict__ root, const int* __restrict__ compkey,
          const int* __restrict__ ncore, const u32* __restrict__ srow, int* __restrict__ owner, int* __restrict__ bsize,
@@ -1067,29 +1071,44 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
     __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
     __shared__ int lx[NT + 2 * HALO];
     __shared__ short l_list[NT];
-    __shared__ int l_wcount[NT / 64];
+    __shared__ int l_total;
     __shared__ unsigned long long l_mask[(NT + 2 * HALO) / 64];
     __shared__ int l_enc[NT];
     const int M = strip_start[g.S];
     Tile t;
-    if (!tile_stage<NT, HALO>(t, lw, lx, ntiles, M, sv, sa, root, l_mask)) return;
-    const int i0 = t.t0 + threadIdx.x;
-    bool border = false;
-    if (i0 < M) {
-        const int ri = t.x[i0];
-        if (ri >= 0) owner[i0] = ri;
-        else {
-            // K2 left either the neighbour count of a non-core PET (itself included) or its hint word (k_region_core):
-            // nothing within eps -- most of the background noise ends here
-            const int enc = cnt[i0];
-            l_enc[threadIdx.x] = enc;
-            if (enc < 0 ? (((unsigned)enc & K2H_ISOLATED) != 0u) : (enc <= 1)) owner[i0] = -1; else border = true;
+    if (threadIdx.x == 0) l_total = 0;
+    if (!tile_stage<NT, HALO, NTH>(t, lw, lx, ntiles, M, sv, sa, root, l_mask)) return;
+    // first pass, NT / NTH PETs per thread: cores keep their root, isolated non-cores are noise, the rest has to walk
+#pragma unroll
+    for (int u = 0; u < NT / NTH; ++u) {
+        const int tix = (int)threadIdx.x + u * NTH, i0 = t.t0 + tix;
+        bool border = false;
+        if (i0 < M) {
+            const int ri = t.x[i0];
+            if (ri >= 0) owner[i0] = ri;
+            else {
+                // K2 left either the neighbour count of a non-core PET (itself included) or its hint word (k_region_core):
+                // nothing within eps -- most of the background noise ends here
+                const int enc = cnt[i0];
+                l_enc[tix] = enc;
+                if (enc < 0 ? (((unsigned)enc & K2H_ISOLATED) != 0u) : (enc <= 1)) owner[i0] = -1; else border = true;
+            }
         }
+        // workgroup-wide list of the walkers: one LDS atomic per wave and pass
+        const unsigned long long bal = __ballot(border);
+        int base = 0;
+        if (bal) {
+            const int first = __ffsll((long long)bal) - 1;
+            if ((int)(threadIdx.x & 63) == first) base = atomicAdd(&l_total, __popcll(bal));
+            base = __builtin_amdgcn_readlane(base, first);
+        }
+        if (border) l_list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (short)tix;
     }
-    const int total = block_compact<NT>(border, l_list, l_wcount);
-    if ((int)threadIdx.x >= total) return;
-    const int i = t.t0 + l_list[threadIdx.x];
-    const int enc = l_enc[l_list[threadIdx.x]];
+    __syncthreads();
+    const int total = l_total;
+    for (int h = (int)threadIdx.x; h < total; h += NTH) {
+    const int i = t.t0 + l_list[h];
+    const int enc = l_enc[l_list[h]];
     const int2 me = t.w[i];
     const int qlo = sat_add(me.x, -g.eps), qhi = sat_add(me.x, g.eps);
     const bool v1 = g.variant == CL_VARIANT_CDBSCAN1;
@@ -1174,6 +1193,7 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
             }
             pending &= ~m;
         }
+    }
     }
 }
 
@@ -2500,6 +2520,12 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     int* rootlist = c->chainflag.as<int>();
     ev_record(c, 4);
     // K4
+    if (wide == 0) {
+        // 1024 PETs per workgroup of 256 threads (4 per thread in the first pass, the walkers of the whole tile in one list)
+        const int nt_b = nblocks(std::max(1, c->run_m), 1024);
+        hipLaunchKernelGGL((k_border<1024, 128, TPB>), dim3(tile_grid(nt_b)), dim3(TPB), 0, c->stream, g, nt_b, sv, sa, strip, c->root.as<int>(),
+                           c->compkey.as<int>(), c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), cnt, c->tileflag.as<int>());
+    } else
     TILE_LAUNCH_H((wide >= 2 && wide <= 4) ? 512 : (wide >= 5 ? 256 : 128), k_border, g, ntiles, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(),
                        c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), cnt, c->tileflag.as<int>());
     if (variant == CL_VARIANT_CDBSCAN2) {
