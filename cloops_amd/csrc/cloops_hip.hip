@@ -651,8 +651,9 @@ __global__ void k_init_arrays(int n, int* __restrict__ parent, int* __restrict__
 // max-scan then gives every core its chain head.  The union-find forest starts flat
 // (parent = chain head), so no million-long pointer chains ever exist -- dense diagonals
 // (self-ligation PETs) become one chain per strip.
-template <int NT, int HALO>
-__global__ void __launch_bounds__(NT)
+// NT PETs per tile, NTH threads: NT / NTH PETs per thread, 64 consecutive PETs per wave and pass (the staging and its halo are amortised)
+template <int NT, int HALO, int NTH = NT>
+__global__ void __launch_bounds__(NTH)
 k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const int* __restrict__ sa,
               const int* __restrict__ strip_start, const int* __restrict__ cnt, int* __restrict__ chainflag,
               int* __restrict__ head, int* __restrict__ wavelast)
@@ -661,30 +662,36 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
     __shared__ int lx[NT + 2 * HALO];
     const int M = strip_start[g.S];
     if (head) {                                          // filtered tail: singleton cells (keys of the cellfirst scan)
-        const int ig = tile_of_block(blockIdx.x) * NT + threadIdx.x;
-        if (ig >= M && ig < n) head[ig] = ig;
+#pragma unroll
+        for (int u = 0; u < NT / NTH; ++u) {
+            const int ig = tile_of_block(blockIdx.x) * NT + (int)threadIdx.x + u * NTH;
+            if (ig >= M && ig < n) head[ig] = ig;
+        }
     }
     Tile t;
-    if (!tile_stage<NT, HALO>(t, lw, lx, ntiles, M, sv, sa, cnt)) return;
-    const int i = t.t0 + threadIdx.x;
-    if (i >= M) return;
+    if (!tile_stage<NT, HALO, NTH>(t, lw, lx, ntiles, M, sv, sa, cnt)) return;
+    for (int u = 0; u < NT / NTH; ++u) {
+    const int i = t.t0 + (int)threadIdx.x + u * NTH;
+    if (i >= M) continue;
     const int2 me = t.w[i];
     if (head) {
         // variant 2: head of the PET's rotated cell (strip, q / eps) = first PET of the sorted order that is
         // neither in an earlier strip nor below the cell's lower q edge -- a bisection on the staged tile
         // instead of head flags + a max-scan over all PETs (variant 2 runs with A0 = V0 = 0)
         const int p0 = me.y & ~(g.peps - 1), q0 = div_eps(g, me.x) * g.eps;      // lower edges of the rotated cell (sp space / q space)
-        int pos = t.wbeg;
-        constexpr int TOP = (NT + HALO < 512) ? 256 : ((NT + HALO < 1024) ? 512 : 1024);      // 2 * TOP - 1 >= the staged range up to i
-        static_assert(2 * TOP > NT + HALO, "cell-head bisection covers the window");
+        // (searched among the 511 staged PETs in front of i -- a cell with more PETs than that, or one that starts before the
+        // staged window, is a pile-up and continues in global memory)
+        const int start = max(t.wbeg, i - 511);
+        int pos = start;
+        constexpr int TOP = 256;
 #pragma unroll
         for (int step = TOP; step >= 1; step >>= 1) {
             const int idx = pos + step - 1;
             const int2 c = t.w[min(idx, i)];
             pos = (idx <= i && (c.y < p0 || c.x < q0)) ? pos + step : pos;
         }
-        if (pos == t.wbeg && t.wbeg > 0) {               // the cell starts before the staged window (pile-up)
-            int lo = 0, hi = t.wbeg;
+        if (pos == start && start > 0) {                 // the cell starts at or before the searched range
+            int lo = 0, hi = start;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if (sa[mid] < p0 || sv[mid] < q0) lo = mid + 1; else hi = mid;
@@ -709,6 +716,7 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
     // find a core's chain head without a scan over all PETs (the lanes still here are the wave's PETs below M; lane 0 is one)
     const unsigned long long ob = __ballot(f != 0);
     if ((threadIdx.x & 63) == 0) wavelast[i >> 6] = ob ? i + (64 - __clzll((long long)ob)) : 0;
+    }
 }
 // parent[] = chain head for core points (flat forest to start from); chainid[] = the same for
 // core points and -1 for everything else (what the union kernel stages as its payload)
@@ -779,8 +787,9 @@ __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const
 // the (latency-bound, global-memory) union-find step -- directly on the chain heads.
 #define UNION_MAXB 4
 
-template <int NT, int HALO>
-__global__ void __launch_bounds__(NT)
+// NT PETs per tile, NTH threads (as k_border): the cores of the whole tile in one list, walked in rounds of NTH
+template <int NT, int HALO, int NTH = NT>
+__global__ void __launch_bounds__(NTH)
 k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
               const int* __restrict__ strip_start, const int* __restrict__ chainid, const int* __restrict__ chain_qend,
               const int* __restrict__ pmax32, int* parent)
@@ -788,14 +797,28 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
     __shared__ int lx[NT + 2 * HALO];
     __shared__ short l_list[NT];
-    __shared__ int l_wcount[NT / 64];
+    __shared__ int l_total;
     const int M = strip_start[g.S];
     Tile t;
-    if (!tile_stage<NT, HALO>(t, lw, lx, ntiles, M, sv, sa, chainid)) return;
-    const int i0 = t.t0 + threadIdx.x;
-    const int total = block_compact<NT>(i0 < M && t.x[i0 < M ? i0 : t.t0] >= 0, l_list, l_wcount);
-    if ((int)threadIdx.x >= total) return;
-    const int i = t.t0 + l_list[threadIdx.x];
+    if (threadIdx.x == 0) l_total = 0;
+    if (!tile_stage<NT, HALO, NTH>(t, lw, lx, ntiles, M, sv, sa, chainid)) return;
+#pragma unroll
+    for (int u = 0; u < NT / NTH; ++u) {
+        const int tix = (int)threadIdx.x + u * NTH, i0 = t.t0 + tix;
+        const bool core = i0 < M && t.x[i0 < M ? i0 : t.t0] >= 0;
+        const unsigned long long bal = __ballot(core);
+        int base = 0;
+        if (bal) {
+            const int first = __ffsll((long long)bal) - 1;
+            if ((int)(threadIdx.x & 63) == first) base = atomicAdd(&l_total, __popcll(bal));
+            base = __builtin_amdgcn_readlane(base, first);
+        }
+        if (core) l_list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (short)tix;
+    }
+    __syncthreads();
+    const int total = l_total;
+    for (int h = (int)threadIdx.x; h < total; h += NTH) {
+    const int i = t.t0 + l_list[h];
     const int2 me = t.w[i];
     const int A = t.x[i];
     const int s = strip_of(g, me.y);
@@ -921,6 +944,7 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
             pending &= ~m;
         }
         if (rep) uf_unite(parent, A, B);
+    }
     }
 }
 
@@ -2492,6 +2516,11 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     {
         // own-strip chains; variant 2: the same tile kernel also finds every PET's cell head
         int* head = variant == CL_VARIANT_CDBSCAN2 ? c->head.as<int>() : nullptr;
+        if (wide == 0) {
+            const int nt_c = nblocks(nm, 1024);
+            hipLaunchKernelGGL((k_chain_flags<1024, 128, TPB>), dim3(tile_grid(nt_c)), dim3(TPB), 0, c->stream, g, nt_c, nm, sv, sa, strip, cnt,
+                               c->chainflag.as<int>(), head, c->chainhead.as<int>() /* wavelast: the buffer is free until the labels */);
+        } else
         TILE_LAUNCH(k_chain_flags, g, ntiles, nm, sv, sa, strip, cnt, c->chainflag.as<int>(),
                            head, c->chainhead.as<int>() /* wavelast: the buffer is free until the labels */);
         if (head) {
@@ -2513,6 +2542,13 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     // the union walk looks one strip back, i.e. about one strip population in front of the PET: a 256-PET halo keeps most of
     // those windows in LDS on dense data (chr1 of the 200 M genome, eps 5000-10000: -12..-16 %); short strips stay with 128
     const int union_halo = (long long)n > 40LL * g.S ? 256 : 128;
+    if (wide == 0) {
+        const int nt_u = nblocks(nm, 1024);
+        if (union_halo == 256) hipLaunchKernelGGL((k_union_cores<1024, 256, TPB>), dim3(tile_grid(nt_u)), dim3(TPB), 0, c->stream, g, nt_u, sv, sa, strip,
+                                                  c->chainflag.as<int>(), c->lo.as<int>(), pmax32, c->parent.as<int>());
+        else hipLaunchKernelGGL((k_union_cores<1024, 128, TPB>), dim3(tile_grid(nt_u)), dim3(TPB), 0, c->stream, g, nt_u, sv, sa, strip,
+                                c->chainflag.as<int>(), c->lo.as<int>(), pmax32, c->parent.as<int>());
+    } else
     TILE_LAUNCH_H((wide == 2 || wide == 4) ? 512 : union_halo, k_union_cores, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
                        pmax32, c->parent.as<int>());
     hipLaunchKernelGGL(k_flatten, dim3(nblocks(nm, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
