@@ -2,9 +2,9 @@
 import os
 import sys
 
-# the sweep keeps one stream per chromosome busy: two hardware queues serve them best; an
+# the sweep keeps one stream per chromosome busy: three hardware queues serve them best; an
 # explicit setting of the user wins.  Must be in the environment before the first HIP call of the process.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
 
 from .pipe import main  # noqa: E402
 

@@ -69,8 +69,8 @@ def load():
     if _lib is not None:
         return _lib
     # (The library reads and writes no environment variable.  An APPLICATION that keeps many chromosome handles busy at
-    # once -- the sweep driver keeps one stream per chromosome -- may want GPU_MAX_HW_QUEUES=2 in the environment before the
-    # first HIP call of the process: the HIP runtime multiplexes streams onto that many hardware queues (default 4), and two
+    # once -- the sweep driver keeps one stream per chromosome -- may want GPU_MAX_HW_QUEUES=3 in the environment before the
+    # first HIP call of the process: the HIP runtime multiplexes streams onto that many hardware queues (default 4), and three
     # serve this pipeline best; bench.py and `python -m cloops_amd` set it unless the user has)
     path = SO_PATH
     if os.environ.get("CLOOPS_DEVEL_LIB") == "1":          # developer build with ablation knobs (cloops_amd/build.py --devel)
