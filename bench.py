@@ -67,6 +67,9 @@ def parse_args(argv=None):
     ap.add_argument("--n-total", type=float, default=N_TOTAL, help="PETs of the synthetic genome (tests use less)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU ranks (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-cpu-baseline", action="store_true",
+                    help="time the sequential oracle over the WHOLE sweep (12 runs x 23 chromosomes, one process per chromosome: about a minute on "
+                         "23+ cores) instead of the bounded 2-run sample, and check its chain against the GPU's")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-with-labels", action="store_true", help="skip the label-inclusive sweep (labels + tables on the host every run)")
     ap.add_argument("--proxy-ranks", type=int, default=8, help="single-GPU scaling proxy: time every rank's LPT share of N alone (0 = off)")
@@ -265,7 +268,7 @@ def main(argv=None):
         if not args.no_secondary:
             line["secondary_5M"] = secondary_5m(api, synth_chrom)
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(api, sizes, steps)
+            line["cpu_baseline"] = cpu_baseline_full(n_total, steps, int(cut), int(ncand)) if args.full_cpu_baseline else cpu_baseline(api, sizes, steps)
     pipe.CACHE.clear()
     if comm is not None:
         comm.barrier()
@@ -476,6 +479,29 @@ def cpu_baseline(api, sizes, steps):
                           workers, os.cpu_count() or 1, ", ".join("(eps %d, minPts %d, cut %d)" % r for r in runs), cpu_s, walls[0], walls[1]),
             "single_thread_pets_per_s": sum(p[r][1] for p in per for r in range(len(runs))) / cpu_s,
             "labels_match_gpu": same, "labels_checked_on": "%s (%d PETs) at eps %d minPts %d cut %d" % ((name, n) + runs[1]),
+            "note": "the Python reference itself runs ~1e5 PETs/s/core (BASELINE.md section 2); the C port is ~20x faster than the reference"}
+
+
+def cpu_baseline_full(n_total, steps, final_cut, ncand):
+    """The sequential C oracle over the whole sweep, in the reference's parallel shape (one worker process per chromosome,
+    cLoops/pipe.py:117; every cut from the concatenated distance lists through the reference's estimator): the chain runner of
+    tests/golden/make_golden_synth200M_chain.py.  Its chain must equal the GPU's (cuts, final cut, candidate count)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import oracle
+    oracle.build()
+    from make_golden_synth200M_chain import run_chain
+    t0 = time.perf_counter()
+    res = run_chain(n_total, CFG, MODE3[0], MODE3[1])
+    wall = time.perf_counter() - t0
+    pets = sum(s["n_in"] for s in res["steps"])
+    same = ([s.get("cut_out") for s in res["steps"]] == [s.get("cut_out") for s in steps] and res["final_cut"] == final_cut
+            and res["candidates"] == ncand)
+    return {"value": pets / res["oracle_wall_s"], "unit": "PETs/s", "cores": min(os.cpu_count() or 1, res["workers"]), "kind": "port",
+            "sample": "the WHOLE sweep: 12 runs x 23 chromosomes, %d worker processes (one chromosome each, %d host cores visible), cut chain "
+                      "estimated from the concatenated distance lists; %.0f s of CPU work, %.1f s wall for the 12 runs (%.1f s with synthesis)" % (
+                          res["workers"], os.cpu_count() or 1, res["oracle_cpu_s"], res["oracle_wall_s"], wall),
+            "sweep_wall_s": res["oracle_wall_s"], "chain_matches_gpu": bool(same),
             "note": "the Python reference itself runs ~1e5 PETs/s/core (BASELINE.md section 2); the C port is ~20x faster than the reference"}
 
 
