@@ -257,3 +257,17 @@ def test_replaced_resident_is_closed_by_its_last_user(monkeypatch, tmp_path):
         assert not getattr(old.chrom, "dead", False) and old.replaced
     assert getattr(old.chrom, "dead", False)              # closed when the pin dropped
     pipe.CACHE.clear()
+
+
+def test_forced_cuts_replace_the_estimated_chain(cpu_pipe):
+    """runSweepFast(forced_cuts=...) (bench.py's scaling proxy: one rank's share replays the genome-wide chain): every step
+    still runs and estimates, but hands the given cut to the next step"""
+    p, f = cpu_pipe
+    free = p.runSweepFast([f], [500, 1000], [5], cut=0)
+    forced = p.runSweepFast([f], [500, 1000], [5], cut=0, forced_cuts=[3000, 7000])
+    assert [s["cut_in"] for s in forced[3]] == [0, 3000] and [s["cut_out"] for s in forced[3]] == [3000, 7000]
+    assert forced[2] == [0, 3000, 7000] and forced[1] == 3000
+    assert [s["cut_out"] for s in free[3]] != [3000, 7000]
+    assert forced[3][0]["n_inter"] == free[3][0]["n_inter"]          # the first step is the same work
+    none = p.runSweepFast([f], [500, 1000], [5], cut=0, forced_cuts=[None, None])
+    assert none[2] == free[2]

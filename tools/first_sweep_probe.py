@@ -44,12 +44,29 @@ def _wrap(name, key):
             _acc[key] += time.perf_counter() - t
     setattr(_api.Chromosome, name, g)
 _wrap("step_async", "enq"); _wrap("wait", "wait"); _wrap("step_result", "res")
+# host gap between the steps: from the end of a step's last step_result to the first step_async of the next step
+_ev = []
+def _stamp(name, when):
+    f = getattr(_api.Chromosome, name)
+    def g(self, *a, **kw):
+        if when == "before":
+            _ev.append((time.perf_counter(), name))
+        try:
+            return f(self, *a, **kw)
+        finally:
+            if when == "after":
+                _ev.append((time.perf_counter(), name))
+    setattr(_api.Chromosome, name, g)
+_stamp("step_async", "before"); _stamp("step_result", "after")
 for k in range(int(os.environ.get("N_SWEEPS", "3"))):
     t0 = time.perf_counter()
     marks = []
     pipe.runSweepFast(fs, [5000, 7500, 10000], [50, 40, 30, 20], cut=0, log=lambda m: marks.append(time.perf_counter()))
     t1 = time.perf_counter()
     steps = [marks[0] - t0] + [b - a for a, b in zip(marks, marks[1:])]
+    evs = sorted(_ev); gaps = [b[0] - a[0] for a, b in zip(evs, evs[1:]) if a[1] == "step_result" and b[1] == "step_async"]
+    print("   host gaps between steps (last step_result -> first step_async), ms: %s; sum %.1f ms" % (" ".join("%.2f" % (x * 1e3) for x in gaps), sum(gaps) * 1e3))
+    del _ev[:]
     print("   host: enqueue %.1f ms, wait %.1f ms (summed over the pool's threads), step_result %.1f ms" % (_acc["enq"] * 1e3, _acc["wait"] * 1e3, _acc["res"] * 1e3))
     for kk in _acc:
         _acc[kk] = 0.0
