@@ -454,7 +454,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         // per cent of the lanes -- strips of 150 .. 300 PETs against a 512-PET halo -- sent nearly every wave through
         // the global path as well.)
         bool okA = tb >= wlo, okB = te <= whi;
-        if (__any(!(okA & okB))) {
+        if (DEFER && __any(!(okA & okB))) {             // (dense shapes; the sparse shape's short strips stay inside its halo)
             const int2 f = lw[wlo], l = lw[whi - 1];
             if (!okA) { okA = (f.y >= pbeg - peps) & (f.y < pbeg) & (f.x < qlo); tb = wlo; }
             if (!okB) { okB = (l.y >= pbeg + peps) & (l.y < pend2) & (l.x > qhi); te = whi; }
