@@ -1808,11 +1808,11 @@ static int reserve_workspace(cl_chrom* c)
     if (!c->arena.p && n > 0) {
         // + what a first run would otherwise allocate piece by piece on the host's critical path: rocPRIM's temporary
         // storage, the strip tables and the compaction scratch for eps >= 1000 (a smaller eps grows them), a first
-        // candidate buffer of max(n / 8, 2^20) boxes (it grows on demand)
+        // candidate buffer of max(n / 8, min(2^20, n)) boxes (it grows on demand)
         size_t sort_bytes = 16, scan_bytes = 16;
         if (workspace_tmp_sizes(c, &sort_bytes, &scan_bytes) != CL_OK) return CL_OK;
         const size_t s_guess = (size_t)(((long long)c->st.vmax - c->st.vmin) / 1000 + 64);
-        const long long cand0 = std::max<long long>((long long)n / 8, 1 << 20);
+        const long long cand0 = std::max<long long>((long long)n / 8, std::min<long long>(1 << 20, (long long)n + 1024));   // (small handles stay small)
         std::vector<Want> all(std::begin(wants), std::end(wants));
         all.push_back({&c->sort_tmp, sort_bytes}); all.push_back({&c->scan_tmp, scan_bytes});
         all.push_back({&c->strip, (s_guess + 2) * 4}); all.push_back({&c->bstrip, (s_guess + 2) * 4}); all.push_back({&c->sel_tmp, (s_guess + 2) * 8 + 64});
