@@ -62,3 +62,111 @@ def test_collectives_at_world_one():
         assert np.array_equal(c.gather_tables(big, dst=0, copy=False)[0], big)
     finally:
         c.close()
+
+
+# ---- the Python side of Comm at world size > 1, over a stand-in for libcloops_comm.so ---------------------------------
+class _Hub(object):
+    """what RCCL does, in one process: every rank deposits its buffer, a barrier, everybody reads what it needs"""
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+
+
+class _FakeCommLib(object):
+    """the C ABI of include/cloops_comm.h on host memory (ctypes pointers in, ctypes pointers out), one instance per rank"""
+    def __init__(self, hub, rank):
+        self.hub, self.rank = hub, rank
+
+    def cl_comm_last_error(self):
+        return b""
+
+    def cl_comm_unique_id(self, buf):
+        return 0
+
+    def cl_comm_init(self, blob, rank, world, device, out):
+        return 0
+
+    def cl_comm_destroy(self, h):
+        pass
+
+    def _exchange(self, arr):
+        self.hub.slots[self.rank] = arr.copy()
+        self.hub.bar.wait()
+        allv = [s.copy() for s in self.hub.slots]
+        self.hub.bar.wait()
+        return allv
+
+    def _view(self, ptr, n, ctype):
+        import ctypes
+        addr = ptr.value if hasattr(ptr, "value") else ctypes.cast(ptr, ctypes.c_void_p).value
+        return np.ctypeslib.as_array((ctype * int(n)).from_address(addr))
+
+    def cl_comm_allreduce_f64(self, h, ptr, n):
+        import ctypes
+        v = self._view(ptr, n, ctypes.c_double)
+        v[:] = np.sum(self._exchange(v), axis=0)
+        return 0
+
+    def cl_comm_allreduce_max_f64(self, h, ptr, n):
+        import ctypes
+        v = self._view(ptr, n, ctypes.c_double)
+        v[:] = np.max(self._exchange(v), axis=0)
+        return 0
+
+    def cl_comm_allgather_i32(self, h, pin, n, pout):
+        import ctypes
+        allv = self._exchange(self._view(pin, n, ctypes.c_int32))
+        self._view(pout, n * self.hub.world, ctypes.c_int32)[:] = np.concatenate(allv)
+        return 0
+
+    def cl_comm_gather_i32(self, h, pin, n, root, pout):
+        import ctypes
+        allv = self._exchange(self._view(pin, n, ctypes.c_int32))
+        if self.rank == root:
+            self._view(pout, n * self.hub.world, ctypes.c_int32)[:] = np.concatenate(allv)
+        return 0
+
+    def cl_comm_barrier(self, h):
+        self.hub.bar.wait()
+        return 0
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_comm_python_side_at_world_n(monkeypatch, world):
+    """allsum (ints come back as ints), allmax, gather_tables (ragged tables, an empty one, dst / all-gather) with the ranks as
+    threads over the stand-in library"""
+    import threading
+    hub = _Hub(world)
+    rng = np.random.RandomState(11)
+    tables = [rng.randint(0, 1 << 30, (k, 4)).astype(np.int32) for k in ([5, 0, 1200][:world])]
+    out = [None] * world
+
+    def rank_main(r):
+        c = comm.Comm.__new__(comm.Comm)
+        c._lib, c._h, c.rank, c.world, c.device = _FakeCommLib(hub, r), 1, r, world, 0
+        res = {}
+        res["sum_i"] = c.allsum(np.arange(10, dtype=np.int64) * (r + 1))
+        res["sum_f"] = c.allsum(np.asarray([0.5 * (r + 1), -1.0]))
+        res["max"] = c.allmax(float(r))
+        res["all"] = c.gather_tables(tables[r], dst=None)
+        res["root"] = c.gather_tables([tables[r], tables[r][:2]], dst=0, copy=False)
+        out[r] = res
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    tri = world * (world + 1) // 2
+    for r in range(world):
+        res = out[r]
+        assert res is not None
+        assert res["sum_i"].dtype == np.int64 and np.array_equal(res["sum_i"], np.arange(10) * tri)
+        assert np.allclose(res["sum_f"], [0.5 * tri, -1.0 * world])
+        assert res["max"] == float(world - 1)
+        assert all(np.array_equal(a, b) for a, b in zip(res["all"], tables))
+        if r == 0:
+            assert all(np.array_equal(a, np.concatenate([t, t[:2]])) for a, t in zip(res["root"], tables))
+        else:
+            assert all(len(a) == 0 for a in res["root"])
