@@ -84,7 +84,9 @@ int cl_device_count(void);
  * columns of the reference's `mat`, cLoops/io.py:49-57,192-203), host pointers if
  * `on_device` == 0, else device pointers on `device` that must stay valid for the life of
  * the handle (no copy is made).  `stream`: a hipStream_t to run on, or NULL for a private
- * stream.  n may be 0.
+ * stream.  n may be 0.  The handle reserves its whole per-PET workspace here (about 225 B/PET in
+ * one allocation: sorted layouts, component / border / label arrays, both result slots, the sweep's
+ * q index and a first candidate buffer), so that no run pays for device or pinned-host allocations.
  */
 int cl_chrom_create(int device, void* stream, const int32_t* x, const int32_t* y, int64_t n,
                     int on_device, cl_chrom** out);
