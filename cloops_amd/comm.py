@@ -22,6 +22,15 @@ SYMBOLS = ("cl_comm_last_error", "cl_comm_unique_id", "cl_comm_init", "cl_comm_d
            "cl_comm_allreduce_f64", "cl_comm_allreduce_max_f64", "cl_comm_allgather_i32", "cl_comm_gather_i32", "cl_comm_barrier")
 ID_BYTES = 128
 _lib = None
+_T_IMPORT = time.time()
+
+
+def default_tag():
+    """names the id file of one launch: the launcher's pid (all local ranks share the parent), MASTER_PORT and -- under
+    torch.distributed.run -- its run id and restart count, so that neither concurrent launches nor a restarted worker group
+    of the same agent meet each other's file"""
+    return "%s_%s_%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                            os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
 
 
 class CommError(RuntimeError):
@@ -59,10 +68,10 @@ def _check(rc):
 
 def exchange_id(rank, world, make_id, tag=None, timeout=300.0, directory="/tmp"):
     """rank 0 makes the id (make_id() -> bytes) and publishes it; every rank returns the same bytes.  The file name carries
-    the launcher's pid (all local ranks share the parent) and MASTER_PORT, so concurrent launches do not meet."""
+    default_tag(); a file older than this process (minus two minutes of start-up skew) is a leftover and is not read."""
     if world == 1:
         return make_id()
-    tag = tag or "%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+    tag = tag or default_tag()
     path = os.path.join(directory, "cloops_comm_id_%s" % tag)
     if rank == 0:
         blob = make_id()
@@ -76,7 +85,7 @@ def exchange_id(rank, world, make_id, tag=None, timeout=300.0, directory="/tmp")
         try:
             with open(path, "rb") as fh:
                 blob = fh.read()
-            if len(blob) == ID_BYTES and time.time() - os.path.getmtime(path) < timeout:
+            if len(blob) == ID_BYTES and os.path.getmtime(path) >= _T_IMPORT - 120.0:
                 return blob
         except (IOError, OSError):
             pass
@@ -104,7 +113,7 @@ class Comm(object):
             self.barrier()
             if self.rank == 0:                             # everyone has joined: the id file has done its job
                 try:
-                    os.remove(os.path.join("/tmp", "cloops_comm_id_%s" % (tag or "%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))))
+                    os.remove(os.path.join("/tmp", "cloops_comm_id_%s" % (tag or default_tag())))
                 except OSError:
                     pass
 

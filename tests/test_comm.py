@@ -170,3 +170,15 @@ def test_comm_python_side_at_world_n(monkeypatch, world):
             assert all(np.array_equal(a, np.concatenate([t, t[:2]])) for a, t in zip(res["root"], tables))
         else:
             assert all(len(a) == 0 for a in res["root"])
+
+
+def test_a_leftover_id_file_is_not_read(tmp_path):
+    """a file left behind by an earlier launch under the same tag (older than this process) must not be taken for rank 0's"""
+    import time
+    path = os.path.join(str(tmp_path), "cloops_comm_id_left")
+    with open(path, "wb") as fh:
+        fh.write(b"x" * comm.ID_BYTES)
+    old = time.time() - 3600
+    os.utime(path, (old, old))
+    with pytest.raises(comm.CommError):
+        comm.exchange_id(1, 2, lambda: b"", tag="left", timeout=0.3, directory=str(tmp_path))
