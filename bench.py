@@ -112,9 +112,17 @@ def main(argv=None):
     # launcher): with torch imported its bundled HIP runtime serves libcloops_hip.so as well and a sweep runs ~6 % slower.
     # CLOOPS_BENCH_COMM=torch keeps the torch.distributed path; the CPU tests (--backend gloo) always use it.
     direct = use_dist and on_gpu and os.environ.get("CLOOPS_BENCH_COMM", "rccl") != "torch"
+    comm_note = None
     if direct:
-        from cloops_amd.comm import Comm
-        comm = Comm(rank, world, local_rank)
+        try:
+            from cloops_amd.comm import Comm
+            comm = Comm(rank, world, local_rank)
+        except Exception as e:                              # library missing / RCCL refused to initialise: the torch path still works
+            comm_note = "libcloops_comm.so unavailable (%s: %s), fell back to torch.distributed" % (type(e).__name__, e)
+            sys.stderr.write("bench.py: %s\n" % comm_note)
+            direct = False
+    if direct:
+        pass
     elif use_dist:
         # torch first: its bundled HIP runtime then also serves libcloops_hip.so (same SONAME; the other order aborts
         # at the first RCCL call)
@@ -233,7 +241,8 @@ def main(argv=None):
             "data": "synthetic",
             "sweep_wall_s": elapsed / max(1, args.steps),
             "first_sweep_s": first_sweep_s,
-            "comm": ("rccl (libcloops_comm.so, no torch in the process)" if comm is not None else ("torch.distributed/%s" % args.backend if use_dist else None)),
+            "comm": ("rccl (libcloops_comm.so, no torch in the process)" if comm is not None else
+                     (("torch.distributed/%s" % args.backend) + ("; " + comm_note if comm_note else "") if use_dist else None)),
             "config": {"workload": "synthetic-%s-23chr-mode3 (BASELINE.json configs[3])" % _human(n_total),
                        "variant": "cDBSCAN2", "pets": n_total, "chromosomes": len(sizes), "eps": eps_list, "minPts": minpts_list,
                        "runs_per_sweep": len(steps), "chained_cut": True, "cuts": [s.get("cut_out") for s in steps],
