@@ -33,9 +33,10 @@ extern "C" {
                                  being an exact grid                                          */
 #define CL_ERR_GRID      -5   /* eps so small that the strip/row table would exceed 2^28 rows, or coordinate
                                  extent so large that (X+Y range / eps + 2) * 2^ceil(log2 eps) leaves int32
-                                 (never for |X|,|Y| < 2^28); also: candidate buffer of a sweep full      */
+                                 (never for |X|,|Y| < 2^28).  (The candidate buffer of a sweep grows on demand.)      */
 #define CL_ERR_NODEVICE  -6   /* no usable HIP device                                         */
-#define CL_ERR_HASH      -7   /* cl_cand_finish: two different boxes share a 64-bit hash (redo on the host) */
+#define CL_ERR_HASH      -7   /* cl_cand_finish: two different boxes shared a 64-bit hash under each of four independent
+                                 salts (the pass is redone under another salt three times before this is reported) */
 
 /* ---- clustering variants ---------------------------------------------------------- */
 #define CL_VARIANT_CDBSCAN1  1   /* cLoops/cDBSCAN.py:6      class cDBSCAN      (scripts/callStripes:29,
