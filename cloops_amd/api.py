@@ -166,6 +166,19 @@ class Chromosome(object):
         0 = built at the handle's second sort (default), 1 = at the first, -1 = never (cl_set_sort_index)"""
         self._lib.cl_set_sort_index(self._h, int(mode))
 
+    def set_count_reuse(self, on=True):
+        """region-query words of the first run at an eps re-used by the later runs at that eps (default on; results
+        identical either way -- cl_set_count_reuse of include/cloops_hip.h)"""
+        self._lib.cl_set_count_reuse(self._h, 1 if on else 0)
+
+    def set_count_floor(self, min_pts):
+        """the smallest minPts that will follow at the current eps (cl_set_count_floor); 0 = unknown"""
+        self._lib.cl_set_count_floor(self._h, int(min_pts))
+
+    def last_region_mode(self):
+        """0 = the last enqueued run did a full region query, 1 = re-used the kept words, 2 = re-used them outside the cut band"""
+        return int(self._lib.cl_last_region_mode(self._h))
+
     def set_layout_reuse(self, on=True):
         """keep the sorted arrays of the last eps and start further runs at that eps from a compaction by the cut
         (default on; results identical either way -- cl_set_layout_reuse of include/cloops_hip.h)"""

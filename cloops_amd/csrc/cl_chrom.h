@@ -99,6 +99,19 @@ struct cl_chrom {
     // walks eps in the outer loop).  Nothing of a result is kept: neighbour counts, components, labels are redone.
     DevBuf bq, bsp, brow, bstrip, btile, sel_tmp;
     struct BaseLayout { bool valid = false; int layout = -1, eps = 0; } base;
+    // Count cache: the K2 words (cl_common.h "K2W") of the FIRST run on a base layout, kept while the layout lives.  A word
+    // holds the PET's neighbour count (exact from `floor` up, saturated at `cap`) and does not depend on minPts otherwise;
+    // a cut removes a prefix of every strip (q IS the distance), so between two runs of one eps the count of a PET changes
+    // only if q - eps < max(the two cuts): every later run with floor <= minPts <= cap takes the words of the PETs beyond that
+    // band as they are (k_cut_copy<true> carries them through its compaction) and runs K2 on the band alone.  Results are
+    // identical with the cache switched off (cl_set_count_reuse); cLoops/pipe.py:247-250 walks minPts inside eps, descending.
+    struct CountCache { bool valid = false; int layout = -1, eps = 0, thr = 0 /* q threshold of the run's cut, 0 = none */, cap = 0, floor = 0; } rc;
+    DevBuf rc_cnt, rc_pre, rc_poff, rc_dpre;   // the words in the sorted order of the run that made them; per strip: PETs its cut removed
+                                      // from the strip / from all strips up to and including it
+    bool reuse_counts = true;         // cl_set_count_reuse
+    int count_floor = 0;              // cl_set_count_floor: smallest minPts later runs of this eps will ask for (0 = unknown)
+    int* w_cnt = nullptr;             // K2 words of the run being enqueued (cnt or rc_cnt)
+    int last_k2_mode = 0;             // 0 = full K2, 1 = words re-used as they are (same cut), 2 = remapped + K2 on the band
     std::vector<long long> dcum;      // dcum[k] = number of PETs with Y - X < k, k = 0 .. 65536 (empty: unknown)
     const int* k_total = nullptr;     // device: where the run left the number of ids handed out (null: rankscan[n])
     bool hdr_packed = false;          // the run's own kernels have written the slot header (no k_pack_header)

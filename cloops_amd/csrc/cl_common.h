@@ -69,6 +69,10 @@ struct GridParams {
     int qbits;    // sort key = strip << (qbits+rbits) | q << rbits | (p mod eps): both coordinates ride
     int rbits;    //   in the key, so the sorted (q,p) arrays are DECODED, not gathered through row ids;
                   //   the radix sort skips the low rbits (they are payload, not order)
+    int floor;    // K2 (clustering form): neighbour counts of non-core PETs are EXACT from `floor` up (below it the word may hold an
+                  //   upper bound): floor == minPts for a one-off run; a run whose words later runs at a smaller minPts re-use
+                  //   (count cache of the handle, cl_set_count_floor) is made with the smallest minPts that will follow
+    int bandq;    // K2 on the cut band only (k_region_core<.., BAND>): PETs with q >= bandq keep the word the compaction wrote
     int peps;     // 1 << rbits.  The kernels never see p itself but its ORDER-PRESERVING re-encoding
                   //   sp = strip << rbits | (p mod eps)   (the strip and remainder fields of the sort key):
                   //   strip(p) = sp >> rbits (no division), and |p_j - p_i| <= eps  <=>  |sp_j - sp_i| <= peps
@@ -340,13 +344,23 @@ __device__ __forceinline__ int block_compact_with(bool active, short* l_list, in
 #define K2F_NS 256        // staged strip-table slice: strips s0-1 .. s0+254 of the tile's first strip s0
 #define K2F_SLACK 128     // LDS entries behind the window that unclamped search probes may touch
 #define SORT_PAD 4224     // >= largest tile + largest halo + slack
-#define K2H_BITS 14
-#define K2H_MASK 0x3fffu
-#define K2H_ISOLATED 0x40000000u
-#define K2H_NONE 0x0fffffffu
+// The word K2 leaves per PET (cnt[]; every consumer decodes it with cw_count / cw_core):
+//   w >= 0   a neighbour count, saturated: k_region_core stores minPts (or more) for a core PET, k_region_count the count;
+//   w <  0   a PET that is NOT core at the minPts the word was made with: bits 24..30 its neighbour count (itself included;
+//            exact from GridParams::floor up, an upper bound below), bits 0..11 / 12..23 how many sorted positions back its
+//            q window in strip s-1 starts / how many positions ahead the one in strip s+1 starts (all ones = no hints).
+// A word stays valid for every minPts in [floor, minPts of the run that made it]: the count cache of a handle re-uses the
+// words of the first run of an eps for the runs that follow (cLoops/pipe.py:247-250 walks minPts inside eps).
+#define K2H_BITS 12
+#define K2H_MASK 0xfffu
+#define K2H_NONE 0x00ffffffu
+#define K2W_CSHIFT 24
+__device__ __forceinline__ int cw_count(int w) { return w >= 0 ? w : (int)(((unsigned)w >> K2W_CSHIFT) & 0x7fu); }
+__device__ __forceinline__ bool cw_core(int w, int minPts) { return cw_count(w) >= minPts; }
 
 static inline int nblocks(long long n, int tpb = TPB) { return (int)((n + tpb - 1) / tpb); }
 
 // k_region.hip: K2 (neighbour counts / core decision) on the sorted arrays of a run
+// band: only the PETs with q < g.bandq are computed (the run's other words come from the handle's count cache)
 int cl_launch_region(hipStream_t stream, const GridParams& g, int n, int run_m, bool exact, const int* sv, const int* sa,
-                     const int* strip_start, const int* tile_s0, int* cnt);
+                     const int* strip_start, const int* tile_s0, int* cnt, bool band = false);

@@ -360,7 +360,7 @@ static inline int tile_grid(int ntiles) { return ((ntiles + 8 * K2_RUN - 1) / (8
 template <int NT, int HALO, int NTH = NT>
 __device__ __forceinline__ bool tile_stage(Tile& t, int2* lw, int* lx, int ntiles, int M,
                                            const int* __restrict__ gq, const int* __restrict__ gp,
-                                           const int* __restrict__ gx, unsigned long long* lmask = nullptr)
+                                           const int* __restrict__ gx, unsigned long long* lmask = nullptr, int fill = -1)
 {
     constexpr int T_WIN = NT + 2 * HALO, NV = T_WIN / 4;
     static_assert(NT % 64 == 0 && HALO % 64 == 0 && NT + HALO + 64 <= SORT_PAD, "window shape");
@@ -381,7 +381,7 @@ __device__ __forceinline__ bool tile_stage(Tile& t, int2* lw, int* lx, int ntile
     for (int k = threadIdx.x; k < T_WIN; k += NTH) {
         const int gi = base + k;
         const bool in = gi >= 0 && gi < M;
-        const int x = in ? gx[gi] : -1;                  // every payload test is `>= (something >= 0)`
+        const int x = in ? gx[gi] : fill;                // every payload test is `>= (something >= 0)` (K2 words: fill = 0, "no neighbour")
         lx[k] = x;
         if (lmask) {
             const unsigned long long bal = __ballot(in && x >= 0);
@@ -669,7 +669,7 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
         }
     }
     Tile t;
-    if (!tile_stage<NT, HALO, NTH>(t, lw, lx, ntiles, M, sv, sa, cnt)) return;
+    if (!tile_stage<NT, HALO, NTH>(t, lw, lx, ntiles, M, sv, sa, cnt, nullptr, 0)) return;
     for (int u = 0; u < NT / NTH; ++u) {
     const int i = t.t0 + (int)threadIdx.x + u * NTH;
     if (i >= M) continue;
@@ -701,15 +701,15 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
         head[i] = pos;
     }
     int f = 0, last = 0;
-    if (t.x[i] >= g.minPts) {
+    if (cw_core(t.x[i], g.minPts)) {
         const int s = strip_of(g, me.y);
         const int b = strip_start[s], e = strip_start[s + 1];
         f = i + 1;
         last = 1;
         tile_visit_own(t, sv, cnt, i, b, e, sat_add(me.x, -g.eps), sat_add(me.x, g.eps), 1,
-                       [&](int, int cj) { if (cj >= g.minPts) { f = 0; return true; } return false; });
+                       [&](int, int cj) { if (cw_core(cj, g.minPts)) { f = 0; return true; } return false; });
         tile_visit_own(t, sv, cnt, i, b, e, sat_add(me.x, -g.eps), sat_add(me.x, g.eps), 2,
-                       [&](int, int cj) { if (cj >= g.minPts) { last = 0; return true; } return false; });
+                       [&](int, int cj) { if (cw_core(cj, g.minPts)) { last = 0; return true; } return false; });
     }
     chainflag[i] = f | (last ? (int)0x80000000u : 0);   // sign bit: last core of its chain (its q is the chain's upper end)
     // wavelast[w] = the last chain-opening PET (+1) among the 64 PETs [64 w, 64 w + 64), 0 = none: what k_chain_parent needs to
@@ -744,14 +744,14 @@ __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const
         ii[e] = (blockIdx.x * CP_PER + e) * (int)blockDim.x + (int)threadIdx.x;
         const bool in = ii[e] < M;
         fl[e] = in ? chainid[ii[e]] : 0;                 // i + 1 if the PET opens a chain, sign bit: last core of its chain
-        cn[e] = in ? cnt[ii[e]] : INT_MIN;
+        cn[e] = in ? cnt[ii[e]] : 0;
         spv[e] = (in && pmax32) ? sa[ii[e]] : INT_MIN;
         qv[e] = (in && fl[e] < 0) ? sv[ii[e]] : 0;
     }
 #pragma unroll
     for (int e = 0; e < CP_PER; ++e) {
         const int i = ii[e];
-        const bool core = cn[e] >= minPts;
+        const bool core = cw_core(cn[e], minPts);
         const unsigned long long open = __ballot((fl[e] & 0x7fffffff) != 0);
         const unsigned long long upto = open & ((2ull << lane) - 1ull);
         int head1 = upto ? (i - lane) + (64 - __clzll((long long)upto)) : 0;
@@ -982,7 +982,7 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
 #pragma unroll
     for (int e = 0; e < FLAT_PER; ++e) {
         ii[e] = (blockIdx.x * FLAT_PER + e) * BIGTPB + (int)threadIdx.x;
-        core[e] = ii[e] < M && cnt[ii[e]] >= g.minPts;
+        core[e] = ii[e] < M && cw_core(cnt[ii[e]], g.minPts);
     }
 #pragma unroll
     for (int e = 0; e < FLAT_PER; ++e) {
@@ -1111,11 +1111,11 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
             const int ri = t.x[i0];
             if (ri >= 0) owner[i0] = ri;
             else {
-                // K2 left either the neighbour count of a non-core PET (itself included) or its hint word (k_region_core):
-                // nothing within eps -- most of the background noise ends here
+                // K2 left either the neighbour count of a non-core PET (itself included) or its word with count and hints
+                // (k_region_core): a count <= 1 = nothing within eps -- most of the background noise ends here
                 const int enc = cnt[i0];
                 l_enc[tix] = enc;
-                if (enc < 0 ? (((unsigned)enc & K2H_ISOLATED) != 0u) : (enc <= 1)) owner[i0] = -1; else border = true;
+                if (cw_count(enc) <= 1) owner[i0] = -1; else border = true;
             }
         }
         // workgroup-wide list of the walkers: one LDS atomic per wave and pass
@@ -1545,7 +1545,8 @@ static void free_chrom(cl_chrom* c)
     DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->qb_key, &c->qb_val, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->slot[0].d_step, &c->slot[1].d_step, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
-                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->tileflag, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out, &c->dhist};
+                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->tileflag, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out, &c->dhist,
+                      &c->rc_cnt, &c->rc_pre, &c->rc_poff, &c->rc_dpre};
     for (DevBuf* b : bufs) b->release();
     c->arena.release();                                  // (after its slices have been dropped)
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
@@ -1565,7 +1566,10 @@ static void free_chrom(cl_chrom* c)
 extern "C" void cl_chrom_destroy(cl_chrom* c) { free_chrom(c); }
 extern "C" int64_t cl_chrom_size(const cl_chrom* c) { return c ? c->n : -1; }
 extern "C" void cl_set_profiling(cl_chrom* c, int enabled) { if (c) c->profiling = enabled != 0; }
-extern "C" void cl_set_layout_reuse(cl_chrom* c, int enabled) { if (c) { c->reuse_layout = enabled != 0; c->base.valid = false; } }
+extern "C" void cl_set_layout_reuse(cl_chrom* c, int enabled) { if (c) { c->reuse_layout = enabled != 0; c->base.valid = false; c->rc.valid = false; } }
+extern "C" void cl_set_count_reuse(cl_chrom* c, int enabled) { if (c) { c->reuse_counts = enabled != 0; c->rc.valid = false; } }
+extern "C" int cl_last_region_mode(const cl_chrom* c) { return c ? c->last_k2_mode : 0; }
+extern "C" void cl_set_count_floor(cl_chrom* c, int32_t min_pts) { if (c) c->count_floor = min_pts > 0 ? min_pts : 0; }
 extern "C" void cl_set_sort_index(cl_chrom* c, int mode) { if (c) c->sort_index_mode = mode > 0 ? 1 : (mode < 0 ? -1 : 0); }
 extern "C" int cl_get_timing(const cl_chrom* c, cl_timing* out)
 {
@@ -1692,24 +1696,40 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
 // -- which IS the new strip table -- and one copy pass (12 B/PET read, 12 B per kept PET written) that also leaves the tile
 // table, the sentinels behind the last kept PET and M.  (Round 2 first did it by flags: per-block counts over all PETs, a
 // scan over the blocks, a ballot-ranked scatter, then bisections of the compacted array for the strip table -- 5 launches.)
+// Count cache (see run_sort_and_count): pre_out (a run whose K2 words are kept) = the number of PETs the cut removes from
+// every strip; pre_ref + dpre_out (a run that re-uses kept words) = how many MORE PETs this cut removes from the strip than
+// the cut of the run that made the words (negative: fewer) -- what the hint fields of a word shift by.
 __global__ void k_cut_strips(int S, int thr, const int* __restrict__ bstrip, const int* __restrict__ bq,
-                             int* __restrict__ kept /* [S+1] */, int* __restrict__ src0 /* [S] first kept source index */)
+                             int* __restrict__ kept /* [S+1] */, int* __restrict__ src0 /* [S] first kept source index */,
+                             int* __restrict__ pre_out /* or null */, const int* __restrict__ pre_ref /* or null */,
+                             int* __restrict__ dpre_out /* with pre_ref */)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s > S) return;
-    if (s == S) { kept[S] = 0; return; }
-    int lo = bstrip[s];
+    if (s == S) { kept[S] = 0; if (pre_out) pre_out[S] = 0; if (pre_ref) dpre_out[S] = 0; return; }
+    const int b = bstrip[s];
+    int lo = b;
     const int e = bstrip[s + 1];
     int hi = e;
     while (lo < hi) { const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1); if (bq[mid] < thr) lo = mid + 1; else hi = mid; }
     kept[s] = e - lo;
     src0[s] = lo;
+    if (pre_out) pre_out[s] = lo - b;
+    if (pre_ref) dpre_out[s] = (lo - b) - pre_ref[s];
 }
+// REMAP (count cache): the K2 word of every kept PET outside the cut band rides along -- read at the PET's place in the
+// layout of the run that made the words (base index - poff_ref[strip]), its two hint fields shifted by what this cut removes
+// from the PET's own strip / the strip above beyond what that run's cut removed (a word whose shifted hints leave their
+// fields loses them: K2H_NONE, k_border then searches for itself).  Words of the band (q < bandq) are left to K2.
+// poff_out (a run whose words are kept, with a cut): poff_out[s] = PETs the cut removes in front of strip s's kept PETs.
+template <bool REMAP>
 __global__ void __launch_bounds__(CMP_TPB)
 k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const int* __restrict__ bsp, const u32* __restrict__ brow,
            const int* __restrict__ src0, int* __restrict__ strip_start /* [0..S] = the scan; [S+1] written here */,
            int* __restrict__ sv, int* __restrict__ sa, u32* __restrict__ srow, int* __restrict__ tile_s0, int* __restrict__ d_M,
-           int expect_m, int* __restrict__ counters)
+           int expect_m, int* __restrict__ counters, int* __restrict__ poff_out /* or null */,
+           const int* __restrict__ rc_words, const int* __restrict__ poff_ref, const int* __restrict__ dpre, int bandq,
+           int* __restrict__ cnt)
 {
     const int M = strip_start[S];
     const int base = blockIdx.x * CMP_BLOCK;
@@ -1728,11 +1748,19 @@ k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const i
         sp[k] = keep[k] ? bsp[i] : 0;
         row[k] = keep[k] ? brow[i] : 0u;
     }
+    int wd[CMP_PER], dA[CMP_PER], dB[CMP_PER];
 #pragma unroll
     for (int k = 0; k < CMP_PER; ++k) {
         const int st = sp[k] >> rbits;
         d0[k] = keep[k] ? strip_start[st] : 0;
         s0[k] = keep[k] ? src0[st] : 0;
+        if (REMAP) {
+            const int i = base + k * CMP_TPB + (int)threadIdx.x;
+            const bool take = keep[k] && q[k] >= bandq;
+            wd[k] = take ? rc_words[i - poff_ref[st]] : 0;
+            dA[k] = take ? dpre[st] : 0;
+            dB[k] = take ? dpre[st + 1] : 0;
+        }
     }
 #pragma unroll
     for (int k = 0; k < CMP_PER; ++k) {
@@ -1741,8 +1769,20 @@ k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const i
             const int dst = d0[k] + (i - s0[k]);
             sv[dst] = q[k]; sa[dst] = sp[k]; srow[dst] = row[k];
             if ((dst & 255) == 0) tile_s0[dst >> 8] = sp[k] >> rbits;
+            if (REMAP && q[k] >= bandq) {
+                int w = wd[k];
+                if (w < 0 && ((unsigned)w & K2H_NONE) != K2H_NONE) {
+                    const int da = (int)((unsigned)w & K2H_MASK) - dA[k], db = (int)(((unsigned)w >> K2H_BITS) & K2H_MASK) - dB[k];
+                    const bool ok = (da >= 0) & (da < (int)K2H_MASK) & (db >= 0) & (db < (int)K2H_MASK);
+                    w = (int)(((unsigned)w & ~K2H_NONE) | (ok ? ((unsigned)da | ((unsigned)db << K2H_BITS)) : K2H_NONE));
+                }
+                cnt[dst] = w;
+            }
         }
     }
+    if (poff_out)
+        for (int u = blockIdx.x * CMP_TPB + (int)threadIdx.x; u <= S; u += gridDim.x * CMP_TPB)
+            poff_out[u] = (u < S ? src0[u] : n) - strip_start[u];
     // what k_after_compact did besides the strip table: tiles behind M, sentinels, M itself
     const int t = blockIdx.x * CMP_TPB + (int)threadIdx.x;
     for (int u = t; u <= n / 256; u += gridDim.x * CMP_TPB) if (u * 256 >= M) tile_s0[u] = S;
@@ -1770,7 +1810,7 @@ k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const i
         {&c->ulist, n * 4}, {&c->lo, n * 4}, {&c->hi, n * 4}, {&c->recs, n * sizeof(Rec)}, \
         {&c->chainflag, n * 4}, {&c->chainhead, n * 4}, {&c->usize, n * 4}, {&c->tile_s0, (n / 256 + 2) * 4}, {&c->tileflag, (n / 256 + 2) * 4}, \
         {&c->bq, (n + 2 * SORT_PAD) * 4}, {&c->bsp, (n + 2 * SORT_PAD) * 4}, {&c->brow, n * 4}, {&c->btile, (n / 256 + 2) * 4}, \
-        {&c->qb_key, n * 4}, {&c->qb_val, n * 8}, {&c->k7_cls, n + 16}, \
+        {&c->qb_key, n * 4}, {&c->qb_val, n * 8}, {&c->k7_cls, n + 16}, {&c->rc_cnt, n * 4}, \
         {&c->slot[0].d_step, 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8 + K7_BLOCKS * sizeof(K7Part)}, \
         {&c->slot[1].d_step, 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8 + K7_BLOCKS * sizeof(K7Part)}, \
     };
@@ -1837,7 +1877,7 @@ int ensure_workspace(cl_chrom* c, int S)
     if (!c->arena.p) (void)reserve_workspace(c);
     const cl_chrom::Slot* other = &c->slot[1 - c->cur];
     for (const Want& w : wants) if (w.b != &other->labels && w.b != &other->table && w.b != &other->slab && w.b != &c->slot[0].d_step && w.b != &c->slot[1].d_step && w.b != &c->bq && w.b != &c->bsp && w.b != &c->brow && w.b != &c->btile && w.b != &c->qb_key &&
-                                    w.b != &c->qb_val && w.b != &c->k7_cls && (rc = w.b->ensure(w.bytes))) return rc;
+                                    w.b != &c->qb_val && w.b != &c->k7_cls && w.b != &c->rc_cnt && (rc = w.b->ensure(w.bytes))) return rc;
     if ((rc = c->strip.ensure(((size_t)S + 2) * 4)) || (rc = c->counters.ensure(256))) return rc;      // (counters: allocated at upload)
     if (c->sv.fresh || c->sa.fresh) {
         // sentinel pads around the sorted arrays (k_region_core stages its windows without bounds checks)
@@ -2001,6 +2041,11 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     if (g.cut > 0 && g.cut < DCUM_BINS && !c->dcum.empty()) { c->run_m = (int)(n - c->dcum[g.cut]); c->run_m_exact = true; }
     int* wsv = c->sv.as<int>() + SORT_PAD;
     int* wsa = c->sa.as<int>() + SORT_PAD;
+    c->w_cnt = c->cnt.as<int>();
+    c->last_k2_mode = 0;
+    GridParams gk = g;                                    // what K2 sees: floor / bandq filled in below
+    gk.floor = g.minPts; gk.bandq = INT_MAX;
+    bool k2_band = false, k2_skip = false;
     if (!c->reuse_layout) {
         // every run sorts for itself (the cut filter rides in the keys: filtered rows go behind the last strip)
         if ((rc = sort_layout(c, g, wsv, wsa, nullptr, c->strip.as<int>(), c->tile_s0.as<int>()))) return rc;
@@ -2018,6 +2063,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
             }
             GridParams g0 = g;
             g0.cut = 0;
+            c->rc.valid = false;                          // the cached words belong to the layout that is being replaced
             if ((rc = sort_layout(c, g0, c->bq.as<int>() + SORT_PAD, c->bsp.as<int>() + SORT_PAD, c->brow.as<u32>(),
                                   c->bstrip.as<int>(), c->btile.as<int>()))) return rc;
             c->base.valid = true; c->base.layout = layout; c->base.eps = g.eps;
@@ -2026,7 +2072,43 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
             ev_record(c, 1);
         }
         const long long dmin = g.swap ? c->st.amin : 0;   // swap == 0 is a developer layout: always compacts
-        if (g.cut <= 0 || (g.swap && (long long)g.cut <= dmin)) {
+        const bool on_base = g.cut <= 0 || (g.swap && (long long)g.cut <= dmin);
+        // ---- count cache (cl_chrom::rc): what this run does about its K2 words -------------------------------------
+        //   make : the run's K2 writes the cache (first clustering run on this layout, or one the cached words cannot serve)
+        //   same : same cut as the run that made the words -- nothing to do, the consumers read the cache
+        //   remap: another cut -- the compaction carries the words of the PETs beyond the band, K2 runs on the band
+        const int m1 = g.minPts - 1;
+        const bool cacheable = !exact && c->reuse_counts && g.swap && m1 >= 1 && m1 <= 127;
+        const int thr_new = on_base ? 0 : g.cut - g.V0;   // q >= 0 everywhere: threshold 0 removes nothing
+        enum { RC_NONE, RC_MAKE, RC_SAME, RC_REMAP } rcmode = RC_NONE;
+        if (cacheable) {
+            const bool serves = c->rc.valid && c->rc.layout == layout && c->rc.eps == g.eps && g.minPts <= c->rc.cap && g.minPts >= c->rc.floor;
+            if (serves && thr_new == c->rc.thr) rcmode = RC_SAME;
+            else if (serves && !on_base) rcmode = RC_REMAP;
+            else rcmode = RC_MAKE;
+            if ((rc = c->rc_cnt.ensure((size_t)n * 4)) || (rc = c->rc_pre.ensure(((size_t)g.S + 2) * 4)) ||
+                (rc = c->rc_poff.ensure(((size_t)g.S + 2) * 4)) || (rc = c->rc_dpre.ensure(((size_t)g.S + 2) * 4))) return rc;
+        }
+        if (rcmode == RC_MAKE) {
+            c->rc.valid = true; c->rc.layout = layout; c->rc.eps = g.eps; c->rc.thr = thr_new; c->rc.cap = g.minPts;
+            c->rc.floor = (c->count_floor > 0 && c->count_floor < g.minPts) ? std::max(2, c->count_floor) : g.minPts;
+            gk.floor = c->rc.floor;
+            c->w_cnt = c->rc_cnt.as<int>();
+            if (on_base) {
+                HIP_TRY(hipMemsetAsync(c->rc_pre.p, 0, ((size_t)g.S + 2) * 4, c->stream));
+                HIP_TRY(hipMemsetAsync(c->rc_poff.p, 0, ((size_t)g.S + 2) * 4, c->stream));
+            }
+        } else if (rcmode == RC_SAME) {
+            c->w_cnt = c->rc_cnt.as<int>();
+            k2_skip = true;
+            c->last_k2_mode = 1;
+        } else if (rcmode == RC_REMAP) {
+            // the two cuts differ in the PETs with q in [min, max) of the thresholds: a PET keeps its count iff q - eps >= max
+            gk.bandq = std::max(thr_new, c->rc.thr) + g.eps;
+            k2_band = true;
+            c->last_k2_mode = 2;
+        }
+        if (on_base) {
             // no row is filtered: the run works on the base layout itself
             c->w_sv = c->bq.as<int>() + SORT_PAD; c->w_sa = c->bsp.as<int>() + SORT_PAD; c->srow = c->brow.as<u32>();
             c->w_strip = c->bstrip.as<int>(); c->w_tile = c->btile.as<int>();
@@ -2041,19 +2123,29 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
             int* d_M = c->counters.as<int>() + CTR_M;
             const int thr = g.cut - g.V0;
             const int* bq = c->bq.as<int>() + SORT_PAD;
-            LAUNCH(k_cut_strips, g.S + 1, g.S, thr, (const int*)c->bstrip.as<int>(), bq, kept, src0);
+            LAUNCH(k_cut_strips, g.S + 1, g.S, thr, (const int*)c->bstrip.as<int>(), bq, kept, src0,
+                   rcmode == RC_MAKE ? c->rc_pre.as<int>() : (int*)nullptr,
+                   rcmode == RC_REMAP ? (const int*)c->rc_pre.as<int>() : (const int*)nullptr,
+                   rcmode == RC_REMAP ? c->rc_dpre.as<int>() : (int*)nullptr);
             size_t tb = c->scan_tmp.bytes;
             hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, kept, c->strip.as<int>(), 0, (size_t)g.S + 1, rocprim::plus<int>(), c->stream);
             if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan(cut)", hipGetErrorString(e));
-            hipLaunchKernelGGL(k_cut_copy, dim3(nb), dim3(CMP_TPB), 0, c->stream, n, g.S, g.rbits, thr, bq, (const int*)(c->bsp.as<int>() + SORT_PAD),
-                               (const u32*)c->brow.as<u32>(), (const int*)src0, c->strip.as<int>(), wsv, wsa, c->vals_out.as<u32>(), c->tile_s0.as<int>(),
-                               d_M, c->run_m_exact ? c->run_m : -1, c->counters.as<int>());
+            if (rcmode == RC_REMAP)
+                hipLaunchKernelGGL(k_cut_copy<true>, dim3(nb), dim3(CMP_TPB), 0, c->stream, n, g.S, g.rbits, thr, bq, (const int*)(c->bsp.as<int>() + SORT_PAD),
+                                   (const u32*)c->brow.as<u32>(), (const int*)src0, c->strip.as<int>(), wsv, wsa, c->vals_out.as<u32>(), c->tile_s0.as<int>(),
+                                   d_M, c->run_m_exact ? c->run_m : -1, c->counters.as<int>(), (int*)nullptr,
+                                   (const int*)c->rc_cnt.as<int>(), (const int*)c->rc_poff.as<int>(), (const int*)c->rc_dpre.as<int>(), gk.bandq, c->cnt.as<int>());
+            else
+                hipLaunchKernelGGL(k_cut_copy<false>, dim3(nb), dim3(CMP_TPB), 0, c->stream, n, g.S, g.rbits, thr, bq, (const int*)(c->bsp.as<int>() + SORT_PAD),
+                                   (const u32*)c->brow.as<u32>(), (const int*)src0, c->strip.as<int>(), wsv, wsa, c->vals_out.as<u32>(), c->tile_s0.as<int>(),
+                                   d_M, c->run_m_exact ? c->run_m : -1, c->counters.as<int>(), rcmode == RC_MAKE ? c->rc_poff.as<int>() : (int*)nullptr,
+                                   (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, 0, (int*)nullptr);
             c->w_sv = wsv; c->w_sa = wsa; c->srow = c->vals_out.as<u32>();
             c->w_strip = c->strip.as<int>(); c->w_tile = c->tile_s0.as<int>();
         }
     }
     ev_record(c, 2);
-    if ((rc = cl_launch_region(c->stream, g, n, c->run_m, exact, c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->cnt.as<int>()))) return rc;
+    if (!k2_skip && (rc = cl_launch_region(c->stream, gk, n, c->run_m, exact, c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->w_cnt, k2_band))) return rc;
     ev_record(c, 3);
     HIP_TRY(hipGetLastError());
     return CL_OK;
@@ -2384,7 +2476,6 @@ extern "C" int cl_cluster_step_async(cl_chrom* c, int variant, int32_t eps, int3
 {
     if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
     if (step < 0) return fail(CL_ERR_ARG, "cl_cluster_step_async: step must be >= 0");
-    if (variant == CL_VARIANT_BLOCK) return fail(CL_ERR_ARG, "cl_cluster_step_async: rotated variants only");
     if (c->enq != c->deq) return fail(CL_ERR_ARG, "cl_cluster_step_async: one sweep step in flight per chromosome");
     c->pending_step = step;
     c->pending_cut = cut;
@@ -2466,7 +2557,6 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     if ((rc = ensure_events(c))) return rc;
     ENQ_MARK();
     const int n = (int)c->n;
-    int* cnt = c->cnt.as<int>();
     int* counters = c->counters.as<int>();
     // tile shape of the traversal kernels.  The wide shape (1024 PETs + 512 halo: long strips stay in LDS) measured SLOWER
     // than the narrow one on the dense workloads (chr1 of the 200 M genome, eps 5000-10000: K3 +7 %, K4 +12..22 %): the
@@ -2493,6 +2583,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     const bool rows = labels_out != nullptr || c->device_labels;
     if (rows && cut > 0) HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
     if ((rc = run_sort_and_count(c, g, false))) return rc;
+    const int* cnt = c->w_cnt;                          // K2 words of this run (the handle's count cache or the work buffer)
     ENQ_MARK();
     {
         cl_chrom::Slot& sl = c->slot[c->cur];

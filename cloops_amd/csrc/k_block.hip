@@ -445,6 +445,6 @@ int run_block(cl_chrom* c, int eps, int minPts, int cut, int32_t* labels_out)
     HIP_TRY(hipGetLastError());
     // blockDBSCAN.py:74: an empty (fully filtered) mat raises only when the class is called
     // on it; pipe.py:64-65 returns before that, so cut > 0 with no survivors is just empty.
-    { cl_chrom::Slot& sl = c->slot[c->cur]; sl.rows_valid = true; sl.sorted_src = false; }
+    { cl_chrom::Slot& sl = c->slot[c->cur]; sl.rows_valid = true; sl.sorted_src = false; sl.kmax = n; }      // ids <= cells <= n
     return finish_enqueue(c, p.R + 1, &sc->M, labels_out);
 }

@@ -265,9 +265,11 @@ __device__ __forceinline__ int first_true_clamped(const int2* __restrict__ w, in
 // TAIL: the run has a cut, i.e. the sorted arrays end in a filtered tail whose tiles leave right after the scalar load of
 // tile_s0 (before staging anything); without a cut every tile has work and the staging loads are issued BEFORE that load
 // is waited for (its latency hides behind them).
-// hints of k_region_core for the non-core PETs (negative words in cnt[]): bit 30 isolated, bits 0..13 / 14..27 the distance
-// (in sorted positions) back to the start of its window in strip s-1 / forward to the one in strip s+1, all ones = no hints
-template <int U, int HALO, bool TAIL>
+// The word of a non-core PET (negative, cl_common.h "K2W"): its count in bits 24..30, in bits 0..11 / 12..23 the distance (in
+// sorted positions) back to the start of its window in strip s-1 / forward to the one in strip s+1, all ones = no hints.
+// BAND: the run re-uses the words of an earlier run of this eps (count cache) -- the compaction has already written the word
+// of every PET whose neighbourhood the two cuts treat alike (q >= g.bandq); only the PETs of the cut band are computed here.
+template <int U, int HALO, bool TAIL, bool BAND = false>
 __global__ void __launch_bounds__(K2F_TPB)
 k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
               const int* __restrict__ strip_start, const int* __restrict__ tile_s0, int* __restrict__ cnt)
@@ -277,6 +279,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     constexpr int RUN = (2048 / TILE) > 0 ? (2048 / TILE) : 1;          // consecutive tiles per XCD (halo reuse in its L2)
     static_assert(HALO % 4 == 0 && HALO >= 128 && TILE + HALO + K2F_SLACK <= SORT_PAD && TILE % 256 == 0, "window shape");
     static_assert(WIN + K2F_SLACK < (int)K2H_MASK, "window offsets fit the hint fields");
+    static_assert(!BAND || TAIL, "a band run has a cut");
     __shared__ __attribute__((aligned(16))) int2 lw[WIN + K2F_SLACK];   // (q, sp) pairs, window index = sorted index - (t0 - HALO)
     __shared__ int l_st[K2F_NS + 4];
     __shared__ unsigned int l_list[TILE];                                // undecided PETs, one region of 64*U entries per wave
@@ -317,6 +320,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     K2_ABL(32);
     const int m1 = g.minPts - 1;                        // 1 <= m1 <= 127 < HALO (the host guarantees it)
     const int eps = g.eps, peps = g.peps, minPts = g.minPts;
+    const int floorc = g.floor;                         // counts are exact from here up (<= minPts)
     const int nmask = ~(peps - 1);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned int* my_list = l_list + wv * (64 * U);
@@ -333,7 +337,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         const int tix = (int)threadIdx.x + u * K2F_TPB;
         const int2 me = p_me[u], rr = p_rr[u], ll = p_ll[u];
         const int pbeg = me.y & nmask;
-        const bool valid = t0 + tix < M;
+        const bool valid = (t0 + tix < M) & (!BAND || me.x < g.bandq);
         // the (minPts-1)-th next / previous PET is in the same strip and within eps in q (unsigned add: a sentinel q wraps harmlessly)
         const bool core = ((rr.y < pbeg + peps) & (rr.x <= (int)((unsigned)me.x + (unsigned)eps))) | ((ll.y >= pbeg) & (ll.x >= me.x - eps));
         if (valid & core) cnt[t0 + tix] = minPts;
@@ -394,7 +398,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         // searching again (and without the strip table)
         int outv = c;
         if (c < minPts) {
-            unsigned enc = 0x80000000u | (c <= 1 ? K2H_ISOLATED : 0u);
+            unsigned enc = 0x80000000u | ((unsigned)c << K2W_CSHIFT);
             enc |= (hja >= 0) ? ((unsigned)(li - hja) | ((unsigned)(hjb - li) << K2H_BITS)) : K2H_NONE;
             outv = (int)enc;
         }
@@ -517,8 +521,10 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
 #ifdef CLOOPS_DEVEL
                 if (g.dbg & 512) { cnt[t0 + tix] = c + ja + jb + ka + kb; continue; }
 #endif
+                // (a search that ran out of steps reports >= minPts - 1 positions, so an ub below floorc <= minPts is the exact size
+                // of both windows: a true upper bound of the count)
                 const int ub = c + (ka - ja) + (kb - jb);
-                if (ub < minPts) c = ub;                // not core; what is stored is an upper bound of the count (k_border: <= 1 = isolated)
+                if (ub < floorc) c = ub;                // not core at any minPts >= floor; what is stored is an upper bound of the count (<= 1 = isolated)
                 else {
                     // candidates to test: phase 3 (all lanes of this round have read their entries; what the round
                     // has consumed so far, 64 entries per round, is free -- an entry that would not fit is counted here)
@@ -581,7 +587,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
 // host side: pick the tile shape and launch
 // ------------------------------------------------------------------------------------------
 int cl_launch_region(hipStream_t stream, const GridParams& g, int n, int run_m, bool exact, const int* sv, const int* sa,
-                     const int* strip_start, const int* tile_s0, int* cnt)
+                     const int* strip_start, const int* tile_s0, int* cnt, bool band)
 {
         const int m1 = g.minPts - 1;
         if (!exact && m1 >= 1 && m1 <= 127) {
@@ -599,7 +605,9 @@ int cl_launch_region(hipStream_t stream, const GridParams& g, int n, int run_m, 
             {                                                                                                           \
                 const int tile = K2F_TPB * UU, ntiles = nblocks(std::max(1, run_m), tile), run = std::max(1, 2048 / tile); \
                 const int grid = ((ntiles + 8 * run - 1) / (8 * run)) * (8 * run);                                      \
-                if (g.cut > 0) hipLaunchKernelGGL((k_region_core<UU, HH, true>), dim3(grid), dim3(K2F_TPB), padlds, stream, g, ntiles, \
+                if (band) hipLaunchKernelGGL((k_region_core<UU, HH, true, true>), dim3(grid), dim3(K2F_TPB), padlds, stream, g, ntiles, \
+                                   sv, sa, strip_start, tile_s0, cnt);                            \
+                else if (g.cut > 0) hipLaunchKernelGGL((k_region_core<UU, HH, true>), dim3(grid), dim3(K2F_TPB), padlds, stream, g, ntiles, \
                                    sv, sa, strip_start, tile_s0, cnt);                            \
                 else hipLaunchKernelGGL((k_region_core<UU, HH, false>), dim3(grid), dim3(K2F_TPB), padlds, stream, g, ntiles, \
                                    sv, sa, strip_start, tile_s0, cnt); \

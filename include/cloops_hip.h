@@ -261,6 +261,23 @@ void cl_set_layout_reuse(cl_chrom* c, int enabled);
  * coming); -1: never.  Results are identical in every mode. */
 void cl_set_sort_index(cl_chrom* c, int mode);
 
+/* Region-query reuse inside one eps (default: enabled; needs layout reuse).  The neighbour count of a PET
+ * (cDBSCAN.py:186-205 regionQuery, cDBSCAN2.py:333-334) does not depend on minPts, and a cut (pipe.py:59-62) removes
+ * only PETs whose distance is below it -- in the sorted layout a prefix of every strip -- so the count of a PET changes
+ * between two runs of one eps only if its distance lies within eps above the larger of their cuts.  The sweep of
+ * cLoops/pipe.py:247-250 walks minPts (descending) INSIDE eps: the handle keeps the per-PET words of the first run at
+ * an eps (counts saturated at its minPts) and every later run at that eps with a minPts in [floor, that minPts] runs
+ * the region query on the cut band alone; the other PETs' words ride through the cut compaction.  Results are
+ * identical with enabled = 0 (every run does its own full region query).
+ * cl_set_count_floor: the smallest minPts the caller will ask for at the current eps (the sweep driver knows its
+ * list); the first run then keeps counts exact from there up.  0 (default) = unknown: only runs that repeat the
+ * first run's minPts re-use its words.
+ * cl_last_region_mode: what the last enqueued run did -- 0 full region query, 1 words re-used as they were (same
+ * cut), 2 words carried through the compaction + region query on the band. */
+void cl_set_count_reuse(cl_chrom* c, int enabled);
+void cl_set_count_floor(cl_chrom* c, int32_t min_pts);
+int cl_last_region_mode(const cl_chrom* c);
+
 /* Page-locked host memory for result buffers (labels_out / boxes_out / counts_out): D2H
  * copies into pinned memory run at PCIe rate instead of through a staging buffer.  Plain
  * malloc'ed memory works everywhere too, only slower. */

@@ -26,6 +26,12 @@ class FakeChromosome(object):
     def set_device_labels(self, on=True):
         pass
 
+    def set_count_reuse(self, on=True):
+        pass
+
+    def set_count_floor(self, min_pts):
+        pass
+
     def set_sort_index(self, mode=1):
         pass
 

@@ -4,7 +4,8 @@
  * runs are deterministic (lock-free union-find, atomics, two result slots),
  * a run with `cut` equals a run on the pre-filtered chromosome (pipe.py:59-63),
  * neighbour counts: every pair is counted from both ends, counts grow with eps.
-(Bit-exact comparison with the oracle at 5 M PETs is part of bench.py's cpu_baseline leg.)"""
+plus, because the C oracle does 2 M PETs/s, the bit-exact comparison of configs[1] itself: the labels of all 5 M PETs
+against the sequential oracle for the three variants (test_cfg2_labels_equal_oracle)."""
 import numpy as np
 import pytest
 
@@ -51,6 +52,21 @@ def test_cfg2_table_and_determinism(cfg2, variant):
         assert r1.n_clusters > 50000 and (l1 >= 0).mean() > 0.5          # the workload really clusters
     finally:
         ch.close()
+
+
+@pytest.mark.parametrize("variant", ["v2", "v1", "block"])
+def test_cfg2_labels_equal_oracle(cfg2, variant):
+    """BASELINE.json configs[1] at full size, bit-exact: 5 M PETs, eps 2000, minPts 5 -- every label against the
+    sequential C oracle (cDBSCAN2.py:7-383 / cDBSCAN.py:6-205 / blockDBSCAN.py:6-239 restated)"""
+    import oracle
+    X, Y = cfg2
+    ch = api.Chromosome(X, Y)
+    try:
+        got = ch.cluster(variant, 2000, 5).labels
+    finally:
+        ch.close()
+    want = oracle.labels(variant, X, Y, 2000, 5)
+    assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("variant", ["v2", "v1", "block"])

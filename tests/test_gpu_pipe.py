@@ -34,6 +34,16 @@ def test_sweep_fast_gpu_statistics(jd):
     pipe_checks.check_sweep_fast(pipe, jd)
 
 
+def test_dispatch_under_variant1(jd, monkeypatch):
+    """scripts/jd2saturation:56-127 and scripts/callStripes:37-72 run the same dispatch with `cDBSCAN` (v1) imported as
+    DBSCAN: runDBSCAN step by step (boxes in order, distance multisets, both stderr lines, the cut), runSweep and
+    runSweepFast, against the goldens the reference's own dispatch functions produced under variant 1"""
+    monkeypatch.setattr(pipe, "DBSCAN_VARIANT", "v1")
+    pipe_checks.check_run_dbscan_chain(pipe, jd, variant="v1")
+    pipe_checks.check_sweep(pipe, jd, variant="v1")
+    pipe_checks.check_sweep_fast(pipe, jd, variant="v1")
+
+
 @pytest.mark.parametrize("variant", ["v2", "v1", "block"])
 @pytest.mark.parametrize("device_labels", [True, False])
 def test_dist_stats_match_numpy(jd, variant, device_labels):

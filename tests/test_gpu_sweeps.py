@@ -10,8 +10,9 @@ synth200M_mode3_oracle_chain.json, made by tests/golden/make_golden_synth200M_ch
 cut, the final cut, per chromosome the number and a checksum of the surviving candidate boxes); (iii) runSweepFast
 (statistics on the GPU) == runSweep (labels and distance lists on the host, the reference's data flow) on a scaled
 genome; (iv) equality with the C oracle's chain, run by run, on one chromosome of the 200 M genome at the mode-3 /
-mode-4 parameters and on one chromosome of the 500 M genome at configs[4]'s parameters (eps 1000 / 4000 / 10000 x minPts
-50, 30, 20, 10, 5 in the reference's order, pipe.py:310-324), chained cut included."""
+mode-4 parameters (mode 3 also under cDBSCAN v1 and blockDBSCAN), on chr1 of the 40 M genome at configs[2]'s own mode and
+on one chromosome of the 500 M genome at ALL of configs[4]'s parameters (eps 1000 .. 10000 x minPts 50, 30, 20, 10, 5 in
+the reference's order, pipe.py:310-324), chained cut included."""
 import json
 import multiprocessing as mp
 import os
@@ -117,32 +118,36 @@ _ORACLE_XY = None          # the chromosome of the running test: the forked orac
 
 
 def _oracle_run(job):
-    ep, m, cut = job
+    ep, m, cut, variant = job
     X, Y = _ORACLE_XY
-    ref = oracle.single_dbscan("v2", X, Y, ep, m, cut)
+    ref = oracle.single_dbscan(variant, X, Y, ep, m, cut)
     return ref["dataI"], len(ref["dataS"]), ref["dis"], ref["dss"]
 
 
-@pytest.mark.parametrize("n_total,cfg,mode,ci", [
-    (200000000, 3, MODE3, 20), (200000000, 3, MODE4, 18),
-    (500000000, 5, ([1000, 4000, 10000], DENSE[1]), 20),
-], ids=["mode3-chr21", "mode4-chr19", "configs4-chr21"])
-def test_chain_equals_oracle_on_one_chromosome(n_total, cfg, mode, ci):
-    """one chromosome of the 200 M genome (3.1 M / 3.9 M PETs) or of the 500 M genome (7.7 M PETs): every run of the
-    chained sweep against the sequential C oracle -- candidate boxes of every step, the distance lists' statistics through
-    the reference's estimator, the cut handed to the next step.  The oracle's runs are independent once each is given the
-    cut the GPU chain handed in (which the previous run's check has just pinned), so they run side by side."""
+@pytest.mark.parametrize("n_total,cfg,mode,ci,variant", [
+    (200000000, 3, MODE3, 20, "v2"), (200000000, 3, MODE4, 18, "v2"),
+    (40000000, 4, MODE4, 0, "v2"),                       # configs[2]: chr1 of the 40 M genome itself (3.3 M PETs), its own mode
+    (500000000, 5, DENSE, 20, "v2"),                     # configs[4]: all 10 eps x 5 minPts on chr21 of the 500 M genome
+    (200000000, 3, MODE3, 20, "v1"), (200000000, 3, MODE3, 20, "block"),
+], ids=["mode3-chr21", "mode4-chr19", "configs2-chr1-of-40M", "configs4-chr21-all50", "mode3-chr21-v1", "mode3-chr21-block"])
+def test_chain_equals_oracle_on_one_chromosome(n_total, cfg, mode, ci, variant):
+    """one chromosome of the 200 M genome (3.1 M / 3.9 M PETs), of the 40 M genome (chr1, 3.3 M) or of the 500 M genome
+    (7.7 M PETs): every run of the chained sweep against the sequential C oracle -- candidate boxes of every step, the
+    distance lists' statistics through the reference's estimator, the cut handed to the next step -- for the production
+    variant and, on the mode-3 chromosome, for cDBSCAN (v1) and blockDBSCAN through the same sweep driver.  The oracle's
+    runs are independent once each is given the cut the GPU chain handed in (which the previous run's check has just
+    pinned), so they run side by side."""
     name, length, n = chrom_sizes(n_total)[ci]
     X, Y = synth_chrom(n, length, 1000 * cfg + ci)
     pipe.CACHE.clear()
     f = pipe.CACHE.put_arrays("%s-%s" % (name, name), X, Y)
     try:
-        dataI, final_cut, cuts, steps = pipe.runSweepFast([f], mode[0], mode[1], cut=0)
+        dataI, final_cut, cuts, steps = pipe.runSweepFast([f], mode[0], mode[1], cut=0, variant=variant)
         settings = [(ep, m) for ep in mode[0] for m in mode[1]]
         assert len(steps) == len(settings)
         global _ORACLE_XY
         _ORACLE_XY = (X, Y)
-        jobs = [(ep, m, st["cut_in"]) for (ep, m), st in zip(settings, steps)]
+        jobs = [(ep, m, st["cut_in"], variant) for (ep, m), st in zip(settings, steps)]
         with mp.get_context("fork").Pool(min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as pool:
             refs = pool.map(_oracle_run, jobs, chunksize=1)
         cut = 0
