@@ -106,11 +106,13 @@ struct cl_chrom {
     // band as they are (k_cut_copy<true> carries them through its compaction) and runs K2 on the band alone.  Results are
     // identical with the cache switched off (cl_set_count_reuse); cLoops/pipe.py:247-250 walks minPts inside eps, descending.
     struct CountCache { bool valid = false; int layout = -1, eps = 0, thr = 0 /* q threshold of the run's cut, 0 = none */, cap = 0, floor = 0; } rc;
-    DevBuf rc_cnt, rc_pre, rc_poff, rc_dpre;   // the words in the sorted order of the run that made them; per strip: PETs its cut removed
+    DevBuf rc_cnt, rc_pre, rc_poff, rc_dpre, rc_D, rc_blen;   // the words in the sorted order of the run that made them; per strip: PETs its cut removed
                                       // from the strip / from all strips up to and including it
     bool reuse_counts = true;         // cl_set_count_reuse
     int count_floor = 0;              // cl_set_count_floor: smallest minPts later runs of this eps will ask for (0 = unknown)
-    int* w_cnt = nullptr;             // K2 words of the run being enqueued (cnt or rc_cnt)
+    int* w_cnt = nullptr;             // where K2 writes the words of the run being enqueued (cnt or rc_cnt)
+    WordSrc ws{};                     // where its consumers read them
+    DevBuf rootlist, cflag8;          // K3: the components' roots (k_flatten); per PET: core / opens a chain / ends one (k_chain_flags)
     int last_k2_mode = 0;             // 0 = full K2, 1 = words re-used as they are (same cut), 2 = remapped + K2 on the band
     std::vector<long long> dcum;      // dcum[k] = number of PETs with Y - X < k, k = 0 .. 65536 (empty: unknown)
     const int* k_total = nullptr;     // device: where the run left the number of ids handed out (null: rankscan[n])
@@ -202,7 +204,7 @@ __global__ void k_rank_flags(GridParams g, const int* __restrict__ strip_start, 
                              const int* __restrict__ compkey, const int* __restrict__ state, int* __restrict__ flag);
 __global__ void __launch_bounds__(BIGTPB)
 k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ cnt,
-          int* parent, const u32* __restrict__ srow,
+          const int* __restrict__ chainid, int* parent, const u32* __restrict__ srow,
           const int* __restrict__ head, const int* __restrict__ cellfirst,
           int* __restrict__ root, int* __restrict__ compkey, int* __restrict__ ncore,
           int* __restrict__ rootlist , int* __restrict__ counters);

@@ -72,7 +72,6 @@ struct GridParams {
     int floor;    // K2 (clustering form): neighbour counts of non-core PETs are EXACT from `floor` up (below it the word may hold an
                   //   upper bound): floor == minPts for a one-off run; a run whose words later runs at a smaller minPts re-use
                   //   (count cache of the handle, cl_set_count_floor) is made with the smallest minPts that will follow
-    int bandq;    // K2 on the cut band only (k_region_core<.., BAND>): PETs with q >= bandq keep the word the compaction wrote
     int peps;     // 1 << rbits.  The kernels never see p itself but its ORDER-PRESERVING re-encoding
                   //   sp = strip << rbits | (p mod eps)   (the strip and remainder fields of the sort key):
                   //   strip(p) = sp >> rbits (no division), and |p_j - p_i| <= eps  <=>  |sp_j - sp_i| <= peps
@@ -358,9 +357,38 @@ __device__ __forceinline__ int block_compact_with(bool active, short* l_list, in
 __device__ __forceinline__ int cw_count(int w) { return w >= 0 ? w : (int)(((unsigned)w >> K2W_CSHIFT) & 0x7fu); }
 __device__ __forceinline__ bool cw_core(int w, int minPts) { return cw_count(w) >= minPts; }
 
+// Where the K2 word of sorted position i of the running layout lives.  A run that made its own words (or runs on the very
+// layout they were made on): rc[i] (D == nullptr).  A run that re-uses the words of an earlier run of this eps under another
+// cut (count cache, cl_chrom::rc): the PETs of the cut band (q < bandq) have a fresh word in band[i] (k_region_band); every
+// other PET has its word at its place in the layout the words were made on, rc[i + D[strip]] (D[s] = how many more PETs
+// this run's cut removes up to and including strip s than that run's cut did), with the two hint fields counted in THAT
+// layout: they shift by dpre[s] / dpre[s + 1] (what this cut removes from the PET's own strip / the strip above beyond
+// what that cut removed); hints that leave their fields are dropped (K2H_NONE: k_border then searches for itself).
+struct WordSrc {
+    const int* rc; const int* band; const int* D; const int* dpre; int bandq; int rbits;
+    __device__ __forceinline__ int raw(int i, int q, int sp) const          // count field valid, hints not shifted
+    {
+        if (!D) return rc[i];
+        return q < bandq ? band[i] : rc[i + D[sp >> rbits]];
+    }
+    __device__ __forceinline__ int word(int i, int q, int sp) const
+    {
+        if (!D) return rc[i];
+        if (q < bandq) return band[i];
+        const int s = sp >> rbits;
+        int w = rc[i + D[s]];
+        if (w < 0 && ((unsigned)w & K2H_NONE) != K2H_NONE) {
+            const int da = (int)((unsigned)w & K2H_MASK) - dpre[s], db = (int)(((unsigned)w >> K2H_BITS) & K2H_MASK) - dpre[s + 1];
+            const bool ok = (da >= 0) & (da < (int)K2H_MASK) & (db >= 0) & (db < (int)K2H_MASK);
+            w = (int)(((unsigned)w & ~K2H_NONE) | (ok ? ((unsigned)da | ((unsigned)db << K2H_BITS)) : K2H_NONE));
+        }
+        return w;
+    }
+};
+
 static inline int nblocks(long long n, int tpb = TPB) { return (int)((n + tpb - 1) / tpb); }
 
 // k_region.hip: K2 (neighbour counts / core decision) on the sorted arrays of a run
-// band: only the PETs with q < g.bandq are computed (the run's other words come from the handle's count cache)
 int cl_launch_region(hipStream_t stream, const GridParams& g, int n, int run_m, bool exact, const int* sv, const int* sa,
-                     const int* strip_start, const int* tile_s0, int* cnt, bool band = false);
+                     const int* strip_start, const int* tile_s0, int* cnt);
+

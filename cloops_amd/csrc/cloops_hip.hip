@@ -25,6 +25,7 @@
 //   K5 k_rank_flags / scan / k_final_labels   reference cluster ids + cluster table
 //   K6 block variant    cell table, links, cell-level union (blockDBSCAN.py)
 #include "cl_chrom.h"
+#include "cl_band.h"
 
 // ------------------------------------------------------------------------------------------
 // error plumbing
@@ -312,6 +313,7 @@ k_strip_sort(int n, GridParams g, const u64* __restrict__ keys, const u32* __res
 // Two shapes: NT = 256 PETs + 128 halo where strips are short (sparse data), NT = 1024 + 512 where strips hold hundreds
 // of PETs (dense data at large eps: the three strips of a query must fit the window, or the walk falls back to global memory).
 #define T_STEPS_LONG 11          // search depth for staged segments of 256 .. 2047 PETs
+enum { CF_CORE = 1, CF_OPEN = 2, CF_LAST = 4 };      // k_chain_flags -> k_chain_parent
 
 struct Tile {
     LdsPairs w;         // (q, p), indexed by global sorted index
@@ -390,6 +392,43 @@ __device__ __forceinline__ bool tile_stage(Tile& t, int2* lw, int* lx, int ntile
     }
     __syncthreads();
     t.w.a = lw; t.w.base = base; t.x.a = lx; t.x.base = base; t.m = lmask;
+    t.wbeg = max(base, 0); t.wend = min(base + T_WIN, M);
+    return true;
+}
+
+// The same staging with the K2 WORDS as the payload, read through a WordSrc (a run that re-uses the words of an earlier run
+// of its eps finds them at another place, strip by strip): the thread that loads four consecutive (q, sp) pairs also loads
+// their four words -- the strip of a pair is in its sp.  Outside [0, M): word 0 ("no neighbour").
+template <int NT, int HALO, int NTH = NT>
+__device__ __forceinline__ bool tile_stage_words(Tile& t, int2* lw, int* lx, int ntiles, int M,
+                                                 const int* __restrict__ gq, const int* __restrict__ gp, const WordSrc& ws)
+{
+    constexpr int T_WIN = NT + 2 * HALO, NV = T_WIN / 4;
+    static_assert(NT % 64 == 0 && HALO % 64 == 0 && NT + HALO + 64 <= SORT_PAD, "window shape");
+    const int tile = tile_of_block(blockIdx.x);
+    t.t0 = tile * NT;
+    if (tile >= ntiles || t.t0 >= M) return false;
+    const int base = t.t0 - HALO;
+    {
+        const int4* __restrict__ gq4 = reinterpret_cast<const int4*>(gq + base);
+        const int4* __restrict__ gp4 = reinterpret_cast<const int4*>(gp + base);
+        int4* l4 = reinterpret_cast<int4*>(lw);
+        int4* x4 = reinterpret_cast<int4*>(lx);
+        for (int c = threadIdx.x; c < NV; c += NTH) {
+            const int4 q = gq4[c], p = gp4[c];
+            const int gi = base + 4 * c;
+            int4 w;
+            w.x = (gi >= 0 && gi < M) ? ws.raw(gi, q.x, p.x) : 0;
+            w.y = (gi + 1 >= 0 && gi + 1 < M) ? ws.raw(gi + 1, q.y, p.y) : 0;
+            w.z = (gi + 2 >= 0 && gi + 2 < M) ? ws.raw(gi + 2, q.z, p.z) : 0;
+            w.w = (gi + 3 >= 0 && gi + 3 < M) ? ws.raw(gi + 3, q.w, p.w) : 0;
+            l4[2 * c] = make_int4(q.x, p.x, q.y, p.y);
+            l4[2 * c + 1] = make_int4(q.z, p.z, q.w, p.w);
+            x4[c] = w;
+        }
+    }
+    __syncthreads();
+    t.w.a = lw; t.w.base = base; t.x.a = lx; t.x.base = base; t.m = nullptr;
     t.wbeg = max(base, 0); t.wend = min(base + T_WIN, M);
     return true;
 }
@@ -539,8 +578,9 @@ __device__ __forceinline__ void tile_walk_from(const Tile& t, const int* __restr
 
 // own strip: walk left from i-1 down to b while q >= qlo, then right from i+1 up to e while
 // q <= qhi; f(j, x_j) returns true to stop that direction early.  `dirs`: bit0 left, bit1 right.
-template <typename F>
-__device__ __forceinline__ void tile_visit_own(const Tile& t, const int* __restrict__ gq, const int* __restrict__ gx,
+// gxf(j, q_j): the payload of a PET outside the staged range.
+template <typename GX, typename F>
+__device__ __forceinline__ void tile_visit_own(const Tile& t, const int* __restrict__ gq, GX&& gxf,
                                                int i, int b, int e, int qlo, int qhi, int dirs, F&& f)
 {
     if (dirs & 1)
@@ -548,14 +588,14 @@ __device__ __forceinline__ void tile_visit_own(const Tile& t, const int* __restr
             const bool in = j >= t.wbeg;
             const int q = in ? t.w[j].x : gq[j];
             if (q < qlo) break;
-            if (f(j, in ? t.x[j] : gx[j])) break;
+            if (f(j, in ? t.x[j] : gxf(j, q))) break;
         }
     if (dirs & 2)
         for (int j = i + 1; j < e; ++j) {
             const bool in = j < t.wend;
             const int q = in ? t.w[j].x : gq[j];
             if (q > qhi) break;
-            if (f(j, in ? t.x[j] : gx[j])) break;
+            if (f(j, in ? t.x[j] : gxf(j, q))) break;
         }
 }
 
@@ -655,11 +695,11 @@ __global__ void k_init_arrays(int n, int* __restrict__ parent, int* __restrict__
 template <int NT, int HALO, int NTH = NT>
 __global__ void __launch_bounds__(NTH)
 k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const int* __restrict__ sa,
-              const int* __restrict__ strip_start, const int* __restrict__ cnt, int* __restrict__ chainflag,
+              const int* __restrict__ strip_start, WordSrc ws, unsigned char* __restrict__ chainflag,
               int* __restrict__ head, int* __restrict__ wavelast)
 {
     __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
-    __shared__ int lx[NT + 2 * HALO];
+    __shared__ __attribute__((aligned(16))) int lx[NT + 2 * HALO];
     const int M = strip_start[g.S];
     if (head) {                                          // filtered tail: singleton cells (keys of the cellfirst scan)
 #pragma unroll
@@ -669,7 +709,7 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
         }
     }
     Tile t;
-    if (!tile_stage<NT, HALO, NTH>(t, lw, lx, ntiles, M, sv, sa, cnt, nullptr, 0)) return;
+    if (!tile_stage_words<NT, HALO, NTH>(t, lw, lx, ntiles, M, sv, sa, ws)) return;
     for (int u = 0; u < NT / NTH; ++u) {
     const int i = t.t0 + (int)threadIdx.x + u * NTH;
     if (i >= M) continue;
@@ -701,17 +741,21 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
         head[i] = pos;
     }
     int f = 0, last = 0;
-    if (cw_core(t.x[i], g.minPts)) {
+    const bool core = cw_core(t.x[i], g.minPts);
+    if (core) {
         const int s = strip_of(g, me.y);
         const int b = strip_start[s], e = strip_start[s + 1];
         f = i + 1;
         last = 1;
-        tile_visit_own(t, sv, cnt, i, b, e, sat_add(me.x, -g.eps), sat_add(me.x, g.eps), 1,
+        auto gxf = [&](int j, int qj) { return ws.raw(j, qj, me.y); };      // (own strip: the same strip coordinate block)
+        tile_visit_own(t, sv, gxf, i, b, e, sat_add(me.x, -g.eps), sat_add(me.x, g.eps), 1,
                        [&](int, int cj) { if (cw_core(cj, g.minPts)) { f = 0; return true; } return false; });
-        tile_visit_own(t, sv, cnt, i, b, e, sat_add(me.x, -g.eps), sat_add(me.x, g.eps), 2,
+        tile_visit_own(t, sv, gxf, i, b, e, sat_add(me.x, -g.eps), sat_add(me.x, g.eps), 2,
                        [&](int, int cj) { if (cw_core(cj, g.minPts)) { last = 0; return true; } return false; });
     }
-    chainflag[i] = f | (last ? (int)0x80000000u : 0);   // sign bit: last core of its chain (its q is the chain's upper end)
+    // one byte per PET for k_chain_parent: CF_CORE, CF_OPEN (no earlier core of its strip within eps), CF_LAST (no later one:
+    // its q is the chain's upper end)
+    chainflag[i] = (unsigned char)((core ? CF_CORE : 0) | (f ? CF_OPEN : 0) | (last ? CF_LAST : 0));
     // wavelast[w] = the last chain-opening PET (+1) among the 64 PETs [64 w, 64 w + 64), 0 = none: what k_chain_parent needs to
     // find a core's chain head without a scan over all PETs (the lanes still here are the wave's PETs below M; lane 0 is one)
     const unsigned long long ob = __ballot(f != 0);
@@ -725,8 +769,8 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
 // pmax32 (optional): the 32-PET block summaries of the union scan (max strip coordinate over the block's CORE PETs, see
 // k_union_cores) come out of the same pass -- every thread already knows whether its PET is a core
 #define CP_PER 4
-__global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const int* __restrict__ cnt, int minPts,
-                               const int* __restrict__ wavelast, int* __restrict__ parent, int* chainid /* in: chain flags */,
+__global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const unsigned char* __restrict__ cflag,
+                               const int* __restrict__ wavelast, int* __restrict__ parent, int* __restrict__ chainid,
                                int* __restrict__ compkey, int* __restrict__ ncore, int* __restrict__ bsize,
                                int* __restrict__ usize, int* __restrict__ state,
                                const int* __restrict__ sv, int* __restrict__ chain_qend,
@@ -738,21 +782,20 @@ __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const
     // (k_chain_flags left wavelast[]; normally the group right in front -- 64 groups are looked at per round trip).
     // CP_PER PETs per thread (a wave handles CP_PER runs of 64 consecutive PETs): all their loads are in flight together.
     const int lane = threadIdx.x & 63;
-    int ii[CP_PER], fl[CP_PER], cn[CP_PER], spv[CP_PER], qv[CP_PER];
+    int ii[CP_PER], fl[CP_PER], spv[CP_PER], qv[CP_PER];
 #pragma unroll
     for (int e = 0; e < CP_PER; ++e) {
         ii[e] = (blockIdx.x * CP_PER + e) * (int)blockDim.x + (int)threadIdx.x;
         const bool in = ii[e] < M;
-        fl[e] = in ? chainid[ii[e]] : 0;                 // i + 1 if the PET opens a chain, sign bit: last core of its chain
-        cn[e] = in ? cnt[ii[e]] : 0;
-        spv[e] = (in && pmax32) ? sa[ii[e]] : INT_MIN;
-        qv[e] = (in && fl[e] < 0) ? sv[ii[e]] : 0;
+        fl[e] = in ? (int)cflag[ii[e]] : 0;              // CF_CORE | CF_OPEN | CF_LAST
+        spv[e] = (in && pmax32 && (fl[e] & CF_CORE)) ? sa[ii[e]] : INT_MIN;
+        qv[e] = (in && (fl[e] & CF_LAST)) ? sv[ii[e]] : 0;
     }
 #pragma unroll
     for (int e = 0; e < CP_PER; ++e) {
         const int i = ii[e];
-        const bool core = cw_core(cn[e], minPts);
-        const unsigned long long open = __ballot((fl[e] & 0x7fffffff) != 0);
+        const bool core = (fl[e] & CF_CORE) != 0;
+        const unsigned long long open = __ballot((fl[e] & CF_OPEN) != 0);
         const unsigned long long upto = open & ((2ull << lane) - 1ull);
         int head1 = upto ? (i - lane) + (64 - __clzll((long long)upto)) : 0;
         if (__any(core && !upto)) {
@@ -767,13 +810,13 @@ __global__ void k_chain_parent(const int* __restrict__ strip_start, int S, const
         }
         if (i < M) {
             const int h = core ? head1 - 1 : -1;
-            if (core) parent[i] = h;                            // (only cores are ever looked up in the forest)
             chainid[i] = h;
-            if (h == i) { compkey[i] = INT_MAX; ncore[i] = 0; bsize[i] = 0; usize[i] = 0; state[i] = ST_LIVE; }
-            if (core && fl[e] < 0) chain_qend[h] = qv[e];       // indexed by chain head
+            // (only chain heads are ever looked up in the forest: k_union_cores unites heads, k_flatten starts from chainid)
+            if (h == i) { parent[i] = i; compkey[i] = INT_MAX; ncore[i] = 0; bsize[i] = 0; usize[i] = 0; state[i] = ST_LIVE; }
+            if (core && (fl[e] & CF_LAST)) chain_qend[h] = qv[e];       // indexed by chain head
         }
         if (pmax32) {                                          // uniform: every lane of the wave takes part in the reduction
-            int v = core ? spv[e] : INT_MIN;
+            int v = spv[e];
             v = dpp_reduce_halves(v, OpMax());                 // lanes 31 and 63 hold the maxima of their 32-PET blocks
             if ((threadIdx.x & 31) == 31 && (i - 31) < M) pmax32[i >> 5] = v;
         }
@@ -963,8 +1006,8 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
 //   variant 2: key = smallest cellfirst over the cells holding its core points
 //              (cDBSCAN2.py:117-140)
 __global__ void __launch_bounds__(BIGTPB)
-k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ cnt,
-          int* parent, const u32* __restrict__ srow,
+k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restrict__ cnt /* plain counts, or null with chainid */,
+          const int* __restrict__ chainid /* or null: chain head of a core PET, -1 otherwise */, int* parent, const u32* __restrict__ srow,
           const int* __restrict__ head, const int* __restrict__ cellfirst,
           int* __restrict__ root, int* __restrict__ compkey, int* __restrict__ ncore,
           int* __restrict__ rootlist /* or null */, int* __restrict__ counters)
@@ -982,11 +1025,12 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
 #pragma unroll
     for (int e = 0; e < FLAT_PER; ++e) {
         ii[e] = (blockIdx.x * FLAT_PER + e) * BIGTPB + (int)threadIdx.x;
-        core[e] = ii[e] < M && cw_core(cnt[ii[e]], g.minPts);
+        if (!chainid) { core[e] = ii[e] < M && cw_core(cnt[ii[e]], g.minPts); x[e] = -1; }
+        else { x[e] = ii[e] < M ? chainid[ii[e]] : -1; core[e] = x[e] >= 0; }      // the walk starts at the PET's chain head
     }
 #pragma unroll
     for (int e = 0; e < FLAT_PER; ++e) {
-        x[e] = core[e] ? parent[ii[e]] : -1;            // a core's parent is its chain head to start with
+        if (!chainid) x[e] = core[e] ? parent[ii[e]] : -1;
         hd[e] = (core[e] && g.variant == CL_VARIANT_CDBSCAN2) ? head[ii[e]] : 0;
     }
 #pragma unroll
@@ -1086,7 +1130,7 @@ __global__ void __launch_bounds__(NTH)
 k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
          const int* __restrict__ strip_start, const int* __restrict__ root, const int* __restrict__ compkey,
          const int* __restrict__ ncore, const u32* __restrict__ srow, int* __restrict__ owner, int* __restrict__ bsize,
-         int* __restrict__ usize, const int* __restrict__ cnt, int* __restrict__ tileflag)
+         int* __restrict__ usize, WordSrc ws, int* __restrict__ tileflag)
 {
     // tileflag[k] = 1 if the 256 PETs [256 k, 256 k + 256) hold a CONTESTED border point (one adjacent to more than one component)
     // whose owner is not live on its cores alone: only such tiles can have anything for k_emit_records, which then leaves after
@@ -1113,7 +1157,8 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
             else {
                 // K2 left either the neighbour count of a non-core PET (itself included) or its word with count and hints
                 // (k_region_core): a count <= 1 = nothing within eps -- most of the background noise ends here
-                const int enc = cnt[i0];
+                const int2 pe = t.w[i0];
+                const int enc = ws.word(i0, pe.x, pe.y);
                 l_enc[tix] = enc;
                 if (cw_count(enc) <= 1) owner[i0] = -1; else border = true;
             }
@@ -1546,7 +1591,7 @@ static void free_chrom(cl_chrom* c)
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->slot[0].d_step, &c->slot[1].d_step, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
                       &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->tileflag, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out, &c->dhist,
-                      &c->rc_cnt, &c->rc_pre, &c->rc_poff, &c->rc_dpre};
+                      &c->rc_cnt, &c->rc_pre, &c->rc_poff, &c->rc_dpre, &c->rc_D, &c->rc_blen, &c->rootlist, &c->cflag8};
     for (DevBuf* b : bufs) b->release();
     c->arena.release();                                  // (after its slices have been dropped)
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
@@ -1699,10 +1744,12 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
 // Count cache (see run_sort_and_count): pre_out (a run whose K2 words are kept) = the number of PETs the cut removes from
 // every strip; pre_ref + dpre_out (a run that re-uses kept words) = how many MORE PETs this cut removes from the strip than
 // the cut of the run that made the words (negative: fewer) -- what the hint fields of a word shift by.
+// ... and for such a run blen_out[s] = how many of the strip's kept PETs lie in the cut band (q < bandq) / within eps of it
+// (q < bandq + eps): the work list and the staging ranges of k_region_band.
 __global__ void k_cut_strips(int S, int thr, const int* __restrict__ bstrip, const int* __restrict__ bq,
                              int* __restrict__ kept /* [S+1] */, int* __restrict__ src0 /* [S] first kept source index */,
                              int* __restrict__ pre_out /* or null */, const int* __restrict__ pre_ref /* or null */,
-                             int* __restrict__ dpre_out /* with pre_ref */)
+                             int* __restrict__ dpre_out /* with pre_ref */, int2* __restrict__ blen_out /* with pre_ref */, int bandq, int eps)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s > S) return;
@@ -1715,24 +1762,42 @@ __global__ void k_cut_strips(int S, int thr, const int* __restrict__ bstrip, con
     kept[s] = e - lo;
     src0[s] = lo;
     if (pre_out) pre_out[s] = lo - b;
-    if (pre_ref) dpre_out[s] = (lo - b) - pre_ref[s];
+    if (pre_ref) {
+        dpre_out[s] = (lo - b) - pre_ref[s];
+        int l1 = lo, h1 = e;
+        while (l1 < h1) { const int mid = (int)(((unsigned)l1 + (unsigned)h1) >> 1); if (bq[mid] < bandq) l1 = mid + 1; else h1 = mid; }
+        int l2 = l1; h1 = e;
+        const int q2 = bandq + eps;
+        while (l2 < h1) { const int mid = (int)(((unsigned)l2 + (unsigned)h1) >> 1); if (bq[mid] < q2) l2 = mid + 1; else h1 = mid; }
+        blen_out[s] = make_int2(l1 - lo, l2 - lo);
+    }
 }
-// REMAP (count cache): the K2 word of every kept PET outside the cut band rides along -- read at the PET's place in the
-// layout of the run that made the words (base index - poff_ref[strip]), its two hint fields shifted by what this cut removes
-// from the PET's own strip / the strip above beyond what that run's cut removed (a word whose shifted hints leave their
-// fields loses them: K2H_NONE, k_border then searches for itself).  Words of the band (q < bandq) are left to K2.
-// poff_out (a run whose words are kept, with a cut): poff_out[s] = PETs the cut removes in front of strip s's kept PETs.
-template <bool REMAP>
+// Count cache: poff_out (a run whose words are kept, with a cut): poff_out[s] = PETs the cut removes in strips <= s;
+// poff_ref + D_out (a run that re-uses kept words): D_out[s] = that number for this cut minus poff_ref[s] -- sorted position
+// i of strip s in this layout is position i + D_out[s] of the layout the words were made on (WordSrc).
+// BAND (such a run): the first nbb workgroups do K2 on the cut band (cl_band.h: latency-bound work of a few per cent of the
+// PETs, hidden behind the copy instead of a launch of its own) -- each of their four waves takes KB_SB strips.
+template <bool BAND>
 __global__ void __launch_bounds__(CMP_TPB)
 k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const int* __restrict__ bsp, const u32* __restrict__ brow,
            const int* __restrict__ src0, int* __restrict__ strip_start /* [0..S] = the scan; [S+1] written here */,
            int* __restrict__ sv, int* __restrict__ sa, u32* __restrict__ srow, int* __restrict__ tile_s0, int* __restrict__ d_M,
            int expect_m, int* __restrict__ counters, int* __restrict__ poff_out /* or null */,
-           const int* __restrict__ rc_words, const int* __restrict__ poff_ref, const int* __restrict__ dpre, int bandq,
-           int* __restrict__ cnt)
+           const int* __restrict__ poff_ref /* or null */, int* __restrict__ D_out /* with poff_ref */,
+           int nbb, const int2* __restrict__ blen, int* __restrict__ band_words, int eps, int minPts, int dbg)
 {
+    if (BAND) {
+        __shared__ int2 l_band[CMP_TPB / 64][KB_CAP];
+        if ((int)blockIdx.x < nbb) {
+            const int wv = threadIdx.x >> 6;
+            band_wave(blockIdx.x * (CMP_TPB / 64) + wv, threadIdx.x & 63, l_band[wv], S, eps, 1 << rbits, minPts, bq, bsp, src0,
+                      strip_start, blen, band_words, dbg);
+            return;
+        }
+    }
+    const int cb = (int)blockIdx.x - (BAND ? nbb : 0), ncb = (int)gridDim.x - (BAND ? nbb : 0);      // copy workgroups
     const int M = strip_start[S];
-    const int base = blockIdx.x * CMP_BLOCK;
+    const int base = cb * CMP_BLOCK;
     // stage by stage over the thread's CMP_PER PETs, so that the loads of a stage are all in flight together (q -> sp / row ->
     // the two per-strip table entries are dependent round trips)
     int q[CMP_PER], sp[CMP_PER], d0[CMP_PER], s0[CMP_PER]; u32 row[CMP_PER]; bool keep[CMP_PER];
@@ -1748,19 +1813,11 @@ k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const i
         sp[k] = keep[k] ? bsp[i] : 0;
         row[k] = keep[k] ? brow[i] : 0u;
     }
-    int wd[CMP_PER], dA[CMP_PER], dB[CMP_PER];
 #pragma unroll
     for (int k = 0; k < CMP_PER; ++k) {
         const int st = sp[k] >> rbits;
         d0[k] = keep[k] ? strip_start[st] : 0;
         s0[k] = keep[k] ? src0[st] : 0;
-        if (REMAP) {
-            const int i = base + k * CMP_TPB + (int)threadIdx.x;
-            const bool take = keep[k] && q[k] >= bandq;
-            wd[k] = take ? rc_words[i - poff_ref[st]] : 0;
-            dA[k] = take ? dpre[st] : 0;
-            dB[k] = take ? dpre[st + 1] : 0;
-        }
     }
 #pragma unroll
     for (int k = 0; k < CMP_PER; ++k) {
@@ -1769,24 +1826,17 @@ k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const i
             const int dst = d0[k] + (i - s0[k]);
             sv[dst] = q[k]; sa[dst] = sp[k]; srow[dst] = row[k];
             if ((dst & 255) == 0) tile_s0[dst >> 8] = sp[k] >> rbits;
-            if (REMAP && q[k] >= bandq) {
-                int w = wd[k];
-                if (w < 0 && ((unsigned)w & K2H_NONE) != K2H_NONE) {
-                    const int da = (int)((unsigned)w & K2H_MASK) - dA[k], db = (int)(((unsigned)w >> K2H_BITS) & K2H_MASK) - dB[k];
-                    const bool ok = (da >= 0) & (da < (int)K2H_MASK) & (db >= 0) & (db < (int)K2H_MASK);
-                    w = (int)(((unsigned)w & ~K2H_NONE) | (ok ? ((unsigned)da | ((unsigned)db << K2H_BITS)) : K2H_NONE));
-                }
-                cnt[dst] = w;
-            }
         }
     }
-    if (poff_out)
-        for (int u = blockIdx.x * CMP_TPB + (int)threadIdx.x; u <= S; u += gridDim.x * CMP_TPB)
-            poff_out[u] = (u < S ? src0[u] : n) - strip_start[u];
+    if (poff_out || poff_ref)
+        for (int u = cb * CMP_TPB + (int)threadIdx.x; u <= S; u += ncb * CMP_TPB) {
+            const int po = (u < S ? src0[u] : n) - strip_start[u];
+            if (poff_out) poff_out[u] = po; else D_out[u] = po - poff_ref[u];
+        }
     // what k_after_compact did besides the strip table: tiles behind M, sentinels, M itself
-    const int t = blockIdx.x * CMP_TPB + (int)threadIdx.x;
-    for (int u = t; u <= n / 256; u += gridDim.x * CMP_TPB) if (u * 256 >= M) tile_s0[u] = S;
-    for (int u = t; u < SORT_PAD; u += gridDim.x * CMP_TPB) if (M + u < n) { sv[M + u] = INT_MAX; sa[M + u] = S << rbits; }
+    const int t = cb * CMP_TPB + (int)threadIdx.x;
+    for (int u = t; u <= n / 256; u += ncb * CMP_TPB) if (u * 256 >= M) tile_s0[u] = S;
+    for (int u = t; u < SORT_PAD; u += ncb * CMP_TPB) if (M + u < n) { sv[M + u] = INT_MAX; sa[M + u] = S << rbits; }
     if (t == 0) {
         d_M[0] = M;
         strip_start[S + 1] = n;
@@ -1810,7 +1860,7 @@ k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const i
         {&c->ulist, n * 4}, {&c->lo, n * 4}, {&c->hi, n * 4}, {&c->recs, n * sizeof(Rec)}, \
         {&c->chainflag, n * 4}, {&c->chainhead, n * 4}, {&c->usize, n * 4}, {&c->tile_s0, (n / 256 + 2) * 4}, {&c->tileflag, (n / 256 + 2) * 4}, \
         {&c->bq, (n + 2 * SORT_PAD) * 4}, {&c->bsp, (n + 2 * SORT_PAD) * 4}, {&c->brow, n * 4}, {&c->btile, (n / 256 + 2) * 4}, \
-        {&c->qb_key, n * 4}, {&c->qb_val, n * 8}, {&c->k7_cls, n + 16}, {&c->rc_cnt, n * 4}, \
+        {&c->qb_key, n * 4}, {&c->qb_val, n * 8}, {&c->k7_cls, n + 16}, {&c->rc_cnt, n * 4}, {&c->rootlist, n * 4}, {&c->cflag8, n + 16}, \
         {&c->slot[0].d_step, 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8 + K7_BLOCKS * sizeof(K7Part)}, \
         {&c->slot[1].d_step, 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8 + K7_BLOCKS * sizeof(K7Part)}, \
     };
@@ -1877,7 +1927,7 @@ int ensure_workspace(cl_chrom* c, int S)
     if (!c->arena.p) (void)reserve_workspace(c);
     const cl_chrom::Slot* other = &c->slot[1 - c->cur];
     for (const Want& w : wants) if (w.b != &other->labels && w.b != &other->table && w.b != &other->slab && w.b != &c->slot[0].d_step && w.b != &c->slot[1].d_step && w.b != &c->bq && w.b != &c->bsp && w.b != &c->brow && w.b != &c->btile && w.b != &c->qb_key &&
-                                    w.b != &c->qb_val && w.b != &c->k7_cls && w.b != &c->rc_cnt && (rc = w.b->ensure(w.bytes))) return rc;
+                                    w.b != &c->qb_val && w.b != &c->k7_cls && w.b != &c->rc_cnt && w.b != &c->rootlist && w.b != &c->cflag8 && (rc = w.b->ensure(w.bytes))) return rc;
     if ((rc = c->strip.ensure(((size_t)S + 2) * 4)) || (rc = c->counters.ensure(256))) return rc;      // (counters: allocated at upload)
     if (c->sv.fresh || c->sa.fresh) {
         // sentinel pads around the sorted arrays (k_region_core stages its windows without bounds checks)
@@ -1900,6 +1950,7 @@ static int make_grid(cl_chrom* c, int variant, int eps, int minPts, int cut, Gri
 {
     g->eps = eps; g->minPts = minPts; g->cut = cut; g->variant = variant;
     g->dbg = 0;
+    g->floor = minPts;
 #ifdef CLOOPS_DEVEL
     // developer build only (-DCLOOPS_DEVEL): ablation knobs that can change results; never in the shipped library
     { const char* e = getenv("CLOOPS_DBG"); g->dbg = e ? atoi(e) : 0; }
@@ -2043,9 +2094,10 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     int* wsa = c->sa.as<int>() + SORT_PAD;
     c->w_cnt = c->cnt.as<int>();
     c->last_k2_mode = 0;
-    GridParams gk = g;                                    // what K2 sees: floor / bandq filled in below
-    gk.floor = g.minPts; gk.bandq = INT_MAX;
+    GridParams gk = g;                                    // what K2 sees: floor filled in below
+    gk.floor = g.minPts;
     bool k2_band = false, k2_skip = false;
+    c->ws = WordSrc{c->cnt.as<int>(), nullptr, nullptr, nullptr, 0, g.rbits};
     if (!c->reuse_layout) {
         // every run sorts for itself (the cut filter rides in the keys: filtered rows go behind the last strip)
         if ((rc = sort_layout(c, g, wsv, wsa, nullptr, c->strip.as<int>(), c->tile_s0.as<int>()))) return rc;
@@ -2076,7 +2128,8 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
         // ---- count cache (cl_chrom::rc): what this run does about its K2 words -------------------------------------
         //   make : the run's K2 writes the cache (first clustering run on this layout, or one the cached words cannot serve)
         //   same : same cut as the run that made the words -- nothing to do, the consumers read the cache
-        //   remap: another cut -- the compaction carries the words of the PETs beyond the band, K2 runs on the band
+        //   remap: another cut -- K2 runs on the cut band only (k_region_band), the consumers read every other PET's word at
+        //          its place in the layout the words were made on (WordSrc)
         const int m1 = g.minPts - 1;
         const bool cacheable = !exact && c->reuse_counts && g.swap && m1 >= 1 && m1 <= 127;
         const int thr_new = on_base ? 0 : g.cut - g.V0;   // q >= 0 everywhere: threshold 0 removes nothing
@@ -2084,27 +2137,30 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
         if (cacheable) {
             const bool serves = c->rc.valid && c->rc.layout == layout && c->rc.eps == g.eps && g.minPts <= c->rc.cap && g.minPts >= c->rc.floor;
             if (serves && thr_new == c->rc.thr) rcmode = RC_SAME;
-            else if (serves && !on_base) rcmode = RC_REMAP;
+            else if (serves && !on_base && (long long)g.S <= 8LL * n) rcmode = RC_REMAP;      // (the band kernel works strip by strip)
             else rcmode = RC_MAKE;
             if ((rc = c->rc_cnt.ensure((size_t)n * 4)) || (rc = c->rc_pre.ensure(((size_t)g.S + 2) * 4)) ||
-                (rc = c->rc_poff.ensure(((size_t)g.S + 2) * 4)) || (rc = c->rc_dpre.ensure(((size_t)g.S + 2) * 4))) return rc;
+                (rc = c->rc_poff.ensure(((size_t)g.S + 2) * 4)) || (rc = c->rc_dpre.ensure(((size_t)g.S + 2) * 4)) ||
+                (rc = c->rc_D.ensure(((size_t)g.S + 2) * 4)) || (rc = c->rc_blen.ensure(((size_t)g.S + 2) * 8))) return rc;
         }
         if (rcmode == RC_MAKE) {
             c->rc.valid = true; c->rc.layout = layout; c->rc.eps = g.eps; c->rc.thr = thr_new; c->rc.cap = g.minPts;
             c->rc.floor = (c->count_floor > 0 && c->count_floor < g.minPts) ? std::max(2, c->count_floor) : g.minPts;
             gk.floor = c->rc.floor;
             c->w_cnt = c->rc_cnt.as<int>();
+            c->ws.rc = c->w_cnt;
             if (on_base) {
                 HIP_TRY(hipMemsetAsync(c->rc_pre.p, 0, ((size_t)g.S + 2) * 4, c->stream));
                 HIP_TRY(hipMemsetAsync(c->rc_poff.p, 0, ((size_t)g.S + 2) * 4, c->stream));
             }
         } else if (rcmode == RC_SAME) {
             c->w_cnt = c->rc_cnt.as<int>();
+            c->ws.rc = c->w_cnt;
             k2_skip = true;
             c->last_k2_mode = 1;
         } else if (rcmode == RC_REMAP) {
             // the two cuts differ in the PETs with q in [min, max) of the thresholds: a PET keeps its count iff q - eps >= max
-            gk.bandq = std::max(thr_new, c->rc.thr) + g.eps;
+            c->ws = WordSrc{c->rc_cnt.as<int>(), c->cnt.as<int>(), c->rc_D.as<int>(), c->rc_dpre.as<int>(), std::max(thr_new, c->rc.thr) + g.eps, g.rbits};
             k2_band = true;
             c->last_k2_mode = 2;
         }
@@ -2126,26 +2182,30 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
             LAUNCH(k_cut_strips, g.S + 1, g.S, thr, (const int*)c->bstrip.as<int>(), bq, kept, src0,
                    rcmode == RC_MAKE ? c->rc_pre.as<int>() : (int*)nullptr,
                    rcmode == RC_REMAP ? (const int*)c->rc_pre.as<int>() : (const int*)nullptr,
-                   rcmode == RC_REMAP ? c->rc_dpre.as<int>() : (int*)nullptr);
+                   rcmode == RC_REMAP ? c->rc_dpre.as<int>() : (int*)nullptr, rcmode == RC_REMAP ? c->rc_blen.as<int2>() : (int2*)nullptr,
+                   c->ws.bandq, g.eps);
             size_t tb = c->scan_tmp.bytes;
             hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, kept, c->strip.as<int>(), 0, (size_t)g.S + 1, rocprim::plus<int>(), c->stream);
             if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan(cut)", hipGetErrorString(e));
-            if (rcmode == RC_REMAP)
-                hipLaunchKernelGGL(k_cut_copy<true>, dim3(nb), dim3(CMP_TPB), 0, c->stream, n, g.S, g.rbits, thr, bq, (const int*)(c->bsp.as<int>() + SORT_PAD),
+            if (rcmode == RC_REMAP) {
+                const int nbb = nblocks(nblocks(g.S, KB_SB), CMP_TPB / 64);      // workgroups that do K2 on the cut band (four waves of KB_SB strips each)
+                hipLaunchKernelGGL(k_cut_copy<true>, dim3(nbb + nb), dim3(CMP_TPB), 0, c->stream, n, g.S, g.rbits, thr, bq, (const int*)(c->bsp.as<int>() + SORT_PAD),
                                    (const u32*)c->brow.as<u32>(), (const int*)src0, c->strip.as<int>(), wsv, wsa, c->vals_out.as<u32>(), c->tile_s0.as<int>(),
-                                   d_M, c->run_m_exact ? c->run_m : -1, c->counters.as<int>(), (int*)nullptr,
-                                   (const int*)c->rc_cnt.as<int>(), (const int*)c->rc_poff.as<int>(), (const int*)c->rc_dpre.as<int>(), gk.bandq, c->cnt.as<int>());
-            else
-                hipLaunchKernelGGL(k_cut_copy<false>, dim3(nb), dim3(CMP_TPB), 0, c->stream, n, g.S, g.rbits, thr, bq, (const int*)(c->bsp.as<int>() + SORT_PAD),
-                                   (const u32*)c->brow.as<u32>(), (const int*)src0, c->strip.as<int>(), wsv, wsa, c->vals_out.as<u32>(), c->tile_s0.as<int>(),
-                                   d_M, c->run_m_exact ? c->run_m : -1, c->counters.as<int>(), rcmode == RC_MAKE ? c->rc_poff.as<int>() : (int*)nullptr,
-                                   (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, 0, (int*)nullptr);
+                                   d_M, c->run_m_exact ? c->run_m : -1, c->counters.as<int>(), (int*)nullptr, (const int*)c->rc_poff.as<int>(), c->rc_D.as<int>(),
+                                   nbb, (const int2*)c->rc_blen.as<int2>(), c->cnt.as<int>(), g.eps, g.minPts, g.dbg);
+            } else
+            hipLaunchKernelGGL(k_cut_copy<false>, dim3(nb), dim3(CMP_TPB), 0, c->stream, n, g.S, g.rbits, thr, bq, (const int*)(c->bsp.as<int>() + SORT_PAD),
+                               (const u32*)c->brow.as<u32>(), (const int*)src0, c->strip.as<int>(), wsv, wsa, c->vals_out.as<u32>(), c->tile_s0.as<int>(),
+                               d_M, c->run_m_exact ? c->run_m : -1, c->counters.as<int>(), rcmode == RC_MAKE ? c->rc_poff.as<int>() : (int*)nullptr,
+                               (const int*)nullptr, (int*)nullptr, 0, (const int2*)nullptr, (int*)nullptr, 0, 0, 0);
             c->w_sv = wsv; c->w_sa = wsa; c->srow = c->vals_out.as<u32>();
             c->w_strip = c->strip.as<int>(); c->w_tile = c->tile_s0.as<int>();
         }
     }
     ev_record(c, 2);
-    if (!k2_skip && (rc = cl_launch_region(c->stream, gk, n, c->run_m, exact, c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->w_cnt, k2_band))) return rc;
+    rc = CL_OK;
+    if (!k2_skip && !k2_band) rc = cl_launch_region(c->stream, gk, n, c->run_m, exact, c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->w_cnt);
+    if (rc) return rc;
     ev_record(c, 3);
     HIP_TRY(hipGetLastError());
     return CL_OK;
@@ -2583,7 +2643,9 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     const bool rows = labels_out != nullptr || c->device_labels;
     if (rows && cut > 0) HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
     if ((rc = run_sort_and_count(c, g, false))) return rc;
-    const int* cnt = c->w_cnt;                          // K2 words of this run (the handle's count cache or the work buffer)
+    const WordSrc ws = c->ws;                           // where the K2 words of this run live (the handle's count cache / the work buffer)
+    if ((rc = c->rootlist.ensure((size_t)n * 4)) || (rc = c->cflag8.ensure((size_t)n + 16))) return rc;
+    unsigned char* cflag = c->cflag8.as<unsigned char>();
     ENQ_MARK();
     {
         cl_chrom::Slot& sl = c->slot[c->cur];
@@ -2609,10 +2671,10 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         int* head = variant == CL_VARIANT_CDBSCAN2 ? c->head.as<int>() : nullptr;
         if (wide == 0) {
             const int nt_c = nblocks(nm, 1024);
-            hipLaunchKernelGGL((k_chain_flags<1024, 128, TPB>), dim3(tile_grid(nt_c)), dim3(TPB), 0, c->stream, g, nt_c, nm, sv, sa, strip, cnt,
-                               c->chainflag.as<int>(), head, c->chainhead.as<int>() /* wavelast: the buffer is free until the labels */);
+            hipLaunchKernelGGL((k_chain_flags<1024, 128, TPB>), dim3(tile_grid(nt_c)), dim3(TPB), 0, c->stream, g, nt_c, nm, sv, sa, strip, ws,
+                               cflag, head, c->chainhead.as<int>() /* wavelast: the buffer is free until the labels */);
         } else
-        TILE_LAUNCH(k_chain_flags, g, ntiles, nm, sv, sa, strip, cnt, c->chainflag.as<int>(),
+        TILE_LAUNCH(k_chain_flags, g, ntiles, nm, sv, sa, strip, ws, cflag,
                            head, c->chainhead.as<int>() /* wavelast: the buffer is free until the labels */);
         if (head) {
             // cellfirst: segmented suffix-min of the input rows, keyed by the cell's head index, so that
@@ -2626,7 +2688,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         }
         // long strips (dense data at large eps): 32-PET block summaries for the union scan (`hi` is free until K4)
         pmax32 = ((long long)n > 64LL * g.S) ? c->hi.as<int>() : nullptr;
-        LAUNCH(k_chain_parent, (nm + CP_PER - 1) / CP_PER, strip, g.S, cnt, g.minPts, c->chainhead.as<int>(), c->parent.as<int>(), c->chainflag.as<int>(),
+        LAUNCH(k_chain_parent, (nm + CP_PER - 1) / CP_PER, strip, g.S, (const unsigned char*)cflag, c->chainhead.as<int>(), c->parent.as<int>(), c->chainflag.as<int>(),
                c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                sv, c->lo.as<int>(), sa, pmax32);   // chain ends live in `lo` until the release fix-up reuses it
     }
@@ -2642,19 +2704,20 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     } else
     TILE_LAUNCH_H((wide == 2 || wide == 4) ? 512 : union_halo, k_union_cores, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
                        pmax32, c->parent.as<int>());
-    hipLaunchKernelGGL(k_flatten, dim3(nblocks(nm, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, g, strip, cnt, c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
-           c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->chainflag.as<int>() /* root list: the chain ids are dead */, counters);
-    int* rootlist = c->chainflag.as<int>();
+    hipLaunchKernelGGL(k_flatten, dim3(nblocks(nm, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, g, strip, (const int*)nullptr, (const int*)c->chainflag.as<int>(),
+           c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
+           c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->rootlist.as<int>(), counters);
+    int* rootlist = c->rootlist.as<int>();
     ev_record(c, 4);
     // K4
     if (wide == 0) {
         // 1024 PETs per workgroup of 256 threads (4 per thread in the first pass, the walkers of the whole tile in one list)
         const int nt_b = nblocks(std::max(1, c->run_m), 1024);
         hipLaunchKernelGGL((k_border<1024, 128, TPB>), dim3(tile_grid(nt_b)), dim3(TPB), 0, c->stream, g, nt_b, sv, sa, strip, c->root.as<int>(),
-                           c->compkey.as<int>(), c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), cnt, c->tileflag.as<int>());
+                           c->compkey.as<int>(), c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), ws, c->tileflag.as<int>());
     } else
     TILE_LAUNCH_H((wide >= 2 && wide <= 4) ? 512 : (wide >= 5 ? 256 : 128), k_border, g, ntiles, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(),
-                       c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), cnt, c->tileflag.as<int>());
+                       c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), ws, c->tileflag.as<int>());
     if (variant == CL_VARIANT_CDBSCAN2) {
         const int rec_cap = n;
         hipLaunchKernelGGL(k_mark_uncertain_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, c->ncore.as<int>(), c->bsize.as<int>(), c->state.as<int>(),

@@ -267,9 +267,7 @@ __device__ __forceinline__ int first_true_clamped(const int2* __restrict__ w, in
 // is waited for (its latency hides behind them).
 // The word of a non-core PET (negative, cl_common.h "K2W"): its count in bits 24..30, in bits 0..11 / 12..23 the distance (in
 // sorted positions) back to the start of its window in strip s-1 / forward to the one in strip s+1, all ones = no hints.
-// BAND: the run re-uses the words of an earlier run of this eps (count cache) -- the compaction has already written the word
-// of every PET whose neighbourhood the two cuts treat alike (q >= g.bandq); only the PETs of the cut band are computed here.
-template <int U, int HALO, bool TAIL, bool BAND = false>
+template <int U, int HALO, bool TAIL>
 __global__ void __launch_bounds__(K2F_TPB)
 k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
               const int* __restrict__ strip_start, const int* __restrict__ tile_s0, int* __restrict__ cnt)
@@ -279,7 +277,6 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     constexpr int RUN = (2048 / TILE) > 0 ? (2048 / TILE) : 1;          // consecutive tiles per XCD (halo reuse in its L2)
     static_assert(HALO % 4 == 0 && HALO >= 128 && TILE + HALO + K2F_SLACK <= SORT_PAD && TILE % 256 == 0, "window shape");
     static_assert(WIN + K2F_SLACK < (int)K2H_MASK, "window offsets fit the hint fields");
-    static_assert(!BAND || TAIL, "a band run has a cut");
     __shared__ __attribute__((aligned(16))) int2 lw[WIN + K2F_SLACK];   // (q, sp) pairs, window index = sorted index - (t0 - HALO)
     __shared__ int l_st[K2F_NS + 4];
     __shared__ unsigned int l_list[TILE];                                // undecided PETs, one region of 64*U entries per wave
@@ -337,7 +334,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         const int tix = (int)threadIdx.x + u * K2F_TPB;
         const int2 me = p_me[u], rr = p_rr[u], ll = p_ll[u];
         const int pbeg = me.y & nmask;
-        const bool valid = (t0 + tix < M) & (!BAND || me.x < g.bandq);
+        const bool valid = t0 + tix < M;
         // the (minPts-1)-th next / previous PET is in the same strip and within eps in q (unsigned add: a sentinel q wraps harmlessly)
         const bool core = ((rr.y < pbeg + peps) & (rr.x <= (int)((unsigned)me.x + (unsigned)eps))) | ((ll.y >= pbeg) & (ll.x >= me.x - eps));
         if (valid & core) cnt[t0 + tix] = minPts;
@@ -531,7 +528,10 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
                     const unsigned long long bal = __ballot(true);
                     const int slot = n3 + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
                     if (DEFER && 2 * slot + 1 < (h - lane) + 64) {
-                        my_list[2 * slot] = ent; my_list[2 * slot + 1] = (unsigned)ja | ((unsigned)jb << 16);
+                        // (the sizes of the two q windows ride along, 7 bits each: a size below cap3 is exact -- the search did not
+                        // run out of steps -- and phase 3 then walks the window by count, without testing where it ends)
+                        my_list[2 * slot] = (ent & 0x7fffffu) | ((unsigned)(ka - ja) << 23) | ((unsigned)((kb - jb) & 3) << 30);
+                        my_list[2 * slot + 1] = (unsigned)ja | ((unsigned)jb << 13) | ((unsigned)((kb - jb) >> 2) << 26);
                         deferred = true;
                     } else c = count_candidates(c, ja, jb, qhi, pbeg, pend2, plo, phi);
                 }
@@ -573,10 +573,32 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         const unsigned int* wl = l_list + w * (64 * U);
         const unsigned ent = wl[2 * h], jj = wl[2 * h + 1];
         const int tix = (int)(ent & 0xffffu), li = HALO + tix;
-        const int ja = (int)(jj & 0xffffu), jb = (int)(jj >> 16);
+        const int ja = (int)(jj & 0x1fffu), jb = (int)((jj >> 13) & 0x1fffu);
+        const int na = (int)((ent >> 23) & 0x7fu), nb = (int)((ent >> 30) | ((jj >> 26) << 2));
         const int2 me = lw[li];
         const int pbeg = me.y & nmask;
-        const int c = count_candidates((int)(ent >> 16), ja, jb, me.x + eps, pbeg, pbeg + 2 * peps, me.y - peps, me.y + peps);
+        int c = (int)((ent >> 16) & 0x7fu);
+        if (__any((na >= cap3) | (nb >= cap3)))
+            c = count_candidates(c, ja, jb, me.x + eps, pbeg, pbeg + 2 * peps, me.y - peps, me.y + peps);
+        else {
+            // both windows are known exactly: [ja, ja + na) of strip s-1, [jb, jb + nb) of strip s+1 -- only the strip coordinate
+            // is left to test (one strip below: sp can only be too low; one strip above: only too high)
+            const int plo = me.y - peps, phi = me.y + peps;
+            for (int j = 0; (j < na) & (c < minPts); j += 4) {
+                int2 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = lw[ja + j + k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) c += ((j + k < na) & (v[k].y >= plo)) ? 1 : 0;
+            }
+            for (int j = 0; (j < nb) & (c < minPts); j += 4) {
+                int2 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = lw[jb + j + k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) c += ((j + k < nb) & (v[k].y <= phi)) ? 1 : 0;
+            }
+        }
         emit(tix, li, c, ja, jb);
     }
     K2T(5);
@@ -587,7 +609,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
 // host side: pick the tile shape and launch
 // ------------------------------------------------------------------------------------------
 int cl_launch_region(hipStream_t stream, const GridParams& g, int n, int run_m, bool exact, const int* sv, const int* sa,
-                     const int* strip_start, const int* tile_s0, int* cnt, bool band)
+                     const int* strip_start, const int* tile_s0, int* cnt)
 {
         const int m1 = g.minPts - 1;
         if (!exact && m1 >= 1 && m1 <= 127) {
@@ -605,9 +627,7 @@ int cl_launch_region(hipStream_t stream, const GridParams& g, int n, int run_m, 
             {                                                                                                           \
                 const int tile = K2F_TPB * UU, ntiles = nblocks(std::max(1, run_m), tile), run = std::max(1, 2048 / tile); \
                 const int grid = ((ntiles + 8 * run - 1) / (8 * run)) * (8 * run);                                      \
-                if (band) hipLaunchKernelGGL((k_region_core<UU, HH, true, true>), dim3(grid), dim3(K2F_TPB), padlds, stream, g, ntiles, \
-                                   sv, sa, strip_start, tile_s0, cnt);                            \
-                else if (g.cut > 0) hipLaunchKernelGGL((k_region_core<UU, HH, true>), dim3(grid), dim3(K2F_TPB), padlds, stream, g, ntiles, \
+                if (g.cut > 0) hipLaunchKernelGGL((k_region_core<UU, HH, true>), dim3(grid), dim3(K2F_TPB), padlds, stream, g, ntiles, \
                                    sv, sa, strip_start, tile_s0, cnt);                            \
                 else hipLaunchKernelGGL((k_region_core<UU, HH, false>), dim3(grid), dim3(K2F_TPB), padlds, stream, g, ntiles, \
                                    sv, sa, strip_start, tile_s0, cnt); \
@@ -622,7 +642,6 @@ int cl_launch_region(hipStream_t stream, const GridParams& g, int n, int run_m, 
             case 4: K2F_LAUNCH(6, 256) break;
             case 5: K2F_LAUNCH(2, 768) break;
             case 6: K2F_LAUNCH(1, 384) break;
-            case 7: K2F_LAUNCH(8, 1024) break;
 #endif
             default: K2F_LAUNCH(4, 1024) break;
             }

@@ -188,7 +188,7 @@ int run_weighted(cl_chrom* c, int eps, int minPts, int wx, int wy, int32_t* labe
     LAUNCH(k64_count, n, n, g, sk, p64, strip, cnt);
     ev_record(c, 3);
     LAUNCH(k64_union, n, n, g, sk, p64, strip, cnt, c->parent.as<int>());
-    hipLaunchKernelGGL(k_flatten, dim3(nblocks(n, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, gi, strip, cnt, c->parent.as<int>(), srow,
+    hipLaunchKernelGGL(k_flatten, dim3(nblocks(n, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, gi, strip, cnt, (const int*)nullptr, c->parent.as<int>(), srow,
                        c->head.as<int>(), c->cellfirst.as<int>(), c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), (int*)nullptr, counters);
     ev_record(c, 4);
     LAUNCH(k64_border, n, n, g, sk, p64, strip, c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), srow,

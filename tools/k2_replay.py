@@ -21,7 +21,11 @@ X, Y = synth_chrom(n, length, 3000)
 ch = api.Chromosome(X, Y)
 ch.set_device_labels(False)
 settings = [(eps, m, CUTS_IN[4 * i + j]) for i, eps in enumerate((5000, 7500, 10000)) for j, m in enumerate((50, 40, 30, 20))]
-blk = bench.roofline_block(bench.k2_replay(ch, settings, 20, passes), n)
+rep = bench.k2_replay(ch, settings, 20, passes)
+blk = bench.roofline_block(rep, n)
+for a, f in list(zip(rep["reuse"], rep["full"]))[:12]:
+    print("run (%5d, %2d, %4d) mode %d: sort bracket %6.1f us (full: %6.1f), region %6.1f us (full: %6.1f)" % (
+        a[0], a[1], a[2], a[4], 1e3 * a[3]["ms_sort"], 1e3 * f[3]["ms_sort"], 1e3 * a[3]["ms_region"], 1e3 * f[3]["ms_region"]), file=sys.stderr)
 print(json.dumps(blk, indent=1))
 print("K2 amortised over %d runs: %.1f GB/s algorithmic = %.2f %% of 8 TB/s (first run of an eps %.1f us, band %.1f us + carry %.1f us); "
       "every run its own query: %.2f %%, %.1f us" % (blk["launches"], blk["achieved"], 100 * blk["frac"], 1e3 * blk["first_run_avg_launch_ms"],
