@@ -112,6 +112,7 @@ struct cl_chrom {
     int count_floor = 0;              // cl_set_count_floor: smallest minPts later runs of this eps will ask for (0 = unknown)
     int* w_cnt = nullptr;             // where K2 writes the words of the run being enqueued (cnt or rc_cnt)
     WordSrc ws{};                     // where its consumers read them
+    int init_nclr = 0;                // > 0: the run being enqueued has not cleared its key bitmap / counters yet (words to clear)
     DevBuf rootlist, cflag8;          // K3: the components' roots (k_flatten); per PET: core / opens a chain / ends one (k_chain_flags)
     int last_k2_mode = 0;             // 0 = full K2, 1 = words re-used as they are (same cut), 2 = remapped + K2 on the band
     std::vector<long long> dcum;      // dcum[k] = number of PETs with Y - X < k, k = 0 .. 65536 (empty: unknown)

@@ -696,24 +696,24 @@ template <int NT, int HALO, int NTH = NT>
 __global__ void __launch_bounds__(NTH)
 k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const int* __restrict__ sa,
               const int* __restrict__ strip_start, WordSrc ws, unsigned char* __restrict__ chainflag,
-              int* __restrict__ head, int* __restrict__ wavelast)
+              int* __restrict__ head, int* __restrict__ wavelast, const u32* __restrict__ srow, int* __restrict__ cellfirst)
 {
     __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
     __shared__ __attribute__((aligned(16))) int lx[NT + 2 * HALO];
+    // variant 2: cellfirst[cell head] = smallest input row of the cell's PETs (the dict insertion order of cDBSCAN2.py:117), by LDS
+    // atomics on the tile's own cells; the tile that holds a cell's head also walks the part of the cell behind its last PET
+    __shared__ int lmin[NT];
+    __shared__ int l_hlast;
     const int M = strip_start[g.S];
-    if (head) {                                          // filtered tail: singleton cells (keys of the cellfirst scan)
-#pragma unroll
-        for (int u = 0; u < NT / NTH; ++u) {
-            const int ig = tile_of_block(blockIdx.x) * NT + (int)threadIdx.x + u * NTH;
-            if (ig >= M && ig < n) head[ig] = ig;
-        }
-    }
+    if (head) for (int k = threadIdx.x; k < NT; k += NTH) lmin[k] = INT_MAX;
     Tile t;
     if (!tile_stage_words<NT, HALO, NTH>(t, lw, lx, ntiles, M, sv, sa, ws)) return;
+    unsigned headmask = 0u;                             // bit u: the thread's u-th PET is the head of its cell
     for (int u = 0; u < NT / NTH; ++u) {
     const int i = t.t0 + (int)threadIdx.x + u * NTH;
     if (i >= M) continue;
     const int2 me = t.w[i];
+    const bool core = cw_core(t.x[i], g.minPts);
     if (head) {
         // variant 2: head of the PET's rotated cell (strip, q / eps) = first PET of the sorted order that is
         // neither in an earlier strip nor below the cell's lower q edge -- a bisection on the staged tile
@@ -738,10 +738,12 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
             }
             pos = lo;
         }
-        head[i] = pos;
+        if (core) head[i] = pos;                         // (k_flatten looks the cell up for core PETs only)
+        if (pos >= t.t0) atomicMin(&lmin[pos - t.t0], (int)srow[i]);        // (a cell that began in an earlier tile: that tile walks it)
+        headmask |= (pos == i ? 1u : 0u) << u;
+        if (i == min(t.t0 + NT, M) - 1) l_hlast = pos;
     }
     int f = 0, last = 0;
-    const bool core = cw_core(t.x[i], g.minPts);
     if (core) {
         const int s = strip_of(g, me.y);
         const int b = strip_start[s], e = strip_start[s + 1];
@@ -761,6 +763,30 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
     const unsigned long long ob = __ballot(f != 0);
     if ((threadIdx.x & 63) == 0) wavelast[i >> 6] = ob ? i + (64 - __clzll((long long)ob)) : 0;
     }
+    if (!head) return;
+    __syncthreads();
+    const int tend = t.t0 + NT;
+    if (threadIdx.x < 64 && tend < M && l_hlast >= t.t0) {
+        // the cell of the tile's last PET may go on behind the tile: wave 0 walks it, 64 PETs per round (right halo, then global memory)
+        const int2 lp = t.w[tend - 1];
+        const int p0 = lp.y & ~(g.peps - 1), qend = div_eps(g, lp.x) * g.eps + g.eps;
+        int m = INT_MAX;
+        for (int j0 = tend; j0 < M; j0 += 64) {
+            const int j = j0 + (int)threadIdx.x;
+            bool in = j < M;
+            if (in) {
+                const int2 c = j < t.wend ? t.w[j] : make_int2(sv[j], sa[j]);
+                in = (c.y & ~(g.peps - 1)) == p0 && c.x < qend;
+            }
+            if (in) m = min(m, (int)srow[j]);
+            if (__ballot(in) != ~0ull) break;            // the cell ends inside this round (its PETs are contiguous)
+        }
+        m = dpp_reduce_wave(m, OpMin());
+        if (threadIdx.x == 0 && m != INT_MAX) atomicMin(&lmin[l_hlast - t.t0], m);
+    }
+    __syncthreads();
+    for (int u = 0; u < NT / NTH; ++u)
+        if (headmask & (1u << u)) { const int i = t.t0 + (int)threadIdx.x + u * NTH; cellfirst[i] = lmin[i - t.t0]; }
 }
 // parent[] = chain head for core points (flat forest to start from); chainid[] = the same for
 // core points and -1 for everything else (what the union kernel stages as its payload)
@@ -1142,6 +1168,7 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
     __shared__ int l_total;
     __shared__ unsigned long long l_mask[(NT + 2 * HALO) / 64];
     __shared__ int l_enc[NT];
+    constexpr int T_WIN = NT + 2 * HALO;
     const int M = strip_start[g.S];
     Tile t;
     if (threadIdx.x == 0) l_total = 0;
@@ -1200,7 +1227,6 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
     if (hinted) {
         // variant 2 with K2's hints: no strip table, no searches.  Strips are aligned blocks of the strip coordinate:
         // "same strip" and "still inside the neighbour strip" are predicates of the staged pairs.
-        constexpr int T_WIN = NT + 2 * HALO;
         const int pbeg = me.y & ~(g.peps - 1), pend = pbeg + g.peps, pend2 = pend + g.peps;
         const int plo = me.y - g.peps, phi = me.y + g.peps;
         {
@@ -1749,9 +1775,15 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
 __global__ void k_cut_strips(int S, int thr, const int* __restrict__ bstrip, const int* __restrict__ bq,
                              int* __restrict__ kept /* [S+1] */, int* __restrict__ src0 /* [S] first kept source index */,
                              int* __restrict__ pre_out /* or null */, const int* __restrict__ pre_ref /* or null */,
-                             int* __restrict__ dpre_out /* with pre_ref */, int2* __restrict__ blen_out /* with pre_ref */, int bandq, int eps)
+                             int* __restrict__ dpre_out /* with pre_ref */, int2* __restrict__ blen_out /* with pre_ref */, int bandq, int eps,
+                             int* __restrict__ clr /* or null */, int nclr, int* __restrict__ counters)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (clr) {
+        // the run's first kernel also clears its key bitmap and counters (what k_init_flags does for a run without a cut)
+        for (int u = s; u < nclr; u += gridDim.x * blockDim.x) clr[u] = 0;
+        if (s < 16) counters[s] = 0;
+    }
     if (s > S) return;
     if (s == S) { kept[S] = 0; if (pre_out) pre_out[S] = 0; if (pre_ref) dpre_out[S] = 0; return; }
     const int b = bstrip[s];
@@ -2183,7 +2215,9 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
                    rcmode == RC_MAKE ? c->rc_pre.as<int>() : (int*)nullptr,
                    rcmode == RC_REMAP ? (const int*)c->rc_pre.as<int>() : (const int*)nullptr,
                    rcmode == RC_REMAP ? c->rc_dpre.as<int>() : (int*)nullptr, rcmode == RC_REMAP ? c->rc_blen.as<int2>() : (int2*)nullptr,
-                   c->ws.bandq, g.eps);
+                   c->ws.bandq, g.eps, c->init_nclr > 0 ? c->flag.as<int>() : (int*)nullptr, c->init_nclr, c->counters.as<int>());
+            c->init_nclr = 0;
+            // (the scan that opens a clustering run also clears its key bitmap and counters: init_nclr > 0)
             size_t tb = c->scan_tmp.bytes;
             hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, kept, c->strip.as<int>(), 0, (size_t)g.S + 1, rocprim::plus<int>(), c->stream);
             if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan(cut)", hipGetErrorString(e));
@@ -2637,12 +2671,15 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
 #define TILE_LAUNCH(kernel, ...) TILE_LAUNCH_H(wide == 2 ? 512 : (wide == 6 ? 256 : 128), kernel, __VA_ARGS__)
 
     const int nw = (n + 31) / 32;                       // words of the key bitmap (K5); one more word takes the scan's total
-    LAUNCH(k_init_flags, nw + 1, nw, c->flag.as<int>(), counters);
+    // the bitmap and the counters are cleared by the first kernel of the cut compaction (k_cut_strips); a run without one clears
+    // them in a launch of its own
+    c->init_nclr = nw + 1;
     // row-aligned labels only when somebody reads them: k_final_labels then writes the label (or -1) of every PET that
     // entered DBSCAN and only the rows removed by the cut filter need the -1 fill
     const bool rows = labels_out != nullptr || c->device_labels;
     if (rows && cut > 0) HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
     if ((rc = run_sort_and_count(c, g, false))) return rc;
+    if (c->init_nclr > 0) { LAUNCH(k_init_flags, nw + 1, nw, c->flag.as<int>(), counters); c->init_nclr = 0; }
     const WordSrc ws = c->ws;                           // where the K2 words of this run live (the handle's count cache / the work buffer)
     if ((rc = c->rootlist.ensure((size_t)n * 4)) || (rc = c->cflag8.ensure((size_t)n + 16))) return rc;
     unsigned char* cflag = c->cflag8.as<unsigned char>();
@@ -2672,20 +2709,10 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         if (wide == 0) {
             const int nt_c = nblocks(nm, 1024);
             hipLaunchKernelGGL((k_chain_flags<1024, 128, TPB>), dim3(tile_grid(nt_c)), dim3(TPB), 0, c->stream, g, nt_c, nm, sv, sa, strip, ws,
-                               cflag, head, c->chainhead.as<int>() /* wavelast: the buffer is free until the labels */);
+                               cflag, head, c->chainhead.as<int>() /* wavelast: the buffer is free until the labels */, srow, c->cellfirst.as<int>());
         } else
         TILE_LAUNCH(k_chain_flags, g, ntiles, nm, sv, sa, strip, ws, cflag,
-                           head, c->chainhead.as<int>() /* wavelast: the buffer is free until the labels */);
-        if (head) {
-            // cellfirst: segmented suffix-min of the input rows, keyed by the cell's head index, so that
-            // cellfirst[head] = smallest row of the whole cell (replaces one atomicMin per PET)
-            size_t tb = c->scan_tmp.bytes;
-            hipError_t e = rocprim::inclusive_scan_by_key(c->scan_tmp.p, tb, rocprim::make_reverse_iterator(head + nm),
-                                               rocprim::make_reverse_iterator((int*)srow + nm),
-                                               rocprim::make_reverse_iterator(c->cellfirst.as<int>() + nm), (size_t)nm,
-                                               rocprim::minimum<int>(), rocprim::equal_to<int>(), c->stream);
-            if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan_by_key", hipGetErrorString(e));
-        }
+                           head, c->chainhead.as<int>() /* wavelast: the buffer is free until the labels */, srow, c->cellfirst.as<int>());
         // long strips (dense data at large eps): 32-PET block summaries for the union scan (`hi` is free until K4)
         pmax32 = ((long long)n > 64LL * g.S) ? c->hi.as<int>() : nullptr;
         LAUNCH(k_chain_parent, (nm + CP_PER - 1) / CP_PER, strip, g.S, (const unsigned char*)cflag, c->chainhead.as<int>(), c->parent.as<int>(), c->chainflag.as<int>(),
