@@ -113,16 +113,17 @@ def main(argv=None):
     # CLOOPS_BENCH_COMM=torch keeps the torch.distributed path; the CPU tests (--backend gloo) always use it.
     direct = use_dist and on_gpu and os.environ.get("CLOOPS_BENCH_COMM", "rccl") != "torch"
     comm_note = None
+    comm_so = os.path.join(ROOT, "cloops_amd", "libcloops_comm.so")
+    if direct and not os.path.exists(comm_so):
+        # the ONLY fall-back: the library was never built.  Every rank sees the same file system, so every rank takes the same
+        # branch -- and nothing of either runtime has been loaded yet.  Once libcloops_comm.so is mapped a failure is fatal on
+        # purpose: a rank that quietly moved to torch.distributed would leave the others waiting in an RCCL collective.
+        comm_note = "libcloops_comm.so not built, torch.distributed instead"
+        sys.stderr.write("bench.py: %s\n" % comm_note)
+        direct = False
     if direct:
-        try:
-            from cloops_amd.comm import Comm
-            comm = Comm(rank, world, local_rank)
-        except Exception as e:                              # library missing / RCCL refused to initialise: the torch path still works
-            comm_note = "libcloops_comm.so unavailable (%s: %s), fell back to torch.distributed" % (type(e).__name__, e)
-            sys.stderr.write("bench.py: %s\n" % comm_note)
-            direct = False
-    if direct:
-        pass
+        from cloops_amd.comm import Comm
+        comm = Comm(rank, world, local_rank)
     elif use_dist:
         # torch first: its bundled HIP runtime then also serves libcloops_hip.so (same SONAME; the other order aborts
         # at the first RCCL call)
@@ -241,7 +242,7 @@ def main(argv=None):
             "data": "synthetic",
             "sweep_wall_s": elapsed / max(1, args.steps),
             "first_sweep_s": first_sweep_s,
-            "comm": ("rccl (libcloops_comm.so, no torch in the process)" if comm is not None else
+            "comm": ("rccl %d (libcloops_comm.so built against %d, no torch in the process)" % (comm.rccl_loaded, comm.rccl_built) if comm is not None else
                      (("torch.distributed/%s" % args.backend) + ("; " + comm_note if comm_note else "") if use_dist else None)),
             "config": {"workload": "synthetic-%s-23chr-mode3 (BASELINE.json configs[3])" % _human(n_total),
                        "variant": "cDBSCAN2", "pets": n_total, "chromosomes": len(sizes), "eps": eps_list, "minPts": minpts_list,
@@ -420,32 +421,68 @@ def with_labels_sweep(pipe, fs, steps, pets_per_sweep, reps=2):
 
 
 def scaling_proxy(pipe, lpt_assign, fs, sizes, steps, nranks, one_gpu_sweep_s, reps=2):
-    """Single-GPU evidence for the N-GPU claim: the sweep time of EVERY rank's LPT share of `nranks`, each share alone on
-    this GPU, replaying the genome-wide chain (the cuts a real run all-reduces) -- the makespan over the ranks is what an
-    N-GPU run cannot beat; the per-run statistics all-reduce and the final table gather come on top."""
+    """Single-GPU evidence for the N-GPU claim.  Every rank's LPT share of `nranks` is swept ALONE on this GPU, replaying the
+    genome-wide chain (the cuts a real run all-reduces), and timed step by step.  A real run meets after every step (the cut
+    is a genome-wide estimate: one all-reduce per run), so what bounds it is the SUM over the steps of the slowest rank's
+    step, not the slowest rank's sum; on top come the exchanges themselves, timed here through libcloops_comm.so at world
+    size 1 (staging through pinned memory + the RCCL call + one stream synchronisation; no xGMI hop): 13 all-reduces of the
+    step vector and the gather of the candidate tables at the root.  `predicted_sweep_s` is the sum of those terms."""
+    import numpy as np
     shares = lpt_assign([n for _, _, n in sizes], nranks)
     forced = [s.get("cut_out") for s in steps]
     eps = sorted({s["eps"] for s in steps})
     mps = sorted({s["minPts"] for s in steps}, reverse=True)
-    per = []
+    per, walls, tails, tables = [], [], [], []
     for r, share in enumerate(shares):
         fr = [fs[ci] for ci in sorted(share)]
         if not fr:
             per.append({"rank": r, "chromosomes": [], "pets": 0, "sweep_wall_s": 0.0})
+            walls.append([0.0] * len(steps)); tails.append(0.0)
             continue
         pipe.runSweepFast(fr, eps, mps, cut=0, variant=VARIANT, forced_cuts=forced)
-        t0 = time.perf_counter()
+        acc, tot = np.zeros(len(steps)), 0.0
         for _ in range(reps):
-            pipe.runSweepFast(fr, eps, mps, cut=0, variant=VARIANT, forced_cuts=forced)
-        dt = (time.perf_counter() - t0) / reps
+            t0 = time.perf_counter()
+            res = pipe.runSweepFast(fr, eps, mps, cut=0, variant=VARIANT, forced_cuts=forced)
+            tot += time.perf_counter() - t0
+            acc += np.asarray([st["wall_s"] for st in res[3]])
+        tables += [v["boxes"] for v in res[0].values() if len(v["boxes"])]
+        dt = tot / reps
+        walls.append(list(acc / reps)); tails.append(max(dt - float(acc.sum()) / reps, 0.0))       # tail: candidate dedup + tables to the host
         per.append({"rank": r, "chromosomes": [sizes[ci][0] for ci in sorted(share)], "pets": int(sum(sizes[ci][2] for ci in share)),
-                    "sweep_wall_s": dt})
+                    "sweep_wall_s": dt, "steps_wall_s": [round(x, 6) for x in walls[-1]]})
     mk = max(p["sweep_wall_s"] for p in per)
-    return {"ranks": nranks, "per_rank": per, "makespan_s": mk, "one_gpu_sweep_s": one_gpu_sweep_s,
-            "implied_speedup": one_gpu_sweep_s / mk if mk > 0 else None, "implied_efficiency": one_gpu_sweep_s / mk / nranks if mk > 0 else None,
-            "lpt_balance": max(p["pets"] for p in per) / (sum(p["pets"] for p in per) / float(nranks)),
-            "note": "each rank's share timed ALONE on one MI355X with the genome-wide cut chain forced (runSweepFast(forced_cuts)); "
-                    "excludes the per-run all-reduce of ~48 KB of statistics and the final RCCL gather of the candidate tables"}
+    sum_of_max = float(np.max(np.asarray(walls), axis=0).sum()) + max(tails)
+    out = {"ranks": nranks, "per_rank": per, "makespan_s": mk, "sum_over_steps_of_slowest_rank_s": sum_of_max, "one_gpu_sweep_s": one_gpu_sweep_s,
+           "implied_speedup": one_gpu_sweep_s / mk if mk > 0 else None, "implied_efficiency": one_gpu_sweep_s / mk / nranks if mk > 0 else None,
+           "lpt_balance": max(p["pets"] for p in per) / (sum(p["pets"] for p in per) / float(nranks)),
+           "note": "each rank's share timed ALONE on one MI355X with the genome-wide cut chain forced (runSweepFast(forced_cuts)); makespan_s = the slowest "
+                   "rank's whole sweep (no meeting between the steps: a lower bound); sum_over_steps_of_slowest_rank_s = with the per-step meeting a real run has"}
+    try:
+        from cloops_amd.comm import Comm
+        c1 = Comm(0, 1, 0)
+        vec = np.zeros(8 + 3840 + 2048 + 6)               # the per-step statistics vector of runSweepFast(allsum=...)
+        c1.allsum(vec)
+        t0 = time.perf_counter()
+        for _ in range(len(steps) + 1):
+            c1.allsum(vec)
+        t_ar = time.perf_counter() - t0
+        rows = tables if tables else np.zeros((0, 4), np.int32)
+        c1.gather_tables(rows, dst=0, copy=False)
+        t0 = time.perf_counter()
+        ncand = sum(len(t) for t in c1.gather_tables(rows, dst=0, copy=False))
+        t_g = time.perf_counter() - t0
+        c1.close()
+        out["exchanges_world1"] = {"allreduce_calls": len(steps) + 1, "allreduce_total_s": t_ar, "gather_rows": int(ncand), "gather_s": t_g,
+                                   "rccl": c1.rccl_loaded,
+                                   "note": "through libcloops_comm.so on ONE rank: host staging + RCCL call + stream synchronisation, without the xGMI hops of a real ring"}
+        out["predicted_sweep_s"] = sum_of_max + t_ar + t_g
+        out["predicted_speedup"] = one_gpu_sweep_s / out["predicted_sweep_s"]
+    except Exception as e:                                   # (no RCCL on this box: the compute terms stand alone)
+        out["exchanges_world1"] = None
+        out["exchanges_note"] = "libcloops_comm.so / RCCL not usable here: %s: %s" % (type(e).__name__, e)
+        out["predicted_sweep_s"] = None
+    return out
 
 
 def secondary_5m(api, synth_chrom, steps=20, warmup=3):
@@ -500,6 +537,18 @@ def _cpu_worker(job):
     return out
 
 
+def reference_python_speed():
+    """the reference's own classes in CPython, one core, measured in the build container (the reference never travels to the GPU
+    box): profiles/reference_python_speed.json, written by tools/measure_reference_python.py"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "reference_python_speed.json")) as fh:
+            j = json.load(fh)
+        return {"reference_python_pets_per_s_per_core": j["reference_python_pets_per_s_per_core"],
+                "reference_python_source": "profiles/reference_python_speed.json (%s; %s)" % (j["reference_python_pets_per_s_per_core_note"], j["what"])}
+    except Exception:
+        return {"reference_python_pets_per_s_per_core": None, "reference_python_source": None}
+
+
 def cpu_baseline(api, sizes, steps):
     """The CPU oracle (C port of cLoops/cDBSCAN2.py) over the SAME 23 chromosomes, one worker process per chromosome
     up to os.cpu_count() (cLoops/pipe.py:117), on a bounded sample of the sweep: 2 of its 12 runs -- (eps 5000,
@@ -536,7 +585,8 @@ def cpu_baseline(api, sizes, steps):
                           workers, os.cpu_count() or 1, ", ".join("(eps %d, minPts %d, cut %d)" % r for r in runs), cpu_s, walls[0], walls[1]),
             "single_thread_pets_per_s": sum(p[r][1] for p in per for r in range(len(runs))) / cpu_s,
             "labels_match_gpu": same, "labels_checked_on": "%s (%d PETs) at eps %d minPts %d cut %d" % ((name, n) + runs[1]),
-            "note": "the Python reference itself runs ~1e5 PETs/s/core (BASELINE.md section 2); the C port is ~20x faster than the reference"}
+            "note": "kind = port: the sequential C restatement of the reference's classes (oracle/), ~20x faster than the Python reference itself, "
+                    "whose own one-core speed is carried in reference_python_pets_per_s_per_core", **reference_python_speed()}
 
 
 def cpu_baseline_full(n_total, steps, final_cut, ncand):
@@ -559,7 +609,8 @@ def cpu_baseline_full(n_total, steps, final_cut, ncand):
                       "estimated from the concatenated distance lists; %.0f s of CPU work, %.1f s wall for the 12 runs (%.1f s with synthesis)" % (
                           res["workers"], os.cpu_count() or 1, res["oracle_cpu_s"], res["oracle_wall_s"], wall),
             "sweep_wall_s": res["oracle_wall_s"], "chain_matches_gpu": bool(same),
-            "note": "the Python reference itself runs ~1e5 PETs/s/core (BASELINE.md section 2); the C port is ~20x faster than the reference"}
+            "note": "kind = port: the sequential C restatement of the reference's classes (oracle/), ~20x faster than the Python reference itself, "
+                    "whose own one-core speed is carried in reference_python_pets_per_s_per_core", **reference_python_speed()}
 
 
 if __name__ == "__main__":

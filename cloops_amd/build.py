@@ -68,14 +68,20 @@ def build(force=False, verbose=False, devel=False):
     environment; loaded only when CLOOPS_DEVEL_LIB=1) -- the shipped library has none of them."""
     out = OUT.replace(".so", "_devel.so") if devel else OUT
     if not devel:
-        build_comm(force, verbose)
+        try:
+            build_comm(force, verbose)
+        except (subprocess.CalledProcessError, OSError) as e:
+            # the single-GPU path does not need RCCL: cloops_amd.comm.load() raises a clear ImportError when it is asked for
+            print("cloops_amd.build: libcloops_comm.so not built (%s); the multi-GPU path is unavailable" % e, file=sys.stderr)
     if not devel and not force and not needs_build():
         return OUT
     os.makedirs(OBJDIR, exist_ok=True)
     hdr_t = max(os.path.getmtime(p) for p in headers())
     jobs, objs = [], []
+    import hashlib
+    tag = hashlib.sha1(" ".join(FLAGS + (["-DCLOOPS_DEVEL"] if devel else [])).encode()).hexdigest()[:8]      # other flags: other objects
     for src in sources():
-        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ("_devel" if devel else "") + ".o")
+        obj = os.path.join(OBJDIR, "%s_%s.o" % (os.path.basename(src)[:-4] + ("_devel" if devel else ""), tag))
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
             jobs.append((src, obj))

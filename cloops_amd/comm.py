@@ -2,7 +2,8 @@
 
 One process per GPU, launched by anything that sets RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run does; it is only
 the launcher -- this module imports no torch).  The ncclUniqueId travels from rank 0 to the others through a file in /tmp
-keyed by the launcher's pid and MASTER_PORT (one node, which is what the path is specified for).
+named after the launcher instance (pid + start time), MASTER_PORT and the communicator's number (one node, which is what the
+path is specified for).
 
     comm = Comm.from_env()
     allsum = comm.make_allsum()          # for cloops_amd.pipe.runSweepFast(..., allsum=allsum)
@@ -18,19 +19,31 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libcloops_comm.so")
-SYMBOLS = ("cl_comm_last_error", "cl_comm_unique_id", "cl_comm_init", "cl_comm_destroy", "cl_comm_rank", "cl_comm_world",
+SYMBOLS = ("cl_comm_last_error", "cl_comm_rccl_version", "cl_comm_unique_id", "cl_comm_init", "cl_comm_destroy", "cl_comm_rank", "cl_comm_world",
            "cl_comm_allreduce_f64", "cl_comm_allreduce_max_f64", "cl_comm_allgather_i32", "cl_comm_gather_i32", "cl_comm_barrier")
 ID_BYTES = 128
+ID_DIR = "/tmp"
 _lib = None
-_T_IMPORT = time.time()
+_SEQ = 0               # communicators formed by this process so far (every rank forms them in the same order)
+
+
+def _parent_start():
+    """start time of the launcher process (clock ticks since boot, /proc/<ppid>/stat field 22): with its pid it names ONE
+    launcher instance, so a file left behind by an earlier launch that happened to get the same pid is never read"""
+    try:
+        with open("/proc/%d/stat" % os.getppid()) as fh:
+            return fh.read().rsplit(")", 1)[1].split()[19]
+    except Exception:
+        return "0"
 
 
 def default_tag():
-    """names the id file of one launch: the launcher's pid (all local ranks share the parent), MASTER_PORT and -- under
-    torch.distributed.run -- its run id and restart count, so that neither concurrent launches nor a restarted worker group
-    of the same agent meet each other's file"""
-    return "%s_%s_%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
-                            os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+    """names the id file of one communicator of one launch: the launcher's pid and start time (all local ranks share the
+    parent), MASTER_PORT, under torch.distributed.run its run id and restart count, and the number of communicators this
+    process has formed before -- neither concurrent launches, nor a restarted worker group of the same agent, nor a second
+    communicator of the same ranks meet each other's file"""
+    return "%s_%s_%s_%s_%s_%d" % (os.getppid(), _parent_start(), os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                                  os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), _SEQ)
 
 
 class CommError(RuntimeError):
@@ -46,6 +59,7 @@ def load():
     lib = ctypes.CDLL(SO_PATH)
     vp, i64 = ctypes.c_void_p, ctypes.c_int64
     lib.cl_comm_last_error.restype = ctypes.c_char_p
+    lib.cl_comm_rccl_version.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     lib.cl_comm_unique_id.argtypes = [vp]
     lib.cl_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
     lib.cl_comm_destroy.argtypes = [vp]
@@ -66,13 +80,24 @@ def _check(rc):
         raise CommError((load().cl_comm_last_error() or b"").decode("utf-8", "replace"))
 
 
-def exchange_id(rank, world, make_id, tag=None, timeout=300.0, directory="/tmp"):
+def id_path(tag=None, directory=ID_DIR):
+    return os.path.join(directory, "cloops_comm_id_%s" % (tag or default_tag()))
+
+
+def rccl_versions():
+    """-> (built_with, loaded) RCCL version codes of libcloops_comm.so / of the librccl mapped into this process"""
+    lib = load()
+    b, l = ctypes.c_int(0), ctypes.c_int(0)
+    _check(lib.cl_comm_rccl_version(ctypes.byref(b), ctypes.byref(l)))
+    return int(b.value), int(l.value)
+
+
+def exchange_id(rank, world, make_id, tag=None, timeout=300.0, directory=ID_DIR):
     """rank 0 makes the id (make_id() -> bytes) and publishes it; every rank returns the same bytes.  The file name carries
-    default_tag(); a file older than this process (minus two minutes of start-up skew) is a leftover and is not read."""
+    default_tag(), which names this launcher instance and this communicator: whatever is found under it was written for it."""
     if world == 1:
         return make_id()
-    tag = tag or default_tag()
-    path = os.path.join(directory, "cloops_comm_id_%s" % tag)
+    path = id_path(tag, directory)
     if rank == 0:
         blob = make_id()
         tmp = path + ".tmp%d" % os.getpid()
@@ -85,7 +110,7 @@ def exchange_id(rank, world, make_id, tag=None, timeout=300.0, directory="/tmp")
         try:
             with open(path, "rb") as fh:
                 blob = fh.read()
-            if len(blob) == ID_BYTES and os.path.getmtime(path) >= _T_IMPORT - 120.0:
+            if len(blob) == ID_BYTES:
                 return blob
         except (IOError, OSError):
             pass
@@ -104,7 +129,16 @@ class Comm(object):
             buf = ctypes.create_string_buffer(ID_BYTES)
             _check(lib.cl_comm_unique_id(buf))
             return buf.raw
-        self._id_path = None
+        global _SEQ
+        tag = tag or default_tag()
+        self._id_path = id_path(tag)
+        _SEQ += 1
+        built, loaded = rccl_versions()
+        self.rccl_built, self.rccl_loaded = built, loaded
+        if self.world > 1 and built // 100 != loaded // 100:
+            # (decided from facts every rank sees alike, before anything is exchanged: all ranks raise together)
+            raise CommError("libcloops_comm.so was built against RCCL %d but the process has librccl %d mapped (another copy was "
+                            "loaded first, e.g. by PyTorch): refusing to form a %d-rank communicator across that skew" % (built, loaded, self.world))
         blob = exchange_id(self.rank, self.world, make_id, tag)
         h = ctypes.c_void_p()
         _check(lib.cl_comm_init(ctypes.c_char_p(blob), self.rank, self.world, self.device, ctypes.byref(h)))
@@ -113,7 +147,7 @@ class Comm(object):
             self.barrier()
             if self.rank == 0:                             # everyone has joined: the id file has done its job
                 try:
-                    os.remove(os.path.join("/tmp", "cloops_comm_id_%s" % (tag or default_tag())))
+                    os.remove(self._id_path)
                 except OSError:
                     pass
 

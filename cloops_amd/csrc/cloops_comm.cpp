@@ -29,6 +29,17 @@ struct cl_comm {
 
 extern "C" const char* cl_comm_last_error(void) { return g_cerr.c_str(); }
 
+extern "C" int cl_comm_rccl_version(int* built_with, int* loaded)
+{
+    // the headers this library was compiled against vs the librccl the process has actually mapped (a process that imported
+    // PyTorch first carries torch's bundled librccl under the same SONAME)
+    if (built_with) *built_with = NCCL_VERSION_CODE;
+    int v = 0;
+    NCC(ncclGetVersion(&v));
+    if (loaded) *loaded = v;
+    return 0;
+}
+
 extern "C" int cl_comm_unique_id(void* id_out)
 {
     if (!id_out) return cfail("cl_comm_unique_id", "null argument");
@@ -119,14 +130,15 @@ static int gather_i32(cl_comm* c, const int32_t* hin, int64_t n, int root, int32
     if (n > 0 && recv && !hout) return cfail("cl_comm_gather_i32", "null receive buffer");
     if (n == 0) return 0;
     const size_t in_bytes = (size_t)n * 4, out_bytes = in_bytes * (size_t)c->world, pad = ((in_bytes + 255) / 256) * 256;
-    int rc = ensure(c, std::max(in_bytes, recv ? out_bytes : (size_t)0), pad + (recv ? out_bytes : (size_t)0));
+    // (every rank hands RCCL a valid receive pointer, the non-root ranks a small dummy area: nothing is written there)
+    int rc = ensure(c, std::max(in_bytes, recv ? out_bytes : (size_t)0), pad + (recv ? out_bytes : (size_t)256));
     if (rc) return rc;
     char* dsend = (char*)c->dev;
     char* drecv = dsend + pad;
     memcpy(c->pin, hin, in_bytes);
     HIPC(hipMemcpyAsync(dsend, c->pin, in_bytes, hipMemcpyHostToDevice, c->stream));
     if (root < 0) NCC(ncclAllGather(dsend, drecv, (size_t)n, ncclInt32, c->comm, c->stream));
-    else NCC(ncclGather(dsend, recv ? drecv : nullptr, (size_t)n, ncclInt32, root, c->comm, c->stream));
+    else NCC(ncclGather(dsend, drecv, (size_t)n, ncclInt32, root, c->comm, c->stream));
     if (recv) HIPC(hipMemcpyAsync(c->pin, drecv, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     if (recv) memcpy(hout, c->pin, out_bytes);

@@ -1890,7 +1890,7 @@ k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const i
         {&c->slot[0].labels, n * 4}, {&c->slot[0].table, (n + 1) * sizeof(cl_box)}, {&c->slot[0].slab, n * 4}, \
         {&c->slot[1].labels, n * 4}, {&c->slot[1].table, (n + 1) * sizeof(cl_box)}, {&c->slot[1].slab, n * 4}, \
         {&c->ulist, n * 4}, {&c->lo, n * 4}, {&c->hi, n * 4}, {&c->recs, n * sizeof(Rec)}, \
-        {&c->chainflag, n * 4}, {&c->chainhead, n * 4}, {&c->usize, n * 4}, {&c->tile_s0, (n / 256 + 2) * 4}, {&c->tileflag, (n / 256 + 2) * 4}, \
+        {&c->chainflag, n * 4}, {&c->chainhead, n * 4}, {&c->usize, n * 4}, {&c->tile_s0, (n / 256 + 2) * 4}, {&c->tileflag, (4 * (n / 1024 + 1) + 4) * 4}, \
         {&c->bq, (n + 2 * SORT_PAD) * 4}, {&c->bsp, (n + 2 * SORT_PAD) * 4}, {&c->brow, n * 4}, {&c->btile, (n / 256 + 2) * 4}, \
         {&c->qb_key, n * 4}, {&c->qb_val, n * 8}, {&c->k7_cls, n + 16}, {&c->rc_cnt, n * 4}, {&c->rootlist, n * 4}, {&c->cflag8, n + 16}, \
         {&c->slot[0].d_step, 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8 + K7_BLOCKS * sizeof(K7Part)}, \
@@ -1923,6 +1923,9 @@ static int workspace_tmp_sizes(cl_chrom* c, size_t* sort_out, size_t* scan_out)
     return CL_OK;
 }
 
+static size_t g_arena_overcommit = 0;
+extern "C" void cl_debug_arena_overcommit(int64_t extra_bytes) { g_arena_overcommit = extra_bytes > 0 ? (size_t)extra_bytes : 0; }
+
 static int reserve_workspace(cl_chrom* c)
 {
     const size_t n = (size_t)c->n;
@@ -1931,8 +1934,11 @@ static int reserve_workspace(cl_chrom* c)
         // + what a first run would otherwise allocate piece by piece on the host's critical path: rocPRIM's temporary
         // storage, the strip tables and the compaction scratch for eps >= 1000 (a smaller eps grows them), a first
         // candidate buffer of max(n / 8, min(2^20, n)) boxes (it grows on demand)
+        // best effort: whatever fails here (size queries, the one big hipMalloc under memory pressure) must leave neither a sticky
+        // HIP error nor an error text behind -- the buffers are then allocated one by one at the first run
+        const std::string keep_err = g_err;
         size_t sort_bytes = 16, scan_bytes = 16;
-        if (workspace_tmp_sizes(c, &sort_bytes, &scan_bytes) != CL_OK) return CL_OK;
+        if (workspace_tmp_sizes(c, &sort_bytes, &scan_bytes) != CL_OK) { (void)hipGetLastError(); g_err = keep_err; return CL_OK; }
         const size_t s_guess = (size_t)(((long long)c->st.vmax - c->st.vmin) / 1000 + 64);
         const long long cand0 = std::max<long long>((long long)n / 8, std::min<long long>(1 << 20, (long long)n + 1024));   // (small handles stay small)
         std::vector<Want> all(std::begin(wants), std::end(wants));
@@ -1942,7 +1948,9 @@ static int reserve_workspace(cl_chrom* c)
         bool untouched = true;
         size_t total = 0;
         for (const Want& w : all) { untouched = untouched && w.b->p == nullptr; total += ((w.bytes + 255) / 256) * 256 + 256; }
-        if (untouched && c->arena.ensure(total) == CL_OK) {
+        total += g_arena_overcommit;                     // (cl_debug_arena_overcommit: tests make this allocation fail)
+        if (untouched && c->arena.ensure(total) != CL_OK) { (void)hipGetLastError(); g_err = keep_err; }
+        else if (untouched) {
             char* at = (char*)c->arena.p;
             for (const Want& w : all) { const size_t sz = ((w.bytes + 255) / 256) * 256 + 256; w.b->adopt(at, sz); at += sz; }
             c->cand_cap = cand0;

@@ -15,6 +15,7 @@ What differs is where the work happens:
 import os
 import sys
 import threading
+import time
 from collections import OrderedDict
 from concurrent.futures import ThreadPoolExecutor
 
@@ -514,6 +515,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                 step_cut = cut
                 this_step = step_no
                 step_no += 1
+                t_step0 = time.perf_counter()
 
                 # chromosomes are independent inside a step: enqueue them all (each handle has its own
                 # streams), then collect -- the kernels of different chromosomes overlap on the GPU
@@ -594,6 +596,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                 g, loghist, fine = gi[:4], gi[8:8 + len(loghist)], gi[8 + len(loghist):]
                 st = {"eps": ep, "minPts": m, "cut_in": int(cut), "n_inter": int(g[0]), "n_self": int(g[1]), "n_in": int(g[2])}
                 steps.append(st)
+                st["wall_s"] = time.perf_counter() - t_step0   # enqueue .. statistics of this rank on the host (+ the exchange); the cut follows
                 if int(g[3]) == 0:                            # pipe.py:251-255
                     if log:
                         log("ERROR: no inter-ligation PETs detected for eps %s minPts %s,can't model the distance cutoff,continue anyway" % (ep, m))

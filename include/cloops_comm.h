@@ -28,6 +28,11 @@ typedef struct cl_comm cl_comm;
 /* last error text of the calling thread */
 const char* cl_comm_last_error(void);
 
+/* RCCL version codes (major * 10000 + minor * 100 + patch): the headers libcloops_comm.so was built against and the
+ * librccl the process has mapped.  They can differ when another copy of librccl (PyTorch bundles one) was loaded first;
+ * cloops_amd/comm.py refuses to form a communicator of more than one rank across a major.minor mismatch. */
+int cl_comm_rccl_version(int* built_with, int* loaded);
+
 /* rank 0: a fresh unique id (CL_COMM_ID_BYTES bytes) for cl_comm_init of all ranks */
 int cl_comm_unique_id(void* id_out);
 

@@ -284,6 +284,11 @@ int cl_last_region_mode(const cl_chrom* c);
 void* cl_host_alloc(int64_t bytes);
 void cl_host_free(void* p);
 
+/* Testing hook: the per-PET workspace of a handle is reserved as ONE allocation when the chromosome is uploaded (best
+ * effort: if that allocation fails the buffers are allocated one by one at the first run).  extra_bytes > 0 is added to
+ * the size of that allocation for the handles created afterwards, so that a test can make it fail; 0 restores it. */
+void cl_debug_arena_overcommit(int64_t extra_bytes);
+
 /* Library version: major*10000 + minor*100 + patch. */
 int cl_version(void);
 

@@ -172,13 +172,18 @@ def test_comm_python_side_at_world_n(monkeypatch, world):
             assert all(len(a) == 0 for a in res["root"])
 
 
-def test_a_leftover_id_file_is_not_read(tmp_path):
-    """a file left behind by an earlier launch under the same tag (older than this process) must not be taken for rank 0's"""
-    import time
-    path = os.path.join(str(tmp_path), "cloops_comm_id_left")
-    with open(path, "wb") as fh:
-        fh.write(b"x" * comm.ID_BYTES)
-    old = time.time() - 3600
-    os.utime(path, (old, old))
-    with pytest.raises(comm.CommError):
-        comm.exchange_id(1, 2, lambda: b"", tag="left", timeout=0.3, directory=str(tmp_path))
+def test_id_file_names_one_launcher_instance_and_one_communicator(monkeypatch):
+    """the id file is found by NAME only (no clock heuristics: a rank may import late): the name carries the launcher's pid AND
+    its start time (a leftover of an earlier launcher that had the same pid is another file), MASTER_PORT, the elastic run id /
+    restart count and the number of communicators the process has formed so far (a second communicator of the same ranks)"""
+    t1 = comm.default_tag()
+    assert str(os.getppid()) in t1 and comm._parent_start() in t1 and comm._parent_start() != "0"
+    monkeypatch.setattr(comm, "_SEQ", comm._SEQ + 1)
+    t2 = comm.default_tag()
+    assert t1 != t2
+    monkeypatch.setenv("MASTER_PORT", "29999")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
+    assert comm.default_tag() not in (t1, t2)
+    monkeypatch.setattr(comm, "_parent_start", lambda: "12345")
+    assert "12345" in comm.default_tag()
+    assert comm.id_path("x", "/d") == "/d/cloops_comm_id_x"

@@ -172,3 +172,26 @@ def test_hybrid_sort_equals_full_radix_sort(variant, monkeypatch):
     Xp = np.concatenate([X, 5000000 + rng.integers(-300, 301, 5000).astype(np.int32)])
     Yp = np.concatenate([Y, 5600000 + rng.integers(-300, 301, 5000).astype(np.int32)])
     run_all(Xp, Yp, 2000, 5, variants=[variant])
+
+
+def test_failed_arena_reservation_is_harmless():
+    """the one-allocation workspace reservation at upload is best effort: when it fails (memory pressure) the handle must
+    work -- buffers allocated one by one -- and no stale HIP error may surface in the next run"""
+    from cloops_amd import _lib as L
+    rng = np.random.default_rng(3)
+    n = 20000
+    X = rng.integers(0, 400000, n)
+    Y = X + rng.integers(0, 30000, n)
+    lib = L.load()
+    lib.cl_debug_arena_overcommit(1 << 60)
+    try:
+        ch = api.Chromosome(X, Y)
+    finally:
+        lib.cl_debug_arena_overcommit(0)
+    try:
+        for v in ALL:
+            got = ch.cluster(v, 500, 4, 300)
+            want = oracle.single_dbscan(v, X, Y, 500, 4, 300)["labels"]
+            assert np.array_equal(got.labels, want), v
+    finally:
+        ch.close()
