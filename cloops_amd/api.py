@@ -86,6 +86,19 @@ class Chromosome(object):
                                        ctypes.c_void_p(y_ptr), self.n, 1, ctypes.byref(self._h)))
         return self
 
+    def subsample(self, rows):
+        """a new resident chromosome made of `rows` of this one, in the order given (`mat[rows, :]` of
+        scripts/jd2saturation:46-47), gathered on the device (cl_chrom_subsample)"""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        new = Chromosome.__new__(Chromosome)
+        new._lib = self._lib
+        new._h = ctypes.c_void_p()
+        new.n = int(rows.shape[0])
+        new.device = self.device
+        new._init_state()
+        _lib.check(self._lib.cl_chrom_subsample(self._h, rows.ctypes.data_as(ctypes.c_void_p), new.n, ctypes.byref(new._h)))
+        return new
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.cl_chrom_destroy(self._h)

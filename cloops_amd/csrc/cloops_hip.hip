@@ -1757,6 +1757,46 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
     return CL_OK;
 }
 
+// ---- a chromosome made of rows of a resident one (scripts/jd2saturation:32-55 re-samples a .jd) ------------------------
+__global__ void k_gather_rows(const int* __restrict__ X, const int* __restrict__ Y, const int* __restrict__ rows, int m,
+                              int* __restrict__ xo, int* __restrict__ yo)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int r = rows[i];
+    xo[i] = X[r]; yo[i] = Y[r];
+}
+extern "C" int cl_chrom_subsample(cl_chrom* src, const int64_t* rows, int64_t m, cl_chrom** out)
+{
+    if (!src || !out) return fail(CL_ERR_ARG, "cl_chrom_subsample: null argument");
+    *out = nullptr;
+    if (m < 0 || m >= (1LL << 31) - 1024 || (m > 0 && !rows)) return fail(CL_ERR_ARG, "cl_chrom_subsample: bad row list");
+    if (src->enq != src->deq) return fail(CL_ERR_ARG, "cl_chrom_subsample: asynchronous runs still in flight on the source, call cl_wait first");
+    HIP_TRY(hipSetDevice(src->device));
+    std::vector<int> r32((size_t)m);
+    for (int64_t i = 0; i < m; ++i) {
+        if (rows[i] < 0 || rows[i] >= src->n) return fail(CL_ERR_ARG, "cl_chrom_subsample: row index out of range");
+        r32[(size_t)i] = (int)rows[i];
+    }
+    int *dx = nullptr, *dy = nullptr, *dr = nullptr;
+    int rc = CL_OK;
+    if (m > 0) {
+        if (hipMalloc((void**)&dx, (size_t)m * 4) != hipSuccess || hipMalloc((void**)&dy, (size_t)m * 4) != hipSuccess ||
+            hipMalloc((void**)&dr, (size_t)m * 4) != hipSuccess) rc = fail(CL_ERR_HIP, "hipMalloc (subsample)");
+        if (rc == CL_OK && hipMemcpyAsync(dr, r32.data(), (size_t)m * 4, hipMemcpyHostToDevice, src->stream) != hipSuccess) rc = fail(CL_ERR_HIP, "hipMemcpy (row list)");
+        if (rc == CL_OK) {
+            hipLaunchKernelGGL(k_gather_rows, dim3(nblocks(m)), dim3(TPB), 0, src->stream, (const int*)src->d_x, (const int*)src->d_y, (const int*)dr, (int)m, dx, dy);
+            if (hipStreamSynchronize(src->stream) != hipSuccess) rc = fail(CL_ERR_HIP, "gather (subsample)");
+        }
+        if (dr) (void)hipFree(dr);
+    }
+    // the coordinates are on the device already: the new handle takes them over (statistics, distance histogram, workspace as usual)
+    if (rc == CL_OK) rc = cl_chrom_create(src->device, nullptr, dx, dy, m, 1, out);
+    if (rc != CL_OK) { std::string keep = g_err; if (dx) (void)hipFree(dx); if (dy) (void)hipFree(dy); g_err = keep; return rc; }
+    (*out)->own_xy = true;
+    return CL_OK;
+}
+
 // ---- cut filter as a stream compaction of the base layout ------------------------------------------------
 // pipe.py:59-62 keeps d = Y - X >= cut; in the strip layout d = q + V0, so the test reads the sorted q alone.
 #define CMP_TPB 256

@@ -134,6 +134,41 @@ class ChromCache(object):
             old.chrom.close()
         return f
 
+    def put_chrom(self, name, chrom, X, Y, ids=None, key=None, device=0):
+        """register a chromosome that is ALREADY resident (e.g. api.Chromosome.subsample of another resident) under the
+        pseudo path `name` ('mem://...'); X, Y: its host copies (distances, ids for the reference-shaped wrappers)"""
+        r = _Resident()
+        tail = name[len("mem://"):].split("/")[-1]
+        r.key = tuple(key) if key is not None else (tuple(tail.split("-")) if "-" in tail else (tail, tail))
+        r.stamp, r.device = ("mem", len(X)), device
+        r.lock = threading.Lock()
+        r.sweep_lock = threading.Lock()
+        r.replaced = False
+        r.pins = 0
+        r.X = np.ascontiguousarray(X)
+        r.Y = np.ascontiguousarray(Y)
+        r.ids = np.arange(len(r.X), dtype=np.int64) if ids is None else np.asarray(ids)
+        r.d = r.Y.astype(np.int64) - r.X.astype(np.int64)
+        r.chrom = chrom
+        r.chrom.set_device_labels(False)
+        with self._lock:
+            old = self._items.pop(name, None)
+            self._items[name] = r
+            if old is not None and old.pins > 0:
+                old.replaced, old = True, None
+        if old is not None:
+            old.chrom.close()
+        return name
+
+    def drop(self, f):
+        """forget one resident (closed at once unless a sweep still holds it)"""
+        with self._lock:
+            r = self._items.pop(f, None)
+            if r is not None and r.pins > 0:
+                r.replaced, r = True, None
+        if r is not None:
+            r.chrom.close()
+
     def get(self, f, device=None, _pin=False):
         """the resident of `f`; `device=None` takes it wherever it already lives (GPU 0 if it has to be loaded),
         an explicit device reloads a chromosome that lives on another GPU"""

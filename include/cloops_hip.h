@@ -284,6 +284,12 @@ int cl_last_region_mode(const cl_chrom* c);
 void* cl_host_alloc(int64_t bytes);
 void cl_host_free(void* p);
 
+/* A new chromosome handle made of `m` rows of a resident one, in the order given (rows may repeat): what
+ * scripts/jd2saturation:32-55 does with `mat[ns, :]` + joblib.dump for every re-sampling depth -- here the rows are
+ * gathered on the device, only the row list crosses PCIe.  The new handle is independent of `src` (own device memory,
+ * own stream); destroy it with cl_chrom_destroy. */
+int cl_chrom_subsample(cl_chrom* src, const int64_t* rows, int64_t m, cl_chrom** out);
+
 /* Testing hook: the per-PET workspace of a handle is reserved as ONE allocation when the chromosome is uploaded (best
  * effort: if that allocation fails the buffers are allocated one by one at the first run).  extra_bytes > 0 is added to
  * the size of that allocation for the handles created afterwards, so that a test can make it fail; 0 restores it. */

@@ -17,6 +17,10 @@ class FakeChromosome(object):
     def close(self):
         pass
 
+    def subsample(self, rows):
+        rows = np.asarray(rows, np.int64)
+        return FakeChromosome(self.X[rows], self.Y[rows], self.device)
+
     def set_profiling(self, on=True):
         pass
 

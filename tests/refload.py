@@ -183,3 +183,37 @@ def ref_stripes_namespace():
     exec(compile(ast.Module(body=body, type_ignores=[]), "callStripes:functions", "exec"), ns)
     _cache["stripes"] = ns
     return ns
+
+
+def ref_saturation_namespace():
+    """The functions of scripts/jd2saturation that can be pinned (generateSamplingData :32-55, singleDBSCAN :56-108,
+    runDBSCAN :111-127, getLoops :154-178), extracted from the parsed script -- it cannot be imported: `from cLoops.pipe import
+    checkOverlap` (:25) names a function cLoops/pipe.py does not have -- and exec'd in a namespace wired to the REAL
+    variant-1 class, the real parseJd / filterClusterByDis / combineTwice / estIntSelCutFrag; `runStat` is replaced by a
+    recorder (the significance step has its own goldens).  Mechanical py2 -> py3 patch: xrange -> range.  Used to MAKE golden
+    vectors only."""
+    import ast
+    import numpy as np
+    import pandas as pd
+    import joblib
+    if "saturation" in _cache:
+        return _cache["saturation"]
+    pn = ref_pipe_namespace("v1")
+
+    class _Log(object):
+        def info(self, *a):
+            pass
+        warning = error = info
+    ns = {"np": np, "pd": pd, "os": os, "joblib": joblib, "logger": _Log(), "DBSCAN": ref_classes()["v1"], "parseJd": pn["parseJd"],
+          "estIntSelCutFrag": ref_ests().estIntSelCutFrag, "filterClusterByDis": pn["filterClusterByDis"], "combineTwice": pn["combineTwice"],
+          "recorded": []}
+    ns["runStat"] = lambda dataI, minPts, cut, fout, hic=0: ns["recorded"].append((dataI, minPts, cut, fout)) or 0
+    with open(os.path.join(REF_ROOT, "scripts", "jd2saturation")) as fh:
+        src = fh.read().replace("xrange", "range")
+    tree = ast.parse(src)
+    want = {"generateSamplingData", "singleDBSCAN", "runDBSCAN", "getLoops"}
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert len(body) == len(want)
+    exec(compile(ast.Module(body=body, type_ignores=[]), "jd2saturation:functions", "exec"), ns)
+    _cache["saturation"] = ns
+    return ns
