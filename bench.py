@@ -45,12 +45,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# three hardware queues serve the 23 per-chromosome streams best (1 queue 0.270 s per sweep, 2 -> 0.190,
-# 3 -> 0.175, 4 -> 0.195, 5 .. 8 -> 0.174 .. 0.186, 12+ -> 0.24 .. 0.33 -- but from 8 queues on the runs that copy labels to the host
-# every step fall off a cliff: with_labels 3.8 s instead of 0.28 s); an application-level choice -- the library itself touches no
-# environment variable -- that has to be made before the first HIP call of the process; an explicit setting wins
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
-
 N_TOTAL = 200000000
 MODE3 = ([5000, 7500, 10000], [50, 40, 30, 20])        # cLoops/pipe.py:337-340
 CFG = 3                                                 # seed family of cloops_amd.synth.synth_genome

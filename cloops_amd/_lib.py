@@ -30,7 +30,7 @@ SYMBOLS = [
     "cl_get_timing", "cl_version", "cl_host_alloc", "cl_host_free", "cl_cluster_async", "cl_wait", "cl_boxes_host",
     "cl_dist_summary", "cl_dist_bin_hist", "cl_last_n_in", "cl_sig_counts", "cl_cluster_weighted",
     "cl_set_layout_reuse", "cl_set_sort_index", "cl_set_device_labels", "cl_set_table_export", "cl_cand_reset", "cl_cand_append", "cl_cand_finish", "cl_cluster_step_async", "cl_step_result",
-    "cl_set_count_reuse", "cl_set_count_floor", "cl_last_region_mode", "cl_debug_arena_overcommit", "cl_chrom_subsample",
+    "cl_set_count_reuse", "cl_set_count_floor", "cl_last_region_mode", "cl_debug_arena_overcommit", "cl_chrom_subsample", "cl_stream_create", "cl_stream_destroy",
 ]
 
 
@@ -69,10 +69,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    # (The library reads and writes no environment variable.  An APPLICATION that keeps many chromosome handles busy at
-    # once -- the sweep driver keeps one stream per chromosome -- may want GPU_MAX_HW_QUEUES=3 in the environment before the
-    # first HIP call of the process: the HIP runtime multiplexes streams onto that many hardware queues (default 4), and three
-    # serve this pipeline best; bench.py and `python -m cloops_amd` set it unless the user has)
+    # (The library reads and writes no environment variable; how many runs execute side by side is decided by the streams the
+    # application hands to cl_chrom_create -- the sweep driver shares three per GPU)
     path = SO_PATH
     if os.environ.get("CLOOPS_DEVEL_LIB") == "1":          # developer build with ablation knobs (cloops_amd/build.py --devel)
         path = SO_PATH.replace(".so", "_devel.so")
@@ -144,6 +142,10 @@ def load():
     lib.cl_set_count_floor.argtypes = [vp, ctypes.c_int32]
     lib.cl_last_region_mode.restype = ctypes.c_int
     lib.cl_last_region_mode.argtypes = [vp]
+    lib.cl_stream_create.restype = vp
+    lib.cl_stream_create.argtypes = [ctypes.c_int]
+    lib.cl_stream_destroy.restype = None
+    lib.cl_stream_destroy.argtypes = [vp]
     lib.cl_chrom_subsample.restype = ctypes.c_int
     lib.cl_chrom_subsample.argtypes = [vp, vp, ctypes.c_int64, ctypes.POINTER(vp)]
     lib.cl_debug_arena_overcommit.restype = None

@@ -162,6 +162,7 @@ struct cl_chrom {
     bool sig_ready = false; int sig_cut = 0;
     bool k7_classified = false;       // k7_cls matches the last completed run
     hipStream_t copy_stream = nullptr, aux_stream = nullptr;
+    int copy_mode = 0;                // 0: the D2H copies of a run go through copy_stream, 1: they are issued in `stream` (caller's stream)
     int enq = 0, deq = 0;             // runs enqueued / completed
     int cur = 0;                      // slot of the run being enqueued
     // last completed result

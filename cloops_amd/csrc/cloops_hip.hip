@@ -46,6 +46,14 @@ extern "C" void* cl_host_alloc(int64_t bytes)
 }
 extern "C" void cl_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+extern "C" void* cl_stream_create(int device)
+{
+    hipStream_t s = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { fail(CL_ERR_HIP, "hipStreamCreate"); return nullptr; }
+    return (void*)s;
+}
+extern "C" void cl_stream_destroy(void* stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
+
 extern "C" int cl_device_count(void)
 {
     int n = 0;
@@ -1697,6 +1705,12 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
             // copies must not queue up behind the next run's kernels: give their streams the highest priority
             int prio_lo = 0, prio_hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+            // A handle with a stream of its own sends the D2H copies of a run through a copy stream (behind an event: they overlap
+            // the kernels of its next run).  A handle on a stream the CALLER made -- typically shared by several handles, whose
+            // kernels overlap each other anyway -- issues them in that stream: a copy stream per handle waiting on events of
+            // other hardware queues is what made the label-copying forms fall off a cliff (23 handles, 8 hardware queues: 3 s
+            // per sweep instead of 0.05 s -- head-of-line blocking of the queues the copy streams share).
+            c->copy_mode = c->own_stream ? 0 : 1;
             if (hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
                 hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipStreamCreate(copy)"); break; }
         }
@@ -2483,12 +2497,13 @@ int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* labels_ou
     if (sl.wait_done) {
         // sweep step: k7_reduce_parts has stored header and step output in pinned host memory; completion = the run's own event
     } else {
-        HIP_TRY(hipStreamWaitEvent(c->copy_stream, sl.ev_done, 0));
-        HIP_TRY(hipMemcpyAsync(sl.h_hdr, dh, 32, hipMemcpyDeviceToHost, c->copy_stream));
-        if (sl.step_valid) HIP_TRY(hipMemcpyAsync(sl.h_step, sl.d_step.p, 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8, hipMemcpyDeviceToHost, c->copy_stream));
-        if (labels_out) HIP_TRY(hipMemcpyAsync(labels_out, sl.labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->copy_stream));
-        if (c->profiling) (void)hipEventRecord(sl.ev[7], c->copy_stream);
-        HIP_TRY(hipEventRecord(sl.ev_copied, c->copy_stream));
+        hipStream_t cs = c->copy_mode == 1 ? c->stream : c->copy_stream;
+        if (cs != c->stream) HIP_TRY(hipStreamWaitEvent(cs, sl.ev_done, 0));
+        HIP_TRY(hipMemcpyAsync(sl.h_hdr, dh, 32, hipMemcpyDeviceToHost, cs));
+        if (sl.step_valid) HIP_TRY(hipMemcpyAsync(sl.h_step, sl.d_step.p, 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8, hipMemcpyDeviceToHost, cs));
+        if (labels_out) HIP_TRY(hipMemcpyAsync(labels_out, sl.labels.p, (size_t)n * 4, hipMemcpyDeviceToHost, cs));
+        if (c->profiling) (void)hipEventRecord(sl.ev[7], cs);
+        HIP_TRY(hipEventRecord(sl.ev_copied, cs));
     }
     sl.pending = true;
     sl.n_strips = n_strips;

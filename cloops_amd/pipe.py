@@ -47,6 +47,65 @@ def parseJd(f, cut=0):
 # ---------------------------------------------------------------------------------------
 # resident chromosomes
 # ---------------------------------------------------------------------------------------
+#: The chromosomes of one GPU share this many HIP streams (0: every chromosome gets a stream of its own).  A sweep step
+#: enqueues every chromosome's run and then collects them; how many of those runs execute side by side is what the streams
+#: decide.  One stream per chromosome leaves that to how the HIP runtime maps 23+ streams onto its hardware queues
+#: (GPU_MAX_HW_QUEUES, default 4): measured on the 200 M-PET mode-3 sweep 1 queue 0.270 s, 2: 0.190, 3: 0.175, 4: 0.195,
+#: 8: 0.174, 12+: 0.24-0.32 -- and the forms that copy labels to the host every run fell off a cliff at 8 (DESIGN.md
+#: section 8).  Three shared streams, filled largest chromosome first, are the measured optimum made explicit: the same
+#: schedule whatever the environment says.
+SWEEP_STREAMS = 3
+
+
+class _StreamPool(object):
+    """per device: up to SWEEP_STREAMS library-made streams (cl_stream_create), handed out to the least loaded one; they
+    live as long as the process (handles may outlive the cache entry that made them)"""
+
+    def __init__(self):
+        self._by_dev = {}
+        self._lock = threading.Lock()
+
+    def pick(self, device, n):
+        if SWEEP_STREAMS <= 0:
+            return None, None
+        from . import _lib
+        with self._lock:
+            slots = self._by_dev.setdefault(device, [])
+            if len(slots) < SWEEP_STREAMS:
+                ptr = _lib.load().cl_stream_create(int(device))
+                if not ptr:                               # (no such device: the handle's own creation reports it)
+                    return None, None
+                slots.append([ptr, 0])
+            slot = min(slots, key=lambda s: s[1])
+            slot[1] += max(1, int(n))
+            return slot[0], slot
+
+    @staticmethod
+    def release(slot, n):
+        if slot is not None:
+            slot[1] -= max(1, int(n))
+
+
+STREAMS = _StreamPool()
+
+
+def _make_chrom(X, Y, device):
+    """a resident chromosome on one of the device's shared streams; -> (chromosome, pool slot)"""
+    stream, slot = STREAMS.pick(device, len(X))
+    try:
+        ch = api.Chromosome(X, Y, device=device, stream=stream) if stream else api.Chromosome(X, Y, device=device)
+    except Exception:
+        _StreamPool.release(slot, len(X))
+        raise
+    close = ch.close
+
+    def close_and_release():
+        close()
+        _StreamPool.release(close_and_release.slot, len(X))
+        close_and_release.slot = None
+    close_and_release.slot = slot
+    ch.close = close_and_release
+    return ch
 class _Resident(object):
     __slots__ = ("key", "ids", "X", "Y", "d", "chrom", "device", "stamp", "lock", "pins", "sweep_lock", "replaced")
 
@@ -123,7 +182,7 @@ class ChromCache(object):
         r.Y = np.ascontiguousarray(Y)
         r.ids = np.arange(len(r.X), dtype=np.int64) if ids is None else np.asarray(ids)
         r.d = r.Y.astype(np.int64) - r.X.astype(np.int64)
-        r.chrom = api.Chromosome(r.X, r.Y, device=device)
+        r.chrom = _make_chrom(r.X, r.Y, device)
         r.chrom.set_device_labels(False)        # runs without a host destination (the sweep) skip the row-order scatter
         with self._lock:
             old = self._items.pop(f, None)
@@ -201,7 +260,7 @@ class ChromCache(object):
         else:
             r.ids = r.X = r.Y = np.zeros(0, np.int64)
         r.d = r.Y - r.X
-        r.chrom = api.Chromosome(r.X, r.Y, device=device)
+        r.chrom = _make_chrom(r.X, r.Y, device)
         r.chrom.set_device_labels(False)
         with self._lock:
             old = self._items.pop(f, None)

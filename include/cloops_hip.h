@@ -278,6 +278,15 @@ void cl_set_count_reuse(cl_chrom* c, int enabled);
 void cl_set_count_floor(cl_chrom* c, int32_t min_pts);
 int cl_last_region_mode(const cl_chrom* c);
 
+/* A HIP stream for cl_chrom_create(..., stream, ...) made by the library (for callers without a HIP binding of their
+ * own, like the ctypes host side).  Several handles may share one stream: their runs then execute in enqueue order in
+ * that stream, and the D2H copies of a run are issued in it too (a handle with a stream of its own -- stream == NULL at
+ * creation -- overlaps them with its next run through a copy stream).  The sweep driver keeps a few shared streams per
+ * device instead of one per chromosome: how many kernels run side by side is then the application's choice, not a
+ * property of how the runtime maps dozens of streams onto its hardware queues.  Destroy a stream after its handles. */
+void* cl_stream_create(int device);
+void cl_stream_destroy(void* stream);
+
 /* Page-locked host memory for result buffers (labels_out / boxes_out / counts_out): D2H
  * copies into pinned memory run at PCIe rate instead of through a staging buffer.  Plain
  * malloc'ed memory works everywhere too, only slower. */

@@ -4,7 +4,6 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cloops_amd import pipe
 from cloops_amd.synth import synth_chrom, chrom_sizes
