@@ -69,18 +69,34 @@ __device__ __forceinline__ void table_accumulate(const Table& t, TableLds& h, in
                 atomicMin(&t.miny[L], mny); atomicMax(&t.maxy[L], mxy);
             }
         }
-    } else if (lab >= 0) {
-        // several clusters (and noise) in the wave: every lane straight into the LDS table -- lanes of one cluster meet on
-        // one LDS address, which the LDS unit serialises at a fraction of what a loop over the distinct labels costs
-        const int sl = tab_slot(h.key, lab);
-        if (sl >= 0) {
-            atomicAdd(&h.cnt[sl], 1);
-            atomicMin(&h.mnx[sl], x); atomicMax(&h.mxx[sl], x);
-            atomicMin(&h.mny[sl], y); atomicMax(&h.mxy[sl], y);
-        } else {
-            atomicAdd(&t.count[lab], 1);
-            atomicMin(&t.minx[lab], x); atomicMax(&t.maxx[lab], x);
-            atomicMin(&t.miny[lab], y); atomicMax(&t.maxy[lab], y);
+    } else {
+        // several clusters (and noise) in the wave.  Sorted order keeps a cluster's PETs of one strip in NEIGHBOURING lanes: the
+        // wave is cut into runs of equal labels, every run is reduced over its lanes (segmented shuffles: a lane takes the
+        // partial of the lane d further on while that lane still belongs to its run) and only the first lane of a run goes to
+        // the LDS table -- one set of atomics per run instead of one per PET, and no two lanes of a run on one LDS address.
+        const int prev = __shfl_up(lab, 1);
+        const bool brk = lane == 0 || prev != lab;
+        const unsigned long long B = __ballot(brk);
+        const unsigned long long rest = lane == 63 ? 0ull : (B >> (lane + 1));
+        const int nb = rest ? lane + __ffsll((long long)rest) : 64;        // first lane behind this lane's run
+        int mnx = x, mxx = x, mny = y, mxy = y;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int a = __shfl_down(mnx, d), b = __shfl_down(mxx, d), c = __shfl_down(mny, d), e = __shfl_down(mxy, d);
+            if (lane + d < nb) { mnx = min(mnx, a); mxx = max(mxx, b); mny = min(mny, c); mxy = max(mxy, e); }
+        }
+        if (brk && lab >= 0) {
+            const int cm = nb - lane;
+            const int sl = tab_slot(h.key, lab);
+            if (sl >= 0) {
+                atomicAdd(&h.cnt[sl], cm);
+                atomicMin(&h.mnx[sl], mnx); atomicMax(&h.mxx[sl], mxx);
+                atomicMin(&h.mny[sl], mny); atomicMax(&h.mxy[sl], mxy);
+            } else {
+                atomicAdd(&t.count[lab], cm);
+                atomicMin(&t.minx[lab], mnx); atomicMax(&t.maxx[lab], mxx);
+                atomicMin(&t.miny[lab], mny); atomicMax(&t.maxy[lab], mxy);
+            }
         }
     }
 }

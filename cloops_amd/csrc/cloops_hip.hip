@@ -1675,6 +1675,13 @@ __global__ void k_init_pads(int* __restrict__ svbuf, int* __restrict__ sabuf, lo
 }
 
 static int reserve_workspace(cl_chrom* c);
+#ifdef CLOOPS_DEVEL
+// developer build: CLOOPS_SKIP=<mask> leaves kernels of a run out (results invalid; what a kernel costs the SWEEP, not its own time)
+static int skip_mask() { static const int m = getenv("CLOOPS_SKIP") ? atoi(getenv("CLOOPS_SKIP")) : 0; return m; }
+#define SKIP(bit) (skip_mask() & (bit))
+#else
+#define SKIP(bit) 0
+#endif
 
 extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const int32_t* y, int64_t n,
                                int on_device, cl_chrom** out)
@@ -2300,7 +2307,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     }
     ev_record(c, 2);
     rc = CL_OK;
-    if (!k2_skip && !k2_band) rc = cl_launch_region(c->stream, gk, n, c->run_m, exact, c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->w_cnt);
+    if (!k2_skip && !k2_band && !SKIP(256)) rc = cl_launch_region(c->stream, gk, n, c->run_m, exact, c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->w_cnt);
     if (rc) return rc;
     ev_record(c, 3);
     HIP_TRY(hipGetLastError());
@@ -2480,7 +2487,7 @@ int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* labels_ou
         src.sorted = sl.sorted_src ? 1 : 0; src.n = n; src.M = 0; src.v0 = sl.k7_v0; src.dM = d_M;
         src.X = c->d_x; src.Y = c->d_y; src.labels = sl.labels.as<int>(); src.sv = sl.k7_sv; src.slab = sl.slab.as<int>();
         src.dh = k7_hist_for(c, c->pending_cut);
-        hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, src, c->pending_cut, cls, parts, lh,
+        if (!SKIP(16)) hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, src, c->pending_cut, cls, parts, lh,
                            (unsigned)c->pending_fine_lo, c->pending_fine_lo >= 0 ? lh + K7_LOGBINS : (unsigned long long*)nullptr);
         static_assert((16 + sizeof(K7Part)) % 8 == 0, "step output in 8-byte words");
         hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, (const K7Part*)parts, K7_BLOCKS, (K7Part*)(ds + 16),
@@ -2771,14 +2778,14 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         int* head = variant == CL_VARIANT_CDBSCAN2 ? c->head.as<int>() : nullptr;
         if (wide == 0) {
             const int nt_c = nblocks(nm, 1024);
-            hipLaunchKernelGGL((k_chain_flags<1024, 128, TPB>), dim3(tile_grid(nt_c)), dim3(TPB), 0, c->stream, g, nt_c, nm, sv, sa, strip, ws,
+            if (!SKIP(32)) hipLaunchKernelGGL((k_chain_flags<1024, 128, TPB>), dim3(tile_grid(nt_c)), dim3(TPB), 0, c->stream, g, nt_c, nm, sv, sa, strip, ws,
                                cflag, head, c->chainhead.as<int>() /* wavelast: the buffer is free until the labels */, srow, c->cellfirst.as<int>());
         } else
         TILE_LAUNCH(k_chain_flags, g, ntiles, nm, sv, sa, strip, ws, cflag,
                            head, c->chainhead.as<int>() /* wavelast: the buffer is free until the labels */, srow, c->cellfirst.as<int>());
         // long strips (dense data at large eps): 32-PET block summaries for the union scan (`hi` is free until K4)
         pmax32 = ((long long)n > 64LL * g.S) ? c->hi.as<int>() : nullptr;
-        LAUNCH(k_chain_parent, (nm + CP_PER - 1) / CP_PER, strip, g.S, (const unsigned char*)cflag, c->chainhead.as<int>(), c->parent.as<int>(), c->chainflag.as<int>(),
+        if (!SKIP(64)) LAUNCH(k_chain_parent, (nm + CP_PER - 1) / CP_PER, strip, g.S, (const unsigned char*)cflag, c->chainhead.as<int>(), c->parent.as<int>(), c->chainflag.as<int>(),
                c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                sv, c->lo.as<int>(), sa, pmax32);   // chain ends live in `lo` until the release fix-up reuses it
     }
@@ -2787,14 +2794,14 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     const int union_halo = (long long)n > 40LL * g.S ? 256 : 128;
     if (wide == 0) {
         const int nt_u = nblocks(nm, 1024);
-        if (union_halo == 256) hipLaunchKernelGGL((k_union_cores<1024, 256, TPB>), dim3(tile_grid(nt_u)), dim3(TPB), 0, c->stream, g, nt_u, sv, sa, strip,
+        if (SKIP(2)) { } else if (union_halo == 256) hipLaunchKernelGGL((k_union_cores<1024, 256, TPB>), dim3(tile_grid(nt_u)), dim3(TPB), 0, c->stream, g, nt_u, sv, sa, strip,
                                                   c->chainflag.as<int>(), c->lo.as<int>(), pmax32, c->parent.as<int>());
         else hipLaunchKernelGGL((k_union_cores<1024, 128, TPB>), dim3(tile_grid(nt_u)), dim3(TPB), 0, c->stream, g, nt_u, sv, sa, strip,
                                 c->chainflag.as<int>(), c->lo.as<int>(), pmax32, c->parent.as<int>());
     } else
     TILE_LAUNCH_H((wide == 2 || wide == 4) ? 512 : union_halo, k_union_cores, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
                        pmax32, c->parent.as<int>());
-    hipLaunchKernelGGL(k_flatten, dim3(nblocks(nm, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, g, strip, (const int*)nullptr, (const int*)c->chainflag.as<int>(),
+    if (!SKIP(4)) hipLaunchKernelGGL(k_flatten, dim3(nblocks(nm, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, g, strip, (const int*)nullptr, (const int*)c->chainflag.as<int>(),
            c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
            c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->rootlist.as<int>(), counters);
     int* rootlist = c->rootlist.as<int>();
@@ -2803,7 +2810,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     if (wide == 0) {
         // 1024 PETs per workgroup of 256 threads (4 per thread in the first pass, the walkers of the whole tile in one list)
         const int nt_b = nblocks(std::max(1, c->run_m), 1024);
-        hipLaunchKernelGGL((k_border<1024, 128, TPB>), dim3(tile_grid(nt_b)), dim3(TPB), 0, c->stream, g, nt_b, sv, sa, strip, c->root.as<int>(),
+        if (!SKIP(1)) hipLaunchKernelGGL((k_border<1024, 128, TPB>), dim3(tile_grid(nt_b)), dim3(TPB), 0, c->stream, g, nt_b, sv, sa, strip, c->root.as<int>(),
                            c->compkey.as<int>(), c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), ws, c->tileflag.as<int>());
     } else
     TILE_LAUNCH_H((wide >= 2 && wide <= 4) ? 512 : (wide >= 5 ? 256 : 128), k_border, g, ntiles, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(),
@@ -2812,7 +2819,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         const int rec_cap = n;
         hipLaunchKernelGGL(k_mark_uncertain_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, c->ncore.as<int>(), c->bsize.as<int>(), c->state.as<int>(),
                            c->ulist.as<int>(), counters);
-        TILE_LAUNCH(k_emit_records, g, ntiles, sv, sa, strip, c->root.as<int>(),
+        if (!SKIP(128)) TILE_LAUNCH(k_emit_records, g, ntiles, sv, sa, strip, c->root.as<int>(),
                            c->compkey.as<int>(), c->state.as<int>(), c->owner.as<int>(), c->recs.as<Rec>(), rec_cap, counters,
                            (const int*)c->tileflag.as<int>(), ntiles);
         hipLaunchKernelGGL(k_resolve_release, dim3(1), dim3(1024), 0, c->stream, minPts, c->ncore.as<int>(), c->usize.as<int>(), c->state.as<int>(),
@@ -2835,7 +2842,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
                        c->state.as<int>(), c->flag.as<unsigned>(), c->rankscan.as<int>(), c->chainhead.as<int>(), t, nw,
                        c->hdr.as<int>() + 16 * c->cur, (const int*)(strip + g.S));
     c->hdr_packed = true;
-    hipLaunchKernelGGL(k_final_labels, dim3(nblocks(nm, BIGTPB * FINAL_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow, c->owner.as<int>(),
+    if (!SKIP(8)) hipLaunchKernelGGL(k_final_labels, dim3(nblocks(nm, BIGTPB * FINAL_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow, c->owner.as<int>(),
                        c->chainhead.as<int>(), rows ? c->slot[c->cur].labels.as<int>() : (int*)nullptr, c->slot[c->cur].slab.as<int>(), t);
     HIP_TRY(hipGetLastError());
     return finish_enqueue(c, g.S + 2, strip + g.S, labels_out);

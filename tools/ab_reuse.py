@@ -1,5 +1,5 @@
 """developer tool: the 200 M-PET mode-3 sweep with the region-query reuse (count cache) on / off, alternating inside ONE
-process on one box (sweeps inside a process reproduce to +-0.5 %).   python tools/ab_reuse.py [reps] [n_total]"""
+process on one box (sweeps inside a process reproduce to +-0.5 %).   python tools/ab_reuse.py [reps] [n_total] [mode 3 | 4 | 5]"""
 import os
 import sys
 import time
@@ -14,7 +14,8 @@ fs = []
 for ci, (name, length, n) in enumerate(chrom_sizes(n_total)):
     X, Y = synth_chrom(n, length, 3000 + ci)
     fs.append(pipe.CACHE.put_arrays("%s-%s" % (name, name), X, Y))
-eps, mps = [5000, 7500, 10000], [50, 40, 30, 20]
+MODES = {3: ([5000, 7500, 10000], [50, 40, 30, 20]), 4: ([2500, 5000, 7500, 10000], [30, 20]), 5: (list(range(1000, 10001, 1000)), [50, 30, 20, 10, 5])}
+eps, mps = MODES[int(sys.argv[3]) if len(sys.argv) > 3 else 3]
 
 
 def sweep(on):
@@ -34,4 +35,4 @@ for k in range(reps):
 for on in (True, False):
     v = sorted(tot[on])
     print("count reuse %-3s: median %.1f ms, min %.1f ms  %s" % ("on" if on else "off", 1e3 * v[len(v) // 2], 1e3 * v[0], ["%.1f" % (1e3 * x) for x in tot[on]]))
-print("final cut", cut, cuts)
+print("final cut", cut, cuts[:12])
