@@ -371,6 +371,27 @@ struct WordSrc {
         if (!D) return rc[i];
         return q < bandq ? band[i] : rc[i + D[sp >> rbits]];
     }
+    // the same in two steps, so that a thread can have the loads of several PETs in flight: where() -> the table entries, then
+    // load(), then shifted()
+    struct Where { const int* src; int idx, dA, dB; };
+    __device__ __forceinline__ Where where(int i, int q, int sp) const
+    {
+        Where w; w.src = rc; w.idx = i; w.dA = 0; w.dB = 0;
+        if (D) {
+            if (q < bandq) w.src = band;
+            else { const int s = sp >> rbits; w.idx = i + D[s]; w.dA = dpre[s]; w.dB = dpre[s + 1]; }
+        }
+        return w;
+    }
+    __device__ __forceinline__ int shifted(int w, const Where& at) const
+    {
+        if ((at.dA | at.dB) != 0 && w < 0 && ((unsigned)w & K2H_NONE) != K2H_NONE) {
+            const int da = (int)((unsigned)w & K2H_MASK) - at.dA, db = (int)(((unsigned)w >> K2H_BITS) & K2H_MASK) - at.dB;
+            const bool ok = (da >= 0) & (da < (int)K2H_MASK) & (db >= 0) & (db < (int)K2H_MASK);
+            w = (int)(((unsigned)w & ~K2H_NONE) | (ok ? ((unsigned)da | ((unsigned)db << K2H_BITS)) : K2H_NONE));
+        }
+        return w;
+    }
     __device__ __forceinline__ int word(int i, int q, int sp) const
     {
         if (!D) return rc[i];

@@ -525,12 +525,17 @@ __device__ __forceinline__ void tile_visit_segment(const Tile& t, const int* __r
 // (most windows of non-core PETs end there); longer windows go from set bit to set bit of the tile's mask, and the pair at
 // the start of the next mask word tells whether the window reaches it.  What lies outside the staged range (the
 // sentinel pads included in it) is read from global memory.
-template <int T_WIN, typename MORE, typename ACC, typename SEE>
+// skip(x): the walk may pass over a staged PET with payload x without looking at its pair (k_border, variant 2: a core of a
+// component the point is already known to be adjacent to cannot change anything -- a window next to a cluster is mostly that).
+template <int T_WIN, typename MORE, typename ACC, typename SEE, typename SKIPF>
 __device__ __forceinline__ void tile_walk_from(const Tile& t, const int* __restrict__ gq, const int* __restrict__ gp,
-                                               const int* __restrict__ gx, int M, int j, MORE&& more, ACC&& acc, SEE&& see)
+                                               const int* __restrict__ gx, int M, int j, MORE&& more, ACC&& acc, SEE&& see, SKIPF&& skip, int dbg = 0)
 {
     const int base = t.w.base;
     int k = j - base;
+#ifdef CLOOPS_DEVEL
+    if ((dbg & 4194304) && !(k >= 0 && k + 4 <= T_WIN)) return;       // developer ablation: no walk that starts outside the staged range
+#endif
     if (k >= 0 && k + 4 <= T_WIN) {
         const int2* __restrict__ lw = t.w.a; const int* __restrict__ lx = t.x.a;
         {
@@ -545,7 +550,43 @@ __device__ __forceinline__ void tile_walk_from(const Tile& t, const int* __restr
             }
             if (out) return;
         }
+#ifdef CLOOPS_DEVEL
+        if (dbg & 2097152) return;                                       // developer ablation: the first four candidates only
+#endif
         k += 4;
+        {
+            // The window goes on: where does it end?  more() is monotone along the sorted order, so its end among the next 63
+            // staged PETs is a 6-step search on the pairs; the cores of exactly that stretch are the set bits of a 64-bit slice of
+            // the mask (it may straddle two words) -- they are visited without asking more() again, and none beyond the end.
+            int len = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const int idx = k + len + step - 1;
+                const int2 v = lw[min(idx, T_WIN - 1)];
+                len = (idx < T_WIN && more(v)) ? len + step : len;
+            }
+            const int w0 = k >> 6, sh = k & 63;
+            constexpr int NW = T_WIN / 64;
+            unsigned long long win = t.m[w0] >> sh;
+            if (sh && w0 + 1 < NW) win |= t.m[w0 + 1] << (64 - sh);
+            win &= (1ull << len) - 1ull;                          // len <= 63
+            while (win) {                                        // two cores per round
+                const int i0 = k + __ffsll((long long)win) - 1;
+                win &= win - 1;
+                const bool two = win != 0;
+                const int i1 = two ? k + __ffsll((long long)win) - 1 : i0;
+                win &= win - 1;
+                const int x0 = lx[i0], x1 = lx[i1];
+                const bool s0 = skip(x0), s1 = !two || skip(x1);
+                if (s0 & s1) continue;
+                const int2 c0 = lw[i0], c1 = lw[i1];
+                if (!s0 && acc(c0)) see(i0 + base, x0);
+                if (!s1 && acc(c1)) see(i1 + base, x1);
+            }
+            if (k + len >= T_WIN) { j = T_WIN + base; goto global_part; }       // the window reaches the end of the staged range: global memory
+            if (len < 63) return;                                // the window ended inside the slice
+            k += 63;
+        }
         while (k < T_WIN) {
             const int knext = (k | 63) + 1;
             unsigned long long bits = t.m[k >> 6] >> (k & 63);
@@ -557,11 +598,16 @@ __device__ __forceinline__ void tile_walk_from(const Tile& t, const int* __restr
                 const bool two = bits != 0;
                 const int i1 = two ? k + __ffsll((long long)bits) - 1 : i0;
                 bits &= bits - 1;
-                const int2 c0 = lw[i0], c1 = lw[i1];
                 const int x0 = lx[i0], x1 = lx[i1];
-                if (!more(c0)) return;
-                if (acc(c0)) see(i0 + base, x0);
-                if (two) {
+                const bool s0 = skip(x0), s1 = !two || skip(x1);
+                if (s0 & s1) continue;                          // (passing over them may carry the walk beyond the window's end, inside
+                                                                //  this mask word: the next PET that is looked at ends it)
+                const int2 c0 = lw[i0], c1 = lw[i1];
+                if (!s0) {
+                    if (!more(c0)) return;
+                    if (acc(c0)) see(i0 + base, x0);
+                }
+                if (!s1) {
                     if (!more(c1)) return;
                     if (acc(c1)) see(i1 + base, x1);
                 }
@@ -571,6 +617,10 @@ __device__ __forceinline__ void tile_walk_from(const Tile& t, const int* __restr
         }
         j = k + base;
     }
+global_part:
+#ifdef CLOOPS_DEVEL
+    if (dbg & 8388608) return;                                           // developer ablation: nothing in global memory
+#endif
     for (;;) {
         int q[4], p[4], x[4];
 #pragma unroll
@@ -1181,19 +1231,38 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
     Tile t;
     if (threadIdx.x == 0) l_total = 0;
     if (!tile_stage<NT, HALO, NTH>(t, lw, lx, ntiles, M, sv, sa, root, l_mask)) return;
+#ifdef CLOOPS_DEVEL
+#define KB_ABL(bit) (g.dbg & (bit))
+    if (KB_ABL(65536)) return;                           // developer ablation (results invalid): staging only
+#else
+#define KB_ABL(bit) 0
+#endif
     // first pass, NT / NTH PETs per thread: cores keep their root, isolated non-cores are noise, the rest has to walk
+    // (the K2 words of the thread's non-core PETs: table entries first, then the words -- all loads of a stage in flight together)
+    constexpr int PER = NT / NTH;
+    int ri_[PER], enc_[PER];
+    WordSrc::Where at_[PER];
 #pragma unroll
-    for (int u = 0; u < NT / NTH; ++u) {
+    for (int u = 0; u < PER; ++u) {
+        const int tix = (int)threadIdx.x + u * NTH, i0 = t.t0 + tix;
+        ri_[u] = i0 < M ? t.x[i0] : 0;
+        const int2 pe = t.w[i0 < M ? i0 : t.t0];
+        at_[u] = ws.where(i0, pe.x, pe.y);
+        if (ri_[u] >= 0) at_[u].src = nullptr;
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) enc_[u] = at_[u].src ? at_[u].src[at_[u].idx] : 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
         const int tix = (int)threadIdx.x + u * NTH, i0 = t.t0 + tix;
         bool border = false;
         if (i0 < M) {
-            const int ri = t.x[i0];
+            const int ri = ri_[u];
             if (ri >= 0) owner[i0] = ri;
             else {
                 // K2 left either the neighbour count of a non-core PET (itself included) or its word with count and hints
                 // (k_region_core): a count <= 1 = nothing within eps -- most of the background noise ends here
-                const int2 pe = t.w[i0];
-                const int enc = ws.word(i0, pe.x, pe.y);
+                const int enc = ws.shifted(enc_[u], at_[u]);
                 l_enc[tix] = enc;
                 if (cw_count(enc) <= 1) owner[i0] = -1; else border = true;
             }
@@ -1209,7 +1278,7 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
         if (border) l_list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (short)tix;
     }
     __syncthreads();
-    const int total = l_total;
+    const int total = KB_ABL(131072) ? 0 : l_total;      // (ablation: no walkers)
     for (int h = (int)threadIdx.x; h < total; h += NTH) {
     const int i = t.t0 + l_list[h];
     const int enc = l_enc[l_list[h]];
@@ -1217,9 +1286,11 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
     const int qlo = sat_add(me.x, -g.eps), qhi = sat_add(me.x, g.eps);
     const bool v1 = g.variant == CL_VARIANT_CDBSCAN1;
     int bestk = INT_MAX, best = -1, tk = -1, tbest = -1, lastr = -1, lastk = 0, first = -1;
+    int adj = -1;                                       // variant 2: the component seen last (cores of it are passed over from then on)
     bool contested = false;
     auto see = [&](int j, int r) {
         if (r < 0) return;
+        if (!v1) adj = r;
         if (first < 0) first = r; else if (r != first) contested = true;
         int k;
         if (r == lastr) k = lastk; else { k = compkey[r]; lastr = r; lastk = k; }
@@ -1237,7 +1308,7 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
         // "same strip" and "still inside the neighbour strip" are predicates of the staged pairs.
         const int pbeg = me.y & ~(g.peps - 1), pend = pbeg + g.peps, pend2 = pend + g.peps;
         const int plo = me.y - g.peps, phi = me.y + g.peps;
-        {
+        if (!KB_ABL(262144)) {
             const int lb = max(i - (g.minPts - 1), t.w.base), re = min(i + g.minPts, t.w.base + T_WIN);
             const int jl = t.prev_set(i - 1, lb), jr = t.next_set(i + 1, re);
             const bool hl = jl >= lb, hr = jr < re;
@@ -1247,10 +1318,12 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
             if (hr && cr.y < pend && cr.x <= qhi) see(jr, rr);
         }
         const int ja = i - (int)((unsigned)enc & K2H_MASK), jb = i + (int)(((unsigned)enc >> K2H_BITS) & K2H_MASK);
+        if (!KB_ABL(524288))
         tile_walk_from<T_WIN>(t, sv, sa, root, M, ja, [&](int2 c) { return (c.y < pbeg) & (c.x <= qhi); },
-                              [&](int2 c) { return c.y >= plo; }, see);       // one strip below: sp can only be too low
+                              [&](int2 c) { return c.y >= plo; }, see, [&](int x) { return x == adj; }, g.dbg);       // one strip below: sp can only be too low
+        if (!KB_ABL(1048576))
         tile_walk_from<T_WIN>(t, sv, sa, root, M, jb, [&](int2 c) { return (c.y < pend2) & (c.x <= qhi); },
-                              [&](int2 c) { return c.y <= phi; }, see);       // one strip above: only too high
+                              [&](int2 c) { return c.y <= phi; }, see, [&](int x) { return x == adj; }, g.dbg);       // one strip above: only too high
     } else {
         const int s = strip_of(g, me.y);
         const int b = strip_start[s], e = strip_start[s + 1];
