@@ -305,7 +305,8 @@ def k2_replay(chrom, settings, floor, passes=3):
     (eps, minPts, cut, timing dict, region mode 0 / 1 / 2 of cl_last_region_mode)."""
     out = {}
     chrom.set_profiling(True)
-    for key, on in (("reuse", True), ("full", False)):
+    only = os.environ.get("CLOOPS_REPLAY_ONLY")                          # "reuse" / "full": one kind of pass (tools/profile_bench.sh)
+    for key, on in [kv for kv in (("reuse", True), ("full", False)) if only in (None, "", kv[0])]:
         chrom.set_count_reuse(on)
         chrom.set_count_floor(floor if on else 0)
         rows = []
@@ -320,6 +321,8 @@ def k2_replay(chrom, settings, floor, passes=3):
     chrom.set_count_reuse(True)
     chrom.set_count_floor(floor)
     chrom.set_profiling(False)
+    if only:
+        out["full" if only == "reuse" else "reuse"] = out[only]
     return out
 
 
