@@ -20,7 +20,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libcloops_comm.so")
 SYMBOLS = ("cl_comm_last_error", "cl_comm_rccl_version", "cl_comm_unique_id", "cl_comm_init", "cl_comm_destroy", "cl_comm_rank", "cl_comm_world",
-           "cl_comm_allreduce_f64", "cl_comm_allreduce_max_f64", "cl_comm_allgather_i32", "cl_comm_gather_i32", "cl_comm_barrier")
+           "cl_comm_allreduce_f64", "cl_comm_allreduce_max_f64", "cl_comm_allgather_i32", "cl_comm_gather_i32", "cl_comm_barrier",
+           "cl_comm_host_alloc", "cl_comm_host_free", "cl_comm_gather_i32_pinned")
 ID_BYTES = 128
 ID_DIR = "/tmp"
 _lib = None
@@ -71,6 +72,11 @@ def load():
     lib.cl_comm_allgather_i32.argtypes = [vp, vp, i64, vp]
     lib.cl_comm_gather_i32.argtypes = [vp, vp, i64, ctypes.c_int, vp]
     lib.cl_comm_barrier.argtypes = [vp]
+    lib.cl_comm_host_alloc.restype = vp
+    lib.cl_comm_host_alloc.argtypes = [i64]
+    lib.cl_comm_host_free.restype = None
+    lib.cl_comm_host_free.argtypes = [vp]
+    lib.cl_comm_gather_i32_pinned.argtypes = [vp, vp, i64, ctypes.c_int, vp]
     _lib = lib
     return lib
 
@@ -159,9 +165,28 @@ class Comm(object):
         return cls(rank, world, local if device is None else device)
 
     def close(self):
+        for k in ("_pin_send", "_pin_recv"):
+            buf = getattr(self, k, None)
+            if buf is not None:
+                self._lib.cl_comm_host_free(ctypes.c_void_p(buf[0]))
+                setattr(self, k, None)
         if getattr(self, "_h", None):
             self._lib.cl_comm_destroy(self._h)
             self._h = None
+
+    def _pinned(self, which, nbytes):
+        """a page-locked int32 buffer of at least nbytes, kept with the communicator (grown on demand) -> numpy view"""
+        buf = getattr(self, which, None)
+        if buf is None or buf[1] < nbytes:
+            if buf is not None:
+                self._lib.cl_comm_host_free(ctypes.c_void_p(buf[0]))
+            want = int(nbytes + nbytes // 4 + 4096)
+            p = self._lib.cl_comm_host_alloc(want)
+            if not p:
+                raise CommError("cl_comm_host_alloc(%d) failed" % want)
+            buf = (p, want)
+            setattr(self, which, buf)
+        return np.ctypeslib.as_array(ctypes.cast(buf[0], ctypes.POINTER(ctypes.c_int32)), shape=(buf[1] // 4,))
 
     def barrier(self):
         _check(self._lib.cl_comm_barrier(self._h))
@@ -186,16 +211,10 @@ class Comm(object):
         """variable-length int32 [K_r, C] tables from every rank -> list of per-rank arrays (on `dst` only when given; the
         other ranks get empty tables).  `table` may be a list of tables (their concatenation).  Two collectives: the row
         counts, then the rows padded to the longest table."""
-        if isinstance(table, (list, tuple)):
-            tabs = [np.asarray(t) for t in table]
-            if not tabs or any(t.ndim != 2 for t in tabs) or len({t.shape[1] for t in tabs}) > 1:
-                raise ValueError("tables must be a non-empty list of [K, C] arrays with one C")
-            parts = [np.ascontiguousarray(t, dtype=np.int32) for t in tabs if len(t)]
-            table = np.concatenate(parts) if parts else np.zeros((0, tabs[0].shape[1]), np.int32)
-        table = np.ascontiguousarray(table, dtype=np.int32)
-        if table.ndim != 2:
-            raise ValueError("table must be [K, C]")
-        k, c = table.shape
+        tabs = [np.asarray(t) for t in table] if isinstance(table, (list, tuple)) else [np.asarray(table)]
+        if not tabs or any(t.ndim != 2 for t in tabs) or len({t.shape[1] for t in tabs}) > 1:
+            raise ValueError("tables must be a non-empty list of [K, C] arrays with one C")
+        k, c = sum(len(t) for t in tabs), tabs[0].shape[1]
         mine = np.asarray([k, c], dtype=np.int32)
         ks = np.zeros(2 * self.world, dtype=np.int32)
         _check(self._lib.cl_comm_allgather_i32(self._h, mine.ctypes.data_as(ctypes.c_void_p), 2, ks.ctypes.data_as(ctypes.c_void_p)))
@@ -203,15 +222,19 @@ class Comm(object):
         if len({int(x) for x in ks[:, 1]}) != 1:
             raise ValueError("the ranks' tables differ in their number of columns")
         kmax = max(int(ks[:, 0].max()), 1)
-        pad = np.zeros((kmax, c), dtype=np.int32)
-        pad[:k] = table
+        # the tables go straight into a page-locked send buffer (one copy, no concatenation), the rows of all ranks arrive in a
+        # page-locked receive buffer (views of it are handed out with copy=False: valid until the next gather)
+        pad = self._pinned("_pin_send", kmax * c * 4)[: kmax * c].reshape(kmax, c)
+        at = 0
+        for t in tabs:
+            if len(t):
+                pad[at:at + len(t)] = t
+                at += len(t)
+        pad[at:] = 0
         recv = dst is None or dst == self.rank
-        out = np.empty((self.world, kmax, c), dtype=np.int32) if recv else None
+        out = self._pinned("_pin_recv", self.world * kmax * c * 4)[: self.world * kmax * c].reshape(self.world, kmax, c) if recv else None
         outp = out.ctypes.data_as(ctypes.c_void_p) if recv else None
-        if dst is None:
-            _check(self._lib.cl_comm_allgather_i32(self._h, pad.ctypes.data_as(ctypes.c_void_p), kmax * c, outp))
-        else:
-            _check(self._lib.cl_comm_gather_i32(self._h, pad.ctypes.data_as(ctypes.c_void_p), kmax * c, int(dst), outp))
+        _check(self._lib.cl_comm_gather_i32_pinned(self._h, pad.ctypes.data_as(ctypes.c_void_p), kmax * c, -1 if dst is None else int(dst), outp))
         if not recv:
             return [np.zeros((0, c), np.int32) for _ in range(self.world)]
         return [out[r, : int(ks[r, 0])].copy() if copy else out[r, : int(ks[r, 0])] for r in range(self.world)]

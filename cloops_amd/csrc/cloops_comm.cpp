@@ -123,6 +123,35 @@ extern "C" int cl_comm_allreduce_max_f64(cl_comm* c, double* h, int64_t n) { ret
 
 // n int32 per rank from host memory; ROOT < 0: all-gather (every rank receives world * n values in rank order), else only
 // rank ROOT receives (the others neither copy back nor need host_out)
+extern "C" void* cl_comm_host_alloc(int64_t bytes)
+{
+    void* p = nullptr;
+    if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { cfail("cl_comm_host_alloc", "hipHostMalloc failed"); return nullptr; }
+    return p;
+}
+extern "C" void cl_comm_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+// the same exchange for buffers the caller allocated with cl_comm_host_alloc (page-locked): the device copies read / write them
+// directly, no staging copy on either side
+extern "C" int cl_comm_gather_i32_pinned(cl_comm* c, const int32_t* pin_in, int64_t n, int root, int32_t* pin_out)
+{
+    if (!c || n < 0 || root >= c->world || (n > 0 && !pin_in)) return cfail("cl_comm_gather_i32_pinned", "bad arguments");
+    const bool recv = root < 0 || root == c->rank;
+    if (n > 0 && recv && !pin_out) return cfail("cl_comm_gather_i32_pinned", "null receive buffer");
+    if (n == 0) return 0;
+    const size_t in_bytes = (size_t)n * 4, out_bytes = in_bytes * (size_t)c->world, pad = ((in_bytes + 255) / 256) * 256;
+    int rc = ensure(c, 0, pad + (recv ? out_bytes : (size_t)256));
+    if (rc) return rc;
+    char* dsend = (char*)c->dev;
+    char* drecv = dsend + pad;
+    HIPC(hipMemcpyAsync(dsend, pin_in, in_bytes, hipMemcpyHostToDevice, c->stream));
+    if (root < 0) NCC(ncclAllGather(dsend, drecv, (size_t)n, ncclInt32, c->comm, c->stream));
+    else NCC(ncclGather(dsend, drecv, (size_t)n, ncclInt32, root, c->comm, c->stream));
+    if (recv) HIPC(hipMemcpyAsync(pin_out, drecv, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 static int gather_i32(cl_comm* c, const int32_t* hin, int64_t n, int root, int32_t* hout)
 {
     if (!c || n < 0 || root >= c->world || (n > 0 && !hin)) return cfail("cl_comm_gather_i32", "bad arguments");

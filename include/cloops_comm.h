@@ -56,6 +56,13 @@ int cl_comm_allgather_i32(cl_comm* c, const int32_t* host_in, int64_t n, int32_t
  * sweep go to the rank that writes the result, like the reference's parent process (cLoops/pipe.py:119-127) */
 int cl_comm_gather_i32(cl_comm* c, const int32_t* host_in, int64_t n, int root, int32_t* host_out);
 
+/* Page-locked host buffers, and the gather (root >= 0) / all-gather (root < 0) of `n` int32 per rank between such buffers:
+ * the device copies read `pinned_in` and write `pinned_out` directly, no staging copy on either side -- the candidate
+ * tables of a 200 M-PET sweep are 58 MB at the root (cloops_amd/comm.py keeps one send and one receive buffer). */
+void* cl_comm_host_alloc(int64_t bytes);
+void cl_comm_host_free(void* p);
+int cl_comm_gather_i32_pinned(cl_comm* c, const int32_t* pinned_in, int64_t n, int root, int32_t* pinned_out);
+
 /* hipDeviceSynchronize() of this rank's device, then a barrier over all ranks (an all-reduce of one element) */
 int cl_comm_barrier(cl_comm* c);
 

@@ -132,6 +132,19 @@ class _FakeCommLib(object):
         self.hub.bar.wait()
         return 0
 
+    def cl_comm_host_alloc(self, nbytes):
+        import ctypes
+        self._bufs = getattr(self, "_bufs", {})
+        b = (ctypes.c_char * int(nbytes))()
+        self._bufs[ctypes.addressof(b)] = b
+        return ctypes.addressof(b)
+
+    def cl_comm_host_free(self, p):
+        self._bufs.pop(p.value if hasattr(p, "value") else p, None)
+
+    def cl_comm_gather_i32_pinned(self, h, pin, n, root, pout):
+        return self.cl_comm_allgather_i32(h, pin, n, pout) if root < 0 else self.cl_comm_gather_i32(h, pin, n, root, pout)
+
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_comm_python_side_at_world_n(monkeypatch, world):
