@@ -162,7 +162,9 @@ struct cl_chrom {
     bool sig_ready = false; int sig_cut = 0;
     bool k7_classified = false;       // k7_cls matches the last completed run
     hipStream_t copy_stream = nullptr, aux_stream = nullptr;
-    int copy_mode = 0;                // 0: the D2H copies of a run go through copy_stream, 1: they are issued in `stream` (caller's stream)
+    int copy_mode = 0;                // 0: the D2H copies of a run go through copy_stream, 1: they are issued in `stream` (caller's stream),
+                                      // 2: through the copy stream that cl_stream_create made for `stream` (shared by its handles)
+    hipStream_t shared_copy = nullptr;
     int enq = 0, deq = 0;             // runs enqueued / completed
     int cur = 0;                      // slot of the run being enqueued
     // last completed result

@@ -24,6 +24,8 @@
 //   K4 k_border         border ownership per variant rule; v2 release fix-up
 //   K5 k_rank_flags / scan / k_final_labels   reference cluster ids + cluster table
 //   K6 block variant    cell table, links, cell-level union (blockDBSCAN.py)
+#include <map>
+#include <mutex>
 #include "cl_chrom.h"
 #include "cl_band.h"
 
@@ -46,13 +48,54 @@ extern "C" void* cl_host_alloc(int64_t bytes)
 }
 extern "C" void cl_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+// A stream made here gets a COPY stream of its own the first time one of its handles has labels to send to the host: the handles
+// that share the stream send their device-to-host copies through it (behind an event of the run), so that a run's labels cross
+// PCIe while the next handle's kernels execute.  One copy stream per shared compute stream -- not one per handle: dozens of
+// copy streams waiting on events of other hardware queues is what blocked those queues head of line --
+// and made late: the HIP runtime deals hardware queues to streams in the order they are created, a sweep (which copies
+// nothing) keeps the mapping of its three compute streams.
+static std::mutex g_pair_mu;
+static std::map<hipStream_t, hipStream_t> g_copy_of;
 extern "C" void* cl_stream_create(int device)
 {
     hipStream_t s = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { fail(CL_ERR_HIP, "hipStreamCreate"); return nullptr; }
+    std::lock_guard<std::mutex> lk(g_pair_mu);
+    g_copy_of[s] = nullptr;
     return (void*)s;
 }
-extern "C" void cl_stream_destroy(void* stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
+extern "C" void cl_stream_destroy(void* stream)
+{
+    if (!stream) return;
+    hipStream_t cs = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pair_mu);
+        auto it = g_copy_of.find((hipStream_t)stream);
+        if (it != g_copy_of.end()) { cs = it->second; g_copy_of.erase(it); }
+    }
+    if (cs) (void)hipStreamDestroy(cs);
+    (void)hipStreamDestroy((hipStream_t)stream);
+}
+static bool library_made_stream(hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_pair_mu);
+    return g_copy_of.find(s) != g_copy_of.end();
+}
+// the copy stream of a library-made stream (made on first use), or null
+static hipStream_t paired_copy_stream(hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_pair_mu);
+    auto it = g_copy_of.find(s);
+    if (it == g_copy_of.end()) return nullptr;
+    if (!it->second) {
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        hipStream_t cs = nullptr;
+        if (hipStreamCreateWithPriority(&cs, hipStreamNonBlocking, prio_hi) != hipSuccess) return nullptr;
+        it->second = cs;
+    }
+    return it->second;
+}
 
 extern "C" int cl_device_count(void)
 {
@@ -756,62 +799,129 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
               const int* __restrict__ strip_start, WordSrc ws, unsigned char* __restrict__ chainflag,
               int* __restrict__ head, int* __restrict__ wavelast, const u32* __restrict__ srow, int* __restrict__ cellfirst)
 {
-    __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
-    __shared__ __attribute__((aligned(16))) int lx[NT + 2 * HALO];
+    constexpr int T_WIN = NT + 2 * HALO, NG = NT / 64;
+    __shared__ __attribute__((aligned(16))) int2 lw[T_WIN];
+    __shared__ __attribute__((aligned(16))) int lx[T_WIN];
     // variant 2: cellfirst[cell head] = smallest input row of the cell's PETs (the dict insertion order of cDBSCAN2.py:117), by LDS
     // atomics on the tile's own cells; the tile that holds a cell's head also walks the part of the cell behind its last PET
     __shared__ int lmin[NT];
     __shared__ int l_hlast;
+    __shared__ unsigned long long l_core[T_WIN / 64];   // bit k of word w: the staged PET with window index 64 w + k is a core
+    __shared__ unsigned long long l_chead[NG];          // variant 2, bit k of word w: PET t0 + 64 w + k is the first of its rotated cell
     const int M = strip_start[g.S];
     if (head) for (int k = threadIdx.x; k < NT; k += NTH) lmin[k] = INT_MAX;
     Tile t;
     if (!tile_stage_words<NT, HALO, NTH>(t, lw, lx, ntiles, M, sv, sa, ws)) return;
+#ifdef CLOOPS_DEVEL
+    if (g.dbg & (1 << 27)) return;                      // developer ablation (results invalid): staging only
+#endif
+    const int lane = threadIdx.x & 63;
+    // Two bit masks instead of per-PET searches.  (1) The cores of the staged window (word 0 = "no neighbour" outside [0, M)): a
+    // core's nearest earlier / later core in sorted order is a find-first-set away, and since a strip is sorted by q that PET
+    // alone decides whether ANY core of the strip lies within eps on that side.  (2) Variant 2: a PET starts a rotated cell
+    // (strip, q / eps) iff its predecessor lies in an earlier strip or below the cell's lower q edge; the head of a PET's cell
+    // is then the latest such PET at or before it.
+    for (int k = threadIdx.x; k < T_WIN; k += NTH) {
+        const unsigned long long bal = __ballot(cw_core(lx[k], g.minPts));
+        if (lane == 0) l_core[k >> 6] = bal;
+    }
+    if (head)
+        for (int u = 0; u < NT / NTH; ++u) {
+            const int i = t.t0 + (int)threadIdx.x + u * NTH;
+            const int2 me = t.w[i], pv = t.w[i - 1];     // (HALO >= 1: the predecessor is staged; i = 0 has none)
+            const int p0 = me.y & ~(g.peps - 1), q0 = div_eps(g, me.x) * g.eps;      // lower edges of the rotated cell (sp space / q space)
+            const unsigned long long bal = __ballot(i < M && (i == 0 || (pv.y & ~(g.peps - 1)) != p0 || pv.x < q0));
+            if (lane == 0) l_chead[u * (NTH / 64) + (threadIdx.x >> 6)] = bal;
+        }
+    __syncthreads();
+    t.m = l_core;
     unsigned headmask = 0u;                             // bit u: the thread's u-th PET is the head of its cell
     for (int u = 0; u < NT / NTH; ++u) {
     const int i = t.t0 + (int)threadIdx.x + u * NTH;
     if (i >= M) continue;
     const int2 me = t.w[i];
     const bool core = cw_core(t.x[i], g.minPts);
+#ifdef CLOOPS_DEVEL
+    if (head && !(g.dbg & (1 << 28))) {
+#else
     if (head) {
-        // variant 2: head of the PET's rotated cell (strip, q / eps) = first PET of the sorted order that is
-        // neither in an earlier strip nor below the cell's lower q edge -- a bisection on the staged tile
-        // instead of head flags + a max-scan over all PETs (variant 2 runs with A0 = V0 = 0)
-        const int p0 = me.y & ~(g.peps - 1), q0 = div_eps(g, me.x) * g.eps;      // lower edges of the rotated cell (sp space / q space)
-        // (searched among the 511 staged PETs in front of i -- a cell with more PETs than that, or one that starts before the
-        // staged window, is a pile-up and continues in global memory)
-        const int start = max(t.wbeg, i - 511);
-        int pos = start;
-        constexpr int TOP = 256;
-#pragma unroll
-        for (int step = TOP; step >= 1; step >>= 1) {
-            const int idx = pos + step - 1;
-            const int2 c = t.w[min(idx, i)];
-            pos = (idx <= i && (c.y < p0 || c.x < q0)) ? pos + step : pos;
-        }
-        if (pos == start && start > 0) {                 // the cell starts at or before the searched range
-            int lo = 0, hi = start;
+#endif
+        // variant 2: head of the PET's rotated cell = the latest cell-opening PET at or before it: inside the 64-PET group from
+        // its ballot, else the nearest earlier group of the tile that has one, else the cell began in front of the tile
+        // (variant 2 runs with A0 = V0 = 0)
+        const int grp = u * (NTH / 64) + (int)(threadIdx.x >> 6);
+        const unsigned long long upto = l_chead[grp] & ((2ull << lane) - 1ull);
+        int pos = -1;
+        if (upto) pos = (i - lane) + 63 - __clzll((long long)upto);
+        else
+            for (int g2 = grp - 1; g2 >= 0; --g2) {
+                const unsigned long long o2 = l_chead[g2];
+                if (o2) { pos = t.t0 + 64 * g2 + 63 - __clzll((long long)o2); break; }
+            }
+        if (pos < 0 && core) {
+            // the cell began in front of the tile (that tile takes care of its minimum) and only a core needs to know where:
+            // a bisection on the left halo, then on the strip in global memory
+            const int p0 = me.y & ~(g.peps - 1), q0 = div_eps(g, me.x) * g.eps;
+            int lo = t.wbeg, hi = t.t0;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                if (sa[mid] < p0 || sv[mid] < q0) lo = mid + 1; else hi = mid;
+                const int2 c = t.w[mid];
+                if (c.y < p0 || c.x < q0) lo = mid + 1; else hi = mid;
+            }
+            if (lo == t.wbeg && lo > 0) {
+                lo = strip_start[strip_of(g, me.y)]; hi = t.wbeg;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sv[mid] < q0) lo = mid + 1; else hi = mid;          // (inside the PET's own strip)
+                }
             }
             pos = lo;
         }
         if (core) head[i] = pos;                         // (k_flatten looks the cell up for core PETs only)
+#ifdef CLOOPS_DEVEL
+        if (!(g.dbg & (1 << 30)))
+#endif
         if (pos >= t.t0) atomicMin(&lmin[pos - t.t0], (int)srow[i]);        // (a cell that began in an earlier tile: that tile walks it)
         headmask |= (pos == i ? 1u : 0u) << u;
         if (i == min(t.t0 + NT, M) - 1) l_hlast = pos;
     }
     int f = 0, last = 0;
+#ifdef CLOOPS_DEVEL
+    if (core && !(g.dbg & (1 << 29))) {
+#else
     if (core) {
-        const int s = strip_of(g, me.y);
-        const int b = strip_start[s], e = strip_start[s + 1];
+#endif
+        const int p0 = me.y & ~(g.peps - 1);             // the strip's block of sp values
+        const int qlo = sat_add(me.x, -g.eps), qhi = sat_add(me.x, g.eps);
         f = i + 1;
         last = 1;
-        auto gxf = [&](int j, int qj) { return ws.raw(j, qj, me.y); };      // (own strip: the same strip coordinate block)
-        tile_visit_own(t, sv, gxf, i, b, e, sat_add(me.x, -g.eps), sat_add(me.x, g.eps), 1,
-                       [&](int, int cj) { if (cw_core(cj, g.minPts)) { f = 0; return true; } return false; });
-        tile_visit_own(t, sv, gxf, i, b, e, sat_add(me.x, -g.eps), sat_add(me.x, g.eps), 2,
-                       [&](int, int cj) { if (cw_core(cj, g.minPts)) { last = 0; return true; } return false; });
+        // the nearest earlier core of the sorted order: if it lies in this strip and within eps, the PET continues its chain;
+        // if it does not, no earlier core of the strip does (sorted by q).  The same on the other side.  (The strip table is
+        // looked up only when a strip goes on outside the staged range.)
+        {
+            const int j = t.prev_set(i - 1, t.wbeg);
+            if (j >= t.wbeg) { const int2 c = t.w[j]; f = ((c.y & ~(g.peps - 1)) == p0 && c.x >= qlo) ? 0 : f; }
+            else if (t.wbeg > 0 && (t.w[t.wbeg].y & ~(g.peps - 1)) == p0) {
+                const int b = strip_start[strip_of(g, me.y)];
+                for (int k = t.wbeg - 1; k >= b; --k) {           // the strip began in front of the staged range: global memory
+                    const int qk = sv[k];
+                    if (qk < qlo) break;
+                    if (cw_core(ws.raw(k, qk, me.y), g.minPts)) { f = 0; break; }
+                }
+            }
+        }
+        {
+            const int j = t.next_set(i + 1, t.wend);
+            if (j < t.wend) { const int2 c = t.w[j]; last = ((c.y & ~(g.peps - 1)) == p0 && c.x <= qhi) ? 0 : last; }
+            else if (t.wend < M && (t.w[t.wend - 1].y & ~(g.peps - 1)) == p0) {
+                const int e = strip_start[strip_of(g, me.y) + 1];
+                for (int k = t.wend; k < e; ++k) {
+                    const int qk = sv[k];
+                    if (qk > qhi) break;
+                    if (cw_core(ws.raw(k, qk, me.y), g.minPts)) { last = 0; break; }
+                }
+            }
+        }
     }
     // one byte per PET for k_chain_parent: CF_CORE, CF_OPEN (no earlier core of its strip within eps), CF_LAST (no later one:
     // its q is the chain's upper end)
@@ -944,6 +1054,9 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     }
     __syncthreads();
     const int total = l_total;
+#ifdef CLOOPS_DEVEL
+    if (g.dbg & (1 << 24)) return;                      // developer ablation (results invalid): staging and the core list only
+#endif
     for (int h = (int)threadIdx.x; h < total; h += NTH) {
     const int i = t.t0 + l_list[h];
     const int2 me = t.w[i];
@@ -987,6 +1100,9 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
             else if (!__any(b - tb > 63)) j = lds_lower_bound8<6>(t.w, tb, b, qlo);
             else if (!longA) j = lds_lower_bound8<8>(t.w, tb, b, qlo);
             else j = lds_lower_bound8<T_STEPS_LONG>(t.w, tb, b, qlo);
+#ifdef CLOOPS_DEVEL
+            if (g.dbg & (1 << 25)) j = b;                // developer ablation: the searches, no candidate
+#endif
             while (j < b) {
                 // four candidates per round, all LDS reads in flight before the first compare
                 int2 cv[4]; int bv[4];
@@ -1070,6 +1186,9 @@ k_union_cores(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
             if (lane == leader) rep = true;
             pending &= ~m;
         }
+#ifdef CLOOPS_DEVEL
+        if (g.dbg & (1 << 26)) rep = false;              // developer ablation: no union-find step
+#endif
         if (rep) uf_unite(parent, A, B);
     }
     }
@@ -1791,6 +1910,13 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
             // other hardware queues is what made the label-copying forms fall off a cliff (23 handles, 8 hardware queues: 3 s
             // per sweep instead of 0.05 s -- head-of-line blocking of the queues the copy streams share).
             c->copy_mode = c->own_stream ? 0 : 1;
+            if (!c->own_stream) {
+                // ... unless the library made the stream (cl_stream_create): its handles share ONE copy stream
+                if (library_made_stream(c->stream)) c->copy_mode = 2;
+#ifdef CLOOPS_DEVEL
+                if (getenv("CLOOPS_COPY_IN_STREAM")) c->copy_mode = 1;     // developer A/B: the copies in the compute stream itself
+#endif
+            }
             if (hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
                 hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipStreamCreate(copy)"); break; }
         }
@@ -2577,7 +2703,8 @@ int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* labels_ou
     if (sl.wait_done) {
         // sweep step: k7_reduce_parts has stored header and step output in pinned host memory; completion = the run's own event
     } else {
-        hipStream_t cs = c->copy_mode == 1 ? c->stream : c->copy_stream;
+        if (c->copy_mode == 2 && !c->shared_copy && !(c->shared_copy = paired_copy_stream(c->stream))) return fail(CL_ERR_HIP, "hipStreamCreate(copy)");
+        hipStream_t cs = c->copy_mode == 1 ? c->stream : (c->copy_mode == 2 ? c->shared_copy : c->copy_stream);
         if (cs != c->stream) HIP_TRY(hipStreamWaitEvent(cs, sl.ev_done, 0));
         HIP_TRY(hipMemcpyAsync(sl.h_hdr, dh, 32, hipMemcpyDeviceToHost, cs));
         if (sl.step_valid) HIP_TRY(hipMemcpyAsync(sl.h_step, sl.d_step.p, 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8, hipMemcpyDeviceToHost, cs));
