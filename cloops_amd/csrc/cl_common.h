@@ -51,7 +51,7 @@ static inline int fail(int code, const char* what, const char* detail = nullptr)
 #define TPB 256
 
 enum { ST_LIVE = 0, ST_DEAD = 1, ST_UNKNOWN = 2 };          // variant-2 release state of a component
-enum { CTR_NU = 0, CTR_NREC = 1, CTR_OVERFLOW = 2, CTR_NROOT = 3 };         // device counters
+enum { CTR_NU = 0, CTR_NREC = 1, CTR_OVERFLOW = 2, CTR_NROOT = 3, CTR_NFLAG = 4 };         // device counters
 
 struct GridParams {
     int eps;      // cell / strip width (cDBSCAN.py:29, cDBSCAN2.py:30: cw = eps)
@@ -64,6 +64,7 @@ struct GridParams {
     int S;        // number of strips in the table; key strip S marks filtered rows
     int variant;
     int dbg;      // developer knobs (CLOOPS_DBG env), 0 in production
+    int dbg2;     // more of them (CLOOPS_DBG2)
     u32 magic;    // strip(a) = a / eps by multiply-shift (Granlund-Montgomery, exact for all u32)
     int sh1, sh2;
     int qbits;    // sort key = strip << (qbits+rbits) | q << rbits | (p mod eps): both coordinates ride

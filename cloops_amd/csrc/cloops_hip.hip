@@ -413,11 +413,12 @@ static inline int tile_grid(int ntiles) { return ((ntiles + 8 * K2_RUN - 1) / (8
 template <int NT, int HALO, int NTH = NT>
 __device__ __forceinline__ bool tile_stage(Tile& t, int2* lw, int* lx, int ntiles, int M,
                                            const int* __restrict__ gq, const int* __restrict__ gp,
-                                           const int* __restrict__ gx, unsigned long long* lmask = nullptr, int fill = -1)
+                                           const int* __restrict__ gx, unsigned long long* lmask = nullptr, int fill = -1,
+                                           int tile_in = -1 /* the tile, if it is not the workgroup's own */)
 {
     constexpr int T_WIN = NT + 2 * HALO, NV = T_WIN / 4;
     static_assert(NT % 64 == 0 && HALO % 64 == 0 && NT + HALO + 64 <= SORT_PAD, "window shape");
-    const int tile = tile_of_block(blockIdx.x);
+    const int tile = tile_in >= 0 ? tile_in : tile_of_block(blockIdx.x);
     t.t0 = tile * NT;
     if (tile >= ntiles || t.t0 >= M) return false;
     const int base = t.t0 - HALO;
@@ -841,6 +842,7 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
     if (i >= M) continue;
     const int2 me = t.w[i];
     const bool core = cw_core(t.x[i], g.minPts);
+    int pos = -1;
 #ifdef CLOOPS_DEVEL
     if (head && !(g.dbg & (1 << 28))) {
 #else
@@ -851,7 +853,6 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
         // (variant 2 runs with A0 = V0 = 0)
         const int grp = u * (NTH / 64) + (int)(threadIdx.x >> 6);
         const unsigned long long upto = l_chead[grp] & ((2ull << lane) - 1ull);
-        int pos = -1;
         if (upto) pos = (i - lane) + 63 - __clzll((long long)upto);
         else
             for (int g2 = grp - 1; g2 >= 0; --g2) {
@@ -877,7 +878,6 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
             }
             pos = lo;
         }
-        if (core) head[i] = pos;                         // (k_flatten looks the cell up for core PETs only)
 #ifdef CLOOPS_DEVEL
         if (!(g.dbg & (1 << 30)))
 #endif
@@ -900,6 +900,11 @@ k_chain_flags(GridParams g, int ntiles, int n, const int* __restrict__ sv, const
         // looked up only when a strip goes on outside the staged range.)
         {
             const int j = t.prev_set(i - 1, t.wbeg);
+            // variant 2: the component key is a minimum over the CELLS of its cores (cDBSCAN2.py:117-140), so one core per cell
+            // is enough to carry the cell to k_flatten: the first one (no core between the cell's head and the PET; a core
+            // that cannot tell, because the cell began in front of the staged range, carries it as well) -- the others get -1
+            // and cost k_flatten neither the look-up of the cell nor an atomic
+            if (head) head[i] = (j < pos || j < t.wbeg) ? pos : -1;
             if (j >= t.wbeg) { const int2 c = t.w[j]; f = ((c.y & ~(g.peps - 1)) == p0 && c.x >= qlo) ? 0 : f; }
             else if (t.wbeg > 0 && (t.w[t.wbeg].y & ~(g.peps - 1)) == p0) {
                 const int b = strip_start[strip_of(g, me.y)];
@@ -1238,12 +1243,18 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
     }
 #pragma unroll
     for (int e = 0; e < FLAT_PER; ++e)
-        key[e] = !core[e] ? INT_MAX : ((g.variant == CL_VARIANT_CDBSCAN2) ? cellfirst[hd[e]] : (int)srow[ii[e]]);
+        key[e] = !core[e] ? INT_MAX : ((g.variant == CL_VARIANT_CDBSCAN2) ? (hd[e] >= 0 ? cellfirst[hd[e]] : INT_MAX) : (int)srow[ii[e]]);      // (-1: an earlier core of the cell carries it)
+#ifdef CLOOPS_DEVEL
+    if (g.dbg2 & 1) { if (key[0] == 12345 && x[0] == 54321) root[0] = 0; return; }      // developer ablation: the loads only
+#endif
     {
         // the union kernel has completed (kernel boundary = coherent): plain loads, all chains of the thread step together
         bool todo = false;
 #pragma unroll
         for (int e = 0; e < FLAT_PER; ++e) todo |= core[e];
+#ifdef CLOOPS_DEVEL
+        if (g.dbg2 & 2) todo = false;                    // developer ablation: no forest walk
+#endif
         while (todo) {
             int p[FLAT_PER];
 #pragma unroll
@@ -1258,6 +1269,9 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
         r[e] = core[e] ? x[e] : -1;
         if (ii[e] < M) root[ii[e]] = r[e];
     }
+#ifdef CLOOPS_DEVEL
+    if (g.dbg2 & 4) return;                              // developer ablation: no root list, no aggregation
+#endif
     const int lane = threadIdx.x & 63;
     // the components' roots as a compact list (the per-component kernels that follow walk K entries instead of
     // testing every PET): ranks inside the workgroup through LDS, one global atomic per workgroup
@@ -1295,9 +1309,11 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
                     else { atomicMin(&compkey[R], mk); atomicAdd(&ncore[R], __popcll(m)); }
                 }
             } else if (r[e] >= 0) {
+                // (a segmented reduction over runs of one root -- as table_accumulate does for labels -- measured +29 % here: the
+                //  runs are short and broken by non-core PETs)
                 const int sl = agg_slot(hkey, r[e]);
-                if (sl >= 0) { atomicMin(&hmin[sl], key[e]); atomicAdd(&hcnt[sl], 1); }
-                else { atomicMin(&compkey[r[e]], key[e]); atomicAdd(&ncore[r[e]], 1); }
+                if (sl >= 0) { if (key[e] != INT_MAX) atomicMin(&hmin[sl], key[e]); atomicAdd(&hcnt[sl], 1); }
+                else { if (key[e] != INT_MAX) atomicMin(&compkey[r[e]], key[e]); atomicAdd(&ncore[r[e]], 1); }
             }
         }
     }
@@ -1333,12 +1349,8 @@ __global__ void __launch_bounds__(NTH)
 k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
          const int* __restrict__ strip_start, const int* __restrict__ root, const int* __restrict__ compkey,
          const int* __restrict__ ncore, const u32* __restrict__ srow, int* __restrict__ owner, int* __restrict__ bsize,
-         int* __restrict__ usize, WordSrc ws, int* __restrict__ tileflag)
+         int* __restrict__ usize, WordSrc ws, int* __restrict__ clist, int* __restrict__ counters)
 {
-    // tileflag[k] = 1 if the 256 PETs [256 k, 256 k + 256) hold a CONTESTED border point (one adjacent to more than one component)
-    // whose owner is not live on its cores alone: only such tiles can have anything for k_emit_records, which then leaves after
-    // one load instead of testing 256 PETs
-    if (threadIdx.x < NT / 256) { const int tl = tile_of_block(blockIdx.x); if (tl < ntiles) tileflag[tl * (NT / 256) + threadIdx.x] = 0; }
     __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
     __shared__ int lx[NT + 2 * HALO];
     __shared__ short l_list[NT];
@@ -1473,9 +1485,19 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
     {
         const int lane = threadIdx.x & 63;
         const bool cnt_me = o >= 0 && ncore[o] < g.minPts;
-        // only a component that is not live on its cores alone can end up uncertain (k_mark_uncertain_l): the tiles without a
-        // contested border point of such a component have nothing for k_emit_records
-        if (cnt_me && contested) tileflag[i >> 8] = 1;          // (behind the staging barrier: ordered after the reset above)
+        // only a component that is not live on its cores alone can end up uncertain (k_mark_uncertain_l): its CONTESTED border
+        // points are all k_emit_records has to look at -- they are listed here (one atomic per wave)
+        {
+            const bool want = cnt_me && contested;
+            const unsigned long long wb = __ballot(want);
+            if (wb) {
+                const int first = __ffsll((long long)wb) - 1;
+                int base = 0;
+                if (lane == first) base = atomicAdd(&counters[CTR_NFLAG], __popcll(wb));
+                base = __builtin_amdgcn_readlane(base, first);
+                if (want) clist[base + __builtin_amdgcn_mbcnt_hi((unsigned)(wb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wb, 0u))] = i;
+            }
+        }
         unsigned long long pending = __ballot(cnt_me);
         while (pending) {
             const int leader = __ffsll((long long)pending) - 1;
@@ -1501,79 +1523,122 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
 // bound) distinct adjacent components in ascending key order
 struct Rec { int pt; int r[4]; };
 
-template <int NT, int HALO>
-__global__ void __launch_bounds__(NT)
-k_emit_records(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
+// The contested border points that k_border listed (clist: points of components that are not live on their cores alone; a few
+// hundred to a few ten thousand per run), one WAVE each.  Only one whose first-come owner (its lowest-key adjacent component)
+// is UNCERTAIN can change hands: the fix-up walks a record's components in key order and a component that is surely live ends
+// the walk (k_resolve_release), so a record that starts with a live component contributes nothing -- most listed points leave
+// after that test.  The others collect their adjacent components.  The kernel is a handful of waves deep in dependent loads,
+// so what counts is the number of round trips per point: the four walks (own strip downwards / upwards, one strip below, one
+// above) start where K2's hints say -- no strip table, no search -- each is "from a start index while a monotone predicate of
+// (q, sp) holds", the wave reads 64 candidates of every walk at once, all four first rounds in flight together, and looks at
+// every DISTINCT root once.  (A thread per point that walked its windows one load after the other took 40 us per run.)
+__global__ void __launch_bounds__(TPB)
+k_emit_records(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
                const int* __restrict__ strip_start, const int* __restrict__ root, const int* __restrict__ compkey,
                const int* __restrict__ state, const int* __restrict__ owner, Rec* __restrict__ recs, int rec_cap,
-               int* __restrict__ counters, const int* __restrict__ tileflag, int nflags)
+               int* __restrict__ counters, const int* __restrict__ clist, WordSrc ws)
 {
-    __shared__ __attribute__((aligned(16))) int2 lw[NT + 2 * HALO];
-    __shared__ int lx[NT + 2 * HALO];
-    __shared__ short l_list[NT];
-    __shared__ int l_wcount[NT / 64];
     if (counters[CTR_NU] == 0) return;
-    {
-        // (k_border's flags are per 256-PET tile; this kernel may run on larger tiles)
-        const int tl = tile_of_block(blockIdx.x);
-        if (tl >= ntiles) return;
-        constexpr int F = NT / 256;
-        int any = 0;
-#pragma unroll
-        for (int k = 0; k < F; ++k) any |= (tl * F + k < nflags) ? tileflag[tl * F + k] : 0;
-        if (any == 0) return;
-    }
+    const int nlist = counters[CTR_NFLAG];
     const int M = strip_start[g.S];
-    {
-        // Only a CONTESTED border point whose first-come owner (its lowest-key adjacent component) is
-        // UNCERTAIN can change hands: the fix-up walks a record's components in key order and a component
-        // that is surely live ends the walk (k_resolve_release), so a record that starts with a live component
-        // contributes nothing.  Nearly all tiles have no such point and leave before staging anything.
-        const int ip = tile_of_block(blockIdx.x) * NT + threadIdx.x;
-        const int op = ip < M ? owner[ip] : -1;
-        const bool cand = op >= 0 && (op & OWNER_CONTESTED) && state[owner_root(op)] == ST_UNKNOWN;
-        if (!__syncthreads_or(cand)) return;
+    const int lane = threadIdx.x & 63;
+    const int nwaves = gridDim.x * (TPB / 64);
+    const int wave = blockIdx.x * (TPB / 64) + (int)(threadIdx.x >> 6);
+    for (int k0 = 0; k0 < nlist; k0 += 64 * nwaves) {
+    // the test, 64 listed points per wave at once; a wave's 64 are spread over the whole list (neighbours in the list are
+    // neighbours on the chromosome and tend to pass or fail together)
+    const int kl = k0 + lane * nwaves + wave;
+    const int ci = kl < nlist ? clist[kl] : -1;
+    const int co = ci >= 0 ? owner[ci] : -1;
+    unsigned long long todo = __ballot(ci >= 0 && state[owner_root(co)] == ST_UNKNOWN);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int i = __builtin_amdgcn_readlane(ci, src);                // (wave-uniform from here on)
+        const int qi = sv[i], pi = sa[i];
+        const int enc = ws.word(i, qi, pi);
+        const int qlo = sat_add(qi, -g.eps), qhi = sat_add(qi, g.eps);
+        const int pbeg = pi & ~(g.peps - 1), pend = pbeg + g.peps, pend2 = pend + g.peps;      // strips are aligned blocks of sp
+        const int plo = pi - g.peps, phi = pi + g.peps;
+        int ja, jb;
+        if (enc < 0 && ((unsigned)enc & K2H_NONE) != K2H_NONE) {
+            ja = i - (int)((unsigned)enc & K2H_MASK); jb = i + (int)(((unsigned)enc >> K2H_BITS) & K2H_MASK);
+        } else {
+            const int s = strip_of(g, pi);
+            const int b = strip_start[s], e = strip_start[s + 1];
+            ja = s > 0 ? lower_bound_4(sv, strip_start[s - 1], b, qlo) : b;
+            jb = lower_bound_4(sv, e, s + 1 < g.S ? strip_start[s + 2] : e, qlo);
+        }
+        int rr[4] = {-1, -1, -1, -1};
+        int kk[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
+        int nr = 0;
+        bool any_u = false, overflow = false;
+        auto see = [&](int r) {                                          // (every lane keeps the same list)
+            for (int q = 0; q < 4; ++q) if (rr[q] == r) return;
+            if (nr == 4) { overflow = true; return; }
+            const int key = compkey[r];
+            int q = nr++;
+            while (q > 0 && kk[q - 1] > key) { kk[q] = kk[q - 1]; rr[q] = rr[q - 1]; --q; }
+            kk[q] = key; rr[q] = r;
+            if (state[r] == ST_UNKNOWN) any_u = true;
+        };
+        // walk w: 0 = own strip downwards from i - 1, 1 = own strip upwards from i + 1, 2 = one strip below from ja, 3 = one above from jb
+        const int start[4] = {i - 1, i + 1, ja, jb};
+        auto more = [&](int w, int q, int p) {
+            return w == 0 ? ((p >= pbeg) & (q >= qlo)) : w == 1 ? ((p < pend) & (q <= qhi)) : w == 2 ? ((p < pbeg) & (q <= qhi)) : ((p < pend2) & (q <= qhi));
+        };
+        auto acc = [&](int w, int p) { return w == 2 ? p >= plo : (w == 3 ? p <= phi : true); };
+        int q0[4], p0[4], r0[4];
+        bool in0[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int j = w == 0 ? start[w] - lane : start[w] + lane;
+            in0[w] = j >= 0 && j < M;
+            q0[w] = in0[w] ? sv[j] : 0; p0[w] = in0[w] ? sa[j] : 0; r0[w] = in0[w] ? root[j] : -1;
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            // one round: 64 candidates -> true if the walk goes on behind them
+            auto round = [&](bool in, int q, int p, int r) {
+                const bool ok = in && more(w, q, p);
+                const int rv = (ok && acc(w, p)) ? r : -1;
+                unsigned long long pending = __ballot(rv >= 0);
+                while (pending) {
+                    const int R = __builtin_amdgcn_readlane(rv, __ffsll((long long)pending) - 1);
+                    pending &= ~__ballot(rv == R);
+                    see(R);
+                }
+                return __ballot(ok) == ~0ull;
+            };
+            bool on = round(in0[w], q0[w], p0[w], r0[w]);
+            // a window that is longer than the first 64 (dense data: up to thousands): four rounds' loads in flight together
+            for (int rnd = 1; on; rnd += 4) {
+                int q[4], p[4], r[4];
+                bool in[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = w == 0 ? start[w] - lane - 64 * (rnd + u) : start[w] + lane + 64 * (rnd + u);
+                    in[u] = j >= 0 && j < M;
+                    q[u] = in[u] ? sv[j] : 0; p[u] = in[u] ? sa[j] : 0; r[u] = in[u] ? root[j] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (on) on = round(in[u], q[u], p[u], r[u]);
+            }
+        }
+        if (lane == 0) {
+            if (overflow) atomicExch(&counters[CTR_OVERFLOW], 1);
+            if (any_u) {
+                const int idx = atomicAdd(&counters[CTR_NREC], 1);
+                if (idx >= rec_cap) atomicExch(&counters[CTR_OVERFLOW], 2);
+                else {
+                    Rec rec; rec.pt = i;
+                    for (int q = 0; q < 4; ++q) rec.r[q] = rr[q];
+                    recs[idx] = rec;
+                }
+            }
+        }
     }
-    Tile t;
-    if (!tile_stage<NT, HALO>(t, lw, lx, ntiles, M, sv, sa, root)) return;
-    const int i0 = t.t0 + threadIdx.x;
-    const bool act = i0 < M && t.x[i0] < 0 && owner[i0] >= 0 && (owner[i0] & OWNER_CONTESTED) &&
-                     state[owner_root(owner[i0])] == ST_UNKNOWN;
-    const int total = block_compact<NT>(act, l_list, l_wcount);
-    if ((int)threadIdx.x >= total) return;
-    const int i = t.t0 + l_list[threadIdx.x];
-    const int2 me = t.w[i];
-    const int s = strip_of(g, me.y);
-    const int qlo = sat_add(me.x, -g.eps), qhi = sat_add(me.x, g.eps);
-    const int b = strip_start[s], e = strip_start[s + 1];
-    const int tb = s > 0 ? strip_start[s - 1] : b;
-    const int te = s + 1 < g.S ? strip_start[s + 2] : e;
-    int rr[4] = {-1, -1, -1, -1};
-    int kk[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
-    int nr = 0;
-    bool any_u = false, overflow = false;
-    auto see = [&](int r) {
-        if (r < 0) return;
-        for (int q = 0; q < 4; ++q) if (rr[q] == r) return;
-        if (nr == 4) { overflow = true; return; }
-        const int k = compkey[r];
-        int q = nr++;
-        while (q > 0 && kk[q - 1] > k) { kk[q] = kk[q - 1]; rr[q] = rr[q - 1]; --q; }
-        kk[q] = k; rr[q] = r;
-        if (state[r] == ST_UNKNOWN) any_u = true;
-    };
-    tile_visit_own_all(t, sv, root, i, b, e, qlo, qhi, [&](int, int r) { see(r); });
-    tile_visit_segment(t, sv, sa, root, tb, b, qlo, qhi, [&](int, int, int pj, int r) {
-        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.peps) see(r); });
-    tile_visit_segment(t, sv, sa, root, e, te, qlo, qhi, [&](int, int, int pj, int r) {
-        const int da = pj - me.y; if ((da < 0 ? -da : da) <= g.peps) see(r); });
-    if (overflow) atomicExch(&counters[CTR_OVERFLOW], 1);
-    if (!any_u) return;
-    const int idx = atomicAdd(&counters[CTR_NREC], 1);
-    if (idx >= rec_cap) { atomicExch(&counters[CTR_OVERFLOW], 2); return; }
-    Rec rec; rec.pt = i;
-    for (int q = 0; q < 4; ++q) rec.r[q] = rr[q];
-    recs[idx] = rec;
+    }
 }
 
 // one workgroup; rounds until every uncertain component is decided.  lo = borders surely
@@ -1767,6 +1832,9 @@ k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __r
     }
 #pragma unroll
     for (int ch = 0; ch < FINAL_CHUNKS; ++ch) lab[ch] = own[ch] >= 0 ? rlabel[own[ch]] : -1;
+#ifdef CLOOPS_DEVEL
+    if (g.dbg2 & 16) { if (lab[0] == 123456789) slab[0] = 0; return; }      // developer ablation: owner -> label only
+#endif
 #pragma unroll
     for (int ch = 0; ch < FINAL_CHUNKS; ++ch) {
         const int i = idx[ch];
@@ -1783,6 +1851,9 @@ k_final_labels(GridParams g, const int* __restrict__ strip_start, const int* __r
             }
         }
     }
+#ifdef CLOOPS_DEVEL
+    if (g.dbg2 & 32) return;                             // developer ablation: no cluster table
+#endif
 #pragma unroll
     for (int ch = 0; ch < FINAL_CHUNKS; ++ch) table_accumulate(t, h, lab[ch], x[ch], y[ch]);
     table_flush(t, h);
@@ -2249,11 +2320,12 @@ int ensure_workspace(cl_chrom* c, int S)
 static int make_grid(cl_chrom* c, int variant, int eps, int minPts, int cut, GridParams* g)
 {
     g->eps = eps; g->minPts = minPts; g->cut = cut; g->variant = variant;
-    g->dbg = 0;
+    g->dbg = 0; g->dbg2 = 0;
     g->floor = minPts;
 #ifdef CLOOPS_DEVEL
     // developer build only (-DCLOOPS_DEVEL): ablation knobs that can change results; never in the shipped library
     { const char* e = getenv("CLOOPS_DBG"); g->dbg = e ? atoi(e) : 0; }
+    { const char* e = getenv("CLOOPS_DBG2"); g->dbg2 = e ? atoi(e) : 0; }
 #endif
     g->swap = (g->dbg & 16) ? 0 : 1;
     {
@@ -2745,6 +2817,13 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
     }
     sl.pending = false;
     c->deq++;
+#ifdef CLOOPS_DEVEL
+    if (getenv("CLOOPS_DBG_COUNTERS")) {                 // developer build: the device counters of the run that has just completed
+        int h[8] = {0};
+        (void)hipMemcpy(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[counters] n=%lld uncertain=%d records=%d overflow=%d roots=%d listed=%d\n", (long long)c->n, h[CTR_NU], h[CTR_NREC], h[CTR_OVERFLOW], h[CTR_NROOT], h[CTR_NFLAG]);
+    }
+#endif
     const int K = sl.h_hdr[0];
     if (sl.h_hdr[1] != 0)
         return fail(CL_ERR_HIP, sl.h_hdr[1] == 8 ? "internal: the number of PETs that passed the cut differs from the host's count"
@@ -3007,21 +3086,22 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     int* rootlist = c->rootlist.as<int>();
     ev_record(c, 4);
     // K4
+    int* clist = c->chainflag.as<int>();                // the contested border points k_emit_records looks at (the chain ids of K3 are dead)
     if (wide == 0) {
         // 1024 PETs per workgroup of 256 threads (4 per thread in the first pass, the walkers of the whole tile in one list)
         const int nt_b = nblocks(std::max(1, c->run_m), 1024);
         if (!SKIP(1)) hipLaunchKernelGGL((k_border<1024, 128, TPB>), dim3(tile_grid(nt_b)), dim3(TPB), 0, c->stream, g, nt_b, sv, sa, strip, c->root.as<int>(),
-                           c->compkey.as<int>(), c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), ws, c->tileflag.as<int>());
+                           c->compkey.as<int>(), c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), ws, clist, counters);
     } else
     TILE_LAUNCH_H((wide >= 2 && wide <= 4) ? 512 : (wide >= 5 ? 256 : 128), k_border, g, ntiles, sv, sa, strip, c->root.as<int>(), c->compkey.as<int>(),
-                       c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), ws, c->tileflag.as<int>());
+                       c->ncore.as<int>(), srow, c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), ws, clist, counters);
     if (variant == CL_VARIANT_CDBSCAN2) {
         const int rec_cap = n;
         hipLaunchKernelGGL(k_mark_uncertain_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, c->ncore.as<int>(), c->bsize.as<int>(), c->state.as<int>(),
                            c->ulist.as<int>(), counters);
-        if (!SKIP(128)) TILE_LAUNCH(k_emit_records, g, ntiles, sv, sa, strip, c->root.as<int>(),
+        if (!SKIP(128)) hipLaunchKernelGGL(k_emit_records, dim3(2048), dim3(TPB), 0, c->stream, g, sv, sa, strip, c->root.as<int>(),
                            c->compkey.as<int>(), c->state.as<int>(), c->owner.as<int>(), c->recs.as<Rec>(), rec_cap, counters,
-                           (const int*)c->tileflag.as<int>(), ntiles);
+                           (const int*)clist, ws);
         hipLaunchKernelGGL(k_resolve_release, dim3(1), dim3(1024), 0, c->stream, minPts, c->ncore.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                            c->ulist.as<int>(), c->recs.as<Rec>(), c->lo.as<int>(), c->hi.as<int>(), counters);
     }
