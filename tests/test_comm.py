@@ -155,9 +155,10 @@ def test_comm_python_side_at_world_n(monkeypatch, world):
     rng = np.random.RandomState(11)
     tables = [rng.randint(0, 1 << 30, (k, 4)).astype(np.int32) for k in ([5, 0, 1200][:world])]
     out = [None] * world
+    comms = [None] * world          # (kept until the checks are done: copy=False hands out views of the communicator's buffers)
 
     def rank_main(r):
-        c = comm.Comm.__new__(comm.Comm)
+        c = comms[r] = comm.Comm.__new__(comm.Comm)
         c._lib, c._h, c.rank, c.world, c.device = _FakeCommLib(hub, r), 1, r, world, 0
         res = {}
         res["sum_i"] = c.allsum(np.arange(10, dtype=np.int64) * (r + 1))
