@@ -7,7 +7,7 @@
 // chromosome, a handful of PETs per strip.  That little work is pure latency (table row -> strip prefixes -> a few LDS
 // searches -> one store per PET), so it does not get a launch of its own: the first workgroups of the run's compaction
 // kernel do it while the others stream the copy, reading the prefixes straight from the BASE layout (the kept PETs of strip
-// s start at src0[s] there) and writing the words at the PETs' places in the new one (strip_new[s] + position).
+// s start at src0[s] there) and writing the words at the PETs' places in the new one (new strip start + position).
 //
 // One WAVE takes KB_SB consecutive strips (their table rows live in its lanes, the offsets come from shuffles -- no
 // barrier anywhere), stages the KB_SB + 2 strip prefixes as (q, sp) pairs in its own 4 KB of LDS with all loads of a lane in
@@ -105,14 +105,16 @@ __device__ __forceinline__ void band_rounds(int eps, int peps, int minPts, const
 // one wave: the strips [group * KB_SB, group * KB_SB + KB_SB).  lw: KB_CAP pairs of LDS owned by this wave.
 __device__ __forceinline__ void band_wave(int group, int lane, int2* lw, int S, int eps, int peps, int minPts,
                                           const int* __restrict__ bq, const int* __restrict__ bsp, const int* __restrict__ src0,
-                                          const int* __restrict__ strip_new, const int2* __restrict__ blen, int* __restrict__ cnt, int dbg)
+                                          const int* __restrict__ sloc, const int* __restrict__ sboffs /* the new strip table in its two-level form: k_cut_strips */,
+                                          const int2* __restrict__ blen, int* __restrict__ cnt, int dbg)
 {
     const int s_first = group * KB_SB;                  // lane k holds segment k = strip s_first - 1 + k, k = 0 .. KB_SB + 1
     int ssrc = 0, sg0 = 0, slen = 0, snb = 0;
     if (lane < KB_SB + 2) {
         const int s = s_first - 1 + lane;
         const bool ok = s >= 0 && s < S;
-        sg0 = strip_new[min(max(s, 0), S)];              // (a strip that does not exist: an empty prefix at its place)
+        const int sc = min(max(s, 0), S);
+        sg0 = sloc[sc] + sboffs[sc >> 8];                // (a strip that does not exist: an empty prefix at its place)
         ssrc = ok ? src0[s] : 0;
         const int2 bl = ok ? blen[s] : make_int2(0, 0);
         slen = bl.y;

@@ -113,6 +113,7 @@ struct cl_chrom {
     int* w_cnt = nullptr;             // where K2 writes the words of the run being enqueued (cnt or rc_cnt)
     WordSrc ws{};                     // where its consumers read them
     int init_nclr = 0;                // > 0: the run being enqueued has not cleared its key bitmap / counters yet (words to clear)
+    DevBuf blk_tmp;                   // block sums / offsets of the in-kernel scan over the key bitmap (k_rank_scan)
     DevBuf rootlist, cflag8;          // K3: the components' roots (k_flatten); per PET: core / opens a chain / ends one (k_chain_flags)
     int last_k2_mode = 0;             // 0 = full K2, 1 = words re-used as they are (same cut), 2 = remapped + K2 on the band
     std::vector<long long> dcum;      // dcum[k] = number of PETs with Y - X < k, k = 0 .. 65536 (empty: unknown)

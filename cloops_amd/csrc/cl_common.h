@@ -52,6 +52,7 @@ static inline int fail(int code, const char* what, const char* detail = nullptr)
 
 enum { ST_LIVE = 0, ST_DEAD = 1, ST_UNKNOWN = 2 };          // variant-2 release state of a component
 enum { CTR_NU = 0, CTR_NREC = 1, CTR_OVERFLOW = 2, CTR_NROOT = 3, CTR_NFLAG = 4 };         // device counters
+enum { CTR_TICKET_A = 50, CTR_TICKET_B = 51 };          // "last workgroup" tickets of the in-kernel scans: zero between kernels, never cleared with the counters
 
 struct GridParams {
     int eps;      // cell / strip width (cDBSCAN.py:29, cDBSCAN2.py:30: cw = eps)
@@ -203,6 +204,52 @@ __device__ __forceinline__ int lower_bound_4(const int* pv, int lo, int hi, int 
     }
     while (lo < hi && pv[lo] < val) ++lo;
     return lo;
+}
+
+// inclusive scan over the 256 threads of a workgroup (all of them call); red: 4 ints of LDS; total = the workgroup's sum
+__device__ __forceinline__ int wg256_inclusive_scan(int v, int* red, int& total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(v, d); v += lane >= d ? t : 0; }
+    if (lane == 63) red[wave] = v;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int x = red[w]; off += w < wave ? x : 0; tot += x; }
+    __syncthreads();
+    total = tot;
+    return v + off;
+}
+// The tail of a two-level exclusive scan inside the kernel that made its input (no launch of its own, nothing spins): every
+// workgroup has written the sum of its 256 elements to bsum[blockIdx.x] and takes a ticket; the LAST one to arrive scans the
+// block sums -> boff[0 .. nblk] (boff[nblk] = the total) and puts the ticket back to zero.  Element e of the scan is then
+// loc[e] (exclusive inside its workgroup) + boff[e >> 8].  Called by all 256 threads of every workgroup.
+__device__ __forceinline__ void scan_tail_last_block(int mysum, int* __restrict__ bsum, int* __restrict__ boff, int* ticket, int* red)
+{
+    __shared__ int l_is_last;
+    if (threadIdx.x == 0) {
+        // The block sum goes out as a device-scope ATOMIC (performed at the point all XCDs agree on) whose return is awaited
+        // before the ticket is taken; the last workgroup reads the sums with atomic loads.  A release fence instead would
+        // write back the whole L2 of the XCD (each of the eight has its own): 10+ us per kernel.
+        const int old = __hip_atomic_exchange(&bsum[blockIdx.x], mysum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+        asm volatile("" :: "v"(old) : "memory");
+        l_is_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!l_is_last) return;
+    const int nblk = (int)gridDim.x;
+    int carry = 0;
+    for (int base = 0; base < nblk; base += 256) {
+        const int k = base + (int)threadIdx.x;
+        const int v = k < nblk ? __hip_atomic_load(&bsum[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        int tot;
+        const int incl = wg256_inclusive_scan(v, red, tot);
+        if (k < nblk) boff[k] = carry + incl - v;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) { boff[nblk] = carry; __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
 struct LdsPairs {       // LDS window of (q = in-strip coord, p = strip coord), addressed by GLOBAL sorted index

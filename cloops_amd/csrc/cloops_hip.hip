@@ -1784,13 +1784,34 @@ __global__ void k_init_table(Table t, const int* __restrict__ rankscan, int n)
     t.count[k] = 0; t.minx[k] = INT_MAX; t.maxx[k] = INT_MIN; t.miny[k] = INT_MAX; t.maxy[k] = INT_MIN;
 }
 
+// Exclusive scan of the popcounts of the key bitmap's words, two-level: wloc[w] = set bits in front of word w inside its
+// workgroup's 1024 words, wboff[block] by the last workgroup to finish (scan_tail_last_block; wboff[gridDim.x] = the number of
+// ids).  One launch where rocPRIM's scan was three (a fill, the look-back state, the scan).
+__global__ void __launch_bounds__(256)
+k_rank_scan(int nw, const unsigned* __restrict__ bits, int* __restrict__ wloc, int* __restrict__ bsum, int* __restrict__ wboff, int* ticket)
+{
+    __shared__ int red[4];
+    const int w0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    int c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = w0 + k < nw ? __popc(bits[w0 + k]) : 0;
+    const int mine = c[0] + c[1] + c[2] + c[3];
+    int tot;
+    int run = wg256_inclusive_scan(mine, red, tot) - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (w0 + k < nw) wloc[w0 + k] = run; run += c[k]; }
+    scan_tail_last_block(tot, bsum, wboff, ticket, red);
+}
+
 __global__ void k_root_labels_bits_l(GridParams g, const int* __restrict__ rootlist, const int* __restrict__ counters,
                                      const int* __restrict__ compkey, const int* __restrict__ ncore, const int* __restrict__ bsize,
-                                     const int* __restrict__ state, const unsigned* __restrict__ bits, const int* __restrict__ wordrank,
-                                     int* __restrict__ rlabel, Table t, int nw, int* __restrict__ hdr, const int* __restrict__ d_M)
+                                     const int* __restrict__ state, const unsigned* __restrict__ bits,
+                                     const int* __restrict__ wloc, const int* __restrict__ wboff /* ranks of the bitmap's words, two-level (k_rank_scan) */,
+                                     int* __restrict__ rlabel, Table t, int nblkw, int* __restrict__ hdr, const int* __restrict__ d_M)
 {
+    const int ids = wboff[nblkw];                        // total number of ids handed out
     if (blockIdx.x == 0 && threadIdx.x == 0) {          // k_pack_header rides along (nothing behind this kernel raises a flag)
-        hdr[0] = wordrank[nw]; hdr[1] = counters[CTR_OVERFLOW]; hdr[2] = d_M[0]; hdr[3] = 0; hdr[4] = -1; hdr[5] = 0;
+        hdr[0] = ids; hdr[1] = counters[CTR_OVERFLOW]; hdr[2] = d_M[0]; hdr[3] = 0; hdr[4] = -1; hdr[5] = 0;
     }
     const int K = counters[CTR_NROOT];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
@@ -1798,10 +1819,10 @@ __global__ void k_root_labels_bits_l(GridParams g, const int* __restrict__ rootl
         const bool keep = (g.variant == CL_VARIANT_CDBSCAN2) ? (state[i] != ST_DEAD)
                                                              : (ncore[i] + bsize[i] >= g.minPts);   // cDBSCAN.py:149-152
         const int key = compkey[i];
-        rlabel[i] = keep ? wordrank[key >> 5] + __popc(bits[key >> 5] & ((1u << (key & 31)) - 1u)) : -1;
+        const int w = key >> 5;
+        rlabel[i] = keep ? wloc[w] + wboff[w >> 10] + __popc(bits[w] & ((1u << (key & 31)) - 1u)) : -1;
     }
     // k_init_table rides along: the rows of the ids handed out
-    const int ids = wordrank[nw];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < ids; k += gridDim.x * blockDim.x) {
         t.count[k] = 0; t.minx[k] = INT_MAX; t.maxx[k] = INT_MIN; t.miny[k] = INT_MAX; t.maxy[k] = INT_MIN;
     }
@@ -1888,7 +1909,7 @@ static void free_chrom(cl_chrom* c)
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->slot[0].d_step, &c->slot[1].d_step, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
                       &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->tileflag, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out, &c->dhist,
-                      &c->rc_cnt, &c->rc_pre, &c->rc_poff, &c->rc_dpre, &c->rc_D, &c->rc_blen, &c->rootlist, &c->cflag8};
+                      &c->rc_cnt, &c->rc_pre, &c->rc_poff, &c->rc_dpre, &c->rc_D, &c->rc_blen, &c->rootlist, &c->cflag8, &c->blk_tmp};
     for (DevBuf* b : bufs) b->release();
     c->arena.release();                                  // (after its slices have been dropped)
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
@@ -2011,6 +2032,8 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
         }
         if (n > 0) {
             if ((rc = c->counters.ensure(256))) break;
+            // (the tickets of the in-kernel scans live behind the counters and must start at zero)
+            if (hipMemsetAsync(c->counters.p, 0, 256, c->stream) != hipSuccess) { rc = fail(CL_ERR_HIP, "counters memset"); break; }
             Stats init = {INT_MAX, INT_MIN, INT_MAX, INT_MIN, INT_MAX, INT_MIN, INT_MAX, INT_MIN};
             Stats* hs = (Stats*)c->h_pinned;
             *hs = init;
@@ -2103,37 +2126,49 @@ extern "C" int cl_chrom_subsample(cl_chrom* src, const int64_t* rows, int64_t m,
 // the cut of the run that made the words (negative: fewer) -- what the hint fields of a word shift by.
 // ... and for such a run blen_out[s] = how many of the strip's kept PETs lie in the cut band (q < bandq) / within eps of it
 // (q < bandq + eps): the work list and the staging ranges of k_region_band.
-__global__ void k_cut_strips(int S, int thr, const int* __restrict__ bstrip, const int* __restrict__ bq,
-                             int* __restrict__ kept /* [S+1] */, int* __restrict__ src0 /* [S] first kept source index */,
-                             int* __restrict__ pre_out /* or null */, const int* __restrict__ pre_ref /* or null */,
-                             int* __restrict__ dpre_out /* with pre_ref */, int2* __restrict__ blen_out /* with pre_ref */, int bandq, int eps,
-                             int* __restrict__ clr /* or null */, int nclr, int* __restrict__ counters)
+__global__ void __launch_bounds__(256)
+k_cut_strips(int S, int thr, const int* __restrict__ bstrip, const int* __restrict__ bq,
+             int* __restrict__ sloc /* [S+1]: the new strip table, exclusive inside the workgroup's 256 strips */,
+             int* __restrict__ bsum, int* __restrict__ boff /* [gridDim.x + 1]: ... + the workgroups' offsets */, int* ticket,
+             int* __restrict__ src0 /* [S] first kept source index */,
+             int* __restrict__ pre_out /* or null */, const int* __restrict__ pre_ref /* or null */,
+             int* __restrict__ dpre_out /* with pre_ref */, int2* __restrict__ blen_out /* with pre_ref */, int bandq, int eps,
+             int* __restrict__ clr /* or null */, int nclr, int* __restrict__ counters)
 {
+    __shared__ int red[4];
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (clr) {
         // the run's first kernel also clears its key bitmap and counters (what k_init_flags does for a run without a cut)
         for (int u = s; u < nclr; u += gridDim.x * blockDim.x) clr[u] = 0;
         if (s < 16) counters[s] = 0;
     }
-    if (s > S) return;
-    if (s == S) { kept[S] = 0; if (pre_out) pre_out[S] = 0; if (pre_ref) dpre_out[S] = 0; return; }
-    const int b = bstrip[s];
-    int lo = b;
-    const int e = bstrip[s + 1];
-    int hi = e;
-    while (lo < hi) { const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1); if (bq[mid] < thr) lo = mid + 1; else hi = mid; }
-    kept[s] = e - lo;
-    src0[s] = lo;
-    if (pre_out) pre_out[s] = lo - b;
-    if (pre_ref) {
-        dpre_out[s] = (lo - b) - pre_ref[s];
-        int l1 = lo, h1 = e;
-        while (l1 < h1) { const int mid = (int)(((unsigned)l1 + (unsigned)h1) >> 1); if (bq[mid] < bandq) l1 = mid + 1; else h1 = mid; }
-        int l2 = l1; h1 = e;
-        const int q2 = bandq + eps;
-        while (l2 < h1) { const int mid = (int)(((unsigned)l2 + (unsigned)h1) >> 1); if (bq[mid] < q2) l2 = mid + 1; else h1 = mid; }
-        blen_out[s] = make_int2(l1 - lo, l2 - lo);
+    int kv = 0;                                          // kept length of the strip (0 for s >= S)
+    if (s == S) { if (pre_out) pre_out[S] = 0; if (pre_ref) dpre_out[S] = 0; }
+    if (s < S) {
+        const int b = bstrip[s];
+        int lo = b;
+        const int e = bstrip[s + 1];
+        int hi = e;
+        while (lo < hi) { const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1); if (bq[mid] < thr) lo = mid + 1; else hi = mid; }
+        kv = e - lo;
+        src0[s] = lo;
+        if (pre_out) pre_out[s] = lo - b;
+        if (pre_ref) {
+            dpre_out[s] = (lo - b) - pre_ref[s];
+            int l1 = lo, h1 = e;
+            while (l1 < h1) { const int mid = (int)(((unsigned)l1 + (unsigned)h1) >> 1); if (bq[mid] < bandq) l1 = mid + 1; else h1 = mid; }
+            int l2 = l1; h1 = e;
+            const int q2 = bandq + eps;
+            while (l2 < h1) { const int mid = (int)(((unsigned)l2 + (unsigned)h1) >> 1); if (bq[mid] < q2) l2 = mid + 1; else h1 = mid; }
+            blen_out[s] = make_int2(l1 - lo, l2 - lo);
+        }
     }
+    // the exclusive scan of the kept lengths IS the new strip table: inside the workgroup here, the workgroups' offsets by the
+    // last workgroup to finish (rocPRIM's scan was three launches: a fill, the look-back state, the scan)
+    int tot;
+    const int incl = wg256_inclusive_scan(kv, red, tot);
+    if (s <= S) sloc[s] = incl - kv;
+    scan_tail_last_block(tot, bsum, boff, ticket, red);
 }
 // Count cache: poff_out (a run whose words are kept, with a cut): poff_out[s] = PETs the cut removes in strips <= s;
 // poff_ref + D_out (a run that re-uses kept words): D_out[s] = that number for this cut minus poff_ref[s] -- sorted position
@@ -2143,7 +2178,8 @@ __global__ void k_cut_strips(int S, int thr, const int* __restrict__ bstrip, con
 template <bool BAND>
 __global__ void __launch_bounds__(CMP_TPB)
 k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const int* __restrict__ bsp, const u32* __restrict__ brow,
-           const int* __restrict__ src0, int* __restrict__ strip_start /* [0..S] = the scan; [S+1] written here */,
+           const int* __restrict__ src0, const int* __restrict__ sloc, const int* __restrict__ sboffs /* the new strip table, two-level (k_cut_strips) */,
+           int* __restrict__ strip_start /* [0..S+1]: the table in one piece, written here for everything that follows */,
            int* __restrict__ sv, int* __restrict__ sa, u32* __restrict__ srow, int* __restrict__ tile_s0, int* __restrict__ d_M,
            int expect_m, int* __restrict__ counters, int* __restrict__ poff_out /* or null */,
            const int* __restrict__ poff_ref /* or null */, int* __restrict__ D_out /* with poff_ref */,
@@ -2154,12 +2190,12 @@ k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const i
         if ((int)blockIdx.x < nbb) {
             const int wv = threadIdx.x >> 6;
             band_wave(blockIdx.x * (CMP_TPB / 64) + wv, threadIdx.x & 63, l_band[wv], S, eps, 1 << rbits, minPts, bq, bsp, src0,
-                      strip_start, blen, band_words, dbg);
+                      sloc, sboffs, blen, band_words, dbg);
             return;
         }
     }
     const int cb = (int)blockIdx.x - (BAND ? nbb : 0), ncb = (int)gridDim.x - (BAND ? nbb : 0);      // copy workgroups
-    const int M = strip_start[S];
+    const int M = sloc[S] + sboffs[S >> 8];
     const int base = cb * CMP_BLOCK;
     // stage by stage over the thread's CMP_PER PETs, so that the loads of a stage are all in flight together (q -> sp / row ->
     // the two per-strip table entries are dependent round trips)
@@ -2179,7 +2215,7 @@ k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const i
 #pragma unroll
     for (int k = 0; k < CMP_PER; ++k) {
         const int st = sp[k] >> rbits;
-        d0[k] = keep[k] ? strip_start[st] : 0;
+        d0[k] = keep[k] ? sloc[st] + sboffs[st >> 8] : 0;
         s0[k] = keep[k] ? src0[st] : 0;
     }
 #pragma unroll
@@ -2191,11 +2227,14 @@ k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const i
             if ((dst & 255) == 0) tile_s0[dst >> 8] = sp[k] >> rbits;
         }
     }
-    if (poff_out || poff_ref)
-        for (int u = cb * CMP_TPB + (int)threadIdx.x; u <= S; u += ncb * CMP_TPB) {
-            const int po = (u < S ? src0[u] : n) - strip_start[u];
+    for (int u = cb * CMP_TPB + (int)threadIdx.x; u <= S; u += ncb * CMP_TPB) {
+        const int st = sloc[u] + sboffs[u >> 8];
+        strip_start[u] = st;
+        if (poff_out || poff_ref) {
+            const int po = (u < S ? src0[u] : n) - st;
             if (poff_out) poff_out[u] = po; else D_out[u] = po - poff_ref[u];
         }
+    }
     // what k_after_compact did besides the strip table: tiles behind M, sentinels, M itself
     const int t = cb * CMP_TPB + (int)threadIdx.x;
     for (int u = t; u <= n / 256; u += ncb * CMP_TPB) if (u * 256 >= M) tile_s0[u] = S;
@@ -2545,31 +2584,31 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
             // stable compaction of the base layout by d = q + V0 >= cut (pipe.py:59-62): same order as sorting the
             // filtered rows, one pass over 12 B/PET
             const int nb = nblocks(n, CMP_BLOCK);
-            if ((rc = c->sel_tmp.ensure(((size_t)g.S + 2) * 8 + 64))) return rc;
-            int* kept = c->sel_tmp.as<int>();
-            int* src0 = kept + g.S + 2;
+            const int nblk = nblocks(g.S + 1, 256);       // workgroups of k_cut_strips = blocks of the two-level strip table
+            if ((rc = c->sel_tmp.ensure(((size_t)g.S + 2) * 8 + ((size_t)nblk + 2) * 8 + 64))) return rc;
+            int* sloc = c->sel_tmp.as<int>();
+            int* src0 = sloc + g.S + 2;
+            int* bsum = src0 + g.S + 2;
+            int* sboffs = bsum + nblk + 2;
             int* d_M = c->counters.as<int>() + CTR_M;
             const int thr = g.cut - g.V0;
             const int* bq = c->bq.as<int>() + SORT_PAD;
-            LAUNCH(k_cut_strips, g.S + 1, g.S, thr, (const int*)c->bstrip.as<int>(), bq, kept, src0,
+            LAUNCH(k_cut_strips, g.S + 1, g.S, thr, (const int*)c->bstrip.as<int>(), bq, sloc, bsum, sboffs, c->counters.as<int>() + CTR_TICKET_A, src0,
                    rcmode == RC_MAKE ? c->rc_pre.as<int>() : (int*)nullptr,
                    rcmode == RC_REMAP ? (const int*)c->rc_pre.as<int>() : (const int*)nullptr,
                    rcmode == RC_REMAP ? c->rc_dpre.as<int>() : (int*)nullptr, rcmode == RC_REMAP ? c->rc_blen.as<int2>() : (int2*)nullptr,
                    c->ws.bandq, g.eps, c->init_nclr > 0 ? c->flag.as<int>() : (int*)nullptr, c->init_nclr, c->counters.as<int>());
             c->init_nclr = 0;
-            // (the scan that opens a clustering run also clears its key bitmap and counters: init_nclr > 0)
-            size_t tb = c->scan_tmp.bytes;
-            hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, kept, c->strip.as<int>(), 0, (size_t)g.S + 1, rocprim::plus<int>(), c->stream);
-            if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan(cut)", hipGetErrorString(e));
+            // (the kernel that opens a clustering run also clears its key bitmap and counters: init_nclr > 0)
             if (rcmode == RC_REMAP) {
                 const int nbb = nblocks(nblocks(g.S, KB_SB), CMP_TPB / 64);      // workgroups that do K2 on the cut band (four waves of KB_SB strips each)
                 hipLaunchKernelGGL(k_cut_copy<true>, dim3(nbb + nb), dim3(CMP_TPB), 0, c->stream, n, g.S, g.rbits, thr, bq, (const int*)(c->bsp.as<int>() + SORT_PAD),
-                                   (const u32*)c->brow.as<u32>(), (const int*)src0, c->strip.as<int>(), wsv, wsa, c->vals_out.as<u32>(), c->tile_s0.as<int>(),
+                                   (const u32*)c->brow.as<u32>(), (const int*)src0, (const int*)sloc, (const int*)sboffs, c->strip.as<int>(), wsv, wsa, c->vals_out.as<u32>(), c->tile_s0.as<int>(),
                                    d_M, c->run_m_exact ? c->run_m : -1, c->counters.as<int>(), (int*)nullptr, (const int*)c->rc_poff.as<int>(), c->rc_D.as<int>(),
                                    nbb, (const int2*)c->rc_blen.as<int2>(), c->cnt.as<int>(), g.eps, g.minPts, g.dbg);
             } else
             hipLaunchKernelGGL(k_cut_copy<false>, dim3(nb), dim3(CMP_TPB), 0, c->stream, n, g.S, g.rbits, thr, bq, (const int*)(c->bsp.as<int>() + SORT_PAD),
-                               (const u32*)c->brow.as<u32>(), (const int*)src0, c->strip.as<int>(), wsv, wsa, c->vals_out.as<u32>(), c->tile_s0.as<int>(),
+                               (const u32*)c->brow.as<u32>(), (const int*)src0, (const int*)sloc, (const int*)sboffs, c->strip.as<int>(), wsv, wsa, c->vals_out.as<u32>(), c->tile_s0.as<int>(),
                                d_M, c->run_m_exact ? c->run_m : -1, c->counters.as<int>(), rcmode == RC_MAKE ? c->rc_poff.as<int>() : (int*)nullptr,
                                (const int*)nullptr, (int*)nullptr, 0, (const int2*)nullptr, (int*)nullptr, 0, 0, 0);
             c->w_sv = wsv; c->w_sa = wsa; c->srow = c->vals_out.as<u32>();
@@ -3109,17 +3148,18 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     // K5
     hipLaunchKernelGGL(k_rank_bits_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, counters, c->compkey.as<int>(), c->state.as<int>(), c->flag.as<unsigned>(),
                        variant == CL_VARIANT_CDBSCAN2 ? (const Rec*)c->recs.as<Rec>() : (const Rec*)nullptr, c->owner.as<int>());
-    {
-        size_t tb = c->scan_tmp.bytes;
-        hipError_t e = rocprim::exclusive_scan(c->scan_tmp.p, tb, rocprim::make_transform_iterator(c->flag.as<unsigned>(), PopcWord()),
-                                               c->rankscan.as<int>(), 0, (size_t)nw + 1, rocprim::plus<int>(), c->stream);
-        if (e != hipSuccess) return fail(CL_ERR_HIP, "exclusive_scan", hipGetErrorString(e));
-    }
-    c->k_total = c->rankscan.as<int>() + nw;
+    // ranks of the keys: exclusive scan over the popcounts of the bitmap's words, inside one kernel
+    const int nblkw = nblocks(nw, 1024);
+    if ((rc = c->blk_tmp.ensure(((size_t)nblkw + 2) * 8))) return rc;
+    int* wbsum = c->blk_tmp.as<int>();
+    int* wboff = wbsum + nblkw + 1;
+    hipLaunchKernelGGL(k_rank_scan, dim3(nblkw), dim3(256), 0, c->stream, nw, (const unsigned*)c->flag.as<unsigned>(), c->rankscan.as<int>(), wbsum, wboff,
+                       counters + CTR_TICKET_B);
+    c->k_total = wboff + nblkw;
     Table t = make_table(c);
     // rlabel reuses the chainhead buffer (free after k_chain_parent); the kernel also resets the table rows of the ids handed out
     hipLaunchKernelGGL(k_root_labels_bits_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, counters, c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
-                       c->state.as<int>(), c->flag.as<unsigned>(), c->rankscan.as<int>(), c->chainhead.as<int>(), t, nw,
+                       c->state.as<int>(), c->flag.as<unsigned>(), (const int*)c->rankscan.as<int>(), (const int*)wboff, c->chainhead.as<int>(), t, nblkw,
                        c->hdr.as<int>() + 16 * c->cur, (const int*)(strip + g.S));
     c->hdr_packed = true;
     if (!SKIP(8)) hipLaunchKernelGGL(k_final_labels, dim3(nblocks(nm, BIGTPB * FINAL_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow, c->owner.as<int>(),
