@@ -280,8 +280,11 @@ int cl_last_region_mode(const cl_chrom* c);
 
 /* A HIP stream for cl_chrom_create(..., stream, ...) made by the library (for callers without a HIP binding of their
  * own, like the ctypes host side).  Several handles may share one stream: their runs then execute in enqueue order in
- * that stream, and the D2H copies of a run are issued in it too (a handle with a stream of its own -- stream == NULL at
- * creation -- overlaps them with its next run through a copy stream).  The sweep driver keeps a few shared streams per
+ * that stream; their D2H copies go through ONE copy stream that belongs to the stream (made when the first handle has
+ * labels to copy), behind an event of the run, so that a run's labels cross PCIe while the next handle's kernels
+ * execute.  (A handle on a stream the caller made otherwise issues its copies in that stream; a handle with a stream of
+ * its own -- stream == NULL at creation -- overlaps them with its next run through a copy stream of its own.)  Make the
+ * streams before anything else that makes streams: the runtime deals its hardware queues in creation order.  The sweep driver keeps a few shared streams per
  * device instead of one per chromosome: how many kernels run side by side is then the application's choice, not a
  * property of how the runtime maps dozens of streams onto its hardware queues.  Destroy a stream after its handles. */
 void* cl_stream_create(int device);
