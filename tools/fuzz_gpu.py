@@ -57,6 +57,18 @@ for k in range(ncases):
             bad += 1
             print("MISMATCH case %d kind %d variant %s n=%d eps=%d minPts=%d cut=%d: %d rows differ" % (
                 k, kind, variant, len(X), eps, minPts, cut, int((want != got).sum())))
+        if variant != "block" and cut > 0:
+            # the same handle at another cut: the run re-uses the K2 words of the first (band query, words read in place)
+            cut2 = cut + int(rng.integers(1, 2 * eps))
+            keep2 = Y.astype(np.int64) - X >= cut2
+            if keep2.sum():
+                want2 = np.full(len(X), -1, np.int32)
+                want2[keep2] = oracle.labels(variant, X[keep2], Y[keep2], eps, minPts)
+                got2 = ch.cluster(variant, eps, minPts, cut2).labels
+                if not np.array_equal(want2, got2):
+                    bad += 1
+                    print("MISMATCH (re-used words, mode %d) case %d kind %d variant %s n=%d eps=%d minPts=%d cut=%d -> %d: %d rows differ" % (
+                        ch.last_region_mode(), k, kind, variant, len(X), eps, minPts, cut, cut2, int((want2 != got2).sum())))
     ch.close()
 print("fuzz seed %d: %d cases x 3 variants, %d mismatches, %.1f s" % (seed, ncases, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
