@@ -573,7 +573,8 @@ __device__ __forceinline__ void tile_visit_segment(const Tile& t, const int* __r
 // component the point is already known to be adjacent to cannot change anything -- a window next to a cluster is mostly that).
 template <int T_WIN, typename MORE, typename ACC, typename SEE, typename SKIPF>
 __device__ __forceinline__ void tile_walk_from(const Tile& t, const int* __restrict__ gq, const int* __restrict__ gp,
-                                               const int* __restrict__ gx, int M, int j, MORE&& more, ACC&& acc, SEE&& see, SKIPF&& skip, int dbg = 0)
+                                               const int* __restrict__ gx, int M, int j, MORE&& more, ACC&& acc, SEE&& see, SKIPF&& skip, int dbg = 0,
+                                               const int* uw = nullptr /* optional, per mask word: the payload ALL its set PETs share (-1: none set, -2: several) */)
 {
     const int base = t.w.base;
     int k = j - base;
@@ -611,8 +612,10 @@ __device__ __forceinline__ void tile_walk_from(const Tile& t, const int* __restr
             }
             const int w0 = k >> 6, sh = k & 63;
             constexpr int NW = T_WIN / 64;
-            unsigned long long win = t.m[w0] >> sh;
-            if (sh && w0 + 1 < NW) win |= t.m[w0 + 1] << (64 - sh);
+            // (a mask word whose cores all carry a payload the walk passes over -- the inside of the cluster a border point sits
+            //  next to -- counts as empty: one LDS read instead of a round per two cores)
+            unsigned long long win = (uw && skip(uw[w0])) ? 0ull : t.m[w0] >> sh;
+            if (sh && w0 + 1 < NW && !(uw && skip(uw[w0 + 1]))) win |= t.m[w0 + 1] << (64 - sh);
             win &= (1ull << len) - 1ull;                          // len <= 63
             while (win) {                                        // two cores per round
                 const int i0 = k + __ffsll((long long)win) - 1;
@@ -633,7 +636,7 @@ __device__ __forceinline__ void tile_walk_from(const Tile& t, const int* __restr
         }
         while (k < T_WIN) {
             const int knext = (k | 63) + 1;
-            unsigned long long bits = t.m[k >> 6] >> (k & 63);
+            unsigned long long bits = (uw && skip(uw[k >> 6])) ? 0ull : t.m[k >> 6] >> (k & 63);
             const int2 cn = lw[min(knext, T_WIN - 1)];
             const bool goes_on = knext >= T_WIN || more(cn);
             while (bits) {                                      // two set bits per round
@@ -1356,12 +1359,20 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
     __shared__ short l_list[NT];
     __shared__ int l_total;
     __shared__ unsigned long long l_mask[(NT + 2 * HALO) / 64];
+    __shared__ int l_uroot[(NT + 2 * HALO) / 64];       // per mask word: the root all its cores share (-1: no core, -2: several roots)
     __shared__ int l_enc[NT];
     constexpr int T_WIN = NT + 2 * HALO;
     const int M = strip_start[g.S];
     Tile t;
     if (threadIdx.x == 0) l_total = 0;
     if (!tile_stage<NT, HALO, NTH>(t, lw, lx, ntiles, M, sv, sa, root, l_mask)) return;
+    for (int k = threadIdx.x; k < T_WIN; k += NTH) {
+        const int x = lx[k];
+        const unsigned long long cb = __ballot(x >= 0);
+        const int R = cb ? __builtin_amdgcn_readlane(x, __ffsll((long long)cb) - 1) : -1;
+        const unsigned long long other = __ballot(x >= 0 && x != R);
+        if ((threadIdx.x & 63) == 0) l_uroot[k >> 6] = other ? -2 : R;
+    }
 #ifdef CLOOPS_DEVEL
 #define KB_ABL(bit) (g.dbg & (bit))
     if (KB_ABL(65536)) return;                           // developer ablation (results invalid): staging only
@@ -1451,10 +1462,10 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
         const int ja = i - (int)((unsigned)enc & K2H_MASK), jb = i + (int)(((unsigned)enc >> K2H_BITS) & K2H_MASK);
         if (!KB_ABL(524288))
         tile_walk_from<T_WIN>(t, sv, sa, root, M, ja, [&](int2 c) { return (c.y < pbeg) & (c.x <= qhi); },
-                              [&](int2 c) { return c.y >= plo; }, see, [&](int x) { return x == adj; }, g.dbg);       // one strip below: sp can only be too low
+                              [&](int2 c) { return c.y >= plo; }, see, [&](int x) { return x == adj; }, g.dbg, l_uroot);       // one strip below: sp can only be too low
         if (!KB_ABL(1048576))
         tile_walk_from<T_WIN>(t, sv, sa, root, M, jb, [&](int2 c) { return (c.y < pend2) & (c.x <= qhi); },
-                              [&](int2 c) { return c.y <= phi; }, see, [&](int x) { return x == adj; }, g.dbg);       // one strip above: only too high
+                              [&](int2 c) { return c.y <= phi; }, see, [&](int x) { return x == adj; }, g.dbg, l_uroot);       // one strip above: only too high
     } else {
         const int s = strip_of(g, me.y);
         const int b = strip_start[s], e = strip_start[s + 1];
