@@ -84,7 +84,6 @@ struct cl_chrom {
     int sort_index_mode = 0;          // cl_set_sort_index: 0 = build at the second sort, 1 = at the first, -1 = never
     long long n_sorts = 0;            // layouts sorted on this handle so far
     DevBuf sv, sa, strip, cnt, parent, root, head, headidx, cellfirst, compkey, ncore, bsize, owner, state;
-    DevBuf tileflag;                  // per 256-PET tile: holds a contested border point (k_border -> k_emit_records)
     DevBuf flag, rankscan, ulist, lo, hi, recs, counters, chainflag, chainhead, usize, b_cstart, b_ckey, b_nb, b_cx, b_cy, tile_s0;
     int* h_pinned = nullptr;          // small pinned staging (stats, block scalars)
     struct StripPlan { int layout, eps, maxlen; };

@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <iterator>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 

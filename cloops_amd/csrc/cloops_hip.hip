@@ -244,9 +244,54 @@ __global__ void k_decode_sp(int n, GridParams g, const u32* __restrict__ skey, c
     sv[i] = (int)(v >> 32);
     sa[i] = (int)k;
 }
-__global__ void k_strip_table32(const u32* __restrict__ skeys, int n, int S, int shift, int* __restrict__ strip_start)
+// The same two kernels as ITERATORS of the sort (a layout of all rows: no cut in the keys): the first radix pass makes its
+// keys and values from the q index while it reads it, the last pass writes the sorted sp straight into the layout's sp array and
+// splits its 64-bit values into the q and row arrays -- 24 B/PET of k_make_spkeys and 24 B/PET of k_decode_sp less per layout.
+struct SpKeyOfIndex {
+    const u32* keyq; const u64* valq; GridParams g;
+    __device__ __forceinline__ u32 operator()(int i) const
+    {
+        const int prel = (int)(valq[i] >> 32);
+        const int sabs = div_eps(g, prel);
+        return ((u32)(sabs - g.s0) << g.rbits) | (u32)(prel - sabs * g.eps);
+    }
+};
+struct SpValOfIndex {
+    const u32* keyq; const u64* valq;
+    __device__ __forceinline__ u64 operator()(int i) const { return ((u64)keyq[i] << 32) | (u32)valq[i]; }
+};
+struct SplitRef {
+    int* q; u32* row;
+    __device__ __forceinline__ const SplitRef& operator=(u64 v) const { *q = (int)(v >> 32); *row = (u32)v; return *this; }
+    __device__ __forceinline__ operator u64() const { return ((u64)(u32)*q << 32) | *row; }      // (rocPRIM's small-input merge sort reads its output back)
+    __device__ __forceinline__ const SplitRef& operator=(const SplitRef& o) const { *q = *o.q; *row = *o.row; return *this; }   // values, not pointers
+};
+struct SplitOut {                                       // output iterator: value -> (q array, row array)
+    using iterator_category = std::random_access_iterator_tag;
+    using value_type = u64;
+    using difference_type = std::ptrdiff_t;
+    using pointer = void;
+    using reference = SplitRef;
+    int* q; u32* row;
+    __host__ __device__ __forceinline__ SplitRef operator*() const { return SplitRef{q, row}; }
+    __host__ __device__ __forceinline__ SplitRef operator[](difference_type i) const { return SplitRef{q + i, row + i}; }
+    __host__ __device__ __forceinline__ SplitOut operator+(difference_type d) const { return SplitOut{q + d, row + d}; }
+    __host__ __device__ __forceinline__ SplitOut operator-(difference_type d) const { return SplitOut{q - d, row - d}; }
+    __host__ __device__ __forceinline__ difference_type operator-(const SplitOut& o) const { return q - o.q; }
+    __host__ __device__ __forceinline__ SplitOut& operator+=(difference_type d) { q += d; row += d; return *this; }
+    __host__ __device__ __forceinline__ SplitOut& operator-=(difference_type d) { q -= d; row -= d; return *this; }
+    __host__ __device__ __forceinline__ SplitOut& operator++() { ++q; ++row; return *this; }
+    __host__ __device__ __forceinline__ SplitOut operator++(int) { SplitOut t = *this; ++q; ++row; return t; }
+    __host__ __device__ __forceinline__ bool operator==(const SplitOut& o) const { return q == o.q; }
+    __host__ __device__ __forceinline__ bool operator!=(const SplitOut& o) const { return q != o.q; }
+    __host__ __device__ __forceinline__ bool operator<(const SplitOut& o) const { return q < o.q; }
+};
+
+// tile_s0 (optional): strip of every 256th sorted PET (what k_decode_sp leaves, for a layout that was not decoded)
+__global__ void k_strip_table32(const u32* __restrict__ skeys, int n, int S, int shift, int* __restrict__ strip_start, int* __restrict__ tile_s0 = nullptr)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile_s0) for (int u = t; u < (n + 255) / 256; u += gridDim.x * blockDim.x) tile_s0[u] = min((int)(skeys[u * 256] >> shift), S);
     if (t > S + 1) return;
     if (t == S + 1) { strip_start[t] = n; return; }
     const u32 target = (u32)t << shift;
@@ -1919,7 +1964,7 @@ static void free_chrom(cl_chrom* c)
     DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->qb_key, &c->qb_val, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->slot[0].d_step, &c->slot[1].d_step, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
-                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->tileflag, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out, &c->dhist,
+                      &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out, &c->dhist,
                       &c->rc_cnt, &c->rc_pre, &c->rc_poff, &c->rc_dpre, &c->rc_D, &c->rc_blen, &c->rootlist, &c->cflag8, &c->blk_tmp};
     for (DevBuf* b : bufs) b->release();
     c->arena.release();                                  // (after its slices have been dropped)
@@ -2271,7 +2316,7 @@ k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const i
         {&c->slot[0].labels, n * 4}, {&c->slot[0].table, (n + 1) * sizeof(cl_box)}, {&c->slot[0].slab, n * 4}, \
         {&c->slot[1].labels, n * 4}, {&c->slot[1].table, (n + 1) * sizeof(cl_box)}, {&c->slot[1].slab, n * 4}, \
         {&c->ulist, n * 4}, {&c->lo, n * 4}, {&c->hi, n * 4}, {&c->recs, n * sizeof(Rec)}, \
-        {&c->chainflag, n * 4}, {&c->chainhead, n * 4}, {&c->usize, n * 4}, {&c->tile_s0, (n / 256 + 2) * 4}, {&c->tileflag, (4 * (n / 1024 + 1) + 4) * 4}, \
+        {&c->chainflag, n * 4}, {&c->chainhead, n * 4}, {&c->usize, n * 4}, {&c->tile_s0, (n / 256 + 2) * 4}, \
         {&c->bq, (n + 2 * SORT_PAD) * 4}, {&c->bsp, (n + 2 * SORT_PAD) * 4}, {&c->brow, n * 4}, {&c->btile, (n / 256 + 2) * 4}, \
         {&c->qb_key, n * 4}, {&c->qb_val, n * 8}, {&c->k7_cls, n + 16}, {&c->rc_cnt, n * 4}, {&c->rootlist, n * 4}, {&c->cflag8, n + 16}, \
         {&c->slot[0].d_step, 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8 + K7_BLOCKS * sizeof(K7Part)}, \
@@ -2471,12 +2516,29 @@ static int sort_layout(cl_chrom* c, const GridParams& g, int* dsv, int* dsa, u32
             c->qindex_layout = layout;
         }
         ev_record(c, 0);
+        if (g.cut <= 0) {
+            // every row is in the layout: keys and values are made inside the first radix pass, the last one writes the layout
+            ev_record(c, 1);
+            u32* rows = drow ? drow : k32_in;
+            const auto kin = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), SpKeyOfIndex{c->qb_key.as<u32>(), c->qb_val.as<u64>(), g});
+            const auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), SpValOfIndex{c->qb_key.as<u32>(), c->qb_val.as<u64>()});
+            size_t need = 0;
+            hipError_t e = rocprim::radix_sort_pairs<SortConfig>(nullptr, need, kin, (u32*)dsa, vin, SplitOut{dsv, rows}, (size_t)n, g.rbits, g.rbits + strip_bits, c->stream);
+            if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs(strips) size query", hipGetErrorString(e));
+            if (need > c->sort_tmp.bytes && (rc = c->sort_tmp.ensure(need))) return rc;
+            size_t tb = c->sort_tmp.bytes;
+            e = rocprim::radix_sort_pairs<SortConfig>(c->sort_tmp.p, tb, kin, (u32*)dsa, vin, SplitOut{dsv, rows}, (size_t)n, g.rbits, g.rbits + strip_bits, c->stream);
+            if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs(strips)", hipGetErrorString(e));
+            LAUNCH(k_strip_table32, g.S + 2, (const u32*)dsa, n, g.S, g.rbits, dstrip, dtile);
+            c->srow = rows;
+            return CL_OK;
+        }
         LAUNCH(k_make_spkeys, n, n, g, (const u32*)c->qb_key.as<u32>(), (const u64*)c->qb_val.as<u64>(), k32_in, v64_in);
         ev_record(c, 1);
         size_t tb = c->sort_tmp.bytes;
         hipError_t e = rocprim::radix_sort_pairs<SortConfig>(c->sort_tmp.p, tb, k32_in, k32_out, v64_in, v64_out, (size_t)n, g.rbits, g.rbits + strip_bits, c->stream);
         if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs(strips)", hipGetErrorString(e));
-        LAUNCH(k_strip_table32, g.S + 2, (const u32*)k32_out, n, g.S, g.rbits, dstrip);
+        LAUNCH(k_strip_table32, g.S + 2, (const u32*)k32_out, n, g.S, g.rbits, dstrip, (int*)nullptr);
         u32* rows = drow ? drow : k32_in;                 // the unsorted keys are dead after the sort
         LAUNCH(k_decode_sp, n, n, g, (const u32*)k32_out, (const u64*)v64_out, dsv, dsa, dtile, rows);
         c->srow = rows;
