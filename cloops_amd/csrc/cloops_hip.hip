@@ -2344,7 +2344,16 @@ static int workspace_tmp_sizes(cl_chrom* c, size_t* sort_out, size_t* scan_out)
     e = rocprim::inclusive_scan_by_key(nullptr, scan3, rocprim::make_reverse_iterator((int*)nullptr), rocprim::make_reverse_iterator((int*)nullptr),
                                        rocprim::make_reverse_iterator((int*)nullptr), n, rocprim::minimum<int>(), rocprim::equal_to<int>(), c->stream);
     if (e != hipSuccess) return fail(CL_ERR_HIP, "inclusive_scan_by_key size query", hipGetErrorString(e));
-    *sort_out = std::max<size_t>(std::max(sort_bytes, sb2), 16);
+    size_t sb3 = 0;
+    {
+        // the layout sort with its keys and outputs as iterators (sort_layout): sized here so that the arena covers it
+        GridParams g0{};
+        const auto kin = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), SpKeyOfIndex{nullptr, nullptr, g0});
+        const auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), SpValOfIndex{nullptr, nullptr});
+        e = rocprim::radix_sort_pairs<SortConfig>(nullptr, sb3, kin, (u32*)nullptr, vin, SplitOut{nullptr, nullptr}, n, 0, 32, c->stream);
+        if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs size query (layout)", hipGetErrorString(e));
+    }
+    *sort_out = std::max<size_t>(std::max(std::max(sort_bytes, sb2), sb3), 16);
     *scan_out = std::max<size_t>(std::max(std::max(scan_bytes, scan2), scan3), 16);
     return CL_OK;
 }
