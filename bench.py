@@ -436,14 +436,28 @@ def scaling_proxy(pipe, lpt_assign, fs, sizes, steps, nranks, one_gpu_sweep_s, r
             per.append({"rank": r, "chromosomes": [], "pets": 0, "sweep_wall_s": 0.0})
             walls.append([0.0] * len(steps)); tails.append(0.0)
             continue
-        pipe.runSweepFast(fr, eps, mps, cut=0, variant=VARIANT, forced_cuts=forced)
-        acc, tot = np.zeros(len(steps)), 0.0
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            res = pipe.runSweepFast(fr, eps, mps, cut=0, variant=VARIANT, forced_cuts=forced)
-            tot += time.perf_counter() - t0
-            acc += np.asarray([st["wall_s"] for st in res[3]])
-        tables += [v["boxes"] for v in res[0].values() if len(v["boxes"])]
+        # the share as a rank would hold it: handles of its own, made largest first (a rank's stream pool spreads ITS chromosomes
+        # over the shared streams; the handles of the whole genome sit on the streams the 23-chromosome load balancing gave them,
+        # which can put a share's chromosomes on one stream)
+        copies = {}
+        for f in sorted(fr, key=lambda f: -len(pipe.CACHE.get(f).d)):
+            src = pipe.CACHE.get(f)
+            name = "mem://rank_share/%s-%s" % (src.key[0], src.key[1])
+            pipe.CACHE.put_chrom(name, pipe._make_chrom(src.X, src.Y, src.device), src.X, src.Y, ids=src.ids, key=src.key, device=src.device)
+            copies[f] = name
+        fr = [copies[f] for f in fr]
+        try:
+            pipe.runSweepFast(fr, eps, mps, cut=0, variant=VARIANT, forced_cuts=forced)
+            acc, tot = np.zeros(len(steps)), 0.0
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                res = pipe.runSweepFast(fr, eps, mps, cut=0, variant=VARIANT, forced_cuts=forced)
+                tot += time.perf_counter() - t0
+                acc += np.asarray([st["wall_s"] for st in res[3]])
+            tables += [v["boxes"] for v in res[0].values() if len(v["boxes"])]
+        finally:
+            for name in fr:
+                pipe.CACHE.drop(name)
         dt = tot / reps
         walls.append(list(acc / reps)); tails.append(max(dt - float(acc.sum()) / reps, 0.0))       # tail: candidate dedup + tables to the host
         per.append({"rank": r, "chromosomes": [sizes[ci][0] for ci in sorted(share)], "pets": int(sum(sizes[ci][2] for ci in share)),
@@ -454,7 +468,8 @@ def scaling_proxy(pipe, lpt_assign, fs, sizes, steps, nranks, one_gpu_sweep_s, r
            "implied_speedup": one_gpu_sweep_s / mk if mk > 0 else None, "implied_efficiency": one_gpu_sweep_s / mk / nranks if mk > 0 else None,
            "lpt_balance": max(p["pets"] for p in per) / (sum(p["pets"] for p in per) / float(nranks)),
            "note": "each rank's share timed ALONE on one MI355X with the genome-wide cut chain forced (runSweepFast(forced_cuts)); makespan_s = the slowest "
-                   "rank's whole sweep (no meeting between the steps: a lower bound); sum_over_steps_of_slowest_rank_s = with the per-step meeting a real run has"}
+                   "rank's whole sweep (no meeting between the steps: a lower bound); sum_over_steps_of_slowest_rank_s = with the per-step meeting a real run has; "
+                   "every share runs on handles of its own (made for the proxy, as a rank would make them), not on the handles of the 23-chromosome sweep"}
     try:
         from cloops_amd.comm import Comm
         c1 = Comm(0, 1, 0)
