@@ -1,3 +1,5 @@
+# developer A/B (needs `python -m cloops_amd.build --devel`): label copies on one copy stream per shared stream (0) vs inside the compute streams (1)
+export CLOOPS_DEVEL_LIB=1
 for k in 1 2; do
 for m in 0 1; do
   if [ $m = 1 ]; then export CLOOPS_COPY_IN_STREAM=1; else unset CLOOPS_COPY_IN_STREAM; fi
