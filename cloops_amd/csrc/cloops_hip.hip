@@ -2378,7 +2378,8 @@ static int reserve_workspace(cl_chrom* c)
         const long long cand0 = std::max<long long>((long long)n / 8, std::min<long long>(1 << 20, (long long)n + 1024));   // (small handles stay small)
         std::vector<Want> all(std::begin(wants), std::end(wants));
         all.push_back({&c->sort_tmp, sort_bytes}); all.push_back({&c->scan_tmp, scan_bytes});
-        all.push_back({&c->strip, (s_guess + 2) * 4}); all.push_back({&c->bstrip, (s_guess + 2) * 4}); all.push_back({&c->sel_tmp, (s_guess + 2) * 8 + 64});
+        all.push_back({&c->strip, (s_guess + 2) * 4}); all.push_back({&c->bstrip, (s_guess + 2) * 4}); all.push_back({&c->sel_tmp, (s_guess + 2) * 8 + (s_guess / 256 + 4) * 8 + 64});
+        all.push_back({&c->blk_tmp, (n / 32 / 1024 + 4) * 8});     // (block sums / offsets of the in-kernel scans ride in sel_tmp / blk_tmp)
         all.push_back({&c->cand_box, (size_t)cand0 * 16}); all.push_back({&c->cand_step, (size_t)cand0 * 4});
         bool untouched = true;
         size_t total = 0;
