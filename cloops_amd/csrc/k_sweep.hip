@@ -613,8 +613,20 @@ extern "C" int cl_cand_finish(cl_chrom* c, int32_t final_cut, int32_t* boxes_out
     if (N > INT_MAX - 1024) return fail(CL_ERR_GRID, "cl_cand_finish: more than 2^31 candidates");
     HIP_TRY(hipSetDevice(c->device));
     int rc;
+#ifdef CLOOPS_DEVEL
+    struct CfTrace {
+        double t[8]; int k = 0; long long n;
+        static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+        void mark() { if (k < 8) t[k++] = now(); }
+        ~CfTrace() { mark(); if (getenv("CLOOPS_TRACE_CAND")) { fprintf(stderr, "[cand n=%lld]", n); for (int i = 1; i < k; ++i) fprintf(stderr, " %.2f", t[i] - t[i - 1]); fprintf(stderr, " ms\n"); } }
+    } cft; cft.n = c->n; cft.mark();
+#define CF_MARK() cft.mark()
+#else
+#define CF_MARK() do { } while (0)
+#endif
     if ((rc = ensure_workspace(c, 1))) return rc;
     if ((rc = c->cand_keep.ensure((size_t)N + 64)) || (rc = c->cand_out.ensure((size_t)N * 16))) return rc;
+    CF_MARK();
     const int n = (int)N;
     // the sort buffers of the handle are sized for its PETs; a sweep of many steps on a strongly clustered chromosome can
     // leave more candidates than that: then the dedup sorts in buffers of its own (released at the end), and rocPRIM's
@@ -633,6 +645,7 @@ extern "C" int cl_cand_finish(cl_chrom* c, int32_t final_cut, int32_t* boxes_out
         if (e0 != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs size query (cand)", hipGetErrorString(e0));
         if ((rc = c->sort_tmp.ensure(std::max<size_t>(need, 16)))) return rc;
     }
+    CF_MARK();
     int* flags = c->counters.as<int>() + 60;
     // two different boxes sharing a 64-bit hash would be merged: the exact compare inside k_cand_mark notices, and the
     // pass is redone under another salt (a collision under four independent hashes does not happen)
@@ -649,6 +662,7 @@ extern "C" int cl_cand_finish(cl_chrom* c, int32_t final_cut, int32_t* boxes_out
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (hflag == 0) break;
     }
+    CF_MARK();
     if (hflag != 0) return fail(CL_ERR_HASH, "candidate dedup: hash collisions under four salts");
     hipError_t e;
     const int nb = nblocks(n, CAND_BLOCK);
@@ -664,6 +678,7 @@ extern "C" int cl_cand_finish(cl_chrom* c, int32_t final_cut, int32_t* boxes_out
     HIP_TRY(hipMemcpyAsync(&tail[0], boff + nb - 1, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&tail[1], bcount + nb - 1, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    CF_MARK();
     const long long kept = (long long)tail[0] + tail[1];
     *n_out = kept;
     if (kept > capacity) return fail(CL_ERR_ARG, "cl_cand_finish: boxes_out too small");
