@@ -603,7 +603,10 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
             if len(set(eps)) > 1:
                 r.chrom.set_sort_index(1)                    # several layouts are coming: the q index pays from the first one on
         step_no = 0
-        fine_lo = -1                                         # where the summary should look for the next median (see _select_kth)
+        # where the summary should look for the next median (see _select_kth).  The first step has no earlier median to go by:
+        # it counts the distances 1 .. 2048 exactly (self-ligation distances are a few hundred bp: ests.py's cut model) and falls
+        # back to the refinement passes if the median lies beyond
+        fine_lo = 1
         for ep in eps:
             for m in minPts:
                 step_cut = cut
