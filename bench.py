@@ -252,7 +252,7 @@ def main(argv=None):
             # the same passes with the re-use switched off (every run its own full region query)
             r = pipe.CACHE.get(probe_f)
             settings = [(st["eps"], st["minPts"], st["cut_in"]) for st in steps]
-            line["roofline"] = roofline_block(k2_replay(r.chrom, settings, min(minpts_list), 3), len(r.d))
+            line["roofline"] = roofline_block(k2_replay(r.chrom, settings, sorted(set(minpts_list)), 3), len(r.d))
             if k2_log:
                 line["roofline"]["in_sweep_avg_launch_ms"] = sum(max(t[3]["ms_region"] - t[3]["ms_bracket"], 1e-6) for t in k2_log) / len(k2_log)
                 line["roofline"]["in_sweep_source"] = "HIP events around K2 on chr1's stream during the last warm-up sweep (same work as a timed one; the event records between the kernels cost a sweep ~7 %, so the timed sweeps run without them)"
@@ -298,17 +298,17 @@ def k2_bytes(tm):
     return int(tm["n_in"]) * 12 + int(tm["n_strips"]) * 4
 
 
-def k2_replay(chrom, settings, floor, passes=3):
+def k2_replay(chrom, settings, served, passes=3):
     """The sweep's runs, in the sweep's order, on ONE resident chromosome alone on the GPU, `passes` times, HIP events
     around the kernels (the library's own brackets): first with the region query re-used inside an eps as the sweep
-    driver runs it (count cache, floor announced), then with the re-use off.  -> {"reuse": rows, "full": rows}, a row =
+    driver runs it (count cache, the sweep's minPts list announced: `served`), then with the re-use off.  -> {"reuse": rows, "full": rows}, a row =
     (eps, minPts, cut, timing dict, region mode 0 / 1 / 2 of cl_last_region_mode)."""
     out = {}
     chrom.set_profiling(True)
     only = os.environ.get("CLOOPS_REPLAY_ONLY")                          # "reuse" / "full": one kind of pass (tools/profile_bench.sh)
     for key, on in [kv for kv in (("reuse", True), ("full", False)) if only in (None, "", kv[0])]:
         chrom.set_count_reuse(on)
-        chrom.set_count_floor(floor if on else 0)
+        chrom.set_count_thresholds(served if on else [])
         rows = []
         for p in range(passes + 1):                     # (pass 0 warms the handle up: allocations, the q index)
             for ep, m, cut in settings:
@@ -319,7 +319,7 @@ def k2_replay(chrom, settings, floor, passes=3):
                     rows.append((ep, m, cut, dict(res.timing), mode))
         out[key] = rows
     chrom.set_count_reuse(True)
-    chrom.set_count_floor(floor)
+    chrom.set_count_thresholds(served)
     chrom.set_profiling(False)
     if only:
         out["full" if only == "reuse" else "reuse"] = out[only]

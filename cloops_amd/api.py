@@ -193,6 +193,12 @@ class Chromosome(object):
         """the smallest minPts that will follow at the current eps (cl_set_count_floor); 0 = unknown"""
         self._lib.cl_set_count_floor(self._h, int(min_pts))
 
+    def set_count_thresholds(self, min_pts_list):
+        """the minPts values that will be asked for at the current eps (cl_set_count_thresholds); empty = unknown"""
+        vals = [int(m) for m in min_pts_list]
+        arr = (ctypes.c_int32 * max(1, len(vals)))(*vals)
+        self._lib.cl_set_count_thresholds(self._h, arr, len(vals))
+
     def last_region_mode(self):
         """0 = the last enqueued run did a full region query, 1 = re-used the kept words, 2 = re-used them outside the cut band"""
         return int(self._lib.cl_last_region_mode(self._h))

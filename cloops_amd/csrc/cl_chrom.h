@@ -99,16 +99,17 @@ struct cl_chrom {
     DevBuf bq, bsp, brow, bstrip, btile, sel_tmp;
     struct BaseLayout { bool valid = false; int layout = -1, eps = 0; } base;
     // Count cache: the K2 words (cl_common.h "K2W") of the FIRST run on a base layout, kept while the layout lives.  A word
-    // holds the PET's neighbour count (exact from `floor` up, saturated at `cap`) and does not depend on minPts otherwise;
+    // holds the PET's neighbour count (saturated at `cap`, exact as far as the minPts values of `tmask` need it: GridParams::tmask) and does not depend on minPts otherwise;
     // a cut removes a prefix of every strip (q IS the distance), so between two runs of one eps the count of a PET changes
-    // only if q - eps < max(the two cuts): every later run with floor <= minPts <= cap takes the words of the PETs beyond that
+    // only if q - eps < max(the two cuts): every later run with a minPts of the set takes the words of the PETs beyond that
     // band as they are (k_cut_copy<true> carries them through its compaction) and runs K2 on the band alone.  Results are
     // identical with the cache switched off (cl_set_count_reuse); cLoops/pipe.py:247-250 walks minPts inside eps, descending.
-    struct CountCache { bool valid = false; int layout = -1, eps = 0, thr = 0 /* q threshold of the run's cut, 0 = none */, cap = 0, floor = 0; } rc;
+    struct CountCache { bool valid = false; int layout = -1, eps = 0, thr = 0 /* q threshold of the run's cut, 0 = none */, cap = 0; u32 tmask[4] = {0, 0, 0, 0} /* the minPts values the words serve, bit t - 1 */; } rc;
     DevBuf rc_cnt, rc_pre, rc_poff, rc_dpre, rc_D, rc_blen;   // the words in the sorted order of the run that made them; per strip: PETs its cut removed
                                       // from the strip / from all strips up to and including it
     bool reuse_counts = true;         // cl_set_count_reuse
     int count_floor = 0;              // cl_set_count_floor: smallest minPts later runs of this eps will ask for (0 = unknown)
+    u32 count_tmask[4] = {0, 0, 0, 0}; // cl_set_count_thresholds: the minPts values themselves (bit t - 1; all zero = not announced)
     int* w_cnt = nullptr;             // where K2 writes the words of the run being enqueued (cnt or rc_cnt)
     WordSrc ws{};                     // where its consumers read them
     int init_nclr = 0;                // > 0: the run being enqueued has not cleared its key bitmap / counters yet (words to clear)

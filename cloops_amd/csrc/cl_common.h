@@ -72,9 +72,11 @@ struct GridParams {
     int qbits;    // sort key = strip << (qbits+rbits) | q << rbits | (p mod eps): both coordinates ride
     int rbits;    //   in the key, so the sorted (q,p) arrays are DECODED, not gathered through row ids;
                   //   the radix sort skips the low rbits (they are payload, not order)
-    int floor;    // K2 (clustering form): neighbour counts of non-core PETs are EXACT from `floor` up (below it the word may hold an
-                  //   upper bound): floor == minPts for a one-off run; a run whose words later runs at a smaller minPts re-use
-                  //   (count cache of the handle, cl_set_count_floor) is made with the smallest minPts that will follow
+    u32 tmask[4]; // K2 (clustering form): the minPts values the words of this run have to serve, bit t - 1 = minPts t (2 .. 128).  A
+                  //   one-off run: its own minPts alone.  A run whose words later runs of the eps re-use (count cache of the handle):
+                  //   every minPts that will follow (cl_set_count_thresholds), or all of [floor, minPts] (cl_set_count_floor).  The
+                  //   count a non-core PET's word holds is only as exact as those tests need: for every t of the set,
+                  //   stored >= t  <=>  count >= t (an upper bound of the count otherwise; <= 1 still means "nothing within eps")
     int peps;     // 1 << rbits.  The kernels never see p itself but its ORDER-PRESERVING re-encoding
                   //   sp = strip << rbits | (p mod eps)   (the strip and remainder fields of the sort key):
                   //   strip(p) = sp >> rbits (no division), and |p_j - p_i| <= eps  <=>  |sp_j - sp_i| <= peps

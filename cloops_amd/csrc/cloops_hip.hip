@@ -1988,7 +1988,20 @@ extern "C" void cl_set_profiling(cl_chrom* c, int enabled) { if (c) c->profiling
 extern "C" void cl_set_layout_reuse(cl_chrom* c, int enabled) { if (c) { c->reuse_layout = enabled != 0; c->base.valid = false; c->rc.valid = false; } }
 extern "C" void cl_set_count_reuse(cl_chrom* c, int enabled) { if (c) { c->reuse_counts = enabled != 0; c->rc.valid = false; } }
 extern "C" int cl_last_region_mode(const cl_chrom* c) { return c ? c->last_k2_mode : 0; }
-extern "C" void cl_set_count_floor(cl_chrom* c, int32_t min_pts) { if (c) c->count_floor = min_pts > 0 ? min_pts : 0; }
+extern "C" void cl_set_count_floor(cl_chrom* c, int32_t min_pts)
+{
+    if (!c) return;
+    c->count_floor = min_pts > 0 ? min_pts : 0;
+    for (auto& w : c->count_tmask) w = 0;
+}
+extern "C" void cl_set_count_thresholds(cl_chrom* c, const int32_t* min_pts, int32_t n)
+{
+    if (!c) return;
+    c->count_floor = 0;
+    for (auto& w : c->count_tmask) w = 0;
+    for (int k = 0; min_pts && k < n; ++k)
+        if (min_pts[k] >= 2 && min_pts[k] <= 128) c->count_tmask[(min_pts[k] - 1) >> 5] |= 1u << ((min_pts[k] - 1) & 31);
+}
 extern "C" void cl_set_sort_index(cl_chrom* c, int mode) { if (c) c->sort_index_mode = mode > 0 ? 1 : (mode < 0 ? -1 : 0); }
 extern "C" int cl_get_timing(const cl_chrom* c, cl_timing* out)
 {
@@ -2426,7 +2439,8 @@ static int make_grid(cl_chrom* c, int variant, int eps, int minPts, int cut, Gri
 {
     g->eps = eps; g->minPts = minPts; g->cut = cut; g->variant = variant;
     g->dbg = 0; g->dbg2 = 0;
-    g->floor = minPts;
+    for (auto& w : g->tmask) w = 0;
+    if (minPts >= 1 && minPts <= 128) g->tmask[(minPts - 1) >> 5] = 1u << ((minPts - 1) & 31);      // a one-off run serves its own minPts
 #ifdef CLOOPS_DEVEL
     // developer build only (-DCLOOPS_DEVEL): ablation knobs that can change results; never in the shipped library
     { const char* e = getenv("CLOOPS_DBG"); g->dbg = e ? atoi(e) : 0; }
@@ -2588,8 +2602,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     int* wsa = c->sa.as<int>() + SORT_PAD;
     c->w_cnt = c->cnt.as<int>();
     c->last_k2_mode = 0;
-    GridParams gk = g;                                    // what K2 sees: floor filled in below
-    gk.floor = g.minPts;
+    GridParams gk = g;                                    // what K2 sees: the minPts values its words serve, filled in below
     bool k2_band = false, k2_skip = false;
     c->ws = WordSrc{c->cnt.as<int>(), nullptr, nullptr, nullptr, 0, g.rbits};
     if (!c->reuse_layout) {
@@ -2629,7 +2642,8 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
         const int thr_new = on_base ? 0 : g.cut - g.V0;   // q >= 0 everywhere: threshold 0 removes nothing
         enum { RC_NONE, RC_MAKE, RC_SAME, RC_REMAP } rcmode = RC_NONE;
         if (cacheable) {
-            const bool serves = c->rc.valid && c->rc.layout == layout && c->rc.eps == g.eps && g.minPts <= c->rc.cap && g.minPts >= c->rc.floor;
+            const bool serves = c->rc.valid && c->rc.layout == layout && c->rc.eps == g.eps && g.minPts <= c->rc.cap &&
+                                ((c->rc.tmask[m1 >> 5] >> (m1 & 31)) & 1u);
             if (serves && thr_new == c->rc.thr) rcmode = RC_SAME;
             else if (serves && !on_base && (long long)g.S <= 8LL * n) rcmode = RC_REMAP;      // (the band kernel works strip by strip)
             else rcmode = RC_MAKE;
@@ -2639,8 +2653,15 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
         }
         if (rcmode == RC_MAKE) {
             c->rc.valid = true; c->rc.layout = layout; c->rc.eps = g.eps; c->rc.thr = thr_new; c->rc.cap = g.minPts;
-            c->rc.floor = (c->count_floor > 0 && c->count_floor < g.minPts) ? std::max(2, c->count_floor) : g.minPts;
-            gk.floor = c->rc.floor;
+            // the minPts values these words will be asked about: the announced ones up to this run's (cl_set_count_thresholds), or
+            // everything from the announced floor up (cl_set_count_floor), and this run's own
+            for (int k = 0; k < 4; ++k) c->rc.tmask[k] = 0;
+            for (int t = 2; t < g.minPts; ++t) {
+                const bool in = ((c->count_tmask[(t - 1) >> 5] >> ((t - 1) & 31)) & 1u) || (c->count_floor > 0 && t >= c->count_floor);
+                if (in) c->rc.tmask[(t - 1) >> 5] |= 1u << ((t - 1) & 31);
+            }
+            c->rc.tmask[m1 >> 5] |= 1u << (m1 & 31);
+            for (int k = 0; k < 4; ++k) gk.tmask[k] = c->rc.tmask[k];
             c->w_cnt = c->rc_cnt.as<int>();
             c->ws.rc = c->w_cnt;
             if (on_base) {

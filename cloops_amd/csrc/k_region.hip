@@ -280,6 +280,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     __shared__ __attribute__((aligned(16))) int2 lw[WIN + K2F_SLACK];   // (q, sp) pairs, window index = sorted index - (t0 - HALO)
     __shared__ int l_st[K2F_NS + 4];
     __shared__ unsigned int l_list[TILE];                                // undecided PETs, one region of 64*U entries per wave
+    __shared__ unsigned char l_next[128];                                // smallest minPts of g.tmask above a count c (255: none)
     const int xcd = blockIdx.x & 7, kseq = blockIdx.x >> 3;
     const int tile = ((kseq / RUN) * 8 + xcd) * RUN + (kseq % RUN);
     if (tile >= ntiles) return;
@@ -309,6 +310,17 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         }
         l_st[threadIdx.x] = st;
         if (threadIdx.x < 4) l_st[K2F_NS + threadIdx.x] = 0;
+        if (threadIdx.x < 128) {
+            // the served minPts values as a table: l_next[c] = the smallest one above c (bit t - 1 of the mask = minPts t)
+            const int v = (int)threadIdx.x, wi = v >> 5;
+            int nx = 255;
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                const u32 x = k == wi ? (g.tmask[k] & (~0u << (v & 31))) : (k > wi ? g.tmask[k] : 0u);
+                if (x) nx = k * 32 + __ffs(x);
+            }
+            l_next[v] = (unsigned char)nx;
+        }
         if (threadIdx.x < K2F_SLACK) lw[WIN + threadIdx.x] = make_int2(INT_MAX, INT_MAX);
     }
     K2T(1);
@@ -317,7 +329,6 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     K2_ABL(32);
     const int m1 = g.minPts - 1;                        // 1 <= m1 <= 127 < HALO (the host guarantees it)
     const int eps = g.eps, peps = g.peps, minPts = g.minPts;
-    const int floorc = g.floor;                         // counts are exact from here up (<= minPts)
     const int nmask = ~(peps - 1);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned int* my_list = l_list + wv * (64 * U);
@@ -518,10 +529,13 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
 #ifdef CLOOPS_DEVEL
                 if (g.dbg & 512) { cnt[t0 + tix] = c + ja + jb + ka + kb; continue; }
 #endif
-                // (a search that ran out of steps reports >= minPts - 1 positions, so an ub below floorc <= minPts is the exact size
-                // of both windows: a true upper bound of the count)
+                // The count lies in [c, ub].  If none of the minPts values the words serve (g.tmask) falls into (c, ub], every
+                // one of their tests reads the same from ub as from the count, and no candidate is read: not core at any of them
+                // above c, core at every one up to c.  (A search that ran out of steps reports >= minPts - 1 positions: ub is
+                // then >= minPts, which is in the set -- an ub that passes this test is the exact size of both windows, a true
+                // upper bound of the count; <= 1 = isolated.)
                 const int ub = c + (ka - ja) + (kb - jb);
-                if (ub < floorc) c = ub;                // not core at any minPts >= floor; what is stored is an upper bound of the count (<= 1 = isolated)
+                if (ub < (int)l_next[c]) c = ub;
                 else {
                     // candidates to test: phase 3 (all lanes of this round have read their entries; what the round
                     // has consumed so far, 64 entries per round, is free -- an entry that would not fit is counted here)

@@ -598,8 +598,8 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
         for f, r in live:
             r.chrom.cand_reset()
             # the region query of the first run at an eps serves the later runs at that eps (their minPts are smaller: the
-            # reference sorts them descending, pipe.py:316-320) -- its counts have to be exact from the smallest one up
-            r.chrom.set_count_floor(min(minPts))
+            # reference sorts them descending, pipe.py:316-320) -- its counts have to tell `count >= m` for every m of the list
+            r.chrom.set_count_thresholds(sorted(set(int(m) for m in minPts)))
             if len(set(eps)) > 1:
                 r.chrom.set_sort_index(1)                    # several layouts are coming: the q index pays from the first one on
         step_no = 0

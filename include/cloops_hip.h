@@ -266,16 +266,21 @@ void cl_set_sort_index(cl_chrom* c, int mode);
  * only PETs whose distance is below it -- in the sorted layout a prefix of every strip -- so the count of a PET changes
  * between two runs of one eps only if its distance lies within eps above the larger of their cuts.  The sweep of
  * cLoops/pipe.py:247-250 walks minPts (descending) INSIDE eps: the handle keeps the per-PET words of the first run at
- * an eps (counts saturated at its minPts) and every later run at that eps with a minPts in [floor, that minPts] runs
- * the region query on the cut band alone; the other PETs' words ride through the cut compaction.  Results are
- * identical with enabled = 0 (every run does its own full region query).
- * cl_set_count_floor: the smallest minPts the caller will ask for at the current eps (the sweep driver knows its
- * list); the first run then keeps counts exact from there up.  0 (default) = unknown: only runs that repeat the
- * first run's minPts re-use its words.
+ * an eps (counts saturated at its minPts) and every later run at that eps with an announced minPts runs the region
+ * query on the cut band alone; the other PETs' words are read in place.  Results are identical with enabled = 0
+ * (every run does its own full region query).
+ * cl_set_count_thresholds: the minPts values the caller will ask for at the current eps (the inner loop of
+ * cLoops/pipe.py:247-250; the sweep driver knows its list; values outside 2..128 are ignored).  The first run then
+ * keeps every count as exact as the tests `count >= minPts` of those values need it (a PET whose count is known to lie
+ * between two neighbouring values of the list is not counted further).
+ * cl_set_count_floor: the older, coarser form -- every minPts from min_pts up to the first run's is served (counts
+ * exact from there up).  Either call replaces what the other announced; nothing announced (default) = only runs that
+ * repeat the first run's minPts re-use its words.
  * cl_last_region_mode: what the last enqueued run did -- 0 full region query, 1 words re-used as they were (same
  * cut), 2 words carried through the compaction + region query on the band. */
 void cl_set_count_reuse(cl_chrom* c, int enabled);
 void cl_set_count_floor(cl_chrom* c, int32_t min_pts);
+void cl_set_count_thresholds(cl_chrom* c, const int32_t* min_pts, int32_t n);
 int cl_last_region_mode(const cl_chrom* c);
 
 /* A HIP stream for cl_chrom_create(..., stream, ...) made by the library (for callers without a HIP binding of their

@@ -36,6 +36,9 @@ class FakeChromosome(object):
     def set_count_floor(self, min_pts):
         pass
 
+    def set_count_thresholds(self, min_pts_list):
+        pass
+
     def set_sort_index(self, mode=1):
         pass
 

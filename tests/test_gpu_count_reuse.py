@@ -1,4 +1,4 @@
-"""GPU: region-query reuse inside one eps (cl_set_count_reuse / cl_set_count_floor, include/cloops_hip.h).
+"""GPU: region-query reuse inside one eps (cl_set_count_reuse / cl_set_count_floor / cl_set_count_thresholds, include/cloops_hip.h).
 
 The first run at an eps keeps its per-PET neighbour-count words; later runs at that eps (any cut, a minPts between the
 announced floor and the first run's) take the words of the PETs outside the cut band as they are and run the region query
@@ -16,11 +16,14 @@ from cloops_amd.synth import synth_chrom
 pytestmark = pytest.mark.gpu
 
 
-def _check_seq(X, Y, variant, floor, seq, oracle_at=(), modes=None):
+def _check_seq(X, Y, variant, floor, seq, oracle_at=(), modes=None, served=None):
     a = api.Chromosome(X, Y)
     b = api.Chromosome(X, Y)
     b.set_count_reuse(False)
-    a.set_count_floor(floor)
+    if served is not None:
+        a.set_count_thresholds(served)          # the minPts values themselves (what the sweep driver announces)
+    else:
+        a.set_count_floor(floor)
     got_modes = []
     try:
         for k, (eps, m, cut) in enumerate(seq):
@@ -54,6 +57,24 @@ def test_dense_chain_like_mode3(variant):
     modes = [0, 2, 2, 2, 2, 2, 2, 1, 1, 0, 1, 0, 0, 0, 2, 2, 2]
     # (5000, 12, 4000): the words of (5000, 10, 3000) have cap 10 < 12 -> a new set with cap 12, floor 12 ... then 50 > 12
     _check_seq(X, Y, variant, 20, seq, oracle_at=(1, 3, 7, 11, 14, 16), modes=modes)
+
+
+@pytest.mark.parametrize("variant", ["v2", "v1"])
+def test_dense_chain_announced_list(variant):
+    """the same data with the minPts LIST announced (cl_set_count_thresholds): counts are kept only as exact as the tests of
+    those values need; a minPts outside the list makes a new set of words"""
+    X, Y = synth_chrom(1500000, 20000000, 77)
+    seq = [(5000, 50, 0), (5000, 40, 4536), (5000, 30, 6098), (5000, 20, 6306),          # make, remap x 3
+           (5000, 20, 6306), (5000, 50, 6306), (5000, 30, 5000), (5000, 40, 0),           # remap ... same cut as the making run
+           (5000, 35, 0),                                                                 # not announced: new words (cap 35; serves 20, 30, 35)
+           (5000, 30, 2000), (5000, 20, 0), (5000, 40, 0),                                # remap, same, above the cap: new
+           (7500, 50, 5711), (7500, 40, 3871), (7500, 30, 5004), (7500, 20, 5256),        # words made on a cut layout
+           (10000, 40, 5517), (10000, 50, 5517), (10000, 20, 4896), (10000, 30, 5977)]    # made at 40 (serves 20, 30, 40); 50: new words
+    modes = [0, 2, 2, 2, 2, 2, 2, 1, 0, 2, 1, 0, 0, 2, 2, 2, 0, 0, 2, 2]
+    _check_seq(X, Y, variant, 0, seq, oracle_at=(1, 3, 7, 9, 13, 15, 19), modes=modes, served=[50, 40, 30, 20])
+    # an odd list, values next to each other and far apart
+    seq = [(7500, 64, 0), (7500, 63, 4000), (7500, 33, 5000), (7500, 32, 5200), (7500, 5, 6000), (7500, 2, 0), (7500, 64, 3000)]
+    _check_seq(X, Y, variant, 0, seq, oracle_at=(1, 2, 4), modes=[0, 2, 2, 2, 2, 1, 2], served=[2, 5, 32, 33, 63, 64])
 
 
 @pytest.mark.parametrize("variant", ["v2", "v1"])
@@ -98,7 +119,7 @@ def test_fuzz_orders():
         ms = sorted({int(v) for v in rng.choice([2, 3, 5, 8, 20, 33, 50, 64, 100, 128], 4)}, reverse=True)
         seq = [(eps, m, int(rng.integers(0, 3 * spread)) if k else 0) for k, m in enumerate(ms + ms[::-1])]
         variant = "v2" if case % 2 == 0 else "v1"
-        _check_seq(X, Y, variant, min(ms), seq, oracle_at=(1, len(seq) - 2))
+        _check_seq(X, Y, variant, min(ms), seq, oracle_at=(1, len(seq) - 2), served=ms if case % 3 == 0 else None)
 
 
 def test_async_step_form_matches_sync():

@@ -21,7 +21,7 @@ X, Y = synth_chrom(n, length, 3000)
 ch = api.Chromosome(X, Y)
 ch.set_device_labels(False)
 settings = [(eps, m, CUTS_IN[4 * i + j]) for i, eps in enumerate((5000, 7500, 10000)) for j, m in enumerate((50, 40, 30, 20))]
-rep = bench.k2_replay(ch, settings, 20, passes)
+rep = bench.k2_replay(ch, settings, [20, 30, 40, 50], passes)
 blk = bench.roofline_block(rep, n)
 for a, f in list(zip(rep["reuse"], rep["full"]))[:12]:
     print("run (%5d, %2d, %4d) mode %d: sort bracket %6.1f us (full: %6.1f), region %6.1f us (full: %6.1f)" % (
