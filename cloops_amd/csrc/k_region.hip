@@ -382,6 +382,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         if (m1 <= 4) { lo = first_true<2>(lw, li - 3, inL); hi = first_true<2>(lw, li + 1, outR); }
         else if (m1 <= 8) { lo = first_true<3>(lw, li - 7, inL); hi = first_true<3>(lw, li + 1, outR); }
         else if (m1 <= 32) { lo = first_true<5>(lw, li - 31, inL); hi = first_true<5>(lw, li + 1, outR); }
+        else if (m1 <= 64) { lo = first_true<6>(lw, li - 63, inL); hi = first_true<6>(lw, li + 1, outR); }
         else { lo = first_true<7>(lw, li - 127, inL); hi = first_true<7>(lw, li + 1, outR); }
         const int c = hi - lo;
         const bool need = act & (c < minPts);
@@ -412,7 +413,9 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         }
         cnt[t0 + tix] = outv;
     };
-    const int cap3 = minPts <= 32 ? 31 : (minPts <= 64 ? 63 : 127);           // depth of the upper-bound searches
+    // depth of the upper-bound searches: a search that runs out of steps must leave an ub no served minPts lies above,
+    // i.e. 2^K - 1 >= the widest gap between a count and the next served minPts (minPts - 1 for a one-off run)
+    const int cap3 = g.tgap <= 31 ? 31 : (g.tgap <= 63 ? 63 : 127);
     auto count_candidates = [&](int c, int ja, int jb, int qhi, int pbeg, int pend2, int plo, int phi) {
         bool more = true;
         for (int j = ja; more & (c < minPts); j += 4) {
