@@ -518,16 +518,22 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
                 auto outB = [&](int2 v) { return (v.y >= pend2) | (v.x > qhi); };
                 const int last = WIN + K2F_SLACK - 1;
                 int ja, jb, ka, kb;
+                // (which probes need their index clamped to the LDS array: a search from tb ends at or before the PET itself, so
+                // its probes stay below li + 2^K - 1 -- inside the array for K <= FREEK (9 in the dense shapes); one from e may start at the
+                // end of the window and is free only while 2^K - 1 <= K2F_SLACK; the upper-bound searches start inside the
+                // window and reach at most cap3 <= K2F_SLACK - 1 entries further)
+                constexpr int FREEK = HALO + K2F_SLACK > (1 << 9) - 3 ? 9 : (HALO + K2F_SLACK > (1 << 8) - 3 ? 8 : 7);      // li + 2^K - 2 < WIN + K2F_SLACK
                 if (!__any(longest > 127)) { ja = first_true<7>(lw, tb, inA); jb = first_true<7>(lw, e, inB); }
-                else if (!__any(longest > 255)) { ja = first_true_clamped<8>(lw, tb, last, inA); jb = first_true_clamped<8>(lw, e, last, inB); }
-                else if (!__any(longest > 511)) { ja = first_true_clamped<9>(lw, tb, last, inA); jb = first_true_clamped<9>(lw, e, last, inB); }
+                else if (!__any(longest > 255)) { ja = FREEK >= 8 ? first_true<8>(lw, tb, inA) : first_true_clamped<8>(lw, tb, last, inA); jb = first_true_clamped<8>(lw, e, last, inB); }
+                else if (!__any(longest > 511)) { ja = FREEK >= 9 ? first_true<9>(lw, tb, inA) : first_true_clamped<9>(lw, tb, last, inA); jb = first_true_clamped<9>(lw, e, last, inB); }
                 else if (!__any(longest > 1023)) { ja = first_true_clamped<10>(lw, tb, last, inA); jb = first_true_clamped<10>(lw, e, last, inB); }
                 else { ja = first_true_clamped<12>(lw, tb, last, inA); jb = first_true_clamped<12>(lw, e, last, inB); }
                 // the upper bounds only 2^K - 1 >= minPts - 1 positions deep: "do at least r = minPts - c more PETs follow in the
                 // two windows" is all the rejection test needs (a search that runs out of steps reports 2^K - 1 >= r)
-                if (cap3 == 31) { ka = first_true_clamped<5>(lw, ja, last, outA); kb = first_true_clamped<5>(lw, jb, last, outB); }
-                else if (cap3 == 63) { ka = first_true_clamped<6>(lw, ja, last, outA); kb = first_true_clamped<6>(lw, jb, last, outB); }
-                else { ka = first_true_clamped<7>(lw, ja, last, outA); kb = first_true_clamped<7>(lw, jb, last, outB); }
+                static_assert(K2F_SLACK >= 128, "unclamped upper-bound searches");
+                if (cap3 == 31) { ka = first_true<5>(lw, ja, outA); kb = first_true<5>(lw, jb, outB); }
+                else if (cap3 == 63) { ka = first_true<6>(lw, ja, outA); kb = first_true<6>(lw, jb, outB); }
+                else { ka = first_true<7>(lw, ja, outA); kb = first_true<7>(lw, jb, outB); }
                 hja = ja; hjb = jb;
 #ifdef CLOOPS_DEVEL
                 if (g.dbg & 512) { cnt[t0 + tix] = c + ja + jb + ka + kb; continue; }
