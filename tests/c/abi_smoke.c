@@ -51,6 +51,30 @@ int main(void)
     int32_t nc = 0, ml = -1;
     CHECK(cl_cluster_weighted(c, 20000, 5, 50, 1, lab, &nc, &ml));
     printf("weighted (50,1): %d clusters\n", nc);
+    {
+        /* the inner loop of cLoops/pipe.py:247-250 from C: the minPts list announced, the first run keeps its neighbour counts,
+           the runs that follow at another minPts / cut query their cut band only -- labels equal to a handle without the re-use */
+        const int32_t served[3] = {8, 5, 3};
+        const int32_t runs[4][2] = {{8, 0}, {5, 700}, {3, 1500}, {5, 0}};
+        const int want_mode[4] = {0, 2, 2, 1};
+        cl_chrom* d = NULL;
+        CHECK(cl_chrom_create(0, NULL, x, y, n, 0, &d));
+        cl_set_count_reuse(d, 0);
+        cl_set_count_thresholds(c, served, 3);
+        int32_t* lab2 = malloc((size_t)n * sizeof *lab2);
+        if (!lab2) return 10;
+        for (int r = 0; r < 4; ++r) {
+            int32_t nc2 = 0, ml2 = -1;
+            CHECK(cl_cluster(c, CL_VARIANT_CDBSCAN2, 2000, runs[r][0], runs[r][1], lab, &nc, &ml));
+            if (cl_last_region_mode(c) != want_mode[r]) { fprintf(stderr, "run %d: region mode %d, expected %d\n", r, cl_last_region_mode(c), want_mode[r]); return 11; }
+            CHECK(cl_cluster(d, CL_VARIANT_CDBSCAN2, 2000, runs[r][0], runs[r][1], lab2, &nc2, &ml2));
+            if (cl_last_region_mode(d) != 0 || nc != nc2 || ml != ml2) return 12;
+            for (int64_t i = 0; i < n; ++i) if (lab[i] != lab2[i]) { fprintf(stderr, "run %d: label of row %lld differs\n", r, (long long)i); return 13; }
+        }
+        printf("count cache: 4 runs on kept words, labels equal\n");
+        free(lab2);
+        cl_chrom_destroy(d);
+    }
     if (cl_cluster(c, 7, 2000, 5, 0, lab, &nc, &ml) != CL_ERR_ARG) return 8;          /* unknown variant */
     if (cl_cluster(c, CL_VARIANT_CDBSCAN2, 0, 5, 0, lab, &nc, &ml) != CL_ERR_ARG) return 9;   /* eps = 0 */
     cl_chrom_destroy(c);
