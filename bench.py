@@ -78,6 +78,69 @@ def free_port():
     return p
 
 
+PREFLIGHT_CHILD = r"""
+import sys
+import numpy as np
+rank, world, local, tag = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+from cloops_amd.comm import Comm
+c = Comm(rank, world, local, tag=tag)
+v = c.allsum(np.arange(6, dtype=np.float64) + 1.0)
+assert abs(float(v[0]) - world) < 1e-9 and abs(float(v[5]) - 6.0 * world) < 1e-9, v
+k = c.allsum(np.asarray([rank + 1], dtype=np.int64))
+assert int(k[0]) == world * (world + 1) // 2, k
+tabs = c.gather_tables(np.full((rank + 1, 4), rank, np.int32), dst=0)
+if rank == 0:
+    assert [len(t) for t in tabs] == [r + 1 for r in range(world)] and all(int(t[0, 0]) == r for r, t in enumerate(tabs)), tabs
+c.barrier()
+c.close()
+"""
+
+
+def rccl_preflight(rank, world, local_rank, timeout=None, child=None):
+    """The RCCL-direct exchanges of this run (libcloops_comm.so: communicator from the id file, all-reduce of the step vector,
+    gather of variable-length tables, barrier) tried once in a CHILD process per rank before the run commits to them -- the
+    parent has loaded neither HIP runtime yet, so the torch.distributed path is still open to it.  Every rank leaves its
+    child's outcome in a file named after the launch; a rank reads all `world` of them: the decision is the same everywhere
+    (all children fine -> RCCL direct, otherwise torch.distributed), so the ranks cannot split between two comm stacks.
+    `child`: another script in the child's place (tests).  -> (ok, note)"""
+    from cloops_amd import comm as cm                    # (importing the module loads no library)
+    timeout = float(os.environ.get("CLOOPS_BENCH_PREFLIGHT_TIMEOUT", "120")) if timeout is None else timeout
+    tag = cm.default_tag() + "_pf"
+    mark = os.path.join(cm.ID_DIR, "cloops_comm_pf_%s" % tag)
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    note, ok = "", False
+    try:
+        out = subprocess.run([sys.executable, "-c", child or PREFLIGHT_CHILD, str(rank), str(world), str(local_rank), tag], env=env, cwd=ROOT,
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+        ok = out.returncode == 0
+        if not ok:
+            note = "rank %d: exit %d: %s" % (rank, out.returncode, out.stdout.decode("utf-8", "replace")[-300:].replace("\n", " | "))
+    except subprocess.TimeoutExpired:
+        note = "rank %d: no answer within %.0f s" % (rank, timeout)
+    tmp = "%s.%d.tmp" % (mark, rank)
+    with open(tmp, "w") as fh:
+        fh.write("1" if ok else "0 " + note)
+    os.replace(tmp, "%s.%d" % (mark, rank))
+    # every rank's outcome (a rank whose child hung has waited `timeout` itself: the others wait that long and a little more)
+    verdicts, t0 = {}, time.time()
+    while len(verdicts) < world and time.time() - t0 < timeout + 60.0:
+        for r in range(world):
+            if r not in verdicts:
+                try:
+                    with open("%s.%d" % (mark, r)) as fh:
+                        verdicts[r] = fh.read()
+                except (IOError, OSError):
+                    pass
+        if len(verdicts) < world:
+            time.sleep(0.02)
+    import atexit
+    atexit.register(lambda path="%s.%d" % (mark, rank): os.path.exists(path) and os.remove(path))      # (every rank has read it long before)
+    all_ok = len(verdicts) == world and all(v.startswith("1") for v in verdicts.values())
+    bad = "; ".join(v[2:] for v in verdicts.values() if not v.startswith("1")) or ("missing verdicts of ranks %s" % sorted(set(range(world)) - set(verdicts)) if len(verdicts) < world else "")
+    return all_ok, bad
+
+
 def main(argv=None):
     args = parse_args(argv)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -115,6 +178,16 @@ def main(argv=None):
         comm_note = "libcloops_comm.so not built, torch.distributed instead"
         sys.stderr.write("bench.py: %s\n" % comm_note)
         direct = False
+    if direct and (world > 1 or os.environ.get("CLOOPS_BENCH_PREFLIGHT") == "force") and os.environ.get("CLOOPS_BENCH_PREFLIGHT", "1") != "0":
+        # RCCL through libcloops_comm.so has to work on THIS node for every rank before the run depends on it (its failures --
+        # a rank that cannot open its IPC handles, a communicator that never forms -- are hangs, not errors): tried in child
+        # processes, decided by all ranks alike, while this process can still take the torch.distributed path
+        ok, why = rccl_preflight(rank, world, local_rank)
+        if not ok:
+            comm_note = "RCCL-direct pre-flight failed (%s): torch.distributed instead" % why
+            if rank == 0:
+                sys.stderr.write("bench.py: %s\n" % comm_note)
+            direct = False
     if direct:
         from cloops_amd.comm import Comm
         comm = Comm(rank, world, local_rank)

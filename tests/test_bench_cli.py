@@ -36,3 +36,39 @@ def test_bench_gpus_2_spawns_two_ranks_and_matches_single_process():
     assert two["config"]["final_cut"] == one["config"]["final_cut"]
     assert two["config"]["candidate_loops"] == one["config"]["candidate_loops"]
     assert two["config"]["pets_entering_dbscan_per_sweep"] == one["config"]["pets_entering_dbscan_per_sweep"]
+
+
+def _preflight_world2(children, timeout):
+    """bench.rccl_preflight on two 'ranks' of one launch (two threads: same parent process, i.e. the same launch tag), each
+    with a stand-in for the child that would try RCCL -> [(ok, note), (ok, note)]"""
+    import threading
+    sys.path.insert(0, ROOT)
+    import bench
+    out = [None, None]
+
+    def run(rank):
+        out[rank] = bench.rccl_preflight(rank, 2, rank, timeout=timeout, child=children[rank])
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    return out
+
+
+def test_preflight_all_ranks_take_the_same_decision(monkeypatch):
+    """the RCCL-direct pre-flight of bench.py: whatever happens to one rank's child (error, hang), every rank reads the same
+    verdict -- the ranks cannot split between libcloops_comm.so and torch.distributed"""
+    monkeypatch.setenv("MASTER_PORT", "1")
+    ok = "import sys"
+    bad = "import sys; sys.stderr.write('hipIpcGetMemHandle: invalid argument'); sys.exit(3)"
+    hang = "import time; time.sleep(60)"
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "pf-a")
+    a = _preflight_world2([ok, ok], 20.0)
+    assert a == [(True, ""), (True, "")], a
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "pf-b")
+    b = _preflight_world2([ok, bad], 20.0)
+    assert b[0][0] is False and b[1][0] is False and b[0] == b[1] and "rank 1: exit 3" in b[0][1] and "hipIpcGetMemHandle" in b[0][1], b
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "pf-c")
+    c = _preflight_world2([hang, ok], 2.0)
+    assert c[0][0] is False and c[1][0] is False and c[0] == c[1] and "rank 0: no answer" in c[0][1], c
