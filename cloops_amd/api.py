@@ -4,6 +4,7 @@ This is what the reference-shaped wrappers (cDBSCAN.py, cDBSCAN2.py, blockDBSCAN
 pipe.py) and bench.py are built on.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -14,6 +15,11 @@ VARIANTS = {"v1": _lib.VARIANT_CDBSCAN1, "cDBSCAN": _lib.VARIANT_CDBSCAN1, 1: 1,
             "block": _lib.VARIANT_BLOCK, "blockDBSCAN": _lib.VARIANT_BLOCK, 3: 3}
 
 BOX_DTYPE = np.dtype([("min_x", "<i4"), ("max_x", "<i4"), ("min_y", "<i4"), ("max_y", "<i4"), ("count", "<i4")])
+
+
+# developer / test knob: every new handle is switched to this traversal level (cl_set_traversal; None = the library's default).
+# The library itself reads no environment variable.
+TRAVERSAL_OVERRIDE = int(os.environ["CLOOPS_TRAVERSAL"]) if os.environ.get("CLOOPS_TRAVERSAL", "") != "" else None
 
 
 def device_count():
@@ -63,6 +69,11 @@ class Chromosome(object):
         self._init_state()
         _lib.check(lib.cl_chrom_create(int(device), ctypes.c_void_p(stream), X.ctypes.data_as(ctypes.c_void_p),
                                        Y.ctypes.data_as(ctypes.c_void_p), self.n, 0, ctypes.byref(self._h)))
+        self._after_create()
+
+    def _after_create(self):
+        if TRAVERSAL_OVERRIDE is not None:
+            self._lib.cl_set_traversal(self._h, int(TRAVERSAL_OVERRIDE))
 
     def _init_state(self):
         self._profiling = False
@@ -84,6 +95,7 @@ class Chromosome(object):
         self._init_state()
         _lib.check(lib.cl_chrom_create(int(device), ctypes.c_void_p(stream), ctypes.c_void_p(x_ptr),
                                        ctypes.c_void_p(y_ptr), self.n, 1, ctypes.byref(self._h)))
+        self._after_create()
         return self
 
     def subsample(self, rows):
@@ -97,6 +109,7 @@ class Chromosome(object):
         new.device = self.device
         new._init_state()
         _lib.check(self._lib.cl_chrom_subsample(self._h, rows.ctypes.data_as(ctypes.c_void_p), new.n, ctypes.byref(new._h)))
+        new._after_create()
         return new
 
     def close(self):
@@ -188,6 +201,11 @@ class Chromosome(object):
         """region-query words of the first run at an eps re-used by the later runs at that eps (default on; results
         identical either way -- cl_set_count_reuse of include/cloops_hip.h)"""
         self._lib.cl_set_count_reuse(self._h, 1 if on else 0)
+
+    def set_traversal(self, level=3):
+        """how far a run works on its core / walker lists instead of LDS tiles over every PET: 0 .. 3 (default 3; results
+        identical at every level -- cl_set_traversal of include/cloops_hip.h)"""
+        self._lib.cl_set_traversal(self._h, int(level))
 
     def set_count_floor(self, min_pts):
         """the smallest minPts that will follow at the current eps (cl_set_count_floor); 0 = unknown"""

@@ -32,7 +32,9 @@ static inline int bits_for(unsigned v) { int b = 0; while (v) { ++b; v >>= 1; } 
 #define CAND_BLOCK 2048
 
 struct K7Src {
-    int sorted; int n; int M; int v0;
+    int sorted;                                         // 0 = input rows, 1 = the run's sorted arrays, 2 = the run's lists (sv / slab hold one entry per core and
+                                                        // walker, dM their number)
+    int n; int M; int v0;
     const int* dM;                                      // if set: M is read from the device (the run has not been waited for yet)
     const int* X; const int* Y; const int* labels;      // input rows (+ row-order labels)
     const int* sv; const int* slab;                     // sorted q and sorted-order labels of [0, M)
@@ -115,6 +117,13 @@ struct cl_chrom {
     int init_nclr = 0;                // > 0: the run being enqueued has not cleared its key bitmap / counters yet (words to clear)
     DevBuf blk_tmp;                   // block sums / offsets of the in-kernel scan over the key bitmap (k_rank_scan)
     DevBuf rootlist, cflag8;          // K3: the components' roots (k_flatten); per PET: core / opens a chain / ends one (k_chain_flags)
+    // List form of a run (k_lists.hip): the run's CORES and its WALKERS (non-core PETs with a neighbour: the only ones a border
+    // rule can label) as compact arrays in sorted order, plus a rank index over the run's positions (one bit per PET and the
+    // exclusive core / walker count in front of every 64-PET group), so that any position range of the layout maps to a
+    // contiguous range of the core array in O(1).  K3 / K4 / K5 then touch nothing else.
+    DevBuf l_mask, l_rank, l_blk, l_cstrip, l_wpos, l_wenc, l_dist;
+    int traversal = 3;                // cl_set_traversal: 0 = tile kernels over every PET (rounds 1-4), 1 = K3 on the core list,
+                                      // 2 = + border rule on the walker list, 3 = + labels / table / statistics from the lists
     int last_k2_mode = 0;             // 0 = full K2, 1 = words re-used as they are (same cut), 2 = remapped + K2 on the band
     std::vector<long long> dcum;      // dcum[k] = number of PETs with Y - X < k, k = 0 .. 65536 (empty: unknown)
     const int* k_total = nullptr;     // device: where the run left the number of ids handed out (null: rankscan[n])
@@ -147,7 +156,8 @@ struct cl_chrom {
         char* h_step = nullptr;       // pinned host copy
         bool rows_valid = false;      // `labels` (row order) was produced by the run
         bool sorted_src = false;      // the run left sorted (q, label) arrays for the distance statistics
-        const int* k7_sv = nullptr;   // sorted q of the run
+        const int* k7_sv = nullptr;   // sorted q of the run (list form: q of every core and walker)
+        const int* k7_lcnt = nullptr; // list form (k_lists.hip): device {cores, walkers} -- slab / k7_sv hold one entry per core and walker
         int k7_v0 = 0;                // d = q + k7_v0
     } slot[2];
     bool device_labels = true;        // produce row-order device labels even without a host destination (cl_set_device_labels)
@@ -213,6 +223,26 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
           const int* __restrict__ head, const int* __restrict__ cellfirst,
           int* __restrict__ root, int* __restrict__ compkey, int* __restrict__ ncore,
           int* __restrict__ rootlist , int* __restrict__ counters);
+
+// ---- variant 2 release rule: a border point's adjacent components in ascending key order (cloops_hip.hip) ----
+struct Rec { int pt; int r[4]; };
+#define OWNER_CONTESTED 0x40000000
+__device__ __forceinline__ int owner_root(int o) { return o < 0 ? -1 : (o & (OWNER_CONTESTED - 1)); }
+
+// k_lists.hip: the list form of K3 / K4 / K5 (host side; every function enqueues on c->stream)
+struct ListRun {                                        // device views of the run's lists (valid after lists_build)
+    const int* lcnt;                                    // {C, W}: cores, walkers
+    const unsigned long long* cmask; const unsigned long long* wmask;
+    const int* cgrank; const int* wgrank;
+    int2* cpair; int* cpos; int* ckey; int2* wpair; int* wpos; int* wenc; int* cstrip;
+};
+int lists_build(cl_chrom* c, const GridParams& g, int nm, ListRun* out);
+int lists_union_flatten(cl_chrom* c, const GridParams& g, int nm, const ListRun& L);
+int lists_scatter_root(cl_chrom* c, int nm, const ListRun& L);
+int lists_border(cl_chrom* c, const GridParams& g, int nm, const ListRun& L);
+int lists_emit_records(cl_chrom* c, const GridParams& g, int nm, const ListRun& L);
+int lists_scatter_owner(cl_chrom* c, int nm, const ListRun& L);
+int lists_final(cl_chrom* c, const GridParams& g, int nm, const ListRun& L, bool rows);
 
 // kernels of k_sweep.hip that the step tail (finish_enqueue) launches
 __global__ void __launch_bounds__(256)

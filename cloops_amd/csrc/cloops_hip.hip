@@ -1386,8 +1386,6 @@ k_flatten(GridParams g, const int* __restrict__ strip_start, const int* __restri
 //                   adjacent component (first come, cDBSCAN.py:179-182)
 // owner[i] = root of the owning component (cores: their own root), -1 = noise
 // ------------------------------------------------------------------------------------------
-#define OWNER_CONTESTED 0x40000000
-__device__ __forceinline__ int owner_root(int o) { return o < 0 ? -1 : (o & (OWNER_CONTESTED - 1)); }
 
 // NT PETs per tile, NTH threads: NT / NTH PETs per thread in the first pass (staging and its barrier amortised: a halo of 128 on
 // both sides is 1.25 x the tile at NT = 1024 instead of 2 x at 256), then the border points that have to walk are compacted over the
@@ -1577,7 +1575,6 @@ k_border(GridParams g, int ntiles, const int* __restrict__ sv, const int* __rest
 
 // records: for every border point adjacent to an uncertain component, its (<= 4, geometric
 // bound) distinct adjacent components in ascending key order
-struct Rec { int pt; int r[4]; };
 
 // The contested border points that k_border listed (clist: points of components that are not live on their cores alone; a few
 // hundred to a few ten thousand per run), one WAVE each.  Only one whose first-come owner (its lowest-key adjacent component)
@@ -1965,7 +1962,8 @@ static void free_chrom(cl_chrom* c)
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->slot[0].d_step, &c->slot[1].d_step, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
                       &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out, &c->dhist,
-                      &c->rc_cnt, &c->rc_pre, &c->rc_poff, &c->rc_dpre, &c->rc_D, &c->rc_blen, &c->rootlist, &c->cflag8, &c->blk_tmp};
+                      &c->rc_cnt, &c->rc_pre, &c->rc_poff, &c->rc_dpre, &c->rc_D, &c->rc_blen, &c->rootlist, &c->cflag8, &c->blk_tmp,
+                      &c->l_mask, &c->l_rank, &c->l_blk, &c->l_cstrip, &c->l_wpos, &c->l_wenc, &c->l_dist};
     for (DevBuf* b : bufs) b->release();
     c->arena.release();                                  // (after its slices have been dropped)
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
@@ -1987,6 +1985,7 @@ extern "C" int64_t cl_chrom_size(const cl_chrom* c) { return c ? c->n : -1; }
 extern "C" void cl_set_profiling(cl_chrom* c, int enabled) { if (c) c->profiling = enabled != 0; }
 extern "C" void cl_set_layout_reuse(cl_chrom* c, int enabled) { if (c) { c->reuse_layout = enabled != 0; c->base.valid = false; c->rc.valid = false; } }
 extern "C" void cl_set_count_reuse(cl_chrom* c, int enabled) { if (c) { c->reuse_counts = enabled != 0; c->rc.valid = false; } }
+extern "C" void cl_set_traversal(cl_chrom* c, int level) { if (c) c->traversal = level < 0 ? 0 : (level > 3 ? 3 : level); }
 extern "C" int cl_last_region_mode(const cl_chrom* c) { return c ? c->last_k2_mode : 0; }
 extern "C" void cl_set_count_floor(cl_chrom* c, int32_t min_pts)
 {
@@ -2911,7 +2910,7 @@ int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* labels_ou
                            (int)c->cand_n, c->pending_step, (int)std::min<long long>(c->cand_cap, INT_MAX), c->cand_box.as<int4>(), c->cand_step.as<int>());
         K7Part* parts = (K7Part*)(ds + out_bytes);
         K7Src src{};
-        src.sorted = sl.sorted_src ? 1 : 0; src.n = n; src.M = 0; src.v0 = sl.k7_v0; src.dM = d_M;
+        src.sorted = sl.sorted_src ? (sl.k7_lcnt ? 2 : 1) : 0; src.n = n; src.M = 0; src.v0 = sl.k7_v0; src.dM = sl.k7_lcnt ? sl.k7_lcnt : d_M;
         src.X = c->d_x; src.Y = c->d_y; src.labels = sl.labels.as<int>(); src.sv = sl.k7_sv; src.slab = sl.slab.as<int>();
         src.dh = k7_hist_for(c, c->pending_cut);
         if (!SKIP(16)) hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, src, c->pending_cut, cls, parts, lh,
@@ -3182,7 +3181,11 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     // row-aligned labels only when somebody reads them: k_final_labels then writes the label (or -1) of every PET that
     // entered DBSCAN and only the rows removed by the cut filter need the -1 fill
     const bool rows = labels_out != nullptr || c->device_labels;
-    if (rows && cut > 0) HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
+    // how far the run works on lists (k_lists.hip; cl_set_traversal): 0 = tile kernels over every PET, 1 = K3 on the core list,
+    // 2 = + the border rule on the walker list, 3 = + labels / table / distance list from the lists (only labelled PETs are
+    // written: the row-aligned array is filled with -1 first)
+    const int level = wide == 0 ? c->traversal : 0;
+    if (rows && (cut > 0 || level >= 3)) HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
     if ((rc = run_sort_and_count(c, g, false))) return rc;
     if (c->init_nclr > 0) { LAUNCH(k_init_flags, nw + 1, nw, c->flag.as<int>(), counters); c->init_nclr = 0; }
     const WordSrc ws = c->ws;                           // where the K2 words of this run live (the handle's count cache / the work buffer)
@@ -3191,7 +3194,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     ENQ_MARK();
     {
         cl_chrom::Slot& sl = c->slot[c->cur];
-        sl.rows_valid = rows; sl.sorted_src = g.swap != 0; sl.k7_sv = c->w_sv; sl.k7_v0 = g.V0;
+        sl.rows_valid = rows; sl.sorted_src = g.swap != 0; sl.k7_sv = c->w_sv; sl.k7_v0 = g.V0; sl.k7_lcnt = nullptr;
         // variant 2 hands an id only to a live cluster, which has >= minPts members (cDBSCAN2.py:180-185): K <= n / minPts;
         // variant 1 numbers every component, dropped ones included (cDBSCAN.py:136-152): K <= n
         sl.kmax = (variant == CL_VARIANT_CDBSCAN2 && minPts >= 1) ? n / minPts + 1 : n;
@@ -3208,7 +3211,11 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
 
     // K3
     int* pmax32 = nullptr;
-    {
+    ListRun L{};
+    if (level >= 1) {
+        if ((rc = lists_build(c, g, nm, &L)) || (rc = lists_union_flatten(c, g, nm, L))) return rc;
+        if (level == 1 && (rc = lists_scatter_root(c, nm, L))) return rc;
+    } else {
         // own-strip chains; variant 2: the same tile kernel also finds every PET's cell head
         int* head = variant == CL_VARIANT_CDBSCAN2 ? c->head.as<int>() : nullptr;
         if (wide == 0) {
@@ -3227,7 +3234,8 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     // the union walk looks one strip back, i.e. about one strip population in front of the PET: a 256-PET halo keeps most of
     // those windows in LDS on dense data (chr1 of the 200 M genome, eps 5000-10000: -12..-16 %); short strips stay with 128
     const int union_halo = (long long)n > 40LL * g.S ? 256 : 128;
-    if (wide == 0) {
+    if (level >= 1) { }
+    else if (wide == 0) {
         const int nt_u = nblocks(nm, 1024);
         if (SKIP(2)) { } else if (union_halo == 256) hipLaunchKernelGGL((k_union_cores<1024, 256, TPB>), dim3(tile_grid(nt_u)), dim3(TPB), 0, c->stream, g, nt_u, sv, sa, strip,
                                                   c->chainflag.as<int>(), c->lo.as<int>(), pmax32, c->parent.as<int>());
@@ -3236,14 +3244,15 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     } else
     TILE_LAUNCH_H((wide == 2 || wide == 4) ? 512 : union_halo, k_union_cores, g, ntiles, sv, sa, strip, c->chainflag.as<int>(), c->lo.as<int>(),
                        pmax32, c->parent.as<int>());
-    if (!SKIP(4)) hipLaunchKernelGGL(k_flatten, dim3(nblocks(nm, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, g, strip, (const int*)nullptr, (const int*)c->chainflag.as<int>(),
+    if (level == 0 && !SKIP(4)) hipLaunchKernelGGL(k_flatten, dim3(nblocks(nm, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, g, strip, (const int*)nullptr, (const int*)c->chainflag.as<int>(),
            c->parent.as<int>(), srow, c->head.as<int>(), c->cellfirst.as<int>(),
            c->root.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->rootlist.as<int>(), counters);
     int* rootlist = c->rootlist.as<int>();
     ev_record(c, 4);
     // K4
     int* clist = c->chainflag.as<int>();                // the contested border points k_emit_records looks at (the chain ids of K3 are dead)
-    if (wide == 0) {
+    if (level >= 2) { if ((rc = lists_border(c, g, nm, L))) return rc; }
+    else if (wide == 0) {
         // 1024 PETs per workgroup of 256 threads (4 per thread in the first pass, the walkers of the whole tile in one list)
         const int nt_b = nblocks(std::max(1, c->run_m), 1024);
         if (!SKIP(1)) hipLaunchKernelGGL((k_border<1024, 128, TPB>), dim3(tile_grid(nt_b)), dim3(TPB), 0, c->stream, g, nt_b, sv, sa, strip, c->root.as<int>(),
@@ -3255,7 +3264,8 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         const int rec_cap = n;
         hipLaunchKernelGGL(k_mark_uncertain_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, c->ncore.as<int>(), c->bsize.as<int>(), c->state.as<int>(),
                            c->ulist.as<int>(), counters);
-        if (!SKIP(128)) hipLaunchKernelGGL(k_emit_records, dim3(2048), dim3(TPB), 0, c->stream, g, sv, sa, strip, c->root.as<int>(),
+        if (level >= 2) { if ((rc = lists_emit_records(c, g, nm, L))) return rc; }
+        else if (!SKIP(128)) hipLaunchKernelGGL(k_emit_records, dim3(2048), dim3(TPB), 0, c->stream, g, sv, sa, strip, c->root.as<int>(),
                            c->compkey.as<int>(), c->state.as<int>(), c->owner.as<int>(), c->recs.as<Rec>(), rec_cap, counters,
                            (const int*)clist, ws);
         hipLaunchKernelGGL(k_resolve_release, dim3(1), dim3(1024), 0, c->stream, minPts, c->ncore.as<int>(), c->usize.as<int>(), c->state.as<int>(),
@@ -3279,8 +3289,16 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
                        c->state.as<int>(), c->flag.as<unsigned>(), (const int*)c->rankscan.as<int>(), (const int*)wboff, c->chainhead.as<int>(), t, nblkw,
                        c->hdr.as<int>() + 16 * c->cur, (const int*)(strip + g.S));
     c->hdr_packed = true;
-    if (!SKIP(8)) hipLaunchKernelGGL(k_final_labels, dim3(nblocks(nm, BIGTPB * FINAL_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow, c->owner.as<int>(),
+    if (level >= 3) {
+        if ((rc = lists_final(c, g, nm, L, rows))) return rc;
+        cl_chrom::Slot& sl = c->slot[c->cur];
+        sl.k7_lcnt = L.lcnt; sl.k7_sv = c->l_dist.as<int>();      // the distance statistics read the run's lists (K7Src::sorted == 2)
+    } else {
+        if (level == 2 && (rc = lists_scatter_owner(c, nm, L))) return rc;
+        if (!SKIP(8)) hipLaunchKernelGGL(k_final_labels, dim3(nblocks(nm, BIGTPB * FINAL_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow,
+                       level == 2 ? c->l_dist.as<int>() : c->owner.as<int>(),
                        c->chainhead.as<int>(), rows ? c->slot[c->cur].labels.as<int>() : (int*)nullptr, c->slot[c->cur].slab.as<int>(), t);
+    }
     HIP_TRY(hipGetLastError());
     return finish_enqueue(c, g.S + 2, strip + g.S, labels_out);
 }

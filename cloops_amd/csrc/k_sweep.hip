@@ -43,7 +43,8 @@ template <typename F>
 __device__ __forceinline__ void k7_for_each(const K7Src& s, int cut, const signed char* __restrict__ cls, F&& f)
 {
     if (s.sorted) {
-        const int M = s.dM ? s.dM[0] : s.M;
+        // (list form: the labelled candidates of the run -- its cores and walkers -- instead of every PET of the layout)
+        const int M = s.sorted == 2 ? s.dM[0] + s.dM[1] : (s.dM ? s.dM[0] : s.M);
         const int per = (M + gridDim.x - 1) / gridDim.x;
         const int i0 = blockIdx.x * per, i1 = min(M, i0 + per);
         // four PETs per round: the label loads, then the class gathers, of all four are in flight together (the walk is bound
@@ -511,7 +512,8 @@ static K7Src k7_source(cl_chrom* c, int cut)
     cl_chrom::Slot& sl = c->slot[c->last_slot];
     K7Src s{};
     s.dh = k7_hist_for(c, cut);
-    s.sorted = sl.sorted_src ? 1 : 0; s.n = (int)c->n; s.M = sl.h_hdr[2]; s.v0 = sl.k7_v0;
+    s.sorted = sl.sorted_src ? (sl.k7_lcnt ? 2 : 1) : 0; s.n = (int)c->n; s.M = sl.h_hdr[2]; s.v0 = sl.k7_v0;
+    s.dM = sl.k7_lcnt;
     s.X = c->d_x; s.Y = c->d_y; s.labels = sl.labels.as<int>(); s.sv = sl.k7_sv; s.slab = sl.slab.as<int>();
     return s;
 }

@@ -283,6 +283,14 @@ void cl_set_count_floor(cl_chrom* c, int32_t min_pts);
 void cl_set_count_thresholds(cl_chrom* c, const int32_t* min_pts, int32_t n);
 int cl_last_region_mode(const cl_chrom* c);
 
+/* How the part of a rotated run behind the region query (components, border rule, labels) walks the data.  The reference
+ * expands clusters from core points only (cDBSCAN2.py:114-192 queryGrid, cDBSCAN.py:155-184 expandCluster); level 3
+ * (default) does the same: the run's cores and its non-core PETs that have a neighbour are compacted into two lists
+ * right behind the region query and nothing else is touched again.  Levels 0..2 keep the LDS-tile kernels over every PET
+ * of the run for the components (0), the border rule (<= 1) and the labels (<= 2): results are identical at every level
+ * (the tests compare them). */
+void cl_set_traversal(cl_chrom* c, int level);
+
 /* A HIP stream for cl_chrom_create(..., stream, ...) made by the library (for callers without a HIP binding of their
  * own, like the ctypes host side).  Several handles may share one stream: their runs then execute in enqueue order in
  * that stream; their D2H copies go through ONE copy stream that belongs to the stream (made when the first handle has
