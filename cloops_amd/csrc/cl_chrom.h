@@ -122,6 +122,8 @@ struct cl_chrom {
     // exclusive core / walker count in front of every 64-PET group), so that any position range of the layout maps to a
     // contiguous range of the core array in O(1).  K3 / K4 / K5 then touch nothing else.
     DevBuf l_mask, l_rank, l_blk, l_cstrip, l_wpos, l_wenc, l_dist;
+    bool l_sup_dirty = false;         // k_classify's superblock sums may be non-zero (a run that failed between k_classify and k_chain_c)
+    GridParams dbg_g{}; int dbg_nm = 0;   // the last rotated run's grid and size (developer build: kernels timed on their own)
     int traversal = 3;                // cl_set_traversal: 0 = tile kernels over every PET (rounds 1-4), 1 = K3 on the core list,
                                       // 2 = + border rule on the walker list, 3 = + labels / table / statistics from the lists
     int last_k2_mode = 0;             // 0 = full K2, 1 = words re-used as they are (same cut), 2 = remapped + K2 on the band

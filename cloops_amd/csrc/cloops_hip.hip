@@ -3212,6 +3212,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     // K3
     int* pmax32 = nullptr;
     ListRun L{};
+    c->dbg_g = g; c->dbg_nm = nm;
     if (level >= 1) {
         if ((rc = lists_build(c, g, nm, &L)) || (rc = lists_union_flatten(c, g, nm, L))) return rc;
         if (level == 1 && (rc = lists_scatter_root(c, nm, L))) return rc;

@@ -29,6 +29,31 @@
 // Results are bit-identical to the tile kernels of cloops_hip.hip (cl_set_traversal switches between them; tests compare).
 #include "cl_chrom.h"
 
+#ifdef CLOOPS_DEVEL
+#define L_ABL(bit) (g.dbg2 & (bit))                     // developer ablation (CLOOPS_DBG2; results invalid)
+#else
+#define L_ABL(bit) 0
+#endif
+#ifdef CLOOPS_DEVEL
+// developer build: event counts of the list kernels (walkers, walk iterations, ...), summed per wave; cl_debug_lstats reads and clears them
+__device__ unsigned long long g_lstat[32];
+__device__ __forceinline__ void lstat_add(int slot, int v)
+{
+    int t = v;
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+    if ((threadIdx.x & 63) == 0 && t) atomicAdd(&g_lstat[slot], (unsigned long long)t);
+}
+extern "C" void cl_debug_lstats(unsigned long long* out)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lstat), sizeof(g_lstat));
+    unsigned long long z[32] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lstat), z, sizeof(z));
+}
+#define LSTAT(slot, v) lstat_add((slot), (v))
+#else
+#define LSTAT(slot, v) do { } while (0)
+#endif
 #define LT 2048                  // positions per tile of k_classify / k_make_lists (256 threads x 8)
 #define LG (LT / 64)             // 64-PET groups per tile
 #define L_HALO 128               // variant 2: staged halo of k_classify (cell heads look one PET back, cells run on behind the tile)
@@ -62,40 +87,37 @@ __global__ void __launch_bounds__(256)
 k_classify(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa, const int* __restrict__ strip_start, WordSrc ws,
            const u32* __restrict__ srow, unsigned long long* __restrict__ cmask, unsigned long long* __restrict__ wmask,
            unsigned long long* __restrict__ hmask, int* __restrict__ cgloc, int* __restrict__ wgloc,
-           int* __restrict__ bsum /* [2][nblk + 1] */, int* __restrict__ boff /* [2][nblk + 1] */, int* ticket, int* __restrict__ lcnt,
+           int* __restrict__ bsum /* [2][nblk + 1]: cores / walkers of every tile */, int* __restrict__ sup /* [2][nsup]: ... of every 64 tiles (zero on entry) */,
            int* __restrict__ cellfirst)
 {
-    constexpr int WIN = LT + 2 * L_HALO;
-    __shared__ __attribute__((aligned(16))) int2 lw[V2 ? WIN : 1];
     __shared__ int lmin[V2 ? LT : 1];
     __shared__ unsigned long long l_chead[LG];
     __shared__ int l_cc[LG], l_wc[LG];
-    __shared__ int l_hlast, l_is_last;
-    __shared__ int red[4];
+    __shared__ int l_hlast;
     const int M = strip_start[g.S];
     const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
-    const int t0 = blk * LT, base = t0 - L_HALO;
+    const int t0 = blk * LT;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nmask = ~(g.peps - 1);
-    int q[8], sp[8], w[8];
+    int q[8], sp[8], w[8], pq[8], pp[8];
     u32 row[8];
     if (V2) {
-        // the tile plus a halo as (q, sp) pairs: the padded sorted arrays take unpredicated 16-byte loads
-        const int4* __restrict__ gq4 = reinterpret_cast<const int4*>(sv + base);
-        const int4* __restrict__ gp4 = reinterpret_cast<const int4*>(sa + base);
-        int4* l4 = reinterpret_cast<int4*>(lw);
-        for (int cidx = threadIdx.x; cidx < WIN / 4; cidx += 256) {
-            const int4 a = gq4[cidx], b = gp4[cidx];
-            l4[2 * cidx] = make_int4(a.x, b.x, a.y, b.y);
-            l4[2 * cidx + 1] = make_int4(a.z, b.z, a.w, b.w);
+        // every load of the thread in flight at once: its 8 PETs' (q, sp, row); the predecessor of a PET (cell heads look one PET
+        // back) sits in the neighbouring lane -- only lane 0 loads it (the padded arrays hold a sentinel in front of index 0)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = t0 + u * 256 + (int)threadIdx.x;
+            const bool in = i < M;
+            q[u] = in ? sv[i] : INT_MAX; sp[u] = in ? sa[i] : INT_MAX; row[u] = in ? srow[i] : 0u;
+            pq[u] = (in && lane == 0) ? sv[i - 1] : 0; pp[u] = (in && lane == 0) ? sa[i - 1] : 0;
         }
         for (int k = threadIdx.x; k < LT; k += 256) lmin[k] = INT_MAX;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = t0 + u * 256 + (int)threadIdx.x; row[u] = i < M ? srow[i] : 0u; }
         if (threadIdx.x == 0) l_hlast = -1;
-        __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int2 me = lw[L_HALO + u * 256 + (int)threadIdx.x]; q[u] = me.x; sp[u] = me.y; }
+        for (int u = 0; u < 8; ++u) {
+            const int a = __shfl_up(q[u], 1), b = __shfl_up(sp[u], 1);
+            if (lane != 0) { pq[u] = a; pp[u] = b; }
+        }
     } else {
         const bool need = ws.D != nullptr;               // (a run on the layout its words were made on finds them by position alone)
 #pragma unroll
@@ -104,8 +126,29 @@ k_classify(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
             q[u] = (need && i < M) ? sv[i] : 0; sp[u] = (need && i < M) ? sa[i] : 0;
         }
     }
+    if (L_ABL(1 << 16)) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { const int i = t0 + u * 256 + (int)threadIdx.x; w[u] = i < M ? ws.raw(i, q[u], sp[u]) : 0; }
+        for (int u = 0; u < 8; ++u) w[u] = q[u] & 63;    // (ablation: no word loads)
+    } else
+    {
+        // the K2 words, in two stages with all loads of a stage in flight: the per-strip offset of a run that reads the words of
+        // an earlier run of its eps (WordSrc: position i of strip s is position i + D[s] there; the cut band has fresh words), then
+        // the words themselves
+        const int* src[8]; int idx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = t0 + u * 256 + (int)threadIdx.x;
+            src[u] = ws.rc; idx[u] = i < M ? i : 0;
+            if (ws.D && i < M) {
+                if (q[u] < ws.bandq) src[u] = ws.band;
+                else idx[u] = i + ws.D[sp[u] >> ws.rbits];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = src[u][idx[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = t0 + u * 256 + (int)threadIdx.x; w[u] = i < M ? w[u] : 0; }
+    }
     unsigned headbits = 0u;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -119,9 +162,8 @@ k_classify(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
         if (V2) {
             // a PET starts a rotated cell (strip, q / eps) iff its predecessor lies in an earlier strip or below the cell's lower q
             // edge (cDBSCAN2.py:67-70; variant 2 runs with A0 = V0 = 0)
-            const int2 pv = lw[L_HALO + u * 256 + (int)threadIdx.x - 1];
-            const int q0 = div_eps(g, q[u]) * g.eps;
-            const bool start = in && (i == 0 || (pv.y & nmask) != (sp[u] & nmask) || pv.x < q0);
+            const int q0 = in ? div_eps(g, q[u]) * g.eps : 0;
+            const bool start = in && (i == 0 || (pp[u] & nmask) != (sp[u] & nmask) || pq[u] < q0);
             const unsigned long long hb = __ballot(start);
             if (lane == 0) { l_chead[k] = hb; hmask[gidx] = hb; }
         }
@@ -144,7 +186,17 @@ k_classify(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
         (lane < 32 ? cgloc : wgloc)[(t0 >> 6) + k] = incl - v;
         totC = __shfl(incl, 31); totW = __shfl(incl, 63);
     }
-    if (V2) {
+    // the tile's totals: a plain store, and two atomics NOBODY WAITS FOR into the sums of its 64-tile superblock -- k_make_lists
+    // adds up the superblocks and the tiles in front of its own (a few hundred loads per workgroup).  (First form: block sums as
+    // awaited device-scope atomics, a ticket, the last workgroup scans -- 57 of this kernel's 89 us on chr1: ~5000 workgroups each
+    // ended in two dependent round trips to memory.)
+    if (threadIdx.x == 0) {
+        const int nsup = (nblk + 63) / 64 + 1;
+        bsum[blk] = totC; bsum[nblk + 1 + blk] = totW;
+        if (totC) atomicAdd(&sup[blk >> 6], totC);
+        if (totW) atomicAdd(&sup[nsup + (blk >> 6)], totW);
+    }
+    if (V2 && !L_ABL(256)) {
         // cellfirst[cell head] = the smallest input row of the cell's PETs, by LDS atomics on the cells that begin in this tile
         // (a cell that began in an earlier tile: that tile walks it, below)
 #pragma unroll
@@ -167,15 +219,15 @@ k_classify(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
         __syncthreads();
         const int tend = t0 + LT;
         if (threadIdx.x < 64 && tend < M && l_hlast >= t0) {
-            // the cell of the tile's last PET may go on behind the tile: wave 0 walks it, 64 PETs per round (right halo, then global memory)
-            const int2 lp = lw[L_HALO + LT - 1];
+            // the cell of the tile's last PET may go on behind the tile: wave 0 walks it, 64 PETs per round
+            const int2 lp = make_int2(sv[tend - 1], sa[tend - 1]);
             const int p0 = lp.y & nmask, qend = div_eps(g, lp.x) * g.eps + g.eps;
             int m = INT_MAX;
             for (int j0 = tend; j0 < M; j0 += 64) {
                 const int j = j0 + (int)threadIdx.x;
                 bool in = j < M;
                 if (in) {
-                    const int2 cc = j < base + WIN ? lw[j - base] : make_int2(sv[j], sa[j]);
+                    const int2 cc = make_int2(sv[j], sa[j]);
                     in = (cc.y & nmask) == p0 && cc.x < qend;
                 }
                 if (in) m = min(m, (int)srow[j]);
@@ -189,33 +241,13 @@ k_classify(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
         for (int u = 0; u < 8; ++u)
             if (headbits & (1u << u)) { const int i = t0 + u * 256 + (int)threadIdx.x; cellfirst[i] = lmin[i - t0]; }
     }
-    // the tiles' offsets: both block sums go out as device-scope atomics whose return is awaited before the ticket is taken
-    // (cl_common.h scan_tail_last_block: a release fence would write back the XCD's whole L2); the last workgroup scans them
-    if (threadIdx.x == 0) {
-        const int o1 = __hip_atomic_exchange(&bsum[blk], totC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int o2 = __hip_atomic_exchange(&bsum[nblk + 1 + blk], totW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_waitcnt(0);
-        asm volatile("" :: "v"(o1), "v"(o2) : "memory");
-        l_is_last = atomicAdd(ticket, 1) == nblk - 1;
+#ifdef CLOOPS_DEVEL
+    if (V2 && L_ABL(256)) {                              // (ablation: a valid key all the same -- the head's own row)
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = t0 + u * 256 + (int)threadIdx.x; if (i < M) cellfirst[i] = (int)row[u]; }
     }
-    __syncthreads();
-    if (!l_is_last) return;
-    int carryC = 0, carryW = 0;
-    for (int b0 = 0; b0 < nblk; b0 += 256) {
-        const int k = b0 + (int)threadIdx.x;
-        const int vc = k < nblk ? __hip_atomic_load(&bsum[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        const int vw = k < nblk ? __hip_atomic_load(&bsum[nblk + 1 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        int tc, tw;
-        const int ic = wg256_inclusive_scan(vc, red, tc);
-        const int iw = wg256_inclusive_scan(vw, red, tw);
-        if (k < nblk) { boff[k] = carryC + ic - vc; boff[nblk + 1 + k] = carryW + iw - vw; }
-        carryC += tc; carryW += tw;
-    }
-    if (threadIdx.x == 0) {
-        boff[nblk] = carryC; boff[2 * nblk + 1] = carryW;
-        lcnt[0] = carryC; lcnt[1] = carryW;
-        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -226,38 +258,84 @@ __global__ void __launch_bounds__(256)
 k_make_lists(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa, const int* __restrict__ strip_start, WordSrc ws,
              const u32* __restrict__ srow, const unsigned long long* __restrict__ cmask, const unsigned long long* __restrict__ wmask,
              const unsigned long long* __restrict__ hmask, const int* __restrict__ cgloc, const int* __restrict__ wgloc,
-             const int* __restrict__ boff, const int* __restrict__ cellfirst, int* __restrict__ cgrank, int* __restrict__ wgrank,
+             const int* __restrict__ bsum, const int* __restrict__ sup, const int* __restrict__ cellfirst, int* __restrict__ cgrank, int* __restrict__ wgrank,
              int2* __restrict__ cpair, int* __restrict__ cpos, int* __restrict__ ckey, int2* __restrict__ wpair,
-             int* __restrict__ wpos, int* __restrict__ wenc, int* __restrict__ cstrip)
+             int* __restrict__ wpos, int* __restrict__ wenc, int* __restrict__ lcnt)
 {
-    const int M = strip_start[g.S];
+    __shared__ int l_red[2][4];
     const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
     const int t0 = blk * LT;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int cbase = boff[blk], wbase = boff[nblk + 1 + blk];
-    const int C = boff[nblk], W = boff[2 * nblk + 1];
-    // the cores-only strip table: cstrip[s] = cores in front of strip s (cstrip[S] = cstrip[S + 1] = C)
-    for (int u = blk * 256 + (int)threadIdx.x; u <= g.S + 1; u += nblk * 256) {
-        const int p = u <= g.S ? strip_start[u] : M;
-        int r = C;
-        if (p < M) { const int gi = p >> 6; r = boff[p / LT] + cgloc[gi] + __popcll(cmask[gi] & low_mask(p & 63)); }
-        cstrip[u] = r;
+    // cores / walkers in front of this tile: the 64-tile superblocks in front of its own + the tiles of its own in front of it
+    int cbase, wbase;
+    {
+        const int nsup = (nblk + 63) / 64 + 1, sb = blk >> 6;
+        int pc = 0, pw = 0;
+        for (int k = threadIdx.x; k < sb; k += 256) { pc += sup[k]; pw += sup[nsup + k]; }
+        if (threadIdx.x < 64) { const int k = sb * 64 + (int)threadIdx.x; if (k < blk) { pc += bsum[k]; pw += bsum[nblk + 1 + k]; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { pc += __shfl_down(pc, o); pw += __shfl_down(pw, o); }
+        if (lane == 0) { l_red[0][wv] = pc; l_red[1][wv] = pw; }
+        __syncthreads();
+        cbase = l_red[0][0] + l_red[0][1] + l_red[0][2] + l_red[0][3];
+        wbase = l_red[1][0] + l_red[1][1] + l_red[1][2] + l_red[1][3];
     }
-    if (blk == nblk - 1 && threadIdx.x == 0) { cgrank[nblk * LG] = C; wgrank[nblk * LG] = W; }
+    if (blk == nblk - 1 && threadIdx.x == 0) {
+        // the last tile knows the totals: {C, W} for every kernel behind this one, and the rank of the group behind the last tile
+        const int C = cbase + bsum[blk], W = wbase + bsum[nblk + 1 + blk];
+        lcnt[0] = C; lcnt[1] = W;
+        cgrank[nblk * LG] = C; wgrank[nblk * LG] = W;
+#ifdef CLOOPS_DEVEL
+        atomicAdd(&g_lstat[8], (unsigned long long)C); atomicAdd(&g_lstat[9], (unsigned long long)W); atomicAdd(&g_lstat[10], (unsigned long long)strip_start[g.S]); atomicAdd(&g_lstat[11], 1ull);
+#endif
+    }
+    // stage by stage over the thread's 8 PETs (one per 64-PET group of its wave), all loads of a stage in flight together:
+    // the groups' masks and ranks (wave-uniform), the pairs, then what a core / a walker needs beyond them
+    unsigned long long cbv[8], wbv[8];
+    int cgv[8], wgv[8], q[8], sp[8], aux[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int gidx = (t0 >> 6) + u * 4 + wv;
+        cbv[u] = cmask[gidx]; wbv[u] = wmask[gidx];
+        cgv[u] = cbase + cgloc[gidx]; wgv[u] = wbase + wgloc[gidx];
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int i = t0 + u * 256 + (int)threadIdx.x;
-        const int k = u * 4 + wv, gidx = (t0 >> 6) + k;
-        const unsigned long long cb = cmask[gidx], wb = wmask[gidx];          // (wave-uniform)
-        const int cg = cbase + cgloc[gidx], wg = wbase + wgloc[gidx];
-        if (lane == 0) { cgrank[gidx] = cg; wgrank[gidx] = wg; }
+        const bool any = ((cbv[u] | wbv[u]) >> lane) & 1ull;
+        q[u] = any ? sv[i] : 0; sp[u] = any ? sa[i] : 0;
+        if (lane == 0) { const int gidx = (t0 >> 6) + u * 4 + wv; cgrank[gidx] = cgv[u]; wgrank[gidx] = wgv[u]; }
+    }
+    {
+        // walkers: their K2 word (count + window hints, shifted into this run's layout: WordSrc); variant 1 cores: their input row
+        WordSrc::Where at[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = t0 + u * 256 + (int)threadIdx.x;
+            const bool isw = (wbv[u] >> lane) & 1ull;
+            at[u].src = nullptr; at[u].idx = 0; at[u].dA = 0; at[u].dB = 0;
+            if (isw) at[u] = ws.where(i, q[u], sp[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = t0 + u * 256 + (int)threadIdx.x;
+            const bool isc = (cbv[u] >> lane) & 1ull;
+            aux[u] = at[u].src ? at[u].src[at[u].idx] : ((!V2 && isc) ? (int)srow[i] : 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (at[u].src) aux[u] = ws.shifted(aux[u], at[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = t0 + u * 256 + (int)threadIdx.x;
+        const int gidx = (t0 >> 6) + u * 4 + wv;
+        const unsigned long long cb = cbv[u], wb = wbv[u];
         const bool isc = (cb >> lane) & 1ull, isw = (wb >> lane) & 1ull;
-        if (!(isc | isw)) continue;
-        const int q = sv[i], sp = sa[i];
         if (isc) {
-            const int dst = cg + __popcll(cb & low_mask(lane));
-            int key;
-            if (V2) {
+            const int dst = cgv[u] + __popcll(cb & low_mask(lane));
+            int key = aux[u];                             // variant 1: the component's start point is its smallest-row core (cDBSCAN.py:134-137)
+            if (V2 && L_ABL(512)) key = (int)srow[i];
+            else if (V2) {
                 // the component key is a minimum over the CELLS of its cores (cDBSCAN2.py:117-140): of a cell's cores only the
                 // first carries the cell (two cores of one cell are always one component).  The cell's head = the latest
                 // cell-opening PET at or before the core; "first core" = no core between the head and it.
@@ -284,13 +362,11 @@ k_make_lists(GridParams g, const int* __restrict__ sv, const int* __restrict__ s
                     }
                 }
                 key = first ? cellfirst[head] : INT_MAX;
-            } else {
-                key = (int)srow[i];                       // variant 1: the component's start point is its smallest-row core (cDBSCAN.py:134-137)
             }
-            cpair[dst] = make_int2(q, sp); cpos[dst] = i; ckey[dst] = key;
-        } else {
-            const int dst = wg + __popcll(wb & low_mask(lane));
-            wpair[dst] = make_int2(q, sp); wpos[dst] = i; wenc[dst] = ws.word(i, q, sp);
+            cpair[dst] = make_int2(q[u], sp[u]); cpos[dst] = i; ckey[dst] = key;
+        } else if (isw) {
+            const int dst = wgv[u] + __popcll(wb & low_mask(lane));
+            wpair[dst] = make_int2(q[u], sp[u]); wpos[dst] = i; wenc[dst] = aux[u];
         }
     }
 }
@@ -305,11 +381,23 @@ k_make_lists(GridParams g, const int* __restrict__ sv, const int* __restrict__ s
 __global__ void __launch_bounds__(256)
 k_chain_c(GridParams g, const int* __restrict__ lcnt, const int2* __restrict__ cpair, int* __restrict__ chainid,
           int* __restrict__ parent, int* __restrict__ compkey, int* __restrict__ ncore, int* __restrict__ bsize,
-          int* __restrict__ usize, int* __restrict__ state, int* __restrict__ cend)
+          int* __restrict__ usize, int* __restrict__ state, int* __restrict__ cend,
+          const int* __restrict__ strip_start, const unsigned long long* __restrict__ cmask, const int* __restrict__ cgrank,
+          int* __restrict__ cstrip, int* __restrict__ sup, int nsup2)
 {
     const int C = lcnt[0];
     const int lane = threadIdx.x & 63;
     const int nmask = ~(g.peps - 1);
+    {
+        // the cores-only strip table: cstrip[s] = cores in front of strip s (cstrip[S] = cstrip[S + 1] = C); and the superblock
+        // sums of k_classify go back to zero for the next run (k_make_lists has read them)
+        const int M = strip_start[g.S];
+        for (int u = blockIdx.x * 256 + (int)threadIdx.x; u <= g.S + 1; u += gridDim.x * 256) {
+            const int p = u <= g.S ? strip_start[u] : M;
+            cstrip[u] = p < M ? core_rank(cmask, cgrank, p) : C;
+        }
+        if (blockIdx.x == 0) for (int k = threadIdx.x; k < nsup2; k += 256) sup[k] = 0;
+    }
     int2 me[CH_PER], pv[CH_PER], nx[CH_PER];
 #pragma unroll
     for (int e = 0; e < CH_PER; ++e) {
@@ -396,8 +484,17 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
     const int wbeg = max(base, 0);
     LdsPairs w; w.a = lw; w.base = base;
     const int lane = threadIdx.x & 63;
-#pragma unroll 1
-    for (int u = 0; u < NT / 256; ++u) {
+    constexpr int PER = NT / 256;
+    // the strip bounds of the thread's cores: all table loads in flight together
+    int tbv[PER], bv_[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int i = t0 + u * 256 + (int)threadIdx.x;
+        const int s = i < C ? (lw[i - base].y >> g.rbits) : 0;
+        tbv[u] = s > 0 ? cstrip[s - 1] : 0; bv_[u] = s > 0 ? cstrip[s] : 0;      // (strip 0 has nothing below: an empty range)
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
         const int i = t0 + u * 256 + (int)threadIdx.x;
         const bool in = i < C;
         int Bs[LU_MAXB];
@@ -405,13 +502,15 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
         for (int k = 0; k < LU_MAXB; ++k) Bs[k] = -1;
         int nb = 0;
         int A = -1;
+#ifdef CLOOPS_DEVEL
+        int st_it = 0, st_touch = 0, st_glb = 0, st_jump = 0;
+#endif
         if (in) {
             const int2 me = lw[i - base];
             A = lx[i - base];
-            const int s = me.y >> g.rbits;
-            if (s > 0) {
-                int tb = cstrip[s - 1];
-                const int b = cstrip[s];
+            int tb = tbv[u];
+            const int b = bv_[u];
+            if (tb < b) {
                 const int qlo = me.x - g.eps, qhi = me.x + g.eps;
                 const int T = me.y - g.peps;             // every candidate lies one strip below: "within eps in p" is sp_j >= sp_i - peps
                 // strip s-1 ends where strip s begins, i.e. inside the staged range; if its first staged core lies below qlo the part
@@ -422,6 +521,9 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
 #pragma unroll
                     for (int k = 0; k < LU_MAXB; ++k) seen |= (Bs[k] == B);
                     if (seen) return;
+#ifdef CLOOPS_DEVEL
+                    ++st_touch;
+#endif
                     if (nb < LU_MAXB) {
 #pragma unroll
                         for (int k = 0; k < LU_MAXB; ++k) if (k == nb) Bs[k] = B;
@@ -440,6 +542,9 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
                     else if (len <= 255) j = lds_lower_bound8<8>(w, tb, b, qlo);
                     else j = lds_lower_bound8<11>(w, tb, b, qlo);
                     while (j < b) {
+#ifdef CLOOPS_DEVEL
+                        ++st_it;
+#endif
                         int2 cv[4]; int bv[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) { const int idx = min(j + k, b - 1); cv[k] = lw[idx - base]; bv[k] = lx[idx - base]; }
@@ -452,12 +557,20 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
                             if (cv[k].y >= T) {
                                 touch(bv[k]);
                                 // (a short window is cheaper walked through: touch() passes over a chain it has seen)
-                                if (len > 24) { stop = true; next = cend[bv[k]] + 1; }      // (> j + k: the chain holds this core)
+                                if (len > 24) {
+#ifdef CLOOPS_DEVEL
+                                    ++st_jump;
+#endif
+                                    stop = true; next = cend[bv[k]] + 1;      // (> j + k: the chain holds this core)
+                                }
                             }
                         }
                         j = next;
                     }
                 } else {
+#ifdef CLOOPS_DEVEL
+                    ++st_glb;
+#endif
                     // the strip below starts in front of the staged range (a strip population beyond the halo): global memory
                     int k = lower_bound_pairs(cpair, tb, b, qlo);
                     while (k < b) {
@@ -481,6 +594,7 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
                 }
             }
         }
+        int st_un = 0;
 #pragma unroll
         for (int k = 0; k < LU_MAXB; ++k) {
             const int B = Bs[k];
@@ -493,8 +607,13 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
                 if (lane == leader) rep = true;
                 pending &= ~m;
             }
-            if (rep) uf_unite(parent, A, B);
+            if (rep) { uf_unite(parent, A, B); ++st_un; }
         }
+#ifdef CLOOPS_DEVEL
+        LSTAT(12, in ? 1 : 0); LSTAT(13, st_it); LSTAT(14, st_touch); LSTAT(15, st_un); LSTAT(16, st_glb); LSTAT(17, st_jump);
+#else
+        (void)st_un;
+#endif
     }
 }
 
@@ -506,8 +625,8 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
 // both arrive as ckey[c] (k_make_lists); two-level reduce-by-key as in k_flatten (cloops_hip.hip)
 __global__ void __launch_bounds__(BIGTPB)
 k_flatten_c(const int* __restrict__ lcnt, const int* __restrict__ chainid, const int* __restrict__ parent, const int* __restrict__ ckey,
-            int* __restrict__ croot, int* __restrict__ compkey, int* __restrict__ ncore, int* __restrict__ rootlist,
-            int* __restrict__ counters)
+            const int* __restrict__ cend, int* __restrict__ croot, int* __restrict__ cskip, int* __restrict__ compkey,
+            int* __restrict__ ncore, int* __restrict__ rootlist, int* __restrict__ counters)
 {
     __shared__ int hkey[AGG_H], hmin[AGG_H], hcnt[AGG_H];
     __shared__ int l_nroot, l_rootbase;
@@ -524,6 +643,15 @@ k_flatten_c(const int* __restrict__ lcnt, const int* __restrict__ chainid, const
         in[e] = ii[e] < C;
         x[e] = in[e] ? chainid[ii[e]] : -1;
         key[e] = in[e] ? ckey[ii[e]] : INT_MAX;
+    }
+    {
+        // cskip[c] = the first core behind c's chain: a walk that has found one core of a chain within reach needs no other
+        // (k_border_w; all cores of a chain share the root)
+        int ce[FLAT_PER];
+#pragma unroll
+        for (int e = 0; e < FLAT_PER; ++e) ce[e] = in[e] ? cend[x[e]] : 0;
+#pragma unroll
+        for (int e = 0; e < FLAT_PER; ++e) if (in[e]) cskip[ii[e]] = ce[e] + 1;
     }
     {
         // the union kernel has completed (kernel boundary = coherent): plain loads, all walks of the thread step together
@@ -611,18 +739,19 @@ __global__ void k_scatter_by_pos(const int* __restrict__ cnt_ptr, const int* __r
 // list -- staged once as (q, sp) pairs + roots.  A walker's windows start at the rank of K2's hints (no strip table, no search);
 // "still in the neighbour strip and inside the q window" is a predicate of the staged pair.  Every staged candidate is a core:
 // nothing to step over.
-template <int NT, int HC>
+#define LB_PER 4                 // walkers per thread and pass: the loads of a stage of all of them are in flight together
+template <int NT, int HC, bool V1>
 __global__ void __launch_bounds__(256)
 k_border_w(GridParams g, int ntiles, const int* __restrict__ strip_start, const int* __restrict__ lcnt,
            const unsigned long long* __restrict__ cmask, const int* __restrict__ cgrank, const int* __restrict__ wgrank,
-           const int2* __restrict__ cpair, const int* __restrict__ croot, const int* __restrict__ ckey,
+           const int2* __restrict__ cpair, const int* __restrict__ croot, const int* __restrict__ cskip, const int* __restrict__ ckey,
            const int* __restrict__ cstrip, const int2* __restrict__ wpair, const int* __restrict__ wpos,
            const int* __restrict__ wenc, const int* __restrict__ compkey, const int* __restrict__ ncore,
            int* __restrict__ wowner, int* __restrict__ bsize, int* __restrict__ usize, int* __restrict__ clist, int* __restrict__ counters)
 {
     constexpr int WIN = NT + 2 * HC;
     __shared__ int2 lw[WIN];
-    __shared__ int lx[WIN];
+    __shared__ int2 lx[WIN];                             // (root, first core behind the chain)
     const int M = strip_start[g.S];
     const int C = lcnt[0];
     const int tile = ltile_of_block(blockIdx.x);
@@ -632,109 +761,191 @@ k_border_w(GridParams g, int ntiles, const int* __restrict__ strip_start, const 
     const int w0 = wgrank[g0], w1 = wgrank[g1];
     if (w0 == w1) return;
     const int clo = max(cgrank[g0] - HC, 0), chi = min(cgrank[g1] + HC, C);      // staged cores [clo, chi): at most NT + 2 HC
-    for (int k = threadIdx.x; k < chi - clo; k += 256) { lw[k] = cpair[clo + k]; lx[k] = croot[clo + k]; }
+    for (int k = threadIdx.x; k < chi - clo; k += 256) { lw[k] = cpair[clo + k]; lx[k] = make_int2(croot[clo + k], V1 ? 0 : cskip[clo + k]); }
     __syncthreads();
-    const bool v1 = g.variant == CL_VARIANT_CDBSCAN1;
+    if (L_ABL(4096)) { for (int h = w0 + (int)threadIdx.x; h < w1; h += 256) wowner[h] = -1; return; }
     const int lane = threadIdx.x & 63;
-    auto pair_at = [&](int j) { return (j >= clo && j < chi) ? lw[j - clo] : cpair[j]; };
-    auto root_at = [&](int j) { return (j >= clo && j < chi) ? lx[j - clo] : croot[j]; };
-    for (int h0 = w0; h0 < w1; h0 += 256) {
-        const int h = h0 + (int)threadIdx.x;
-        const bool act = h < w1;
-        int o = -1;
-        bool contested = false;
-        if (act) {
-            const int2 me = wpair[h];
-            const int pos = wpos[h], enc = wenc[h];
-            const int qlo = me.x - g.eps, qhi = me.x + g.eps;
-            const int pbeg = me.y & ~(g.peps - 1), pend = pbeg + g.peps, pend2 = pend + g.peps;
-            const int plo = me.y - g.peps, phi = me.y + g.peps;
-            int bestk = INT_MAX, best = -1, tk = -1, tbest = -1, lastr = -1, lastk = 0, first = -1;
-            auto see = [&](int j, int r) {
-                if (first < 0) first = r; else if (r != first) contested = true;
-                int k;
-                if (r == lastr) k = lastk; else { k = compkey[r]; lastr = r; lastk = k; }
-                if (k < bestk) { bestk = k; best = r; }
-                if (v1 && ckey[j] == k && k > tk) { tk = k; tbest = r; }     // j is its component's start point
-            };
-            const bool hinted = enc < 0 && ((unsigned)enc & K2H_NONE) != K2H_NONE;
-            const int c1 = core_rank(cmask, cgrank, pos);                    // the first core behind the walker
-            int ca, cb;
-            if (hinted) {
-                ca = core_rank(cmask, cgrank, pos - (int)((unsigned)enc & K2H_MASK));
-                cb = core_rank(cmask, cgrank, pos + (int)(((unsigned)enc >> K2H_BITS) & K2H_MASK));
-            } else {
-                // no hints (variant-independent: minPts outside 2..128, pile-ups, hints that left their fields): the cores-only strip table
-                const int s = me.y >> g.rbits;
-                ca = s > 0 ? lower_bound_pairs(cpair, cstrip[s - 1], cstrip[s], qlo) : 0;
-                cb = lower_bound_pairs(cpair, cstrip[s + 1], cstrip[min(s + 2, g.S)], qlo);
-                if (s == 0) ca = C;                                          // (no strip below: an empty walk)
-            }
-            // own strip.  Variant 2: all cores on ONE side of the walker inside its q window are within eps of each other (same
-            // strip, q inside one eps) -- one component: the nearest core on either side stands for all of them.  Variant 1 needs
-            // every neighbour (its start-point rule looks at single PETs).
-            if (!v1) {
-                if (c1 > 0) { const int2 p = pair_at(c1 - 1); if (p.y >= pbeg && p.x >= qlo) see(c1 - 1, root_at(c1 - 1)); }
-                if (c1 < C) { const int2 p = pair_at(c1); if (p.y < pend && p.x <= qhi) see(c1, root_at(c1)); }
-            } else {
-                for (int j = c1 - 1; j >= 0; --j) { const int2 p = pair_at(j); if (!(p.y >= pbeg && p.x >= qlo)) break; see(j, root_at(j)); }
-                for (int j = c1; j < C; ++j) { const int2 p = pair_at(j); if (!(p.y < pend && p.x <= qhi)) break; see(j, root_at(j)); }
-            }
-            // one strip below: sp can only be too low; one strip above: only too high.  Four candidates per round.
-            for (int j = ca; j < C; j += 4) {
-                int2 p[4]; int r[4];
+    // The kernel is a chain of dependent round trips per walker (record -> rank words -> walks -> keys): a thread takes LB_PER
+    // walkers per pass and goes through the stages with the loads of all of them in flight.
+    for (int h0 = w0; h0 < w1; h0 += 256 * LB_PER) {
+        int2 me[LB_PER]; int pos[LB_PER], enc[LB_PER];
+        bool act[LB_PER];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { const int idx = min(j + k, C - 1); p[k] = pair_at(idx); r[k] = root_at(idx); }
-                bool out = false;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (out || j + k >= C || !((p[k].y < pbeg) & (p[k].x <= qhi))) { out = true; continue; }
-                    if (p[k].y >= plo) see(j + k, r[k]);
-                }
-                if (out) break;
-            }
-            for (int j = cb; j < C; j += 4) {
-                int2 p[4]; int r[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { const int idx = min(j + k, C - 1); p[k] = pair_at(idx); r[k] = root_at(idx); }
-                bool out = false;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (out || j + k >= C || !((p[k].y < pend2) & (p[k].x <= qhi))) { out = true; continue; }
-                    if (p[k].y <= phi) see(j + k, r[k]);
-                }
-                if (out) break;
-            }
-            o = (v1 && tbest >= 0) ? tbest : best;
-            wowner[h] = o < 0 ? -1 : (contested ? (o | OWNER_CONTESTED) : o);
+        for (int e = 0; e < LB_PER; ++e) {
+            const int h = h0 + e * 256 + (int)threadIdx.x;
+            act[e] = h < w1;
+            me[e] = act[e] ? wpair[h] : make_int2(0, 0); pos[e] = act[e] ? wpos[h] : 0; enc[e] = act[e] ? wenc[h] : 0;
         }
-        // counts per owning component, reduced over the lanes of the wave that share the owner.  Only components that are not
-        // already >= minPts on their cores need them (release rule of variant 2, drop rule of variant 1).
-        const bool cnt_me = o >= 0 && ncore[o >= 0 ? o : 0] < g.minPts;
+        // where the walks start: the rank of the walker's own position (the first core behind it) and of K2's two hints
+        int c1[LB_PER], ca[LB_PER], cb[LB_PER];
         {
-            // only a component that is not live on its cores alone can end up uncertain: its CONTESTED walkers are all
-            // k_emit_records_w has to look at -- they are listed here (one atomic per wave)
-            const bool want = cnt_me && contested;
-            const unsigned long long wb = __ballot(want);
-            if (wb) {
-                const int firstl = __ffsll((long long)wb) - 1;
-                int lbase = 0;
-                if (lane == firstl) lbase = atomicAdd(&counters[CTR_NFLAG], __popcll(wb));
-                lbase = __builtin_amdgcn_readlane(lbase, firstl);
-                if (want) clist[lbase + lane_rank(wb)] = h;
+            int gr[LB_PER][3]; unsigned long long gm[LB_PER][3]; int pp[LB_PER][3];
+#pragma unroll
+            for (int e = 0; e < LB_PER; ++e) {
+                const bool hinted = enc[e] < 0 && ((unsigned)enc[e] & K2H_NONE) != K2H_NONE;
+                pp[e][0] = pos[e];
+                pp[e][1] = hinted ? pos[e] - (int)((unsigned)enc[e] & K2H_MASK) : pos[e];
+                pp[e][2] = hinted ? pos[e] + (int)(((unsigned)enc[e] >> K2H_BITS) & K2H_MASK) : pos[e];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { gr[e][k] = cgrank[pp[e][k] >> 6]; gm[e][k] = cmask[pp[e][k] >> 6]; }
+            }
+#pragma unroll
+            for (int e = 0; e < LB_PER; ++e) {
+                c1[e] = gr[e][0] + __popcll(gm[e][0] & low_mask(pp[e][0] & 63));
+                ca[e] = gr[e][1] + __popcll(gm[e][1] & low_mask(pp[e][1] & 63));
+                cb[e] = gr[e][2] + __popcll(gm[e][2] & low_mask(pp[e][2] & 63));
+                const bool hinted = enc[e] < 0 && ((unsigned)enc[e] & K2H_NONE) != K2H_NONE;
+                if (act[e] && !hinted) {
+                    // no hints (minPts outside 2..128, pile-ups, hints that left their fields): the cores-only strip table
+                    const int s = me[e].y >> g.rbits, qlo = me[e].x - g.eps;
+                    ca[e] = s > 0 ? lower_bound_pairs(cpair, cstrip[s - 1], cstrip[s], qlo) : C;      // (no strip below: an empty walk)
+                    cb[e] = lower_bound_pairs(cpair, cstrip[s + 1], cstrip[min(s + 2, g.S)], qlo);
+                }
             }
         }
-        unsigned long long pending = __ballot(cnt_me);
-        while (pending) {
-            const int leader = __ffsll((long long)pending) - 1;
-            const int O = __builtin_amdgcn_readlane(o, leader);
-            const unsigned long long m = __ballot(cnt_me && o == O);
-            const unsigned long long mu = __ballot(cnt_me && o == O && !contested);
-            if (lane == leader) {
-                atomicAdd(&bsize[O], __popcll(m));
-                if (mu) atomicAdd(&usize[O], __popcll(mu));
+        int own[LB_PER];                                   // the owner found (root), -1 = none
+        bool cont[LB_PER];
+        int rr[LB_PER][4];                                 // variant 2: the distinct adjacent components
+#pragma unroll
+        for (int e = 0; e < LB_PER; ++e) {
+            own[e] = -1; cont[e] = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rr[e][k] = -1;
+            if (!act[e] || L_ABL(1024)) continue;
+            const int qlo = me[e].x - g.eps, qhi = me[e].x + g.eps;
+            const int pbeg = me[e].y & ~(g.peps - 1), pend = pbeg + g.peps, pend2 = pend + g.peps;
+            const int plo = me[e].y - g.peps, phi = me[e].y + g.peps;
+            if (V1) {
+                // variant 1 needs EVERY core neighbour: its start-point rule looks at single PETs (cDBSCAN.py:172-173)
+                int bestk = INT_MAX, best = -1, tk = -1, tbest = -1, lastr = -1, lastk = 0, first = -1;
+                bool contested = false;
+                auto see = [&](int j, int r) {
+                    if (first < 0) first = r; else if (r != first) contested = true;
+                    int k;
+                    if (r == lastr) k = lastk; else { k = compkey[r]; lastr = r; lastk = k; }
+                    if (k < bestk) { bestk = k; best = r; }
+                    if (ckey[j] == k && k > tk) { tk = k; tbest = r; }       // j is its component's start point
+                };
+                auto pair_at = [&](int j) { return (j >= clo && j < chi) ? lw[j - clo] : cpair[j]; };
+                auto root_at = [&](int j) { return (j >= clo && j < chi) ? lx[j - clo].x : croot[j]; };
+                for (int j = c1[e] - 1; j >= 0; --j) { const int2 p = pair_at(j); if (!((p.y >= pbeg) & (p.x >= qlo))) break; see(j, root_at(j)); }
+                for (int j = c1[e]; j < C; ++j) { const int2 p = pair_at(j); if (!((p.y < pend) & (p.x <= qhi))) break; see(j, root_at(j)); }
+                if (!L_ABL(2048)) {
+                    for (int j = ca[e]; j < C; ++j) { const int2 p = pair_at(j); if (!((p.y < pbeg) & (p.x <= qhi))) break; if (p.y >= plo) see(j, root_at(j)); }
+                    for (int j = cb[e]; j < C; ++j) { const int2 p = pair_at(j); if (!((p.y < pend2) & (p.x <= qhi))) break; if (p.y <= phi) see(j, root_at(j)); }
+                }
+                own[e] = tbest >= 0 ? tbest : best;
+                cont[e] = contested;
+            } else {
+                // variant 2: the DISTINCT adjacent components are all that counts (at most 4: cores of different components are
+                // > eps apart and all within eps of the walker); their keys are looked up once, behind the walks
+                int r0 = -1, r1 = -1, r2 = -1, r3 = -1;
+                auto see = [&](int r) {
+                    if ((r == r0) | (r == r1) | (r == r2) | (r == r3)) return;
+                    if (r0 < 0) r0 = r; else if (r1 < 0) r1 = r; else if (r2 < 0) r2 = r; else if (r3 < 0) r3 = r;
+                    else atomicExch(&counters[CTR_OVERFLOW], 1);             // (beyond the geometric bound: the run fails loudly)
+                };
+                // own strip: all cores on ONE side of the walker inside its q window are within eps of each other (same strip, q
+                // inside one eps) -- one component: the nearest core on either side stands for all of them
+                {
+                    const int jl = max(c1[e] - 1, 0), jr = max(min(c1[e], C - 1), 0);
+                    const bool inl = jl >= clo && jl < chi, inr = jr >= clo && jr < chi;
+                    const int2 pl = inl ? lw[jl - clo] : cpair[jl], pr = inr ? lw[jr - clo] : cpair[jr];
+                    const int rl = inl ? lx[jl - clo].x : croot[jl], rrt = inr ? lx[jr - clo].x : croot[jr];
+                    if (c1[e] > 0 && (pl.y >= pbeg) & (pl.x >= qlo)) see(rl);
+                    if (c1[e] < C && (pr.y < pend) & (pr.x <= qhi)) see(rrt);
+                }
+                // one strip below (sp can only be too low) / above (only too high): from the rank of K2's hint on while the pair
+                // is still in that strip and inside the q window.  A core within reach settles its whole chain: the walk goes on
+                // behind the chain's last core -- a window next to a cluster costs two or three candidates.
+#ifdef CLOOPS_DEVEL
+                int n_it = 0, n_glb = 0;
+#endif
+                auto walk = [&](int j, int pcap, bool below) {
+                    while (j < C) {
+                        const bool in0 = j >= clo && j + 1 < chi;
+#ifdef CLOOPS_DEVEL
+                        ++n_it; n_glb += in0 ? 0 : 1;
+#endif
+                        int2 p0, p1, x0, x1;
+                        if (in0) { p0 = lw[j - clo]; p1 = lw[j + 1 - clo]; x0 = lx[j - clo]; x1 = lx[j + 1 - clo]; }
+                        else {
+                            const int j1 = min(j + 1, C - 1);
+                            p0 = cpair[j]; p1 = cpair[j1]; x0 = make_int2(croot[j], cskip[j]); x1 = make_int2(croot[j1], cskip[j1]);
+                            if (j + 1 >= C) p1 = make_int2(INT_MAX, INT_MAX);
+                        }
+                        if (!((p0.y < pcap) & (p0.x <= qhi))) break;
+                        if (below ? p0.y >= plo : p0.y <= phi) { see(x0.x); j = x0.y; continue; }
+                        if (!((p1.y < pcap) & (p1.x <= qhi))) break;
+                        if (below ? p1.y >= plo : p1.y <= phi) { see(x1.x); j = x1.y; continue; }
+                        j += 2;
+                    }
+                };
+                if (!L_ABL(2048)) { walk(ca[e], pbeg, true); walk(cb[e], pend2, false); }
+                rr[e][0] = r0; rr[e][1] = r1; rr[e][2] = r2; rr[e][3] = r3;
+#ifdef CLOOPS_DEVEL
+                LSTAT(1, n_it); LSTAT(2, n_glb);
+                { int mx = n_it; for (int o2 = 32; o2 > 0; o2 >>= 1) mx = max(mx, __shfl_down(mx, o2)); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_lstat[6], (unsigned long long)mx); atomicAdd(&g_lstat[7], 1ull); } }
+#endif
             }
-            pending &= ~m;
+        }
+        // keys and core counts of the adjacent components, all loads in flight; variant 2: the lowest key among the distinct
+        // adjacent components owns the walker (first come, cDBSCAN2.py:130,212,352)
+        int nco[LB_PER];
+        if (!V1) {
+            int kk[LB_PER][4], nn[LB_PER][4];
+#pragma unroll
+            for (int e = 0; e < LB_PER; ++e)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int r = rr[e][k]; kk[e][k] = r >= 0 ? compkey[r] : INT_MAX; nn[e][k] = r >= 0 ? ncore[r] : 0; }
+#pragma unroll
+            for (int e = 0; e < LB_PER; ++e) {
+                int best = rr[e][0], bestk = kk[e][0], bn = nn[e][0];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) if (kk[e][k] < bestk) { bestk = kk[e][k]; best = rr[e][k]; bn = nn[e][k]; }
+                own[e] = best; cont[e] = rr[e][1] >= 0; nco[e] = bn;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < LB_PER; ++e) nco[e] = own[e] >= 0 ? ncore[own[e]] : 0;
+        }
+#pragma unroll
+        for (int e = 0; e < LB_PER; ++e) {
+            const int h = h0 + e * 256 + (int)threadIdx.x;
+            const int o = own[e];
+            const bool contested = cont[e];
+            if (act[e]) wowner[h] = o < 0 ? -1 : (contested ? (o | OWNER_CONTESTED) : o);
+#ifdef CLOOPS_DEVEL
+            LSTAT(0, act[e] ? 1 : 0); LSTAT(5, (act[e] && o >= 0) ? 1 : 0);
+#endif
+            // counts per owning component, reduced over the lanes of the wave that share the owner.  Only components that are not
+            // already >= minPts on their cores need them (release rule of variant 2, drop rule of variant 1).
+            const bool cnt_me = act[e] && o >= 0 && nco[e] < g.minPts;
+            {
+                // only a component that is not live on its cores alone can end up uncertain: its CONTESTED walkers are all
+                // k_emit_records_w has to look at -- they are listed here (one atomic per wave)
+                const bool want = cnt_me && contested;
+                const unsigned long long wb = __ballot(want);
+                if (wb) {
+                    const int firstl = __ffsll((long long)wb) - 1;
+                    int lbase = 0;
+                    if (lane == firstl) lbase = atomicAdd(&counters[CTR_NFLAG], __popcll(wb));
+                    lbase = __builtin_amdgcn_readlane(lbase, firstl);
+                    if (want) clist[lbase + lane_rank(wb)] = h;
+                }
+            }
+            unsigned long long pending = __ballot(cnt_me);
+            while (pending) {
+                const int leader = __ffsll((long long)pending) - 1;
+                const int O = __builtin_amdgcn_readlane(o, leader);
+                const unsigned long long m = __ballot(cnt_me && o == O);
+                const unsigned long long mu = __ballot(cnt_me && o == O && !contested);
+                if (lane == leader) {
+                    atomicAdd(&bsize[O], __popcll(m));
+                    if (mu) atomicAdd(&usize[O], __popcll(mu));
+                }
+                pending &= ~m;
+            }
         }
     }
 }
@@ -894,7 +1105,8 @@ k_final_lists(GridParams g, const int* __restrict__ lcnt, const int2* __restrict
 struct ListBufs {
     unsigned long long *cmask, *wmask, *hmask;
     int *cgloc, *wgloc, *cgrank, *wgrank;
-    int *bsum, *boff, *lcnt;
+    int *bsum, *sup, *lcnt;
+    int nsup2;                                           // ints of the superblock sums (both halves)
 };
 static int list_bufs(cl_chrom* c, const GridParams& g, int nm, ListBufs* b)
 {
@@ -903,13 +1115,46 @@ static int list_bufs(cl_chrom* c, const GridParams& g, int nm, ListBufs* b)
     const size_t nblk_cap = n / LT + 4;
     int rc;
     if ((rc = c->l_mask.ensure(3 * ngrp_cap * 8)) || (rc = c->l_rank.ensure(4 * ngrp_cap * 4)) ||
-        (rc = c->l_blk.ensure((4 * (nblk_cap + 1) + 8) * 4)) || (rc = c->l_cstrip.ensure(((size_t)g.S + 4) * 4)) ||
+        (rc = c->l_blk.ensure((2 * (nblk_cap + 1) + 2 * (nblk_cap / 64 + 2) + 16) * 4)) || (rc = c->l_cstrip.ensure(((size_t)g.S + 4) * 4)) ||
         (rc = c->l_wpos.ensure(n * 4)) || (rc = c->l_wenc.ensure(n * 4)) || (rc = c->l_dist.ensure(n * 4))) return rc;
     b->cmask = c->l_mask.as<unsigned long long>(); b->wmask = b->cmask + ngrp_cap; b->hmask = b->wmask + ngrp_cap;
     b->cgloc = c->l_rank.as<int>(); b->wgloc = b->cgloc + ngrp_cap; b->cgrank = b->wgloc + ngrp_cap; b->wgrank = b->cgrank + ngrp_cap;
+    // l_blk: {C, W} | superblock sums (both halves; zero between runs: k_chain_c puts them back) | the tiles' sums
     const int nblk = nblocks(nm, LT);
-    b->bsum = c->l_blk.as<int>(); b->boff = b->bsum + 2 * (nblk + 1); b->lcnt = c->l_blk.as<int>() + 4 * (nblk_cap + 1);
+    const size_t nsup_cap = nblk_cap / 64 + 2;
+    if (c->l_blk.fresh) {
+        HIP_TRY(hipMemsetAsync(c->l_blk.p, 0, c->l_blk.bytes, c->stream));
+        c->l_blk.fresh = false;
+    }
+    b->lcnt = c->l_blk.as<int>();
+    b->sup = b->lcnt + 8;
+    b->bsum = b->sup + 2 * nsup_cap;
+    b->nsup2 = 2 * ((nblk + 63) / 64 + 1);
     return CL_OK;
+}
+
+static void launch_classify(cl_chrom* c, const GridParams& g, int nblk, const ListBufs& b)
+{
+#define LA_ARGS g, (const int*)c->w_sv, (const int*)c->w_sa, (const int*)c->w_strip, c->ws, (const u32*)c->srow, b.cmask, b.wmask, b.hmask, b.cgloc, b.wgloc, b.bsum, b.sup, c->cellfirst.as<int>()
+    if (g.variant == CL_VARIANT_CDBSCAN2) hipLaunchKernelGGL(k_classify<true>, dim3(nblk), dim3(256), 0, c->stream, LA_ARGS);
+    else hipLaunchKernelGGL(k_classify<false>, dim3(nblk), dim3(256), 0, c->stream, LA_ARGS);
+#undef LA_ARGS
+}
+static void launch_make_lists(cl_chrom* c, const GridParams& g, int nblk, const ListBufs& b, const ListRun& L)
+{
+#define LM_ARGS g, (const int*)c->w_sv, (const int*)c->w_sa, (const int*)c->w_strip, c->ws, (const u32*)c->srow, (const unsigned long long*)b.cmask,                   \
+                (const unsigned long long*)b.wmask, (const unsigned long long*)b.hmask, (const int*)b.cgloc, (const int*)b.wgloc, (const int*)b.bsum, (const int*)b.sup,  \
+                (const int*)c->cellfirst.as<int>(), b.cgrank, b.wgrank, L.cpair, L.cpos, L.ckey, L.wpair, L.wpos, L.wenc, b.lcnt
+    if (g.variant == CL_VARIANT_CDBSCAN2) hipLaunchKernelGGL(k_make_lists<true>, dim3(nblk), dim3(256), 0, c->stream, LM_ARGS);
+    else hipLaunchKernelGGL(k_make_lists<false>, dim3(nblk), dim3(256), 0, c->stream, LM_ARGS);
+#undef LM_ARGS
+}
+static void list_views(cl_chrom* c, const ListBufs& b, ListRun* L)
+{
+    L->lcnt = b.lcnt; L->cmask = b.cmask; L->wmask = b.wmask; L->cgrank = b.cgrank; L->wgrank = b.wgrank;
+    L->cpair = c->keys_in.as<int2>(); L->wpair = c->keys_out.as<int2>();     // (the sort buffers are dead behind the layout)
+    L->cpos = c->head.as<int>(); L->ckey = c->hi.as<int>();
+    L->wpos = c->l_wpos.as<int>(); L->wenc = c->l_wenc.as<int>(); L->cstrip = c->l_cstrip.as<int>();
 }
 
 int lists_build(cl_chrom* c, const GridParams& g, int nm, ListRun* out)
@@ -918,34 +1163,20 @@ int lists_build(cl_chrom* c, const GridParams& g, int nm, ListRun* out)
     int rc = list_bufs(c, g, nm, &b);
     if (rc) return rc;
     const int nblk = nblocks(nm, LT);
-    const bool v2 = g.variant == CL_VARIANT_CDBSCAN2;
-    int* ticket = c->counters.as<int>() + CTR_TICKET_A;
     ListRun L{};
-    L.lcnt = b.lcnt; L.cmask = b.cmask; L.wmask = b.wmask; L.cgrank = b.cgrank; L.wgrank = b.wgrank;
-    L.cpair = c->keys_in.as<int2>(); L.wpair = c->keys_out.as<int2>();     // (the sort buffers are dead behind the layout)
-    L.cpos = c->head.as<int>(); L.ckey = c->hi.as<int>();
-    L.wpos = c->l_wpos.as<int>(); L.wenc = c->l_wenc.as<int>(); L.cstrip = c->l_cstrip.as<int>();
-    if (v2) {
-        hipLaunchKernelGGL(k_classify<true>, dim3(nblk), dim3(256), 0, c->stream, g, (const int*)c->w_sv, (const int*)c->w_sa, (const int*)c->w_strip, c->ws,
-                           (const u32*)c->srow, b.cmask, b.wmask, b.hmask, b.cgloc, b.wgloc, b.bsum, b.boff, ticket, b.lcnt, c->cellfirst.as<int>());
-        hipLaunchKernelGGL(k_make_lists<true>, dim3(nblk), dim3(256), 0, c->stream, g, (const int*)c->w_sv, (const int*)c->w_sa, (const int*)c->w_strip, c->ws,
-                           (const u32*)c->srow, (const unsigned long long*)b.cmask, (const unsigned long long*)b.wmask, (const unsigned long long*)b.hmask,
-                           (const int*)b.cgloc, (const int*)b.wgloc, (const int*)b.boff, (const int*)c->cellfirst.as<int>(), b.cgrank, b.wgrank,
-                           L.cpair, L.cpos, L.ckey, L.wpair, L.wpos, L.wenc, L.cstrip);
-    } else {
-        hipLaunchKernelGGL(k_classify<false>, dim3(nblk), dim3(256), 0, c->stream, g, (const int*)c->w_sv, (const int*)c->w_sa, (const int*)c->w_strip, c->ws,
-                           (const u32*)c->srow, b.cmask, b.wmask, b.hmask, b.cgloc, b.wgloc, b.bsum, b.boff, ticket, b.lcnt, c->cellfirst.as<int>());
-        hipLaunchKernelGGL(k_make_lists<false>, dim3(nblk), dim3(256), 0, c->stream, g, (const int*)c->w_sv, (const int*)c->w_sa, (const int*)c->w_strip, c->ws,
-                           (const u32*)c->srow, (const unsigned long long*)b.cmask, (const unsigned long long*)b.wmask, (const unsigned long long*)b.hmask,
-                           (const int*)b.cgloc, (const int*)b.wgloc, (const int*)b.boff, (const int*)c->cellfirst.as<int>(), b.cgrank, b.wgrank,
-                           L.cpair, L.cpos, L.ckey, L.wpair, L.wpos, L.wenc, L.cstrip);
-    }
+    list_views(c, b, &L);
+    // the superblock sums are zero between runs (k_chain_c puts them back); a run that failed half-way leaves the flag up
+    if (c->l_sup_dirty) HIP_TRY(hipMemsetAsync(b.sup, 0, (size_t)b.nsup2 * 4, c->stream));
+    c->l_sup_dirty = true;
+    launch_classify(c, g, nblk, b);
+    launch_make_lists(c, g, nblk, b, L);
     // chains (the core count is only known on the device: the grids are sized by the PETs of the run)
     hipLaunchKernelGGL(k_chain_c, dim3(nblocks(nm, 256 * CH_PER)), dim3(256), 0, c->stream, g, L.lcnt, (const int2*)L.cpair, c->chainflag.as<int>(),
                        c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
-                       c->lo.as<int>());
+                       c->lo.as<int>(), (const int*)c->w_strip, L.cmask, L.cgrank, L.cstrip, b.sup, b.nsup2);
     *out = L;
     HIP_TRY(hipGetLastError());
+    c->l_sup_dirty = false;
     return CL_OK;
 }
 
@@ -964,8 +1195,8 @@ int lists_union_flatten(cl_chrom* c, const GridParams& g, int nm, const ListRun&
         hipLaunchKernelGGL((k_union_c<UNT, 128>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, g, nt, L.lcnt, (const int2*)L.cpair, (const int*)c->chainflag.as<int>(),
                            (const int*)L.cstrip, (const int*)c->lo.as<int>(), c->parent.as<int>());
     hipLaunchKernelGGL(k_flatten_c, dim3(nblocks(nm, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, L.lcnt, (const int*)c->chainflag.as<int>(),
-                       (const int*)c->parent.as<int>(), (const int*)L.ckey, croot_of(c), c->compkey.as<int>(), c->ncore.as<int>(), c->rootlist.as<int>(),
-                       c->counters.as<int>());
+                       (const int*)c->parent.as<int>(), (const int*)L.ckey, (const int*)c->lo.as<int>(), croot_of(c), c->cellfirst.as<int>() /* cskip: the cell minima are in the keys */,
+                       c->compkey.as<int>(), c->ncore.as<int>(), c->rootlist.as<int>(), c->counters.as<int>());
     HIP_TRY(hipGetLastError());
     return CL_OK;
 }
@@ -981,10 +1212,13 @@ int lists_border(cl_chrom* c, const GridParams& g, int nm, const ListRun& L)
 {
     constexpr int BNT = 2048, BHC = 256;
     const int nt = nblocks(nm, BNT);
-    hipLaunchKernelGGL((k_border_w<BNT, BHC>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, g, nt, (const int*)c->w_strip, L.lcnt, L.cmask, L.cgrank, L.wgrank,
-                       (const int2*)L.cpair, (const int*)croot_of(c), (const int*)L.ckey, (const int*)L.cstrip, (const int2*)L.wpair, (const int*)L.wpos,
-                       (const int*)L.wenc, (const int*)c->compkey.as<int>(), (const int*)c->ncore.as<int>(), c->owner.as<int>(), c->bsize.as<int>(),
-                       c->usize.as<int>(), c->chainflag.as<int>() /* clist: the chain ids are dead */, c->counters.as<int>());
+#define LB_ARGS g, nt, (const int*)c->w_strip, L.lcnt, L.cmask, L.cgrank, L.wgrank, (const int2*)L.cpair, (const int*)croot_of(c), (const int*)c->cellfirst.as<int>(),    \
+                (const int*)L.ckey, (const int*)L.cstrip, (const int2*)L.wpair, (const int*)L.wpos, (const int*)L.wenc, (const int*)c->compkey.as<int>(),                    \
+                (const int*)c->ncore.as<int>(), c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->chainflag.as<int>() /* clist: the chain ids are dead */,  \
+                c->counters.as<int>()
+    if (g.variant == CL_VARIANT_CDBSCAN1) hipLaunchKernelGGL((k_border_w<BNT, BHC, true>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LB_ARGS);
+    else hipLaunchKernelGGL((k_border_w<BNT, BHC, false>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LB_ARGS);
+#undef LB_ARGS
     HIP_TRY(hipGetLastError());
     return CL_OK;
 }
@@ -1019,3 +1253,43 @@ int lists_final(cl_chrom* c, const GridParams& g, int nm, const ListRun& L, bool
     HIP_TRY(hipGetLastError());
     return CL_OK;
 }
+
+#ifdef CLOOPS_DEVEL
+// developer build: one list kernel of the LAST run on its own, `reps` times between two events (its inputs are still in place;
+// CLOOPS_DBG2 ablations apply).  which: 0 k_classify, 1 k_make_lists, 2 k_chain_c, 3 k_union_c, 4 k_border_w, 5 k_final_lists
+extern "C" int cl_debug_time_lists(cl_chrom* c, int which, int reps, float* ms_out)
+{
+    if (!c || !ms_out || c->dbg_nm <= 0) return fail(CL_ERR_ARG, "cl_debug_time_lists: no rotated run on this handle");
+    HIP_TRY(hipSetDevice(c->device));
+    GridParams g = c->dbg_g;
+    { const char* e = getenv("CLOOPS_DBG2"); g.dbg2 = e ? atoi(e) : 0; }
+    const int nm = c->dbg_nm;
+    ListBufs b;
+    int rc = list_bufs(c, g, nm, &b);
+    if (rc) return rc;
+    const int nblk = nblocks(nm, LT);
+    ListRun L{};
+    list_views(c, b, &L);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; ++r) {
+        if (which == 0) {
+            // (the superblock sums must be zero on entry: k_chain_c does that in a run)
+            HIP_TRY(hipMemsetAsync(b.sup, 0, (size_t)b.nsup2 * 4, c->stream));
+            launch_classify(c, g, nblk, b);
+        } else if (which == 1) {
+            launch_make_lists(c, g, nblk, b, L);
+        } else return fail(CL_ERR_ARG, "cl_debug_time_lists: kernel not supported on its own");
+    }
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    if (which == 1) HIP_TRY(hipMemsetAsync(b.sup, 0, (size_t)b.nsup2 * 4, c->stream));      // (what k_chain_c does in a run)
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / (float)std::max(1, reps);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return CL_OK;
+}
+#endif

@@ -22,6 +22,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import api
+from . import _roctx
 from .cDBSCAN2 import cDBSCAN as DBSCAN          # pipe.py:42  (production variant)
 from .dist import lpt_assign
 from .ests import estIntSelCutFrag, estIntSelCutFrag_from_stats
@@ -613,6 +614,9 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                 this_step = step_no
                 step_no += 1
                 t_step0 = time.perf_counter()
+                # one roctx range per step, from the enqueue to this rank's statistics on the host (rocprofv3 --marker-trace)
+                rng = _roctx.range_("cloops sweep step %d: eps %d minPts %d cut %d" % (this_step, ep, m, step_cut))
+                rng.__enter__()
 
                 # chromosomes are independent inside a step: enqueue them all (each handle has its own
                 # streams), then collect -- the kernels of different chromosomes overlap on the GPU
@@ -637,6 +641,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                             except Exception:
                                 pass
                             r.lock.release()
+                    rng.__exit__(None, None, None)
                     raise [e for e in errs if e is not None][0]
 
                 def collect(fr):
@@ -694,6 +699,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                 st = {"eps": ep, "minPts": m, "cut_in": int(cut), "n_inter": int(g[0]), "n_self": int(g[1]), "n_in": int(g[2])}
                 steps.append(st)
                 st["wall_s"] = time.perf_counter() - t_step0   # enqueue .. statistics of this rank on the host (+ the exchange); the cut follows
+                rng.__exit__(None, None, None)
                 if int(g[3]) == 0:                            # pipe.py:251-255
                     if log:
                         log("ERROR: no inter-ligation PETs detected for eps %s minPts %s,can't model the distance cutoff,continue anyway" % (ep, m))
@@ -760,6 +766,12 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
     finally:
         if pool is not None:
             pool.shutdown(wait=True)
+        for f, r in live:
+            # the announced minPts list belongs to this sweep: a later one-off run on the handle serves its own minPts only
+            try:
+                r.chrom.set_count_thresholds([])
+            except Exception:
+                pass
         for r in held:
             r.sweep_lock.release()
     return dataI, cut, cuts, steps

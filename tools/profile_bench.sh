@@ -48,7 +48,7 @@ def kb(k, what):
 k2s = [k for k in out if "k_region_core" in k]
 runs = 0
 for k in out:
-    if k.startswith("k_final_labels"):
+    if k.startswith("k_final_l"):
         runs = out[k]["launches_FETCH_SIZE"]
 hbm = lambda k: 2 * kb(k, "FETCH_SIZE_KB_sum") + kb(k, "WRITE_SIZE_KB_sum")
 ct = [k for k in out if k.startswith("k_cut_copy<true>")]
@@ -71,7 +71,7 @@ print(json.dumps(t))
 def stats(name):
     return {re.sub(r"\(.*", "", r["Name"]).replace("void ", ""): (int(r["Calls"]), float(r["AverageNs"]) / 1e3) for r in csv.DictReader(open("$OUT/" + name))}
 ru, fu = stats("k2_replay_reuse_kernel_stats.csv"), stats("k2_replay_full_kernel_stats.csv")
-passes = ru["k_final_labels"][0] // 12
+passes = [v for k, v in ru.items() if k.startswith("k_final_l")][0][0] // 12
 core = sum(c * a for k, (c, a) in ru.items() if k.startswith("k_region_core"))
 plain = fu["k_cut_copy<false>"][1]
 carry = ru["k_cut_copy<true>"][0] * (ru["k_cut_copy<true>"][1] - plain) + ru["k_cut_strips"][0] * (ru["k_cut_strips"][1] - fu["k_cut_strips"][1])

@@ -16,7 +16,7 @@ def clean(n):
 
 
 rows = list(csv.DictReader(open(os.path.join(d, "k2_replay_reuse_kernel_stats.csv"))))
-runs = [int(r["Calls"]) for r in rows if clean(r["Name"]).startswith("k_final_labels")][0]
+runs = [int(r["Calls"]) for r in rows if clean(r["Name"]).startswith("k_final_l")][0]
 per = []
 for r in rows:
     n = clean(r["Name"])
@@ -29,7 +29,7 @@ print("kernel time per run: %.1f us in %.1f launches (%d runs; the layout sorts 
 for p in per[:24]:
     print("  %8.1f us %5.2f launches  %s" % p)
 j = json.load(open(os.path.join(d, "pmc_fetch_write_k2replay.json")))
-runs2 = [v["launches_FETCH_SIZE"] for k, v in j.items() if k.startswith("k_final_labels")][0]
+runs2 = [v["launches_FETCH_SIZE"] for k, v in j.items() if k.startswith("k_final_l")][0]
 det = []
 for k, v in j.items():
     if any(k.startswith(s.rstrip("(")) for s in ONE_OFF):
