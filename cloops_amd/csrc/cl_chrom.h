@@ -121,11 +121,22 @@ struct cl_chrom {
     // rule can label) as compact arrays in sorted order, plus a rank index over the run's positions (one bit per PET and the
     // exclusive core / walker count in front of every 64-PET group), so that any position range of the layout maps to a
     // contiguous range of the core array in O(1).  K3 / K4 / K5 then touch nothing else.
-    DevBuf l_mask, l_rank, l_blk, l_cstrip, l_wpos, l_wenc, l_dist;
+    DevBuf l_mask, l_rank, l_blk, l_cstrip, l_wpos, l_wenc, l_dist, l_aux;
+    // ... built straight from the BASE layout (traversal level 4): a cut removes a prefix of every strip, so the list kernels
+    // apply it by index (per strip: first kept base index, end of the cut band, PETs removed: l_tab) and a re-using run
+    // copies nothing at all; variant 2's cell minima are a property of the base layout (bkey, once per eps) except in the one
+    // cell per strip the cut goes through (l_fix, per run)
+    DevBuf l_tab, l_fix, bkey;
+    bool bkey_valid = false;          // bkey belongs to the current base layout
+    int run_level = 0;                // traversal level of the run being enqueued (run_sort_and_count decides: level 4 needs the count cache's tables)
+    const int* w_dM = nullptr;        // device: PETs that entered DBSCAN in the run being enqueued
+    bool l4_cut = false;              // level 4: the run has a cut (the per-strip tables of k_cut_strips apply)
+    bool l4_band = false;             // ... and re-uses counts under another cut (the band's words are fresh: c->cnt, by run position)
     bool l_sup_dirty = false;         // k_classify's superblock sums may be non-zero (a run that failed between k_classify and k_chain_c)
     GridParams dbg_g{}; int dbg_nm = 0;   // the last rotated run's grid and size (developer build: kernels timed on their own)
-    int traversal = 3;                // cl_set_traversal: 0 = tile kernels over every PET (rounds 1-4), 1 = K3 on the core list,
-                                      // 2 = + border rule on the walker list, 3 = + labels / table / statistics from the lists
+    int traversal = 4;                // cl_set_traversal: 0 = tile kernels over every PET (rounds 1-4), 1 = K3 on the core list,
+                                      // 2 = + border rule on the walker list, 3 = + labels / table / statistics from the lists,
+                                      // 4 = + the lists built from the base layout (no copy of the layout for a run that re-uses counts)
     int last_k2_mode = 0;             // 0 = full K2, 1 = words re-used as they are (same cut), 2 = remapped + K2 on the band
     std::vector<long long> dcum;      // dcum[k] = number of PETs with Y - X < k, k = 0 .. 65536 (empty: unknown)
     const int* k_total = nullptr;     // device: where the run left the number of ids handed out (null: rankscan[n])
@@ -233,12 +244,16 @@ __device__ __forceinline__ int owner_root(int o) { return o < 0 ? -1 : (o & (OWN
 
 // k_lists.hip: the list form of K3 / K4 / K5 (host side; every function enqueues on c->stream)
 struct ListRun {                                        // device views of the run's lists (valid after lists_build)
+    int npos;                                           // positions of the layout the lists index (the run's layout: PETs of the run; the base layout: all rows)
+    const int* pstrip;                                  // ... and its strip table
     const int* lcnt;                                    // {C, W}: cores, walkers
     const unsigned long long* cmask; const unsigned long long* wmask;
     const int* cgrank; const int* wgrank;
     int2* cpair; int* cpos; int* ckey; int2* wpair; int* wpos; int* wenc; int* cstrip;
 };
 int lists_build(cl_chrom* c, const GridParams& g, int nm, ListRun* out);
+int lists_build_base(cl_chrom* c, const GridParams& g, int nm, ListRun* out);      // level 4: from the base layout + the cut's per-strip tables
+int lists_base_keys(cl_chrom* c, const GridParams& g);                             // variant 2: cell minima of the base layout (once per eps)
 int lists_union_flatten(cl_chrom* c, const GridParams& g, int nm, const ListRun& L);
 int lists_scatter_root(cl_chrom* c, int nm, const ListRun& L);
 int lists_border(cl_chrom* c, const GridParams& g, int nm, const ListRun& L);

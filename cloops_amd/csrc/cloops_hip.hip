@@ -1963,7 +1963,7 @@ static void free_chrom(cl_chrom* c)
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->slot[0].d_step, &c->slot[1].d_step, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
                       &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out, &c->dhist,
                       &c->rc_cnt, &c->rc_pre, &c->rc_poff, &c->rc_dpre, &c->rc_D, &c->rc_blen, &c->rootlist, &c->cflag8, &c->blk_tmp,
-                      &c->l_mask, &c->l_rank, &c->l_blk, &c->l_cstrip, &c->l_wpos, &c->l_wenc, &c->l_dist};
+                      &c->l_mask, &c->l_rank, &c->l_blk, &c->l_cstrip, &c->l_wpos, &c->l_wenc, &c->l_dist, &c->l_aux, &c->l_tab, &c->l_fix, &c->bkey};
     for (DevBuf* b : bufs) b->release();
     c->arena.release();                                  // (after its slices have been dropped)
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
@@ -1985,7 +1985,7 @@ extern "C" int64_t cl_chrom_size(const cl_chrom* c) { return c ? c->n : -1; }
 extern "C" void cl_set_profiling(cl_chrom* c, int enabled) { if (c) c->profiling = enabled != 0; }
 extern "C" void cl_set_layout_reuse(cl_chrom* c, int enabled) { if (c) { c->reuse_layout = enabled != 0; c->base.valid = false; c->rc.valid = false; } }
 extern "C" void cl_set_count_reuse(cl_chrom* c, int enabled) { if (c) { c->reuse_counts = enabled != 0; c->rc.valid = false; } }
-extern "C" void cl_set_traversal(cl_chrom* c, int level) { if (c) c->traversal = level < 0 ? 0 : (level > 3 ? 3 : level); }
+extern "C" void cl_set_traversal(cl_chrom* c, int level) { if (c) c->traversal = level < 0 ? 0 : (level > 4 ? 4 : level); }
 extern "C" int cl_last_region_mode(const cl_chrom* c) { return c ? c->last_k2_mode : 0; }
 extern "C" void cl_set_count_floor(cl_chrom* c, int32_t min_pts)
 {
@@ -2201,7 +2201,10 @@ k_cut_strips(int S, int thr, const int* __restrict__ bstrip, const int* __restri
              int* __restrict__ src0 /* [S] first kept source index */,
              int* __restrict__ pre_out /* or null */, const int* __restrict__ pre_ref /* or null */,
              int* __restrict__ dpre_out /* with pre_ref */, int2* __restrict__ blen_out /* with pre_ref */, int bandq, int eps,
-             int* __restrict__ clr /* or null */, int nclr, int* __restrict__ counters)
+             int* __restrict__ clr /* or null */, int nclr, int* __restrict__ counters,
+             int4* __restrict__ tab_out /* or null: per strip {first kept base index, end of its cut band, PETs the cut removes from it, 0}: what the
+                                           list kernels need to apply the cut to the BASE layout without a copy (k_lists.hip) */,
+             const u32* __restrict__ brow /* with fix_out */, GridParams g, int2* __restrict__ fix_out /* or null (variant 2): the strip's BOUNDARY cell */)
 {
     __shared__ int red[4];
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2239,7 +2242,35 @@ k_cut_strips(int S, int thr, const int* __restrict__ bstrip, const int* __restri
         kv = e - lo;
         src0[s] = lo;
         if (pre_out) pre_out[s] = lo - b;
+        if (tab_out) tab_out[s] = make_int4(lo, pre_ref ? lo + blen_out[s].x : lo, lo - b, 0);
+        if (fix_out) {
+            // variant 2: the rotated cell (strip, q / eps) that the cut goes THROUGH keeps only its PETs with q >= the threshold; its
+            // smallest input row (cDBSCAN2.py:117) is taken over those -- every other cell keeps the minimum of the base layout
+            // (bkey, once per eps).  {end of that cell (base index), its minimum}; no such cell: {lo, -}.
+            int2 fx = make_int2(lo, INT_MAX);
+            if (lo < e && lo > b) {
+                const int q0 = div_eps(g, bq[lo]) * g.eps;
+                if (bq[lo - 1] >= q0) {
+                    const int qend = q0 + g.eps;
+                    int k = lo, m = INT_MAX;
+                    bool on = true;
+                    while (on) {                          // four PETs per round trip
+                        int qv[4]; u32 rv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int kk = min(k + u, e - 1); qv[u] = bq[kk]; rv[u] = brow[kk]; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (on && k + u < e && qv[u] < qend) m = min(m, (int)rv[u]); else if (on) { on = false; k += u; }
+                        }
+                        if (on) k += 4;
+                    }
+                    fx = make_int2(k, m);
+                }
+            }
+            fix_out[s] = fx;
+        }
     }
+    if (s == S && tab_out) tab_out[S] = make_int4(bstrip[S], bstrip[S], 0, 0);
     // the exclusive scan of the kept lengths IS the new strip table: inside the workgroup here, the workgroups' offsets by the
     // last workgroup to finish (rocPRIM's scan was three launches: a fill, the look-back state, the scan)
     int tot;
@@ -2321,6 +2352,29 @@ k_cut_copy(int n, int S, int rbits, int thr, const int* __restrict__ bq, const i
         strip_start[S + 1] = n;
         if (expect_m >= 0 && expect_m != M) counters[CTR_OVERFLOW] = 8;      // the host sized the run by a wrong M: fail loudly
     }
+}
+
+// K2 on the cut band as a launch of its own (traversal level 4: a run that re-uses counts makes no copy of the layout, so the
+// band query has no compaction kernel to ride in); also leaves M, the PETs that enter DBSCAN (the total of the strip scan)
+__global__ void __launch_bounds__(CMP_TPB)
+k_band(int S, int rbits, int eps, int minPts, const int* __restrict__ bq, const int* __restrict__ bsp, const int* __restrict__ src0,
+       const int* __restrict__ sloc, const int* __restrict__ sboffs, const int2* __restrict__ blen, int* __restrict__ band_words,
+       int* __restrict__ d_M, int expect_m, int* __restrict__ counters, int dbg)
+{
+    __shared__ int2 l_band[CMP_TPB / 64][KB_CAP];
+    const int wv = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int M = sloc[S] + sboffs[S >> 8];
+        d_M[0] = M;
+        if (expect_m >= 0 && expect_m != M) counters[CTR_OVERFLOW] = 8;      // the host sized the run by a wrong M: fail loudly
+    }
+    band_wave(blockIdx.x * (CMP_TPB / 64) + wv, threadIdx.x & 63, l_band[wv], S, eps, 1 << rbits, minPts, bq, bsp, src0, sloc, sboffs, blen, band_words, dbg);
+}
+__global__ void k_store_m(int S, const int* __restrict__ sloc, const int* __restrict__ sboffs, int* __restrict__ d_M, int expect_m, int* __restrict__ counters)
+{
+    const int M = sloc[S] + sboffs[S >> 8];
+    d_M[0] = M;
+    if (expect_m >= 0 && expect_m != M) counters[CTR_OVERFLOW] = 8;
 }
 
 // workspace for a run over n rows
@@ -2614,6 +2668,8 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     GridParams gk = g;                                    // what K2 sees: the minPts values its words serve, filled in below
     bool k2_band = false, k2_skip = false;
     c->ws = WordSrc{c->cnt.as<int>(), nullptr, nullptr, nullptr, 0, g.rbits};
+    c->run_level = exact ? 0 : std::min(c->traversal, 3);
+    c->w_dM = nullptr; c->l4_cut = false; c->l4_band = false;
     if (!c->reuse_layout) {
         // every run sorts for itself (the cut filter rides in the keys: filtered rows go behind the last strip)
         if ((rc = sort_layout(c, g, wsv, wsa, nullptr, c->strip.as<int>(), c->tile_s0.as<int>()))) return rc;
@@ -2632,6 +2688,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
             GridParams g0 = g;
             g0.cut = 0;
             c->rc.valid = false;                          // the cached words belong to the layout that is being replaced
+            c->bkey_valid = false;                        // ... and so do variant 2's cell minima
             if ((rc = sort_layout(c, g0, c->bq.as<int>() + SORT_PAD, c->bsp.as<int>() + SORT_PAD, c->brow.as<u32>(),
                                   c->bstrip.as<int>(), c->btile.as<int>()))) return rc;
             c->base.valid = true; c->base.layout = layout; c->base.eps = g.eps;
@@ -2659,6 +2716,14 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
             if ((rc = c->rc_cnt.ensure((size_t)n * 4)) || (rc = c->rc_pre.ensure(((size_t)g.S + 2) * 4)) ||
                 (rc = c->rc_poff.ensure(((size_t)g.S + 2) * 4)) || (rc = c->rc_dpre.ensure(((size_t)g.S + 2) * 4)) ||
                 (rc = c->rc_D.ensure(((size_t)g.S + 2) * 4)) || (rc = c->rc_blen.ensure(((size_t)g.S + 2) * 8))) return rc;
+        }
+        // traversal level 4 (lists from the base layout) needs the count cache's per-strip tables: a run the cache does not take
+        // (exact counts, minPts outside 2 .. 128, cache switched off) works on a copy of the layout as before
+        c->run_level = (c->traversal >= 4 && rcmode != RC_NONE && g.variant != CL_VARIANT_BLOCK) ? 4 : std::min(c->traversal, 3);
+        if (exact) c->run_level = 0;
+        if (c->run_level == 4 && g.variant == CL_VARIANT_CDBSCAN2 && !c->bkey_valid) {
+            if ((rc = lists_base_keys(c, g))) return rc;
+            c->bkey_valid = true;
         }
         if (rcmode == RC_MAKE) {
             c->rc.valid = true; c->rc.layout = layout; c->rc.eps = g.eps; c->rc.thr = thr_new; c->rc.cap = g.minPts;
@@ -2709,13 +2774,30 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
             int* d_M = c->counters.as<int>() + CTR_M;
             const int thr = g.cut - g.V0;
             const int* bq = c->bq.as<int>() + SORT_PAD;
+            const bool l4 = c->run_level == 4;
+            c->l4_cut = true; c->l4_band = rcmode == RC_REMAP;
+            if (l4 && ((rc = c->l_tab.ensure(((size_t)g.S + 2) * 16)) || (rc = c->l_fix.ensure(((size_t)g.S + 2) * 8)))) return rc;
             LAUNCH(k_cut_strips, g.S + 1, g.S, thr, (const int*)c->bstrip.as<int>(), bq, sloc, bsum, sboffs, c->counters.as<int>() + CTR_TICKET_A, src0,
                    rcmode == RC_MAKE ? c->rc_pre.as<int>() : (int*)nullptr,
                    rcmode == RC_REMAP ? (const int*)c->rc_pre.as<int>() : (const int*)nullptr,
                    rcmode == RC_REMAP ? c->rc_dpre.as<int>() : (int*)nullptr, rcmode == RC_REMAP ? c->rc_blen.as<int2>() : (int2*)nullptr,
-                   c->ws.bandq, g.eps, c->init_nclr > 0 ? c->flag.as<int>() : (int*)nullptr, c->init_nclr, c->counters.as<int>());
+                   c->ws.bandq, g.eps, c->init_nclr > 0 ? c->flag.as<int>() : (int*)nullptr, c->init_nclr, c->counters.as<int>(),
+                   l4 ? c->l_tab.as<int4>() : (int4*)nullptr, (const u32*)c->brow.as<u32>(), g,
+                   (l4 && g.variant == CL_VARIANT_CDBSCAN2) ? c->l_fix.as<int2>() : (int2*)nullptr);
             c->init_nclr = 0;
             // (the kernel that opens a clustering run also clears its key bitmap and counters: init_nclr > 0)
+            if (l4 && rcmode == RC_REMAP) {
+                // no copy of the layout: the band query alone (it reads the base layout and writes its words at the PETs' places in the
+                // run's -- virtual -- layout); the list kernels apply the cut by index
+                const int nbb = nblocks(nblocks(g.S, KB_SB), CMP_TPB / 64);
+                hipLaunchKernelGGL(k_band, dim3(nbb), dim3(CMP_TPB), 0, c->stream, g.S, g.rbits, g.eps, g.minPts, bq, (const int*)(c->bsp.as<int>() + SORT_PAD),
+                                   (const int*)src0, (const int*)sloc, (const int*)sboffs, (const int2*)c->rc_blen.as<int2>(), c->cnt.as<int>(), d_M,
+                                   c->run_m_exact ? c->run_m : -1, c->counters.as<int>(), g.dbg);
+                c->w_dM = d_M;
+            } else if (l4 && rcmode == RC_SAME) {
+                hipLaunchKernelGGL(k_store_m, dim3(1), dim3(1), 0, c->stream, g.S, (const int*)sloc, (const int*)sboffs, d_M, c->run_m_exact ? c->run_m : -1, c->counters.as<int>());
+                c->w_dM = d_M;
+            } else
             if (rcmode == RC_REMAP) {
                 const int nbb = nblocks(nblocks(g.S, KB_SB), CMP_TPB / 64);      // workgroups that do K2 on the cut band (four waves of KB_SB strips each)
                 hipLaunchKernelGGL(k_cut_copy<true>, dim3(nbb + nb), dim3(CMP_TPB), 0, c->stream, n, g.S, g.rbits, thr, bq, (const int*)(c->bsp.as<int>() + SORT_PAD),
@@ -2729,6 +2811,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
                                (const int*)nullptr, (int*)nullptr, 0, (const int2*)nullptr, (int*)nullptr, 0, 0, 0);
             c->w_sv = wsv; c->w_sa = wsa; c->srow = c->vals_out.as<u32>();
             c->w_strip = c->strip.as<int>(); c->w_tile = c->tile_s0.as<int>();
+            if (!c->w_dM) c->w_dM = d_M;
         }
     }
     ev_record(c, 2);
@@ -3184,9 +3267,14 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     // how far the run works on lists (k_lists.hip; cl_set_traversal): 0 = tile kernels over every PET, 1 = K3 on the core list,
     // 2 = + the border rule on the walker list, 3 = + labels / table / distance list from the lists (only labelled PETs are
     // written: the row-aligned array is filled with -1 first)
-    const int level = wide == 0 ? c->traversal : 0;
-    if (rows && (cut > 0 || level >= 3)) HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
-    if ((rc = run_sort_and_count(c, g, false))) return rc;
+    if (rows && (cut > 0 || (wide == 0 && c->traversal >= 3))) HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
+    const int trav_saved = c->traversal;
+    if (wide != 0) c->traversal = 0;                    // (developer tile shapes: the tile kernels)
+    rc = run_sort_and_count(c, g, false);
+    c->traversal = trav_saved;
+    if (rc) return rc;
+    const int level = c->run_level;
+    // (a level-3 default that fell to the tile kernels for this run -- exact counts are not a clustering run -- cannot happen here)
     if (c->init_nclr > 0) { LAUNCH(k_init_flags, nw + 1, nw, c->flag.as<int>(), counters); c->init_nclr = 0; }
     const WordSrc ws = c->ws;                           // where the K2 words of this run live (the handle's count cache / the work buffer)
     if ((rc = c->rootlist.ensure((size_t)n * 4)) || (rc = c->cflag8.ensure((size_t)n + 16))) return rc;
@@ -3214,7 +3302,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     ListRun L{};
     c->dbg_g = g; c->dbg_nm = nm;
     if (level >= 1) {
-        if ((rc = lists_build(c, g, nm, &L)) || (rc = lists_union_flatten(c, g, nm, L))) return rc;
+        if ((rc = (level >= 4 ? lists_build_base(c, g, nm, &L) : lists_build(c, g, nm, &L))) || (rc = lists_union_flatten(c, g, nm, L))) return rc;
         if (level == 1 && (rc = lists_scatter_root(c, nm, L))) return rc;
     } else {
         // own-strip chains; variant 2: the same tile kernel also finds every PET's cell head
@@ -3288,7 +3376,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     // rlabel reuses the chainhead buffer (free after k_chain_parent); the kernel also resets the table rows of the ids handed out
     hipLaunchKernelGGL(k_root_labels_bits_l, dim3(512), dim3(TPB), 0, c->stream, g, rootlist, counters, c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(),
                        c->state.as<int>(), c->flag.as<unsigned>(), (const int*)c->rankscan.as<int>(), (const int*)wboff, c->chainhead.as<int>(), t, nblkw,
-                       c->hdr.as<int>() + 16 * c->cur, (const int*)(strip + g.S));
+                       c->hdr.as<int>() + 16 * c->cur, c->w_dM ? c->w_dM : (const int*)(strip + g.S));
     c->hdr_packed = true;
     if (level >= 3) {
         if ((rc = lists_final(c, g, nm, L, rows))) return rc;
@@ -3297,11 +3385,11 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     } else {
         if (level == 2 && (rc = lists_scatter_owner(c, nm, L))) return rc;
         if (!SKIP(8)) hipLaunchKernelGGL(k_final_labels, dim3(nblocks(nm, BIGTPB * FINAL_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow,
-                       level == 2 ? c->l_dist.as<int>() : c->owner.as<int>(),
+                       level == 2 ? c->l_aux.as<int>() : c->owner.as<int>(),
                        c->chainhead.as<int>(), rows ? c->slot[c->cur].labels.as<int>() : (int*)nullptr, c->slot[c->cur].slab.as<int>(), t);
     }
     HIP_TRY(hipGetLastError());
-    return finish_enqueue(c, g.S + 2, strip + g.S, labels_out);
+    return finish_enqueue(c, g.S + 2, c->w_dM ? c->w_dM : strip + g.S, labels_out);
 }
 
 

@@ -54,6 +54,16 @@ extern "C" void cl_debug_lstats(unsigned long long* out)
 #else
 #define LSTAT(slot, v) do { } while (0)
 #endif
+// What a walker keeps of its K2 word: where its q windows in the strips s-1 / s+1 start, as distances in POSITIONS of the
+// layout the lists index -- low 16 bits back to the first PET of strip s-1 with q >= q - eps, high 16 bits ahead to the first one
+// of strip s+1 (the builders convert K2's hints: cl_common.h "K2W"); LH_NONE = no hints (the cores-only strip table + a search)
+#define LH_NONE 0xffffffffu
+__device__ __forceinline__ unsigned lh_pack(int w, int shiftA, int shiftB)
+{
+    if (!(w < 0 && ((unsigned)w & K2H_NONE) != K2H_NONE)) return LH_NONE;
+    const int da = (int)((unsigned)w & K2H_MASK) + shiftA, db = (int)(((unsigned)w >> K2H_BITS) & K2H_MASK) + shiftB;
+    return ((da >= 0) & (da < 0xffff) & (db >= 0) & (db < 0xffff)) ? ((unsigned)da | ((unsigned)db << 16)) : LH_NONE;
+}
 #define LT 2048                  // positions per tile of k_classify / k_make_lists (256 threads x 8)
 #define LG (LT / 64)             // 64-PET groups per tile
 #define L_HALO 128               // variant 2: staged halo of k_classify (cell heads look one PET back, cells run on behind the tile)
@@ -149,6 +159,13 @@ k_classify(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int i = t0 + u * 256 + (int)threadIdx.x; w[u] = i < M ? w[u] : 0; }
     }
+    if (L_ABL(1 << 20)) {                                // (ablation: the loads alone)
+        int acc = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += w[u] + q[u] + sp[u] + (V2 ? (int)row[u] + pq[u] + pp[u] : 0);
+        if (acc == 0x7f123456) cgloc[0] = acc;
+        return;
+    }
     unsigned headbits = 0u;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -158,7 +175,7 @@ k_classify(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
         const bool walk = in && !core && cw_count(w[u]) > 1;      // (count <= 1: nothing within eps -- most of the background noise ends here)
         const unsigned long long cb = __ballot(core), wb = __ballot(walk);
         const int k = u * 4 + wv, gidx = (t0 >> 6) + k;
-        if (lane == 0) { cmask[gidx] = cb; wmask[gidx] = wb; l_cc[k] = __popcll(cb); l_wc[k] = __popcll(wb); }
+        if (lane == 0) { if (!L_ABL(1 << 19)) { cmask[gidx] = cb; wmask[gidx] = wb; } l_cc[k] = __popcll(cb); l_wc[k] = __popcll(wb); }
         if (V2) {
             // a PET starts a rotated cell (strip, q / eps) iff its predecessor lies in an earlier strip or below the cell's lower q
             // edge (cDBSCAN2.py:67-70; variant 2 runs with A0 = V0 = 0)
@@ -183,14 +200,14 @@ k_classify(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
         int incl = v;
 #pragma unroll
         for (int d = 1; d < 32; d <<= 1) { const int t = __shfl_up(incl, d, 32); incl += k >= d ? t : 0; }
-        (lane < 32 ? cgloc : wgloc)[(t0 >> 6) + k] = incl - v;
+        if (!L_ABL(1 << 19)) (lane < 32 ? cgloc : wgloc)[(t0 >> 6) + k] = incl - v;
         totC = __shfl(incl, 31); totW = __shfl(incl, 63);
     }
     // the tile's totals: a plain store, and two atomics NOBODY WAITS FOR into the sums of its 64-tile superblock -- k_make_lists
     // adds up the superblocks and the tiles in front of its own (a few hundred loads per workgroup).  (First form: block sums as
     // awaited device-scope atomics, a ticket, the last workgroup scans -- 57 of this kernel's 89 us on chr1: ~5000 workgroups each
     // ended in two dependent round trips to memory.)
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !L_ABL(1 << 18)) {
         const int nsup = (nblk + 63) / 64 + 1;
         bsum[blk] = totC; bsum[nblk + 1 + blk] = totW;
         if (totC) atomicAdd(&sup[blk >> 6], totC);
@@ -366,7 +383,279 @@ k_make_lists(GridParams g, const int* __restrict__ sv, const int* __restrict__ s
             cpair[dst] = make_int2(q[u], sp[u]); cpos[dst] = i; ckey[dst] = key;
         } else if (isw) {
             const int dst = wgv[u] + __popcll(wb & low_mask(lane));
-            wpair[dst] = make_int2(q[u], sp[u]); wpos[dst] = i; wenc[dst] = aux[u];
+            wpair[dst] = make_int2(q[u], sp[u]); wpos[dst] = i; wenc[dst] = (int)lh_pack(aux[u], 0, 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Level 4: the lists straight from the BASE layout
+// ------------------------------------------------------------------------------------------
+// The base layout of an eps holds ALL rows, sorted (strip, q); a cut (pipe.py:59-62: d = Y - X >= cut, and q IS d) removes a
+// PREFIX of every strip.  k_cut_strips leaves, per strip, tab[s] = {first kept base index, end of the cut band, PETs removed};
+// the two kernels below classify and compact the KEPT PETs of the base layout by those indices -- no copy of the layout,
+// positions are base positions (a removed PET has neither bit, so rank(any position of a removed prefix) = rank(the strip's
+// first kept PET): K2's window hints, converted from positions of the layout the words were made on to base positions by adding
+// what THAT layout's cut removed from the strip in between, stay valid as they are).
+//
+// Variant 2's component keys are minima over rotated CELLS (cDBSCAN2.py:117-140: the smallest input row of any PET of the cell).
+// A cell is a run of the base layout and the cut removes whole cells plus a part of ONE cell per strip: bkey[b] = the minimum
+// of b's cell over ALL rows is a property of the base layout (k_base_keys, once per eps), and k_cut_strips recomputes the one
+// cell per strip its cut goes through (fix[s] = {end of that cell, its minimum over the kept PETs}).
+
+// bkey[b] for every base position (variant 2): a tile owns the cells that BEGIN in it -- their minima by LDS atomics, the part of
+// its last cell that runs on behind the tile walked (and written) by wave 0.
+__global__ void __launch_bounds__(256)
+k_base_keys(GridParams g, int npos, const int* __restrict__ bq, const int* __restrict__ bsp, const u32* __restrict__ brow, int* __restrict__ bkey)
+{
+    __shared__ int lmin[LT];
+    __shared__ unsigned long long l_chead[LG];
+    __shared__ int l_hlast;
+    const int blk = (int)blockIdx.x, t0 = blk * LT;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nmask = ~(g.peps - 1);
+    int q[8], sp[8], pq[8], pp[8], pos[8];
+    u32 row[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = t0 + u * 256 + (int)threadIdx.x;
+        const bool in = i < npos;
+        q[u] = in ? bq[i] : INT_MAX; sp[u] = in ? bsp[i] : INT_MAX; row[u] = in ? brow[i] : 0u;
+        pq[u] = (in && lane == 0) ? bq[i - 1] : 0; pp[u] = (in && lane == 0) ? bsp[i - 1] : 0;      // (the padded arrays hold a sentinel in front of index 0)
+    }
+    for (int k = threadIdx.x; k < LT; k += 256) lmin[k] = INT_MAX;
+    if (threadIdx.x == 0) l_hlast = -1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int a = __shfl_up(q[u], 1), b = __shfl_up(sp[u], 1);
+        if (lane != 0) { pq[u] = a; pp[u] = b; }
+        const int i = t0 + u * 256 + (int)threadIdx.x;
+        const bool in = i < npos;
+        const int q0 = in ? div_eps(g, q[u]) * g.eps : 0;
+        const bool start = in && (i == 0 || (pp[u] & nmask) != (sp[u] & nmask) || pq[u] < q0);
+        const unsigned long long hb = __ballot(start);
+        if (lane == 0) l_chead[u * 4 + wv] = hb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = t0 + u * 256 + (int)threadIdx.x;
+        pos[u] = -1;
+        if (i >= npos) continue;
+        const int k = u * 4 + wv;
+        const unsigned long long upto = l_chead[k] & ((2ull << lane) - 1ull);
+        if (upto) pos[u] = (i - lane) + 63 - __clzll((long long)upto);
+        else
+            for (int k2 = k - 1; k2 >= 0; --k2) {
+                const unsigned long long o2 = l_chead[k2];
+                if (o2) { pos[u] = t0 + 64 * k2 + 63 - __clzll((long long)o2); break; }
+            }
+        if (pos[u] >= t0) atomicMin(&lmin[pos[u] - t0], (int)row[u]);
+        if (i == min(t0 + LT, npos) - 1) l_hlast = pos[u];
+    }
+    __syncthreads();
+    const int tend = t0 + LT;
+    if (threadIdx.x < 64 && tend < npos && l_hlast >= t0) {
+        // the cell of the tile's last PET may go on behind the tile: its minimum over that part, then the finished minimum written
+        // to that part (the tiles behind leave the PETs of a cell that began in front of them alone)
+        const int2 lp = make_int2(bq[tend - 1], bsp[tend - 1]);
+        const int p0 = lp.y & nmask, qend = div_eps(g, lp.x) * g.eps + g.eps;
+        int m = INT_MAX, jend = tend;
+        for (int j0 = tend; j0 < npos; j0 += 64) {
+            const int j = j0 + (int)threadIdx.x;
+            bool in = j < npos;
+            if (in) in = (bsp[j] & nmask) == p0 && bq[j] < qend;
+            if (in) m = min(m, (int)brow[j]);
+            const unsigned long long bal = __ballot(in);
+            jend = j0 + __popcll(bal);                   // (the cell's PETs are contiguous: the set lanes are a prefix)
+            if (bal != ~0ull) break;
+        }
+        m = dpp_reduce_wave(m, OpMin());
+        const int fin = min(m, lmin[l_hlast - t0]);
+        if (threadIdx.x == 0) lmin[l_hlast - t0] = fin;
+        for (int j = tend + (int)threadIdx.x; j < jend; j += 64) bkey[j] = fin;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = t0 + u * 256 + (int)threadIdx.x;
+        if (i < npos && pos[u] >= t0) bkey[i] = lmin[pos[u] - t0];
+    }
+}
+
+// classify: one bit per base position "core" / "walker" (removed PETs: neither), their counts per 64-position group exclusive
+// inside the tile, the tile's totals (a plain store) and the totals of its 16-tile superblock (ONE atomic nobody waits for:
+// cores in the low, walkers in the high half); pw[b] = a walker's window hints in base positions (lh_pack).
+template <bool CUT>
+__global__ void __launch_bounds__(256)
+k_classify_b(GridParams g, int npos, const int* __restrict__ bsp, const int4* __restrict__ tab, const int* __restrict__ sloc,
+             const int* __restrict__ sboffs, const int* __restrict__ words, const int* __restrict__ woff /* or null */,
+             const int* __restrict__ wpre /* or null */, const int* __restrict__ band /* or null */,
+             unsigned long long* __restrict__ cmask, unsigned long long* __restrict__ wmask, int* __restrict__ cgloc,
+             int* __restrict__ wgloc, int* __restrict__ bsum, unsigned long long* __restrict__ sup, int* __restrict__ pw)
+{
+    __shared__ int l_cc[LG], l_wc[LG];
+    const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
+    const int t0 = blk * LT;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int sp[8], w[8], sh[8];
+    int4 tb[8];
+    bool alive[8], inb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int b = t0 + u * 256 + (int)threadIdx.x; sp[u] = b < npos ? bsp[b] : 0; }
+    {
+        // the word of a kept PET: a fresh one for the PETs of the cut band (by their place in the run's virtual layout: new strip
+        // start + offset), else the word of the layout the words were made on -- base position minus what THAT cut removed in front
+        const int* src[8]; int idx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = t0 + u * 256 + (int)threadIdx.x;
+            const int st = min(sp[u] >> g.rbits, g.S);
+            alive[u] = b < npos; inb[u] = false;
+            tb[u] = make_int4(0, 0, 0, 0);
+            if (CUT && alive[u]) { tb[u] = tab[st]; alive[u] = b >= tb[u].x; inb[u] = band != nullptr && alive[u] && b < tb[u].y; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = t0 + u * 256 + (int)threadIdx.x;
+            const int st = min(sp[u] >> g.rbits, g.S);
+            src[u] = words; idx[u] = 0; sh[u] = 0;
+            if (alive[u]) {
+                if (inb[u]) { src[u] = band; idx[u] = sloc[st] + sboffs[st >> 8] + (b - tb[u].x); }
+                else idx[u] = b - (woff ? woff[st] : 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = alive[u] ? src[u][idx[u]] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const bool core = alive[u] && cw_core(w[u], g.minPts);
+        const bool walk = alive[u] && !core && cw_count(w[u]) > 1;      // (count <= 1: nothing within eps -- most of the background noise ends here)
+        const unsigned long long cb = __ballot(core), wb = __ballot(walk);
+        const int k = u * 4 + wv, gidx = (t0 >> 6) + k;
+        if (lane == 0) { cmask[gidx] = cb; wmask[gidx] = wb; l_cc[k] = __popcll(cb); l_wc[k] = __popcll(wb); }
+        sh[u] = walk ? 1 : 0;
+    }
+    {
+        // walkers: the hints of their word as distances in base positions: + what the cut of the words' layout (band: this run's
+        // cut) removed from the own strip (backwards) / from the strip above (forwards)
+        int sa_[8], sb_[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int st = min(sp[u] >> g.rbits, g.S);
+            sa_[u] = 0; sb_[u] = 0;
+            if (CUT && sh[u]) {
+                if (inb[u]) { sa_[u] = tb[u].z; sb_[u] = tab[min(st + 1, g.S)].z; }
+                else if (wpre) { sa_[u] = wpre[st]; sb_[u] = wpre[min(st + 1, g.S)]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = t0 + u * 256 + (int)threadIdx.x;
+            if (sh[u]) pw[b] = (int)lh_pack(w[u], sa_[u], sb_[u]);
+        }
+    }
+    if (blk == nblk - 1 && threadIdx.x == 0) {
+        const int ge = nblk * LG;                        // one group behind the last tile: position npos may be its first
+        cmask[ge] = 0ull; wmask[ge] = 0ull; cgloc[ge] = 0; wgloc[ge] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int k = lane & 31;
+        const int v = lane < 32 ? l_cc[k] : l_wc[k];
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) { const int t = __shfl_up(incl, d, 32); incl += k >= d ? t : 0; }
+        (lane < 32 ? cgloc : wgloc)[(t0 >> 6) + k] = incl - v;
+        const int totC = __shfl(incl, 31), totW = __shfl(incl, 63);
+        if (threadIdx.x == 0 && !L_ABL(1 << 18)) {
+            bsum[blk] = totC; bsum[nblk + 1 + blk] = totW;
+            const unsigned long long both = (unsigned long long)(unsigned)totC | ((unsigned long long)(unsigned)totW << 32);
+            if (both) atomicAdd(&sup[blk >> 4], both);
+        }
+    }
+}
+
+template <bool V2, bool CUT>
+__global__ void __launch_bounds__(256)
+k_make_lists_b(GridParams g, int npos, const int* __restrict__ bq, const int* __restrict__ bsp, const u32* __restrict__ brow,
+               const int* __restrict__ bkey, const int2* __restrict__ fix, const unsigned long long* __restrict__ cmask,
+               const unsigned long long* __restrict__ wmask, const int* __restrict__ cgloc, const int* __restrict__ wgloc,
+               const int* __restrict__ bsum, const unsigned long long* __restrict__ sup, const int* __restrict__ pw,
+               int* __restrict__ cgrank, int* __restrict__ wgrank, int2* __restrict__ cpair, int* __restrict__ cpos,
+               int* __restrict__ ckey, int2* __restrict__ wpair, int* __restrict__ wpos, int* __restrict__ wenc, int* __restrict__ lcnt)
+{
+    __shared__ int l_red[2][4];
+    const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
+    const int t0 = blk * LT;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long cbv[8], wbv[8];
+    int cgv[8], wgv[8], q[8], sp[8], aux[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int gidx = (t0 >> 6) + u * 4 + wv;
+        cbv[u] = cmask[gidx]; wbv[u] = wmask[gidx];
+        cgv[u] = cgloc[gidx]; wgv[u] = wgloc[gidx];
+    }
+    int cbase, wbase;
+    {
+        // cores / walkers in front of this tile: the 16-tile superblocks in front of its own + the tiles of its own in front of it
+        const int sb = blk >> 4;
+        int pc = 0, pw_ = 0;
+        for (int k = threadIdx.x; k < sb; k += 256) { const unsigned long long v = sup[k]; pc += (int)(unsigned)v; pw_ += (int)(unsigned)(v >> 32); }
+        if (threadIdx.x < 16) { const int k = sb * 16 + (int)threadIdx.x; if (k < blk) { pc += bsum[k]; pw_ += bsum[nblk + 1 + k]; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { pc += __shfl_down(pc, o); pw_ += __shfl_down(pw_, o); }
+        if (lane == 0) { l_red[0][wv] = pc; l_red[1][wv] = pw_; }
+        __syncthreads();
+        cbase = l_red[0][0] + l_red[0][1] + l_red[0][2] + l_red[0][3];
+        wbase = l_red[1][0] + l_red[1][1] + l_red[1][2] + l_red[1][3];
+    }
+    if (blk == nblk - 1 && threadIdx.x == 0) {
+        const int C = cbase + bsum[blk], W = wbase + bsum[nblk + 1 + blk];
+        lcnt[0] = C; lcnt[1] = W;
+        cgrank[nblk * LG] = C; wgrank[nblk * LG] = W;
+#ifdef CLOOPS_DEVEL
+        atomicAdd(&g_lstat[8], (unsigned long long)C); atomicAdd(&g_lstat[9], (unsigned long long)W); atomicAdd(&g_lstat[11], 1ull);
+#endif
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int b = t0 + u * 256 + (int)threadIdx.x;
+        const bool any = ((cbv[u] | wbv[u]) >> lane) & 1ull;
+        q[u] = any ? bq[b] : 0; sp[u] = any ? bsp[b] : 0;
+        cgv[u] += cbase; wgv[u] += wbase;
+        if (lane == 0) { const int gidx = (t0 >> 6) + u * 4 + wv; cgrank[gidx] = cgv[u]; wgrank[gidx] = wgv[u]; }
+    }
+    {
+        // a core's key: variant 1 its input row (the component's start point is its smallest-row core, cDBSCAN.py:134-137);
+        // variant 2 the minimum of its rotated cell (bkey; the cell the cut goes through: fix).  A walker's hints: pw.
+        int2 fx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = t0 + u * 256 + (int)threadIdx.x;
+            const bool isc = (cbv[u] >> lane) & 1ull, isw = (wbv[u] >> lane) & 1ull;
+            aux[u] = isw ? pw[b] : (isc ? (V2 ? bkey[b] : (int)brow[b]) : 0);
+            fx[u] = make_int2(INT_MIN, 0);
+            if (V2 && CUT && isc) fx[u] = fix[sp[u] >> g.rbits];
+        }
+        if (V2 && CUT) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int b = t0 + u * 256 + (int)threadIdx.x; if (b < fx[u].x) aux[u] = fx[u].y; }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int b = t0 + u * 256 + (int)threadIdx.x;
+        const unsigned long long cb = cbv[u], wb = wbv[u];
+        const bool isc = (cb >> lane) & 1ull, isw = (wb >> lane) & 1ull;
+        if (isc) {
+            const int dst = cgv[u] + __popcll(cb & low_mask(lane));
+            cpair[dst] = make_int2(q[u], sp[u]); cpos[dst] = b; ckey[dst] = aux[u];
+        } else if (isw) {
+            const int dst = wgv[u] + __popcll(wb & low_mask(lane));
+            wpair[dst] = make_int2(q[u], sp[u]); wpos[dst] = b; wenc[dst] = aux[u];
         }
     }
 }
@@ -383,7 +672,7 @@ k_chain_c(GridParams g, const int* __restrict__ lcnt, const int2* __restrict__ c
           int* __restrict__ parent, int* __restrict__ compkey, int* __restrict__ ncore, int* __restrict__ bsize,
           int* __restrict__ usize, int* __restrict__ state, int* __restrict__ cend,
           const int* __restrict__ strip_start, const unsigned long long* __restrict__ cmask, const int* __restrict__ cgrank,
-          int* __restrict__ cstrip, int* __restrict__ sup, int nsup2)
+          int* __restrict__ cstrip, int* __restrict__ sup, int nsup2, int* __restrict__ ckey_prune /* or null */)
 {
     const int C = lcnt[0];
     const int lane = threadIdx.x & 63;
@@ -435,6 +724,9 @@ k_chain_c(GridParams g, const int* __restrict__ lcnt, const int2* __restrict__ c
             chainid[c] = head;
             if (head == c) { parent[c] = c; compkey[c] = INT_MAX; ncore[c] = 0; bsize[c] = 0; usize[c] = 0; state[c] = ST_LIVE; }
             if (last) cend[head] = c;
+            // variant 2, keys by cell (level 4): of a cell's cores only the first carries the cell to k_flatten_c (two cores of one
+            // cell are always one component) -- the others cost it neither an atomic nor a compare
+            if (ckey_prune && c > 0 && (pv[e].y & nmask) == p0 && div_eps(g, pv[e].x) == div_eps(g, me[e].x)) ckey_prune[c] = INT_MAX;
         }
     }
 }
@@ -742,7 +1034,7 @@ __global__ void k_scatter_by_pos(const int* __restrict__ cnt_ptr, const int* __r
 #define LB_PER 4                 // walkers per thread and pass: the loads of a stage of all of them are in flight together
 template <int NT, int HC, bool V1>
 __global__ void __launch_bounds__(256)
-k_border_w(GridParams g, int ntiles, const int* __restrict__ strip_start, const int* __restrict__ lcnt,
+k_border_w(GridParams g, int ntiles, int npos, const int* __restrict__ lcnt,
            const unsigned long long* __restrict__ cmask, const int* __restrict__ cgrank, const int* __restrict__ wgrank,
            const int2* __restrict__ cpair, const int* __restrict__ croot, const int* __restrict__ cskip, const int* __restrict__ ckey,
            const int* __restrict__ cstrip, const int2* __restrict__ wpair, const int* __restrict__ wpos,
@@ -752,11 +1044,10 @@ k_border_w(GridParams g, int ntiles, const int* __restrict__ strip_start, const 
     constexpr int WIN = NT + 2 * HC;
     __shared__ int2 lw[WIN];
     __shared__ int2 lx[WIN];                             // (root, first core behind the chain)
-    const int M = strip_start[g.S];
     const int C = lcnt[0];
     const int tile = ltile_of_block(blockIdx.x);
     const int t0 = tile * NT;
-    if (tile >= ntiles || t0 >= M) return;
+    if (tile >= ntiles || t0 >= npos) return;
     const int g0 = t0 >> 6, g1 = (t0 + NT) >> 6;         // (NT is a multiple of 64; the rank arrays reach one group behind the last tile of k_classify)
     const int w0 = wgrank[g0], w1 = wgrank[g1];
     if (w0 == w1) return;
@@ -782,10 +1073,10 @@ k_border_w(GridParams g, int ntiles, const int* __restrict__ strip_start, const 
             int gr[LB_PER][3]; unsigned long long gm[LB_PER][3]; int pp[LB_PER][3];
 #pragma unroll
             for (int e = 0; e < LB_PER; ++e) {
-                const bool hinted = enc[e] < 0 && ((unsigned)enc[e] & K2H_NONE) != K2H_NONE;
+                const bool hinted = (unsigned)enc[e] != LH_NONE;
                 pp[e][0] = pos[e];
-                pp[e][1] = hinted ? pos[e] - (int)((unsigned)enc[e] & K2H_MASK) : pos[e];
-                pp[e][2] = hinted ? pos[e] + (int)(((unsigned)enc[e] >> K2H_BITS) & K2H_MASK) : pos[e];
+                pp[e][1] = hinted ? pos[e] - (int)((unsigned)enc[e] & 0xffffu) : pos[e];
+                pp[e][2] = hinted ? pos[e] + (int)((unsigned)enc[e] >> 16) : pos[e];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { gr[e][k] = cgrank[pp[e][k] >> 6]; gm[e][k] = cmask[pp[e][k] >> 6]; }
             }
@@ -794,7 +1085,7 @@ k_border_w(GridParams g, int ntiles, const int* __restrict__ strip_start, const 
                 c1[e] = gr[e][0] + __popcll(gm[e][0] & low_mask(pp[e][0] & 63));
                 ca[e] = gr[e][1] + __popcll(gm[e][1] & low_mask(pp[e][1] & 63));
                 cb[e] = gr[e][2] + __popcll(gm[e][2] & low_mask(pp[e][2] & 63));
-                const bool hinted = enc[e] < 0 && ((unsigned)enc[e] & K2H_NONE) != K2H_NONE;
+                const bool hinted = (unsigned)enc[e] != LH_NONE;
                 if (act[e] && !hinted) {
                     // no hints (minPts outside 2..128, pile-ups, hints that left their fields): the cores-only strip table
                     const int s = me[e].y >> g.rbits, qlo = me[e].x - g.eps;
@@ -986,9 +1277,9 @@ k_emit_records_w(GridParams g, const int* __restrict__ lcnt, const unsigned long
             const int plo = me.y - g.peps, phi = me.y + g.peps;
             const int c1 = core_rank(cmask, cgrank, pos);
             int ca, cb;
-            if (enc < 0 && ((unsigned)enc & K2H_NONE) != K2H_NONE) {
-                ca = core_rank(cmask, cgrank, pos - (int)((unsigned)enc & K2H_MASK));
-                cb = core_rank(cmask, cgrank, pos + (int)(((unsigned)enc >> K2H_BITS) & K2H_MASK));
+            if ((unsigned)enc != LH_NONE) {
+                ca = core_rank(cmask, cgrank, pos - (int)((unsigned)enc & 0xffffu));
+                cb = core_rank(cmask, cgrank, pos + (int)((unsigned)enc >> 16));
             } else {
                 const int s = me.y >> g.rbits;
                 ca = s > 0 ? lower_bound_pairs(cpair, cstrip[s - 1], cstrip[s], qlo) : C;
@@ -1115,13 +1406,14 @@ static int list_bufs(cl_chrom* c, const GridParams& g, int nm, ListBufs* b)
     const size_t nblk_cap = n / LT + 4;
     int rc;
     if ((rc = c->l_mask.ensure(3 * ngrp_cap * 8)) || (rc = c->l_rank.ensure(4 * ngrp_cap * 4)) ||
-        (rc = c->l_blk.ensure((2 * (nblk_cap + 1) + 2 * (nblk_cap / 64 + 2) + 16) * 4)) || (rc = c->l_cstrip.ensure(((size_t)g.S + 4) * 4)) ||
-        (rc = c->l_wpos.ensure(n * 4)) || (rc = c->l_wenc.ensure(n * 4)) || (rc = c->l_dist.ensure(n * 4))) return rc;
+        (rc = c->l_blk.ensure((2 * (nblk_cap + 1) + 2 * (nblk_cap / 16 + 4) + 16) * 4)) || (rc = c->l_cstrip.ensure(((size_t)g.S + 4) * 4)) ||
+        (rc = c->l_wpos.ensure(n * 4)) || (rc = c->l_wenc.ensure(n * 4)) || (rc = c->l_dist.ensure(n * 4)) ||
+        (c->traversal < 3 && (rc = c->l_aux.ensure(n * 4)))) return rc;
     b->cmask = c->l_mask.as<unsigned long long>(); b->wmask = b->cmask + ngrp_cap; b->hmask = b->wmask + ngrp_cap;
     b->cgloc = c->l_rank.as<int>(); b->wgloc = b->cgloc + ngrp_cap; b->cgrank = b->wgloc + ngrp_cap; b->wgrank = b->cgrank + ngrp_cap;
     // l_blk: {C, W} | superblock sums (both halves; zero between runs: k_chain_c puts them back) | the tiles' sums
     const int nblk = nblocks(nm, LT);
-    const size_t nsup_cap = nblk_cap / 64 + 2;
+    const size_t nsup_cap = nblk_cap / 16 + 4;          // (level 3: two int halves of 64-tile superblocks; level 4: one 64-bit word per 16 tiles)
     if (c->l_blk.fresh) {
         HIP_TRY(hipMemsetAsync(c->l_blk.p, 0, c->l_blk.bytes, c->stream));
         c->l_blk.fresh = false;
@@ -1173,7 +1465,68 @@ int lists_build(cl_chrom* c, const GridParams& g, int nm, ListRun* out)
     // chains (the core count is only known on the device: the grids are sized by the PETs of the run)
     hipLaunchKernelGGL(k_chain_c, dim3(nblocks(nm, 256 * CH_PER)), dim3(256), 0, c->stream, g, L.lcnt, (const int2*)L.cpair, c->chainflag.as<int>(),
                        c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
-                       c->lo.as<int>(), (const int*)c->w_strip, L.cmask, L.cgrank, L.cstrip, b.sup, b.nsup2);
+                       c->lo.as<int>(), (const int*)c->w_strip, L.cmask, L.cgrank, L.cstrip, b.sup, b.nsup2, (int*)nullptr);
+    L.npos = nm; L.pstrip = c->w_strip;
+    *out = L;
+    HIP_TRY(hipGetLastError());
+    c->l_sup_dirty = false;
+    return CL_OK;
+}
+
+int lists_base_keys(cl_chrom* c, const GridParams& g)
+{
+    const int n = (int)c->n;
+    int rc = c->bkey.ensure((size_t)n * 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_base_keys, dim3(nblocks(n, LT)), dim3(256), 0, c->stream, g, n, (const int*)(c->bq.as<int>() + SORT_PAD),
+                       (const int*)(c->bsp.as<int>() + SORT_PAD), (const u32*)c->brow.as<u32>(), c->bkey.as<int>());
+    HIP_TRY(hipGetLastError());
+    return CL_OK;
+}
+
+int lists_build_base(cl_chrom* c, const GridParams& g, int nm, ListRun* out)
+{
+    const int n = (int)c->n;
+    ListBufs b;
+    int rc = list_bufs(c, g, n, &b);
+    if (rc) return rc;
+    const int nblk = nblocks(n, LT);
+    const bool v2 = g.variant == CL_VARIANT_CDBSCAN2;
+    ListRun L{};
+    list_views(c, b, &L);
+    L.npos = n; L.pstrip = c->bstrip.as<int>();
+    unsigned long long* sup64 = (unsigned long long*)b.sup;
+    const int nsup_ints = 2 * (nblk / 16 + 2);
+    if (c->l_sup_dirty) HIP_TRY(hipMemsetAsync(b.sup, 0, (size_t)std::max(nsup_ints, b.nsup2) * 4, c->stream));
+    c->l_sup_dirty = true;
+    const int* bq = c->bq.as<int>() + SORT_PAD;
+    const int* bsp = c->bsp.as<int>() + SORT_PAD;
+    const u32* brow = c->brow.as<u32>();
+    c->srow = c->brow.as<u32>();                         // positions are base positions: their input rows
+    int* pw = c->l_dist.as<int>();                      // (free until the labels)
+    // the cut's per-strip tables (k_cut_strips): sel_tmp = sloc | src0 | bsum | sboffs
+    const int nblk_s = nblocks(g.S + 1, 256);
+    const int* sloc = c->sel_tmp.as<int>();
+    const int* sboffs = sloc + 2 * (g.S + 2) + nblk_s + 2;
+    const int* words = c->ws.rc;                         // the words the run reads (the handle's cache)
+    if (c->l4_cut) {
+        hipLaunchKernelGGL(k_classify_b<true>, dim3(nblk), dim3(256), 0, c->stream, g, n, bsp, (const int4*)c->l_tab.as<int4>(), sloc, sboffs, words,
+                           (const int*)c->rc_poff.as<int>(), (const int*)c->rc_pre.as<int>(), c->l4_band ? (const int*)c->cnt.as<int>() : (const int*)nullptr,
+                           b.cmask, b.wmask, b.cgloc, b.wgloc, b.bsum, sup64, pw);
+    } else {
+        hipLaunchKernelGGL(k_classify_b<false>, dim3(nblk), dim3(256), 0, c->stream, g, n, bsp, (const int4*)nullptr, (const int*)nullptr, (const int*)nullptr, words,
+                           (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, b.cmask, b.wmask, b.cgloc, b.wgloc, b.bsum, sup64, pw);
+    }
+#define LMB_ARGS g, n, bq, bsp, brow, (const int*)c->bkey.as<int>(), (const int2*)c->l_fix.as<int2>(), (const unsigned long long*)b.cmask, (const unsigned long long*)b.wmask,   \
+                 (const int*)b.cgloc, (const int*)b.wgloc, (const int*)b.bsum, (const unsigned long long*)sup64, (const int*)pw, b.cgrank, b.wgrank, L.cpair, L.cpos, L.ckey,      \
+                 L.wpair, L.wpos, L.wenc, b.lcnt
+    if (v2 && c->l4_cut) hipLaunchKernelGGL((k_make_lists_b<true, true>), dim3(nblk), dim3(256), 0, c->stream, LMB_ARGS);
+    else if (v2) hipLaunchKernelGGL((k_make_lists_b<true, false>), dim3(nblk), dim3(256), 0, c->stream, LMB_ARGS);
+    else hipLaunchKernelGGL((k_make_lists_b<false, false>), dim3(nblk), dim3(256), 0, c->stream, LMB_ARGS);
+#undef LMB_ARGS
+    hipLaunchKernelGGL(k_chain_c, dim3(nblocks(nm, 256 * CH_PER)), dim3(256), 0, c->stream, g, L.lcnt, (const int2*)L.cpair, c->chainflag.as<int>(),
+                       c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
+                       c->lo.as<int>(), L.pstrip, L.cmask, L.cgrank, L.cstrip, b.sup, std::max(nsup_ints, b.nsup2), v2 ? L.ckey : (int*)nullptr);
     *out = L;
     HIP_TRY(hipGetLastError());
     c->l_sup_dirty = false;
@@ -1181,7 +1534,7 @@ int lists_build(cl_chrom* c, const GridParams& g, int nm, ListRun* out)
 }
 
 // croot: c->root (levels >= 2) or, while the tile kernels still read roots by position (level 1), the distance-list buffer
-static int* croot_of(cl_chrom* c) { return c->traversal >= 2 ? c->root.as<int>() : c->l_dist.as<int>(); }
+static int* croot_of(cl_chrom* c) { return c->run_level >= 2 ? c->root.as<int>() : c->l_aux.as<int>(); }
 
 int lists_union_flatten(cl_chrom* c, const GridParams& g, int nm, const ListRun& L)
 {
@@ -1211,8 +1564,9 @@ int lists_scatter_root(cl_chrom* c, int nm, const ListRun& L)
 int lists_border(cl_chrom* c, const GridParams& g, int nm, const ListRun& L)
 {
     constexpr int BNT = 2048, BHC = 256;
-    const int nt = nblocks(nm, BNT);
-#define LB_ARGS g, nt, (const int*)c->w_strip, L.lcnt, L.cmask, L.cgrank, L.wgrank, (const int2*)L.cpair, (const int*)croot_of(c), (const int*)c->cellfirst.as<int>(),    \
+    const int nt = nblocks(L.npos, BNT);
+    (void)nm;
+#define LB_ARGS g, nt, L.npos, L.lcnt, L.cmask, L.cgrank, L.wgrank, (const int2*)L.cpair, (const int*)croot_of(c), (const int*)c->cellfirst.as<int>(),    \
                 (const int*)L.ckey, (const int*)L.cstrip, (const int2*)L.wpair, (const int*)L.wpos, (const int*)L.wenc, (const int*)c->compkey.as<int>(),                    \
                 (const int*)c->ncore.as<int>(), c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->chainflag.as<int>() /* clist: the chain ids are dead */,  \
                 c->counters.as<int>()
@@ -1237,7 +1591,7 @@ int lists_emit_records(cl_chrom* c, const GridParams& g, int nm, const ListRun& 
 // level 2: the tile kernel k_final_labels reads owners by position
 int lists_scatter_owner(cl_chrom* c, int nm, const ListRun& L)
 {
-    int* opos = c->l_dist.as<int>();
+    int* opos = c->l_aux.as<int>();
     HIP_TRY(hipMemsetAsync(opos, 0xFF, (size_t)nm * 4, c->stream));
     LAUNCH(k_scatter_by_pos, nm, L.lcnt, (const int*)L.cpos, (const int*)croot_of(c), opos);
     LAUNCH(k_scatter_by_pos, nm, L.lcnt + 1, (const int*)L.wpos, (const int*)c->owner.as<int>(), opos);

@@ -16,7 +16,7 @@ for variant in ("v2", "v1"):
         keep = (Y.astype(np.int64) - X >= cut)
         want = np.full(n, -1, np.int32)
         want[keep] = oracle.labels(variant, X[keep], Y[keep], eps, m)
-        for level in (0, 1, 2, 3):
+        for level in (0, 1, 2, 3, 4):
             ch = api.Chromosome(X, Y)
             ch.set_traversal(level)
             t0 = time.time()
