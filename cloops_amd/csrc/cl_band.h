@@ -23,7 +23,9 @@
 #define KB_CAP 512
 
 // the band PETs of one wave's strips, 64 per round.  LDSP: the strip prefixes are staged in lw (else: global memory, base layout)
-template <bool LDSP>
+// BASEOUT: the words go to the PETs' BASE positions with their hints counted in base positions (traversal level 4: the count
+// cache lives in base-position space, k_lists.hip); else to their places in the run's layout (new strip start + offset)
+template <bool LDSP, bool BASEOUT = false>
 __device__ __forceinline__ void band_rounds(int eps, int peps, int minPts, const int2* lw, const int* __restrict__ bq, const int* __restrict__ bsp,
                                             int* __restrict__ cnt, int lane, int nband, int maxlen,
                                             int ssrc /* base index of the strip's first kept PET */, int sg0 /* its place in the new layout */,
@@ -49,8 +51,9 @@ __device__ __forceinline__ void band_rounds(int eps, int peps, int minPts, const
         const int b0 = LDSP ? __shfl(soff, k) : __shfl(ssrc, k);          // segment bases in the space that is read
         const int ba = LDSP ? __shfl(soff, k - 1) : __shfl(ssrc, k - 1);
         const int bb = LDSP ? __shfl(soff, k + 1) : __shfl(ssrc, k + 1);
+        const int o0 = BASEOUT ? __shfl(ssrc, k) : g0, oa = BASEOUT ? __shfl(ssrc, k - 1) : ga, ob = BASEOUT ? __shfl(ssrc, k + 1) : gb;      // ... in the space that is written
         const int na = act ? lena : 0, nb = act ? lenb : 0, n0 = act ? len : 0;
-        const int ig = g0 + idx;
+        const int ig = o0 + idx;
         auto qat = [&](int pos) { return LDSP ? lw[pos].x : bq[pos]; };
         auto pat = [&](int pos) { return LDSP ? lw[pos].y : bsp[pos]; };
         const int qi = act ? qat(b0 + idx) : 0, pi = act ? pat(b0 + idx) : 0;
@@ -93,7 +96,7 @@ __device__ __forceinline__ void band_rounds(int eps, int peps, int minPts, const
         if (act) {
             int outv = minPts;
             if (c < minPts) {
-                const int da = ig - (ga + ja), db = (gb + jb) - ig;
+                const int da = ig - (oa + ja), db = (ob + jb) - ig;
                 const bool ok = (da >= 0) & (da < (int)K2H_MASK) & (db >= 0) & (db < (int)K2H_MASK);
                 outv = (int)(0x80000000u | ((unsigned)c << K2W_CSHIFT) | (ok ? ((unsigned)da | ((unsigned)db << K2H_BITS)) : K2H_NONE));
             }
@@ -103,6 +106,7 @@ __device__ __forceinline__ void band_rounds(int eps, int peps, int minPts, const
 }
 
 // one wave: the strips [group * KB_SB, group * KB_SB + KB_SB).  lw: KB_CAP pairs of LDS owned by this wave.
+template <bool BASEOUT = false>
 __device__ __forceinline__ void band_wave(int group, int lane, int2* lw, int S, int eps, int peps, int minPts,
                                           const int* __restrict__ bq, const int* __restrict__ bsp, const int* __restrict__ src0,
                                           const int* __restrict__ sloc, const int* __restrict__ sboffs /* the new strip table in its two-level form: k_cut_strips */,
@@ -132,7 +136,7 @@ __device__ __forceinline__ void band_wave(int group, int lane, int2* lw, int S, 
     maxlen = __shfl(maxlen, KB_SB + 1);
     if (nband == 0) return;
     if (total > KB_CAP) {                               // pile-ups: everything from global memory
-        band_rounds<false>(eps, peps, minPts, lw, bq, bsp, cnt, lane, nband, maxlen, ssrc, sg0, slen, soff, sboff, dbg);
+        band_rounds<false, BASEOUT>(eps, peps, minPts, lw, bq, bsp, cnt, lane, nband, maxlen, ssrc, sg0, slen, soff, sboff, dbg);
         return;
     }
     {
@@ -164,5 +168,5 @@ __device__ __forceinline__ void band_wave(int group, int lane, int2* lw, int S, 
     __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): the wave's own LDS writes are done
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    band_rounds<true>(eps, peps, minPts, lw, bq, bsp, cnt, lane, nband, maxlen, ssrc, sg0, slen, soff, sboff, dbg);
+    band_rounds<true, BASEOUT>(eps, peps, minPts, lw, bq, bsp, cnt, lane, nband, maxlen, ssrc, sg0, slen, soff, sboff, dbg);
 }

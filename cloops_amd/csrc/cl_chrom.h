@@ -106,7 +106,7 @@ struct cl_chrom {
     // only if q - eps < max(the two cuts): every later run with a minPts of the set takes the words of the PETs beyond that
     // band as they are (k_cut_copy<true> carries them through its compaction) and runs K2 on the band alone.  Results are
     // identical with the cache switched off (cl_set_count_reuse); cLoops/pipe.py:247-250 walks minPts inside eps, descending.
-    struct CountCache { bool valid = false; int layout = -1, eps = 0, thr = 0 /* q threshold of the run's cut, 0 = none */, cap = 0; u32 tmask[4] = {0, 0, 0, 0} /* the minPts values the words serve, bit t - 1 */; } rc;
+    struct CountCache { bool valid = false; bool base_space = false /* level 4: words by base position, hints in base positions (k_lists.hip) */; int layout = -1, eps = 0, thr = 0 /* q threshold of the run's cut, 0 = none */, cap = 0; u32 tmask[4] = {0, 0, 0, 0} /* the minPts values the words serve, bit t - 1 */; } rc;
     DevBuf rc_cnt, rc_pre, rc_poff, rc_dpre, rc_D, rc_blen;   // the words in the sorted order of the run that made them; per strip: PETs its cut removed
                                       // from the strip / from all strips up to and including it
     bool reuse_counts = true;         // cl_set_count_reuse
@@ -130,6 +130,7 @@ struct cl_chrom {
     bool bkey_valid = false;          // bkey belongs to the current base layout
     int run_level = 0;                // traversal level of the run being enqueued (run_sort_and_count decides: level 4 needs the count cache's tables)
     const int* w_dM = nullptr;        // device: PETs that entered DBSCAN in the run being enqueued
+    bool run_rows = true;             // the run being enqueued produces row-aligned labels
     bool l4_cut = false;              // level 4: the run has a cut (the per-strip tables of k_cut_strips apply)
     bool l4_band = false;             // ... and re-uses counts under another cut (the band's words are fresh: c->cnt, by run position)
     bool l_sup_dirty = false;         // k_classify's superblock sums may be non-zero (a run that failed between k_classify and k_chain_c)
@@ -253,7 +254,8 @@ struct ListRun {                                        // device views of the r
 };
 int lists_build(cl_chrom* c, const GridParams& g, int nm, ListRun* out);
 int lists_build_base(cl_chrom* c, const GridParams& g, int nm, ListRun* out);      // level 4: from the base layout + the cut's per-strip tables
-int lists_base_keys(cl_chrom* c, const GridParams& g);                             // variant 2: cell minima of the base layout (once per eps)
+int lists_base_keys(cl_chrom* c, const GridParams& g);
+int lists_words_to_base(cl_chrom* c, const GridParams& g);                         // level 4, first run of an eps under a cut: its words to base positions                             // variant 2: cell minima of the base layout (once per eps)
 int lists_union_flatten(cl_chrom* c, const GridParams& g, int nm, const ListRun& L);
 int lists_scatter_root(cl_chrom* c, int nm, const ListRun& L);
 int lists_border(cl_chrom* c, const GridParams& g, int nm, const ListRun& L);

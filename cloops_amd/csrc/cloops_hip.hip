@@ -1985,7 +1985,7 @@ extern "C" int64_t cl_chrom_size(const cl_chrom* c) { return c ? c->n : -1; }
 extern "C" void cl_set_profiling(cl_chrom* c, int enabled) { if (c) c->profiling = enabled != 0; }
 extern "C" void cl_set_layout_reuse(cl_chrom* c, int enabled) { if (c) { c->reuse_layout = enabled != 0; c->base.valid = false; c->rc.valid = false; } }
 extern "C" void cl_set_count_reuse(cl_chrom* c, int enabled) { if (c) { c->reuse_counts = enabled != 0; c->rc.valid = false; } }
-extern "C" void cl_set_traversal(cl_chrom* c, int level) { if (c) c->traversal = level < 0 ? 0 : (level > 4 ? 4 : level); }
+extern "C" void cl_set_traversal(cl_chrom* c, int level) { if (c) { c->traversal = level < 0 ? 0 : (level > 4 ? 4 : level); c->rc.valid = false; } }
 extern "C" int cl_last_region_mode(const cl_chrom* c) { return c ? c->last_k2_mode : 0; }
 extern "C" void cl_set_count_floor(cl_chrom* c, int32_t min_pts)
 {
@@ -2368,7 +2368,7 @@ k_band(int S, int rbits, int eps, int minPts, const int* __restrict__ bq, const 
         d_M[0] = M;
         if (expect_m >= 0 && expect_m != M) counters[CTR_OVERFLOW] = 8;      // the host sized the run by a wrong M: fail loudly
     }
-    band_wave(blockIdx.x * (CMP_TPB / 64) + wv, threadIdx.x & 63, l_band[wv], S, eps, 1 << rbits, minPts, bq, bsp, src0, sloc, sboffs, blen, band_words, dbg);
+    band_wave<true>(blockIdx.x * (CMP_TPB / 64) + wv, threadIdx.x & 63, l_band[wv], S, eps, 1 << rbits, minPts, bq, bsp, src0, sloc, sboffs, blen, band_words, dbg);
 }
 __global__ void k_store_m(int S, const int* __restrict__ sloc, const int* __restrict__ sboffs, int* __restrict__ d_M, int expect_m, int* __restrict__ counters)
 {
@@ -2707,9 +2707,12 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
         const bool cacheable = !exact && c->reuse_counts && g.swap && m1 >= 1 && m1 <= 127;
         const int thr_new = on_base ? 0 : g.cut - g.V0;   // q >= 0 everywhere: threshold 0 removes nothing
         enum { RC_NONE, RC_MAKE, RC_SAME, RC_REMAP } rcmode = RC_NONE;
+        // traversal level 4 (lists from the base layout, count cache in base-position space) needs the cache: a run it does not take
+        // (exact counts, minPts outside 2 .. 128, cache switched off) works on a copy of the layout as before
+        const bool want4 = c->traversal >= 4 && cacheable;
         if (cacheable) {
             const bool serves = c->rc.valid && c->rc.layout == layout && c->rc.eps == g.eps && g.minPts <= c->rc.cap &&
-                                ((c->rc.tmask[m1 >> 5] >> (m1 & 31)) & 1u);
+                                ((c->rc.tmask[m1 >> 5] >> (m1 & 31)) & 1u) && c->rc.base_space == want4;
             if (serves && thr_new == c->rc.thr) rcmode = RC_SAME;
             else if (serves && !on_base && (long long)g.S <= 8LL * n) rcmode = RC_REMAP;      // (the band kernel works strip by strip)
             else rcmode = RC_MAKE;
@@ -2717,16 +2720,14 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
                 (rc = c->rc_poff.ensure(((size_t)g.S + 2) * 4)) || (rc = c->rc_dpre.ensure(((size_t)g.S + 2) * 4)) ||
                 (rc = c->rc_D.ensure(((size_t)g.S + 2) * 4)) || (rc = c->rc_blen.ensure(((size_t)g.S + 2) * 8))) return rc;
         }
-        // traversal level 4 (lists from the base layout) needs the count cache's per-strip tables: a run the cache does not take
-        // (exact counts, minPts outside 2 .. 128, cache switched off) works on a copy of the layout as before
-        c->run_level = (c->traversal >= 4 && rcmode != RC_NONE && g.variant != CL_VARIANT_BLOCK) ? 4 : std::min(c->traversal, 3);
+        c->run_level = want4 ? 4 : std::min(c->traversal, 3);
         if (exact) c->run_level = 0;
         if (c->run_level == 4 && g.variant == CL_VARIANT_CDBSCAN2 && !c->bkey_valid) {
             if ((rc = lists_base_keys(c, g))) return rc;
             c->bkey_valid = true;
         }
         if (rcmode == RC_MAKE) {
-            c->rc.valid = true; c->rc.layout = layout; c->rc.eps = g.eps; c->rc.thr = thr_new; c->rc.cap = g.minPts;
+            c->rc.valid = true; c->rc.layout = layout; c->rc.eps = g.eps; c->rc.thr = thr_new; c->rc.cap = g.minPts; c->rc.base_space = want4;
             // the minPts values these words will be asked about: the announced ones up to this run's (cl_set_count_thresholds), or
             // everything from the announced floor up (cl_set_count_floor), and this run's own
             for (int k = 0; k < 4; ++k) c->rc.tmask[k] = 0;
@@ -2740,6 +2741,9 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
             for (int t = 2, prev = 1; t <= g.minPts; ++t)
                 if ((c->rc.tmask[(t - 1) >> 5] >> ((t - 1) & 31)) & 1u) { gk.tgap = std::max(gk.tgap, t - prev); prev = t; }
             c->w_cnt = c->rc_cnt.as<int>();
+            // (level 4 under a cut: K2 queries the compact copy into the work buffer, lists_words_to_base moves the words to their
+            //  base positions in the cache)
+            if (want4 && !on_base) c->w_cnt = c->cnt.as<int>();
             c->ws.rc = c->w_cnt;
             if (on_base) {
                 HIP_TRY(hipMemsetAsync(c->rc_pre.p, 0, ((size_t)g.S + 2) * 4, c->stream));
@@ -2818,6 +2822,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     rc = CL_OK;
     if (!k2_skip && !k2_band && !SKIP(256)) rc = cl_launch_region(c->stream, gk, n, c->run_m, exact, c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->w_cnt);
     if (rc) return rc;
+    if (c->run_level == 4 && c->l4_cut && !k2_skip && !k2_band && (rc = lists_words_to_base(c, g))) return rc;
     ev_record(c, 3);
     HIP_TRY(hipGetLastError());
     return CL_OK;
@@ -3268,6 +3273,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     // 2 = + the border rule on the walker list, 3 = + labels / table / distance list from the lists (only labelled PETs are
     // written: the row-aligned array is filled with -1 first)
     if (rows && (cut > 0 || (wide == 0 && c->traversal >= 3))) HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
+    c->run_rows = rows;
     const int trav_saved = c->traversal;
     if (wide != 0) c->traversal = 0;                    // (developer tile shapes: the tile kernels)
     rc = run_sort_and_count(c, g, false);

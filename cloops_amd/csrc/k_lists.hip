@@ -483,78 +483,60 @@ k_base_keys(GridParams g, int npos, const int* __restrict__ bq, const int* __res
     }
 }
 
+// The count cache of a level-4 handle lives in BASE-POSITION space: words[b] = the K2 word of base position b with its two hint
+// fields counted in base positions.  A run on the base layout itself (no cut) gets that from K2 as it is; the first run of an eps
+// under a cut queries a compact copy of the layout (k_cut_copy + k_region_core, as before) and k_words_to_base moves its words to
+// their base positions, adding to the hints what the cut removed from the strips in between (pre[s] behind the PET's own
+// strip start, pre[s + 1] in front of the strip above).  Every later run of the eps then needs NO per-strip table: a PET is kept
+// iff q >= its threshold, has a fresh word (k_band) iff q < bandq, and the cached one otherwise.
+__global__ void __launch_bounds__(256)
+k_words_to_base(GridParams g, int npos, const int* __restrict__ bsp, const int4* __restrict__ tab, const int* __restrict__ poff,
+                const int* __restrict__ run_words, int* __restrict__ words)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= npos) return;
+    const int st = min(bsp[b] >> g.rbits, g.S);
+    const int4 t = tab[st];
+    if (b < t.x) return;                                  // removed by the cut
+    int w = run_words[b - poff[st]];
+    if (w < 0 && ((unsigned)w & K2H_NONE) != K2H_NONE) {
+        const int da = (int)((unsigned)w & K2H_MASK) + t.z, db = (int)(((unsigned)w >> K2H_BITS) & K2H_MASK) + tab[min(st + 1, g.S)].z;
+        const bool ok = (da < (int)K2H_MASK) & (db < (int)K2H_MASK);
+        w = (int)(((unsigned)w & ~K2H_NONE) | (ok ? ((unsigned)da | ((unsigned)db << K2H_BITS)) : K2H_NONE));
+    }
+    words[b] = w;
+}
+
 // classify: one bit per base position "core" / "walker" (removed PETs: neither), their counts per 64-position group exclusive
 // inside the tile, the tile's totals (a plain store) and the totals of its 16-tile superblock (ONE atomic nobody waits for:
-// cores in the low, walkers in the high half); pw[b] = a walker's window hints in base positions (lh_pack).
-template <bool CUT>
+// cores in the low, walkers in the high half).
+template <bool CUT, bool BAND>
 __global__ void __launch_bounds__(256)
-k_classify_b(GridParams g, int npos, const int* __restrict__ bsp, const int4* __restrict__ tab, const int* __restrict__ sloc,
-             const int* __restrict__ sboffs, const int* __restrict__ words, const int* __restrict__ woff /* or null */,
-             const int* __restrict__ wpre /* or null */, const int* __restrict__ band /* or null */,
-             unsigned long long* __restrict__ cmask, unsigned long long* __restrict__ wmask, int* __restrict__ cgloc,
-             int* __restrict__ wgloc, int* __restrict__ bsum, unsigned long long* __restrict__ sup, int* __restrict__ pw)
+k_classify_q(GridParams g, int npos, int thr, int bandq, const int* __restrict__ bq, const int* __restrict__ words,
+             const int* __restrict__ band, unsigned long long* __restrict__ cmask, unsigned long long* __restrict__ wmask,
+             int* __restrict__ cgloc, int* __restrict__ wgloc, int* __restrict__ bsum, unsigned long long* __restrict__ sup)
 {
     __shared__ int l_cc[LG], l_wc[LG];
     const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
     const int t0 = blk * LT;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int sp[8], w[8], sh[8];
-    int4 tb[8];
-    bool alive[8], inb[8];
+    int q[8], w[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { const int b = t0 + u * 256 + (int)threadIdx.x; sp[u] = b < npos ? bsp[b] : 0; }
-    {
-        // the word of a kept PET: a fresh one for the PETs of the cut band (by their place in the run's virtual layout: new strip
-        // start + offset), else the word of the layout the words were made on -- base position minus what THAT cut removed in front
-        const int* src[8]; int idx[8];
+    for (int u = 0; u < 8; ++u) { const int b = t0 + u * 256 + (int)threadIdx.x; q[u] = (CUT && b < npos) ? bq[b] : INT_MAX; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int b = t0 + u * 256 + (int)threadIdx.x;
-            const int st = min(sp[u] >> g.rbits, g.S);
-            alive[u] = b < npos; inb[u] = false;
-            tb[u] = make_int4(0, 0, 0, 0);
-            if (CUT && alive[u]) { tb[u] = tab[st]; alive[u] = b >= tb[u].x; inb[u] = band != nullptr && alive[u] && b < tb[u].y; }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int b = t0 + u * 256 + (int)threadIdx.x;
-            const int st = min(sp[u] >> g.rbits, g.S);
-            src[u] = words; idx[u] = 0; sh[u] = 0;
-            if (alive[u]) {
-                if (inb[u]) { src[u] = band; idx[u] = sloc[st] + sboffs[st >> 8] + (b - tb[u].x); }
-                else idx[u] = b - (woff ? woff[st] : 0);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = alive[u] ? src[u][idx[u]] : 0;
+    for (int u = 0; u < 8; ++u) {
+        const int b = t0 + u * 256 + (int)threadIdx.x;
+        const bool alive = b < npos && (!CUT || q[u] >= thr);
+        const int* src = (BAND && q[u] < bandq) ? band : words;
+        w[u] = alive ? src[b] : 0;                        // (word 0: neither core nor walker)
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const bool core = alive[u] && cw_core(w[u], g.minPts);
-        const bool walk = alive[u] && !core && cw_count(w[u]) > 1;      // (count <= 1: nothing within eps -- most of the background noise ends here)
+        const bool core = cw_core(w[u], g.minPts) && w[u] != 0;
+        const bool walk = !core && cw_count(w[u]) > 1;      // (count <= 1: nothing within eps -- most of the background noise ends here)
         const unsigned long long cb = __ballot(core), wb = __ballot(walk);
         const int k = u * 4 + wv, gidx = (t0 >> 6) + k;
         if (lane == 0) { cmask[gidx] = cb; wmask[gidx] = wb; l_cc[k] = __popcll(cb); l_wc[k] = __popcll(wb); }
-        sh[u] = walk ? 1 : 0;
-    }
-    {
-        // walkers: the hints of their word as distances in base positions: + what the cut of the words' layout (band: this run's
-        // cut) removed from the own strip (backwards) / from the strip above (forwards)
-        int sa_[8], sb_[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int st = min(sp[u] >> g.rbits, g.S);
-            sa_[u] = 0; sb_[u] = 0;
-            if (CUT && sh[u]) {
-                if (inb[u]) { sa_[u] = tb[u].z; sb_[u] = tab[min(st + 1, g.S)].z; }
-                else if (wpre) { sa_[u] = wpre[st]; sb_[u] = wpre[min(st + 1, g.S)]; }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int b = t0 + u * 256 + (int)threadIdx.x;
-            if (sh[u]) pw[b] = (int)lh_pack(w[u], sa_[u], sb_[u]);
-        }
     }
     if (blk == nblk - 1 && threadIdx.x == 0) {
         const int ge = nblk * LG;                        // one group behind the last tile: position npos may be its first
@@ -577,12 +559,12 @@ k_classify_b(GridParams g, int npos, const int* __restrict__ bsp, const int4* __
     }
 }
 
-template <bool V2, bool CUT>
+template <bool V2, bool CUT, bool BAND>
 __global__ void __launch_bounds__(256)
-k_make_lists_b(GridParams g, int npos, const int* __restrict__ bq, const int* __restrict__ bsp, const u32* __restrict__ brow,
-               const int* __restrict__ bkey, const int2* __restrict__ fix, const unsigned long long* __restrict__ cmask,
-               const unsigned long long* __restrict__ wmask, const int* __restrict__ cgloc, const int* __restrict__ wgloc,
-               const int* __restrict__ bsum, const unsigned long long* __restrict__ sup, const int* __restrict__ pw,
+k_make_lists_q(GridParams g, int npos, int bandq, const int* __restrict__ bq, const int* __restrict__ bsp, const u32* __restrict__ brow,
+               const int* __restrict__ bkey, const int2* __restrict__ fix, const int* __restrict__ words, const int* __restrict__ band,
+               const unsigned long long* __restrict__ cmask, const unsigned long long* __restrict__ wmask, const int* __restrict__ cgloc,
+               const int* __restrict__ wgloc, const int* __restrict__ bsum, const unsigned long long* __restrict__ sup,
                int* __restrict__ cgrank, int* __restrict__ wgrank, int2* __restrict__ cpair, int* __restrict__ cpos,
                int* __restrict__ ckey, int2* __restrict__ wpair, int* __restrict__ wpos, int* __restrict__ wenc, int* __restrict__ lcnt)
 {
@@ -630,19 +612,33 @@ k_make_lists_b(GridParams g, int npos, const int* __restrict__ bq, const int* __
     }
     {
         // a core's key: variant 1 its input row (the component's start point is its smallest-row core, cDBSCAN.py:134-137);
-        // variant 2 the minimum of its rotated cell (bkey; the cell the cut goes through: fix).  A walker's hints: pw.
+        // variant 2 the minimum of its rotated cell (bkey; the cell the cut goes through: fix).  A walker's window hints: its word.
         int2 fx[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int b = t0 + u * 256 + (int)threadIdx.x;
             const bool isc = (cbv[u] >> lane) & 1ull, isw = (wbv[u] >> lane) & 1ull;
-            aux[u] = isw ? pw[b] : (isc ? (V2 ? bkey[b] : (int)brow[b]) : 0);
+            const int* wsrc = (BAND && q[u] < bandq) ? band : words;
+            aux[u] = isw ? wsrc[b] : (isc ? (V2 ? bkey[b] : (int)brow[b]) : 0);
             fx[u] = make_int2(INT_MIN, 0);
-            if (V2 && CUT && isc) fx[u] = fix[sp[u] >> g.rbits];
+            if (V2 && CUT) {
+                // (the rows of the wave's first and last strip are wave-uniform loads; a strip holds tens to hundreds of PETs)
+                const unsigned long long anyb = cbv[u] | wbv[u];
+                const int st = isc ? (sp[u] >> g.rbits) : 0;
+                if (anyb) {
+                    const int s_lo = __builtin_amdgcn_readlane(sp[u], __ffsll((long long)anyb) - 1) >> g.rbits;
+                    const int s_hi = __builtin_amdgcn_readlane(sp[u], 63 - __clzll((long long)anyb)) >> g.rbits;
+                    const int2 fa = fix[s_lo], fz = fix[s_hi];
+                    if (isc) fx[u] = st == s_lo ? fa : (st == s_hi ? fz : fix[st]);
+                }
+            }
         }
-        if (V2 && CUT) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int b = t0 + u * 256 + (int)threadIdx.x; if (b < fx[u].x) aux[u] = fx[u].y; }
+        for (int u = 0; u < 8; ++u) {
+            const int b = t0 + u * 256 + (int)threadIdx.x;
+            const bool isw = (wbv[u] >> lane) & 1ull;
+            if (V2 && CUT && b < fx[u].x) aux[u] = fx[u].y;
+            if (isw) aux[u] = (int)lh_pack(aux[u], 0, 0);
         }
     }
 #pragma unroll
@@ -652,7 +648,8 @@ k_make_lists_b(GridParams g, int npos, const int* __restrict__ bq, const int* __
         const bool isc = (cb >> lane) & 1ull, isw = (wb >> lane) & 1ull;
         if (isc) {
             const int dst = cgv[u] + __popcll(cb & low_mask(lane));
-            cpair[dst] = make_int2(q[u], sp[u]); cpos[dst] = b; ckey[dst] = aux[u];
+            cpair[dst] = make_int2(q[u], sp[u]); ckey[dst] = aux[u];
+            if (cpos) cpos[dst] = b;                     // (only a run with row-aligned labels needs a core's position)
         } else if (isw) {
             const int dst = wgv[u] + __popcll(wb & low_mask(lane));
             wpair[dst] = make_int2(q[u], sp[u]); wpos[dst] = b; wenc[dst] = aux[u];
@@ -1363,8 +1360,8 @@ k_final_lists(GridParams g, const int* __restrict__ lcnt, const int2* __restrict
         idx[ch] = (blockIdx.x * LF_CHUNKS + ch) * BIGTPB + threadIdx.x;
         const int k = idx[ch];
         own[ch] = -1; pos[ch] = 0; pr[ch] = make_int2(0, 0);
-        if (k < C) { own[ch] = croot[k]; pr[ch] = cpair[k]; pos[ch] = cpos[k]; }
-        else if (k < L) { own[ch] = owner_root(wowner[k - C]); pr[ch] = wpair[k - C]; pos[ch] = wpos[k - C]; }
+        if (k < C) { own[ch] = croot[k]; pr[ch] = cpair[k]; pos[ch] = labels ? cpos[k] : 0; }
+        else if (k < L) { own[ch] = owner_root(wowner[k - C]); pr[ch] = wpair[k - C]; pos[ch] = labels ? wpos[k - C] : 0; }
     }
 #pragma unroll
     for (int ch = 0; ch < LF_CHUNKS; ++ch) lab[ch] = own[ch] >= 0 ? rlabel[own[ch]] : -1;
@@ -1503,33 +1500,44 @@ int lists_build_base(cl_chrom* c, const GridParams& g, int nm, ListRun* out)
     const int* bsp = c->bsp.as<int>() + SORT_PAD;
     const u32* brow = c->brow.as<u32>();
     c->srow = c->brow.as<u32>();                         // positions are base positions: their input rows
-    int* pw = c->l_dist.as<int>();                      // (free until the labels)
-    // the cut's per-strip tables (k_cut_strips): sel_tmp = sloc | src0 | bsum | sboffs
-    const int nblk_s = nblocks(g.S + 1, 256);
-    const int* sloc = c->sel_tmp.as<int>();
-    const int* sboffs = sloc + 2 * (g.S + 2) + nblk_s + 2;
-    const int* words = c->ws.rc;                         // the words the run reads (the handle's cache)
-    if (c->l4_cut) {
-        hipLaunchKernelGGL(k_classify_b<true>, dim3(nblk), dim3(256), 0, c->stream, g, n, bsp, (const int4*)c->l_tab.as<int4>(), sloc, sboffs, words,
-                           (const int*)c->rc_poff.as<int>(), (const int*)c->rc_pre.as<int>(), c->l4_band ? (const int*)c->cnt.as<int>() : (const int*)nullptr,
-                           b.cmask, b.wmask, b.cgloc, b.wgloc, b.bsum, sup64, pw);
+    const int* words = c->rc_cnt.as<int>();              // the handle's count cache, base-position space
+    const int* band = c->cnt.as<int>();                  // fresh words of the cut band (k_band), base positions
+    const int thr = c->l4_cut ? g.cut - g.V0 : INT_MIN;
+    const int bandq = c->ws.bandq;
+#define LCQ_ARGS g, n, thr, bandq, bq, words, band, b.cmask, b.wmask, b.cgloc, b.wgloc, b.bsum, sup64
+    if (!c->l4_cut) hipLaunchKernelGGL((k_classify_q<false, false>), dim3(nblk), dim3(256), 0, c->stream, LCQ_ARGS);
+    else if (c->l4_band) hipLaunchKernelGGL((k_classify_q<true, true>), dim3(nblk), dim3(256), 0, c->stream, LCQ_ARGS);
+    else hipLaunchKernelGGL((k_classify_q<true, false>), dim3(nblk), dim3(256), 0, c->stream, LCQ_ARGS);
+#undef LCQ_ARGS
+#define LMQ_ARGS g, n, bandq, bq, bsp, brow, (const int*)c->bkey.as<int>(), (const int2*)c->l_fix.as<int2>(), words, band, (const unsigned long long*)b.cmask,                  \
+                 (const unsigned long long*)b.wmask, (const int*)b.cgloc, (const int*)b.wgloc, (const int*)b.bsum, (const unsigned long long*)sup64, b.cgrank, b.wgrank, L.cpair,  \
+                 c->run_rows ? L.cpos : (int*)nullptr, L.ckey, L.wpair, L.wpos, L.wenc, b.lcnt
+    if (v2) {
+        if (!c->l4_cut) hipLaunchKernelGGL((k_make_lists_q<true, false, false>), dim3(nblk), dim3(256), 0, c->stream, LMQ_ARGS);
+        else if (c->l4_band) hipLaunchKernelGGL((k_make_lists_q<true, true, true>), dim3(nblk), dim3(256), 0, c->stream, LMQ_ARGS);
+        else hipLaunchKernelGGL((k_make_lists_q<true, true, false>), dim3(nblk), dim3(256), 0, c->stream, LMQ_ARGS);
     } else {
-        hipLaunchKernelGGL(k_classify_b<false>, dim3(nblk), dim3(256), 0, c->stream, g, n, bsp, (const int4*)nullptr, (const int*)nullptr, (const int*)nullptr, words,
-                           (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, b.cmask, b.wmask, b.cgloc, b.wgloc, b.bsum, sup64, pw);
+        if (c->l4_band) hipLaunchKernelGGL((k_make_lists_q<false, true, true>), dim3(nblk), dim3(256), 0, c->stream, LMQ_ARGS);
+        else hipLaunchKernelGGL((k_make_lists_q<false, false, false>), dim3(nblk), dim3(256), 0, c->stream, LMQ_ARGS);
     }
-#define LMB_ARGS g, n, bq, bsp, brow, (const int*)c->bkey.as<int>(), (const int2*)c->l_fix.as<int2>(), (const unsigned long long*)b.cmask, (const unsigned long long*)b.wmask,   \
-                 (const int*)b.cgloc, (const int*)b.wgloc, (const int*)b.bsum, (const unsigned long long*)sup64, (const int*)pw, b.cgrank, b.wgrank, L.cpair, L.cpos, L.ckey,      \
-                 L.wpair, L.wpos, L.wenc, b.lcnt
-    if (v2 && c->l4_cut) hipLaunchKernelGGL((k_make_lists_b<true, true>), dim3(nblk), dim3(256), 0, c->stream, LMB_ARGS);
-    else if (v2) hipLaunchKernelGGL((k_make_lists_b<true, false>), dim3(nblk), dim3(256), 0, c->stream, LMB_ARGS);
-    else hipLaunchKernelGGL((k_make_lists_b<false, false>), dim3(nblk), dim3(256), 0, c->stream, LMB_ARGS);
-#undef LMB_ARGS
+#undef LMQ_ARGS
     hipLaunchKernelGGL(k_chain_c, dim3(nblocks(nm, 256 * CH_PER)), dim3(256), 0, c->stream, g, L.lcnt, (const int2*)L.cpair, c->chainflag.as<int>(),
                        c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                        c->lo.as<int>(), L.pstrip, L.cmask, L.cgrank, L.cstrip, b.sup, std::max(nsup_ints, b.nsup2), v2 ? L.ckey : (int*)nullptr);
     *out = L;
     HIP_TRY(hipGetLastError());
     c->l_sup_dirty = false;
+    return CL_OK;
+}
+
+// level 4, first run of an eps under a cut: the words of the compact copy (c->cnt, by run position) to their base positions in the
+// handle's cache, hints in base positions
+int lists_words_to_base(cl_chrom* c, const GridParams& g)
+{
+    const int n = (int)c->n;
+    LAUNCH(k_words_to_base, n, g, n, (const int*)(c->bsp.as<int>() + SORT_PAD), (const int4*)c->l_tab.as<int4>(), (const int*)c->rc_poff.as<int>(),
+           (const int*)c->cnt.as<int>(), c->rc_cnt.as<int>());
+    HIP_TRY(hipGetLastError());
     return CL_OK;
 }
 
@@ -1635,11 +1643,30 @@ extern "C" int cl_debug_time_lists(cl_chrom* c, int which, int reps, float* ms_o
             launch_classify(c, g, nblk, b);
         } else if (which == 1) {
             launch_make_lists(c, g, nblk, b, L);
+        } else if (which == 6 || which == 7) {
+            // level 4 (the last run must have been one with a cut that re-used counts): k_classify_q / k_make_lists_q
+            const int n = (int)c->n;
+            ListBufs bb;
+            if ((rc = list_bufs(c, g, n, &bb))) return rc;
+            const int nb4 = nblocks(n, LT);
+            unsigned long long* sup64 = (unsigned long long*)bb.sup;
+            const int* bq = c->bq.as<int>() + SORT_PAD; const int* bsp = c->bsp.as<int>() + SORT_PAD;
+            const int thr = g.cut - g.V0, bandq = c->ws.bandq;
+            if (which == 6) {
+                HIP_TRY(hipMemsetAsync(bb.sup, 0, (size_t)2 * (nb4 / 16 + 2) * 4, c->stream));
+                hipLaunchKernelGGL((k_classify_q<true, true>), dim3(nb4), dim3(256), 0, c->stream, g, n, thr, bandq, bq, (const int*)c->rc_cnt.as<int>(), (const int*)c->cnt.as<int>(),
+                                   bb.cmask, bb.wmask, bb.cgloc, bb.wgloc, bb.bsum, sup64);
+            } else {
+                hipLaunchKernelGGL((k_make_lists_q<true, true, true>), dim3(nb4), dim3(256), 0, c->stream, g, n, bandq, bq, bsp, (const u32*)c->brow.as<u32>(), (const int*)c->bkey.as<int>(),
+                                   (const int2*)c->l_fix.as<int2>(), (const int*)c->rc_cnt.as<int>(), (const int*)c->cnt.as<int>(), (const unsigned long long*)bb.cmask,
+                                   (const unsigned long long*)bb.wmask, (const int*)bb.cgloc, (const int*)bb.wgloc, (const int*)bb.bsum, (const unsigned long long*)sup64, bb.cgrank, bb.wgrank,
+                                   L.cpair, (int*)nullptr, L.ckey, L.wpair, L.wpos, L.wenc, bb.lcnt);
+            }
         } else return fail(CL_ERR_ARG, "cl_debug_time_lists: kernel not supported on its own");
     }
     HIP_TRY(hipEventRecord(e1, c->stream));
     HIP_TRY(hipEventSynchronize(e1));
-    if (which == 1) HIP_TRY(hipMemsetAsync(b.sup, 0, (size_t)b.nsup2 * 4, c->stream));      // (what k_chain_c does in a run)
+    if (which == 1 || which == 7) HIP_TRY(hipMemsetAsync(b.sup, 0, c->l_blk.bytes - 64, c->stream));      // (what k_chain_c does in a run)
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     *ms_out = ms / (float)std::max(1, reps);

@@ -15,15 +15,17 @@ lib = _lib.load()
 lib.cl_debug_time_lists.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
 ch.cluster("v2", eps, 50, 0)
 ch.cluster("v2", eps, m, cut)
+L4 = os.environ.get("CLOOPS_TRAVERSAL", "4") == "4"
+KA, KB = (6, 7) if L4 else (0, 1)
 for abl in [0] + [int(a) for a in (saved or "").split(",") if a]:
     os.environ["CLOOPS_DBG2"] = str(abl)
     out = []
     ms = ctypes.c_float(0)
-    _lib.check(lib.cl_debug_time_lists(ch._h, 0, 20, ctypes.byref(ms)))
+    _lib.check(lib.cl_debug_time_lists(ch._h, KA, 20, ctypes.byref(ms)))
     out.append(ms.value * 1e3)
     os.environ["CLOOPS_DBG2"] = "0"                       # a valid set of masks for k_make_lists again
-    _lib.check(lib.cl_debug_time_lists(ch._h, 0, 1, ctypes.byref(ms)))
+    _lib.check(lib.cl_debug_time_lists(ch._h, KA, 1, ctypes.byref(ms)))
     os.environ["CLOOPS_DBG2"] = str(abl)
-    _lib.check(lib.cl_debug_time_lists(ch._h, 1, 20, ctypes.byref(ms)))
+    _lib.check(lib.cl_debug_time_lists(ch._h, KB, 20, ctypes.byref(ms)))
     out.append(ms.value * 1e3)
     print("dbg2 %7d: k_classify %.1f us  k_make_lists %.1f us" % (abl, out[0], out[1]), flush=True)
