@@ -50,7 +50,8 @@ extern "C" void cl_debug_lstats(unsigned long long* out)
     unsigned long long z[32] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lstat), z, sizeof(z));
 }
-#define LSTAT(slot, v) lstat_add((slot), (v))
+#define LSTAT_ON (g.dbg2 & (1 << 30))                  // (the counters are same-address atomics: only when asked for)
+#define LSTAT(slot, v) do { if (LSTAT_ON) lstat_add((slot), (v)); } while (0)
 #else
 #define LSTAT(slot, v) do { } while (0)
 #endif
@@ -303,7 +304,7 @@ k_make_lists(GridParams g, const int* __restrict__ sv, const int* __restrict__ s
         lcnt[0] = C; lcnt[1] = W;
         cgrank[nblk * LG] = C; wgrank[nblk * LG] = W;
 #ifdef CLOOPS_DEVEL
-        atomicAdd(&g_lstat[8], (unsigned long long)C); atomicAdd(&g_lstat[9], (unsigned long long)W); atomicAdd(&g_lstat[10], (unsigned long long)strip_start[g.S]); atomicAdd(&g_lstat[11], 1ull);
+        if (LSTAT_ON) { atomicAdd(&g_lstat[8], (unsigned long long)C); atomicAdd(&g_lstat[9], (unsigned long long)W); atomicAdd(&g_lstat[10], (unsigned long long)strip_start[g.S]); atomicAdd(&g_lstat[11], 1ull); }
 #endif
     }
     // stage by stage over the thread's 8 PETs (one per 64-PET group of its wave), all loads of a stage in flight together:
@@ -599,7 +600,7 @@ k_make_lists_q(GridParams g, int npos, int bandq, const int* __restrict__ bq, co
         lcnt[0] = C; lcnt[1] = W;
         cgrank[nblk * LG] = C; wgrank[nblk * LG] = W;
 #ifdef CLOOPS_DEVEL
-        atomicAdd(&g_lstat[8], (unsigned long long)C); atomicAdd(&g_lstat[9], (unsigned long long)W); atomicAdd(&g_lstat[11], 1ull);
+        if (LSTAT_ON) { atomicAdd(&g_lstat[8], (unsigned long long)C); atomicAdd(&g_lstat[9], (unsigned long long)W); atomicAdd(&g_lstat[11], 1ull); }
 #endif
     }
 #pragma unroll
@@ -619,9 +620,9 @@ k_make_lists_q(GridParams g, int npos, int bandq, const int* __restrict__ bq, co
             const int b = t0 + u * 256 + (int)threadIdx.x;
             const bool isc = (cbv[u] >> lane) & 1ull, isw = (wbv[u] >> lane) & 1ull;
             const int* wsrc = (BAND && q[u] < bandq) ? band : words;
-            aux[u] = isw ? wsrc[b] : (isc ? (V2 ? bkey[b] : (int)brow[b]) : 0);
+            aux[u] = L_ABL(1 << 25) ? b : (isw ? wsrc[b] : (isc ? (V2 ? bkey[b] : (int)brow[b]) : 0));
             fx[u] = make_int2(INT_MIN, 0);
-            if (V2 && CUT) {
+            if (V2 && CUT && !L_ABL(1 << 26)) {
                 // (the rows of the wave's first and last strip are wave-uniform loads; a strip holds tens to hundreds of PETs)
                 const unsigned long long anyb = cbv[u] | wbv[u];
                 const int st = isc ? (sp[u] >> g.rbits) : 0;
@@ -646,6 +647,7 @@ k_make_lists_q(GridParams g, int npos, int bandq, const int* __restrict__ bq, co
         const int b = t0 + u * 256 + (int)threadIdx.x;
         const unsigned long long cb = cbv[u], wb = wbv[u];
         const bool isc = (cb >> lane) & 1ull, isw = (wb >> lane) & 1ull;
+        if (L_ABL(1 << 27)) { if (q[u] + sp[u] + aux[u] == 0x7f123457) ckey[0] = 1; continue; }      // (ablation: no stores)
         if (isc) {
             const int dst = cgv[u] + __popcll(cb & low_mask(lane));
             cpair[dst] = make_int2(q[u], sp[u]); ckey[dst] = aux[u];
@@ -774,15 +776,8 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
     LdsPairs w; w.a = lw; w.base = base;
     const int lane = threadIdx.x & 63;
     constexpr int PER = NT / 256;
-    // the strip bounds of the thread's cores: all table loads in flight together
-    int tbv[PER], bv_[PER];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int i = t0 + u * 256 + (int)threadIdx.x;
-        const int s = i < C ? (lw[i - base].y >> g.rbits) : 0;
-        tbv[u] = s > 0 ? cstrip[s - 1] : 0; bv_[u] = s > 0 ? cstrip[s] : 0;      // (strip 0 has nothing below: an empty range)
-    }
-#pragma unroll
+    // (one copy of the body: unrolled over the thread's cores the kernel was 80 KB of code -- more than the instruction cache two CUs share)
+#pragma unroll 1
     for (int u = 0; u < PER; ++u) {
         const int i = t0 + u * 256 + (int)threadIdx.x;
         const bool in = i < C;
@@ -797,8 +792,9 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
         if (in) {
             const int2 me = lw[i - base];
             A = lx[i - base];
-            int tb = tbv[u];
-            const int b = bv_[u];
+            const int s = me.y >> g.rbits;
+            int tb = s > 0 ? cstrip[s - 1] : 0;
+            const int b = s > 0 ? cstrip[s] : 0;          // (strip 0 has nothing below: an empty range)
             if (tb < b) {
                 const int qlo = me.x - g.eps, qhi = me.x + g.eps;
                 const int T = me.y - g.peps;             // every candidate lies one strip below: "within eps in p" is sp_j >= sp_i - peps
@@ -1028,7 +1024,8 @@ __global__ void k_scatter_by_pos(const int* __restrict__ cnt_ptr, const int* __r
 // list -- staged once as (q, sp) pairs + roots.  A walker's windows start at the rank of K2's hints (no strip table, no search);
 // "still in the neighbour strip and inside the q window" is a predicate of the staged pair.  Every staged candidate is a core:
 // nothing to step over.
-#define LB_PER 4                 // walkers per thread and pass: the loads of a stage of all of them are in flight together
+#define LB_PER 1                 // walkers per thread and pass (a 2048-position tile holds a few hundred walkers: one pass; more per thread only
+                                 // multiplies the code -- the kernel's instruction footprint matters: 64 KB of instruction cache per two CUs)
 template <int NT, int HC, bool V1>
 __global__ void __launch_bounds__(256)
 k_border_w(GridParams g, int ntiles, int npos, const int* __restrict__ lcnt,
@@ -1114,8 +1111,8 @@ k_border_w(GridParams g, int ntiles, int npos, const int* __restrict__ lcnt,
                     if (k < bestk) { bestk = k; best = r; }
                     if (ckey[j] == k && k > tk) { tk = k; tbest = r; }       // j is its component's start point
                 };
-                auto pair_at = [&](int j) { return (j >= clo && j < chi) ? lw[j - clo] : cpair[j]; };
-                auto root_at = [&](int j) { return (j >= clo && j < chi) ? lx[j - clo].x : croot[j]; };
+                auto pair_at = [&](int j) { int2 v; if (j >= clo && j < chi) v = lw[j - clo]; else v = cpair[j]; return v; };
+                auto root_at = [&](int j) { int v; if (j >= clo && j < chi) v = lx[j - clo].x; else v = croot[j]; return v; };
                 for (int j = c1[e] - 1; j >= 0; --j) { const int2 p = pair_at(j); if (!((p.y >= pbeg) & (p.x >= qlo))) break; see(j, root_at(j)); }
                 for (int j = c1[e]; j < C; ++j) { const int2 p = pair_at(j); if (!((p.y < pend) & (p.x <= qhi))) break; see(j, root_at(j)); }
                 if (!L_ABL(2048)) {
@@ -1137,9 +1134,9 @@ k_border_w(GridParams g, int ntiles, int npos, const int* __restrict__ lcnt,
                 // inside one eps) -- one component: the nearest core on either side stands for all of them
                 {
                     const int jl = max(c1[e] - 1, 0), jr = max(min(c1[e], C - 1), 0);
-                    const bool inl = jl >= clo && jl < chi, inr = jr >= clo && jr < chi;
-                    const int2 pl = inl ? lw[jl - clo] : cpair[jl], pr = inr ? lw[jr - clo] : cpair[jr];
-                    const int rl = inl ? lx[jl - clo].x : croot[jl], rrt = inr ? lx[jr - clo].x : croot[jr];
+                    int2 pl, pr; int rl, rrt;
+                    if (jl >= clo && jr < chi) { pl = lw[jl - clo]; pr = lw[jr - clo]; rl = lx[jl - clo].x; rrt = lx[jr - clo].x; }      // (LDS and global paths apart: a
+                    else { pl = cpair[jl]; pr = cpair[jr]; rl = croot[jl]; rrt = croot[jr]; }                                            //  select of pointers makes FLAT loads)
                     if (c1[e] > 0 && (pl.y >= pbeg) & (pl.x >= qlo)) see(rl);
                     if (c1[e] < C && (pr.y < pend) & (pr.x <= qhi)) see(rrt);
                 }
@@ -1171,9 +1168,10 @@ k_border_w(GridParams g, int ntiles, int npos, const int* __restrict__ lcnt,
                 };
                 if (!L_ABL(2048)) { walk(ca[e], pbeg, true); walk(cb[e], pend2, false); }
                 rr[e][0] = r0; rr[e][1] = r1; rr[e][2] = r2; rr[e][3] = r3;
+                if (L_ABL(1 << 28) && r0 != 0x7f000001) { rr[e][0] = -1; rr[e][1] = -1; rr[e][2] = -1; rr[e][3] = -1; }      // (ablation: the walks, nothing behind them)
 #ifdef CLOOPS_DEVEL
                 LSTAT(1, n_it); LSTAT(2, n_glb);
-                { int mx = n_it; for (int o2 = 32; o2 > 0; o2 >>= 1) mx = max(mx, __shfl_down(mx, o2)); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_lstat[6], (unsigned long long)mx); atomicAdd(&g_lstat[7], 1ull); } }
+                { int mx = n_it; for (int o2 = 32; o2 > 0; o2 >>= 1) mx = max(mx, __shfl_down(mx, o2)); if ((threadIdx.x & 63) == 0 && LSTAT_ON) { atomicAdd(&g_lstat[6], (unsigned long long)mx); atomicAdd(&g_lstat[7], 1ull); } }
 #endif
             }
         }
@@ -1662,6 +1660,23 @@ extern "C" int cl_debug_time_lists(cl_chrom* c, int which, int reps, float* ms_o
                                    (const unsigned long long*)bb.wmask, (const int*)bb.cgloc, (const int*)bb.wgloc, (const int*)bb.bsum, (const unsigned long long*)sup64, bb.cgrank, bb.wgrank,
                                    L.cpair, (int*)nullptr, L.ckey, L.wpair, L.wpos, L.wenc, bb.lcnt);
             }
+        } else if (which == 4 || which == 3 || which == 5) {
+            // k_border_w / k_union_c + k_flatten_c / k_final_lists of the last run once more (their inputs are in place; the per-component
+            // counters they add to are garbage afterwards)
+            ListRun L2 = L;
+            c->run_level = c->traversal >= 4 ? 4 : 3;
+            if (c->run_level == 4) { ListBufs bb; if ((rc = list_bufs(c, g, (int)c->n, &bb))) return rc; list_views(c, bb, &L2); L2.npos = (int)c->n; L2.pstrip = c->bstrip.as<int>(); }
+            else { L2.npos = nm; L2.pstrip = c->w_strip; }
+            if (which == 4) { if ((rc = lists_border(c, g, nm, L2))) return rc; }
+            else if (which == 3) {
+                // (the chain kernel resets the forest and the per-head accumulators first -- timed with it)
+                ListBufs bb; if ((rc = list_bufs(c, g, c->run_level == 4 ? (int)c->n : nm, &bb))) return rc;
+                hipLaunchKernelGGL(k_chain_c, dim3(nblocks(nm, 256 * CH_PER)), dim3(256), 0, c->stream, g, L2.lcnt, (const int2*)L2.cpair, c->chainflag.as<int>(),
+                                   c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
+                                   c->lo.as<int>(), L2.pstrip, L2.cmask, L2.cgrank, L2.cstrip, bb.sup, 2, (int*)nullptr);
+                HIP_TRY(hipMemsetAsync(c->counters.p, 0, 64, c->stream));
+                if ((rc = lists_union_flatten(c, g, nm, L2))) return rc;
+            } else { if ((rc = lists_final(c, g, nm, L2, false))) return rc; }
         } else return fail(CL_ERR_ARG, "cl_debug_time_lists: kernel not supported on its own");
     }
     HIP_TRY(hipEventRecord(e1, c->stream));

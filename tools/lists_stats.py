@@ -3,6 +3,7 @@ CLOOPS_DEVEL_LIB=1 python tools/lists_stats.py"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["CLOOPS_DEVEL_LIB"] = "1"
+os.environ["CLOOPS_DBG2"] = str(1 << 30)                  # the event counters are opt-in (same-address atomics)
 import bench
 from cloops_amd import api, _lib
 from cloops_amd.synth import synth_chrom, chrom_sizes

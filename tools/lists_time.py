@@ -28,4 +28,10 @@ for abl in [0] + [int(a) for a in (saved or "").split(",") if a]:
     os.environ["CLOOPS_DBG2"] = str(abl)
     _lib.check(lib.cl_debug_time_lists(ch._h, KB, 20, ctypes.byref(ms)))
     out.append(ms.value * 1e3)
+    if os.environ.get("CLOOPS_TIME_BORDER"):
+        for which, name in ((4, "k_border_w"), (5, "k_final_lists"), (3, "chain+union+flatten")):
+            _lib.check(lib.cl_debug_time_lists(ch._h, which, 10, ctypes.byref(ms)))
+            out.append(ms.value * 1e3)
+        print("dbg2 %7d: k_classify %.1f us  k_make_lists %.1f us  k_border_w %.1f us  k_final_lists %.1f us  chain+union+flatten %.1f us" % (abl, out[0], out[1], out[2], out[3], out[4]), flush=True)
+        continue
     print("dbg2 %7d: k_classify %.1f us  k_make_lists %.1f us" % (abl, out[0], out[1]), flush=True)
