@@ -138,6 +138,7 @@ struct cl_chrom {
     int traversal = 4;                // cl_set_traversal: 0 = tile kernels over every PET (rounds 1-4), 1 = K3 on the core list,
                                       // 2 = + border rule on the walker list, 3 = + labels / table / statistics from the lists,
                                       // 4 = + the lists built from the base layout (no copy of the layout for a run that re-uses counts)
+    bool last_k2_mode_make = false;   // the run being enqueued made the words itself (level 4 under a cut: on the base layout, then its band)
     int last_k2_mode = 0;             // 0 = full K2, 1 = words re-used as they are (same cut), 2 = remapped + K2 on the band
     std::vector<long long> dcum;      // dcum[k] = number of PETs with Y - X < k, k = 0 .. 65536 (empty: unknown)
     const int* k_total = nullptr;     // device: where the run left the number of ids handed out (null: rankscan[n])

@@ -2664,7 +2664,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     int* wsv = c->sv.as<int>() + SORT_PAD;
     int* wsa = c->sa.as<int>() + SORT_PAD;
     c->w_cnt = c->cnt.as<int>();
-    c->last_k2_mode = 0;
+    c->last_k2_mode = 0; c->last_k2_mode_make = false;
     GridParams gk = g;                                    // what K2 sees: the minPts values its words serve, filled in below
     bool k2_band = false, k2_skip = false;
     c->ws = WordSrc{c->cnt.as<int>(), nullptr, nullptr, nullptr, 0, g.rbits};
@@ -2749,7 +2749,25 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
                 HIP_TRY(hipMemsetAsync(c->rc_pre.p, 0, ((size_t)g.S + 2) * 4, c->stream));
                 HIP_TRY(hipMemsetAsync(c->rc_poff.p, 0, ((size_t)g.S + 2) * 4, c->stream));
             }
-        } else if (rcmode == RC_SAME) {
+            if (want4 && !on_base && (long long)g.S <= 8LL * n) {
+                // Level 4: the words of an eps are ALWAYS made on the base layout itself (threshold 0: every row), also when the first
+                // run of the eps has a cut -- that run then re-uses them like every later one (fresh words for its cut band, the
+                // cached ones beyond it).  One region query over all rows (213 us on chr1) instead of a copy of the layout, the
+                // query on the copy and the move of its words to base positions (54 + 146 + 77 us) -- and no copy of the layout is
+                // ever made (cLoops/pipe.py:59-63: the cut only removes a prefix of every strip).
+                HIP_TRY(hipMemsetAsync(c->rc_pre.p, 0, ((size_t)g.S + 2) * 4, c->stream));
+                HIP_TRY(hipMemsetAsync(c->rc_poff.p, 0, ((size_t)g.S + 2) * 4, c->stream));
+                GridParams g0 = gk;
+                g0.cut = 0;
+                if ((rc = cl_launch_region(c->stream, g0, n, n, false, c->bq.as<int>() + SORT_PAD, c->bsp.as<int>() + SORT_PAD, c->bstrip.as<int>(),
+                                           c->btile.as<int>(), c->rc_cnt.as<int>()))) return rc;
+                c->rc.thr = 0;
+                c->w_cnt = c->rc_cnt.as<int>();
+                rcmode = RC_REMAP;
+                c->last_k2_mode_make = true;
+            }
+        }
+        if (rcmode == RC_SAME) {
             c->w_cnt = c->rc_cnt.as<int>();
             c->ws.rc = c->w_cnt;
             k2_skip = true;
@@ -2758,7 +2776,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
             // the two cuts differ in the PETs with q in [min, max) of the thresholds: a PET keeps its count iff q - eps >= max
             c->ws = WordSrc{c->rc_cnt.as<int>(), c->cnt.as<int>(), c->rc_D.as<int>(), c->rc_dpre.as<int>(), std::max(thr_new, c->rc.thr) + g.eps, g.rbits};
             k2_band = true;
-            c->last_k2_mode = 2;
+            c->last_k2_mode = c->last_k2_mode_make ? 0 : 2;
         }
         if (on_base) {
             // no row is filtered: the run works on the base layout itself

@@ -1,0 +1,75 @@
+"""GPU: the list form of K3 / K4 / K5 (cloops_amd/csrc/k_lists.hip, cl_set_traversal).
+
+The reference expands clusters from core points only (cDBSCAN2.py:114-192 queryGrid, cDBSCAN.py:155-184 expandCluster); the
+library compacts a run's cores and its non-core PETs with a neighbour into two lists behind the region query (level 3), at
+level 4 straight from the base layout with the cut applied by index (no copy of the layout, count cache in base-position
+space).  Levels 0 .. 2 keep the LDS-tile kernels over every PET for the components / the border rule / the labels.  Every level
+must give the labels of the sequential oracle -- with and without a cut, re-used counts included, both rotated variants."""
+import numpy as np
+import pytest
+
+import oracle
+from cloops_amd import api
+from cloops_amd.synth import synth_chrom
+
+pytestmark = pytest.mark.gpu
+
+N = 150000
+
+
+def _want(variant, X, Y, eps, m, cut):
+    keep = Y.astype(np.int64) - X >= cut
+    want = np.full(len(X), -1, np.int32)
+    want[keep] = oracle.labels(variant, X[keep], Y[keep], eps, m)
+    return want
+
+
+@pytest.mark.parametrize("variant", ["v2", "v1"])
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 4])
+def test_levels_equal_oracle(variant, level):
+    X, Y = synth_chrom(N, 46709983, 23)
+    ch = api.Chromosome(X, Y)
+    ch.set_traversal(level)
+    try:
+        for eps, m, cut in ((2000, 5, 0), (5000, 20, 0), (5000, 10, 3000), (5000, 10, 4500), (5000, 12, 2500), (500, 3, 0), (500, 3, 700)):
+            got = ch.cluster(variant, eps, m, cut)
+            want = _want(variant, X, Y, eps, m, cut)
+            assert np.array_equal(got.labels, want), (variant, level, eps, m, cut, int((got.labels != want).sum()))
+            assert got.n_clusters == len(np.unique(want[want >= 0]))
+    finally:
+        ch.close()
+
+
+def test_level4_makes_no_copy_for_reusing_runs():
+    """at level 4 the words of an eps live in base-position space: a run under a cut re-uses them (mode 2: band query) even when it is
+    the first run of the eps, and a run without a cut takes them as they are (mode 1)"""
+    X, Y = synth_chrom(N, 46709983, 29)
+    ch = api.Chromosome(X, Y)
+    ch.set_count_thresholds([5, 10, 20])
+    try:
+        modes = []
+        for eps, m, cut in ((5000, 20, 3000), (5000, 10, 3500), (5000, 5, 0), (5000, 10, 2000)):
+            got = ch.cluster("v2", eps, m, cut)
+            modes.append(ch.last_region_mode())
+            assert np.array_equal(got.labels, _want("v2", X, Y, eps, m, cut)), (eps, m, cut)
+        assert modes == [0, 2, 1, 2], modes
+    finally:
+        ch.close()
+
+
+def test_sweep_step_statistics_from_the_lists():
+    """the distance statistics of a sweep step read the run's lists (K7, sorted == 2): the chained cut equals the oracle's"""
+    from cloops_amd import pipe, ests
+    X, Y = synth_chrom(120000, 46709983, 31)
+    pipe.CACHE.clear()
+    f = pipe.CACHE.put_arrays("chrL-chrL", X, Y)
+    try:
+        dataI, cut, cuts, steps = pipe.runSweepFast([f], [1500, 3000], [8, 5], cut=0)
+        c = 0
+        for st in steps:
+            ref = oracle.single_dbscan("v2", X, Y, st["eps"], st["minPts"], c)
+            assert st["n_inter"] == len(ref["dataI"]) and st["n_self"] == len(ref["dataS"])
+            c = ests.estIntSelCutFrag(ref["dis"], ref["dss"])[0]
+            assert st["cut_out"] == c
+    finally:
+        pipe.CACHE.clear()
