@@ -43,7 +43,8 @@ class ClTiming(ctypes.Structure):
     _fields_ = [("ms_keys", ctypes.c_float), ("ms_sort", ctypes.c_float), ("ms_region", ctypes.c_float),
                 ("ms_union", ctypes.c_float), ("ms_border", ctypes.c_float), ("ms_table", ctypes.c_float),
                 ("ms_d2h", ctypes.c_float), ("ms_total", ctypes.c_float), ("n_in", ctypes.c_int64),
-                ("n_strips", ctypes.c_int64), ("ms_bracket", ctypes.c_float)]
+                ("n_strips", ctypes.c_int64), ("ms_bracket", ctypes.c_float), ("ms_band", ctypes.c_float),
+                ("n_queried", ctypes.c_int64)]
 
 
 DIST_LOGBINS = 3840

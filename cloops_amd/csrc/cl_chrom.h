@@ -131,6 +131,7 @@ struct cl_chrom {
     int run_level = 0;                // traversal level of the run being enqueued (run_sort_and_count decides: level 4 needs the count cache's tables)
     const int* w_dM = nullptr;        // device: PETs that entered DBSCAN in the run being enqueued
     bool run_rows = true;             // the run being enqueued produces row-aligned labels
+    bool l4_make_base = false;        // level 4: the run makes the words of its eps -- K2 on the base layout, launched behind the band query
     bool l4_cut = false;              // level 4: the run has a cut (the per-strip tables of k_cut_strips apply)
     bool l4_band = false;             // ... and re-uses counts under another cut (the band's words are fresh: c->cnt, by run position)
     bool l_sup_dirty = false;         // k_classify's superblock sums may be non-zero (a run that failed between k_classify and k_chain_c)
@@ -155,7 +156,9 @@ struct cl_chrom {
         bool pending = false;
         int n_strips = 0;
         hipEvent_t ev_done = nullptr, ev_copied = nullptr;
-        hipEvent_t ev[8]{};           // profiling marks of the run that used this slot
+        hipEvent_t ev[10]{};          // profiling marks of the run that used this slot (8, 9: around the band query of a level-4 run)
+        bool band_timed = false;      // ... which ran
+        long long n_queried = 0;      // PETs the run's region query covered (0: none)
         int* h_hdr = nullptr;         // pinned: {K, overflow, M}
         cl_box* h_boxes = nullptr;    // pinned host copy of the cluster table
         size_t h_boxes_cap = 0;

@@ -2669,7 +2669,8 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     bool k2_band = false, k2_skip = false;
     c->ws = WordSrc{c->cnt.as<int>(), nullptr, nullptr, nullptr, 0, g.rbits};
     c->run_level = exact ? 0 : std::min(c->traversal, 3);
-    c->w_dM = nullptr; c->l4_cut = false; c->l4_band = false;
+    c->w_dM = nullptr; c->l4_cut = false; c->l4_band = false; c->l4_make_base = false;
+    c->slot[c->cur].band_timed = false; c->slot[c->cur].n_queried = 0;
     if (!c->reuse_layout) {
         // every run sorts for itself (the cut filter rides in the keys: filtered rows go behind the last strip)
         if ((rc = sort_layout(c, g, wsv, wsa, nullptr, c->strip.as<int>(), c->tile_s0.as<int>()))) return rc;
@@ -2757,10 +2758,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
                 // ever made (cLoops/pipe.py:59-63: the cut only removes a prefix of every strip).
                 HIP_TRY(hipMemsetAsync(c->rc_pre.p, 0, ((size_t)g.S + 2) * 4, c->stream));
                 HIP_TRY(hipMemsetAsync(c->rc_poff.p, 0, ((size_t)g.S + 2) * 4, c->stream));
-                GridParams g0 = gk;
-                g0.cut = 0;
-                if ((rc = cl_launch_region(c->stream, g0, n, n, false, c->bq.as<int>() + SORT_PAD, c->bsp.as<int>() + SORT_PAD, c->bstrip.as<int>(),
-                                           c->btile.as<int>(), c->rc_cnt.as<int>()))) return rc;
+                c->l4_make_base = true;                      // (launched in the region-query bracket, below)
                 c->rc.thr = 0;
                 c->w_cnt = c->rc_cnt.as<int>();
                 rcmode = RC_REMAP;
@@ -2812,9 +2810,11 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
                 // no copy of the layout: the band query alone (it reads the base layout and writes its words at the PETs' places in the
                 // run's -- virtual -- layout); the list kernels apply the cut by index
                 const int nbb = nblocks(nblocks(g.S, KB_SB), CMP_TPB / 64);
+                if (c->profiling) { (void)hipEventRecord(c->slot[c->cur].ev[8], c->stream); c->slot[c->cur].band_timed = true; }
                 hipLaunchKernelGGL(k_band, dim3(nbb), dim3(CMP_TPB), 0, c->stream, g.S, g.rbits, g.eps, g.minPts, bq, (const int*)(c->bsp.as<int>() + SORT_PAD),
                                    (const int*)src0, (const int*)sloc, (const int*)sboffs, (const int2*)c->rc_blen.as<int2>(), c->cnt.as<int>(), d_M,
                                    c->run_m_exact ? c->run_m : -1, c->counters.as<int>(), g.dbg);
+                if (c->profiling) (void)hipEventRecord(c->slot[c->cur].ev[9], c->stream);
                 c->w_dM = d_M;
             } else if (l4 && rcmode == RC_SAME) {
                 hipLaunchKernelGGL(k_store_m, dim3(1), dim3(1), 0, c->stream, g.S, (const int*)sloc, (const int*)sboffs, d_M, c->run_m_exact ? c->run_m : -1, c->counters.as<int>());
@@ -2838,7 +2838,17 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
     }
     ev_record(c, 2);
     rc = CL_OK;
-    if (!k2_skip && !k2_band && !SKIP(256)) rc = cl_launch_region(c->stream, gk, n, c->run_m, exact, c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->w_cnt);
+    if (c->l4_make_base) {
+        // level 4: the words of the eps, on the base layout itself (every row), whatever this run's cut is
+        GridParams g0 = gk;
+        g0.cut = 0;
+        rc = cl_launch_region(c->stream, g0, n, n, false, c->bq.as<int>() + SORT_PAD, c->bsp.as<int>() + SORT_PAD, c->bstrip.as<int>(), c->btile.as<int>(),
+                              c->rc_cnt.as<int>());
+        c->slot[c->cur].n_queried = n;
+    } else if (!k2_skip && !k2_band && !SKIP(256)) {
+        rc = cl_launch_region(c->stream, gk, n, c->run_m, exact, c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->w_cnt);
+        c->slot[c->cur].n_queried = c->run_m;
+    }
     if (rc) return rc;
     if (c->run_level == 4 && c->l4_cut && !k2_skip && !k2_band && (rc = lists_words_to_base(c, g))) return rc;
     ev_record(c, 3);
@@ -3134,6 +3144,9 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
         tm.n_in = sl.h_hdr[2];
         tm.n_strips = sl.n_strips;
         tm.ms_bracket = c->ev_bracket_ms;
+        tm.ms_band = 0.f;
+        if (sl.band_timed) (void)hipEventElapsedTime(&tm.ms_band, ev[8], ev[9]);
+        tm.n_queried = sl.n_queried;
     }
     return CL_OK;
 }

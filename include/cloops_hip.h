@@ -72,6 +72,10 @@ typedef struct {
     float ms_bracket;     /* calibration: the same event bracket around an EMPTY kernel (event packets +
                              dispatch gap + ~1 us of empty kernel); a phase that is one kernel (ms_region)
                              reads kernel time + about this much                                    */
+    float ms_band;        /* K2 on the cut band of a run that re-uses the counts of its eps (traversal level 4: a kernel
+                             of its own, inside the ms_sort phase; 0 = none)                        */
+    int64_t n_queried;    /* PETs the region query of ms_region covered (0 = none ran; level 4 queries the whole base
+                             layout once per eps: all rows)                                         */
 } cl_timing;
 
 /* Human-readable description of the last error on the calling thread. */

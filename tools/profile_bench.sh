@@ -53,13 +53,14 @@ for k in out:
 hbm = lambda k: 2 * kb(k, "FETCH_SIZE_KB_sum") + kb(k, "WRITE_SIZE_KB_sum")
 ct = [k for k in out if k.startswith("k_cut_copy<true>")]
 cf = [k for k in out if k.startswith("k_cut_copy<false>")]
+kb_band = [k for k in out if k.startswith("k_band")]     # traversal level 4: the band query is a kernel of its own, nothing is copied
 plain = (hbm(cf[0]) / out[cf[0]]["launches_FETCH_SIZE"]) if cf else 0.0
-band_extra = sum(hbm(k) - plain * out[k]["launches_FETCH_SIZE"] for k in ct)
+band_extra = sum(hbm(k) - plain * out[k]["launches_FETCH_SIZE"] for k in ct) + sum(hbm(k) for k in kb_band)
 total_kb = sum(hbm(k) for k in k2s) + max(band_extra, 0.0)
 t = {"workload": "chr1 (16.4 M PETs) of synthetic-200M-23chr, the mode-3 sweep's 12 runs in the sweep's order, region query re-used inside an eps",
-     "kernels": k2s + ct, "runs": runs,
+     "kernels": k2s + ct + kb_band, "runs": runs,
      "region_core_KB_per_launch": {k: round(hbm(k) / max(1, out[k]["launches_FETCH_SIZE"]), 1) for k in k2s},
-     "cut_copy_with_band_minus_plain_KB_per_launch": round(band_extra / max(1, sum(out[k]["launches_FETCH_SIZE"] for k in ct)), 1) if ct else None,
+     "band_query_KB_per_launch": round(band_extra / max(1, sum(out[k]["launches_FETCH_SIZE"] for k in ct + kb_band)), 1) if (ct or kb_band) else None,
      "correction": "gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is 1:1",
      "hbm_bytes_per_launch": int(round(total_kb * 1024 / max(1, runs))),
      "hbm_bytes_per_launch_note": "per RUN of the sweep (amortised like roofline.achieved): all region-query traffic of the replay / its runs",
@@ -73,12 +74,16 @@ def stats(name):
 ru, fu = stats("k2_replay_reuse_kernel_stats.csv"), stats("k2_replay_full_kernel_stats.csv")
 passes = [v for k, v in ru.items() if k.startswith("k_final_l")][0][0] // 12
 core = sum(c * a for k, (c, a) in ru.items() if k.startswith("k_region_core"))
-plain = fu["k_cut_copy<false>"][1]
-carry = ru["k_cut_copy<true>"][0] * (ru["k_cut_copy<true>"][1] - plain) + ru["k_cut_strips"][0] * (ru["k_cut_strips"][1] - fu["k_cut_strips"][1])
+plain = fu["k_cut_copy<false>"][1] if "k_cut_copy<false>" in fu else 0.0
+if "k_band" in ru:                                       # level 4: the band query of every run under a cut, a kernel of its own
+    carry = ru["k_band"][0] * ru["k_band"][1]
+else:
+    carry = ru["k_cut_copy<true>"][0] * (ru["k_cut_copy<true>"][1] - plain) + ru["k_cut_strips"][0] * (ru["k_cut_strips"][1] - fu["k_cut_strips"][1])
 full = sum(c * a for k, (c, a) in fu.items() if k.startswith("k_region_core"))
 x = {"passes": passes, "runs_per_pass": 12, "region_core_us_per_pass": round(core / passes, 1), "carry_us_per_pass": round(carry / passes, 1),
      "amortised_us_per_run": round((core + carry) / passes / 12, 2), "full_query_us_per_run": round(full / passes / 12, 2),
-     "kernels_reuse": {k: ru[k] for k in ru if k.startswith(("k_region_core", "k_cut_copy", "k_cut_strips"))},
+     "kernels_reuse": {k: ru[k] for k in ru if k.startswith(("k_region_core", "k_cut_copy", "k_cut_strips", "k_band"))},
+     "per_launch_us": {k: ru[k][1] for k in ru if k.startswith("k_region_core")},
      "kernels_full": {k: fu[k] for k in fu if k.startswith(("k_region_core", "k_cut_copy", "k_cut_strips"))},
      "source": "k2_replay_reuse_kernel_stats.csv / k2_replay_full_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/k2_replay.py 3 with CLOOPS_REPLAY_ONLY=reuse / full; the first of the four passes is the warm-up)"}
 json.dump(x, open("$OUT/k2_from_rocprof.json", "w"), indent=1)
