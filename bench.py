@@ -110,6 +110,12 @@ def rccl_preflight(rank, world, local_rank, timeout=None, child=None):
     env = dict(os.environ)
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     note, ok = "", False
+    for stale in ("%s.%d" % (mark, rank),) + ((cm.id_path(tag),) if rank == 0 else ()):
+        try:
+            os.remove(stale)                               # what an earlier launch under the same tag may have left behind
+        except OSError:
+            pass
+    oldest = cm._process_start_time() - cm.STALE_ID_SKEW_S
     try:
         out = subprocess.run([sys.executable, "-c", child or PREFLIGHT_CHILD, str(rank), str(world), str(local_rank), tag], env=env, cwd=ROOT,
                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
@@ -129,13 +135,17 @@ def rccl_preflight(rank, world, local_rank, timeout=None, child=None):
             if r not in verdicts:
                 try:
                     with open("%s.%d" % (mark, r)) as fh:
-                        verdicts[r] = fh.read()
+                        txt = fh.read()
+                        if os.fstat(fh.fileno()).st_mtime >= oldest:      # (not a verdict of an earlier launch)
+                            verdicts[r] = txt
                 except (IOError, OSError):
                     pass
         if len(verdicts) < world:
             time.sleep(0.02)
     import atexit
     atexit.register(lambda path="%s.%d" % (mark, rank): os.path.exists(path) and os.remove(path))      # (every rank has read it long before)
+    if rank == 0:
+        atexit.register(lambda path=cm.id_path(tag): os.path.exists(path) and os.remove(path))           # the child's id file, if it was killed before its unlink
     all_ok = len(verdicts) == world and all(v.startswith("1") for v in verdicts.values())
     bad = "; ".join(v[2:] for v in verdicts.values() if not v.startswith("1")) or ("missing verdicts of ranks %s" % sorted(set(range(world)) - set(verdicts)) if len(verdicts) < world else "")
     return all_ok, bad
@@ -340,6 +350,7 @@ def main(argv=None):
         pipe.CACHE.clear()
         if not args.no_secondary:
             line["secondary_5M"] = secondary_5m(api, synth_chrom)
+            line["secondary_chr21_cli"] = chr21_cli()
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_full(n_total, steps, int(cut), int(ncand)) if args.full_cpu_baseline else cpu_baseline(api, sizes, steps)
     pipe.CACHE.clear()
@@ -621,6 +632,52 @@ def secondary_5m(api, synth_chrom, steps=20, warmup=3):
            "kernel_ms": {k[3:]: round(float(v), 4) for k, v in k2[-1].items() if k.startswith("ms_") and k != "ms_bracket"}}
     ch.close()
     return out
+
+
+def chr21_cli():
+    """BASELINE.json configs[0] as the reference runs it (examples/run.sh:1: `cLoops -f <chr21 BEDPE> -o out -m 1`): wall time of
+    `python -m cloops_amd -f <bedpe.gz> -o out -m 1` as a child process -- interpreter start, BEDPE parse, upload, the chained
+    sweep (eps 500 / 1000 / 2000, minPts 5), significance test, `.loop` file -- beside BASELINE.md section 2's 9.8 s for the
+    reference (one core, converted copy).  The BEDPE is written from the committed golden mid-points of the example
+    (tests/golden/chr21_input.npz: the same 99 674 PETs); the `.loop` file is compared with the golden table."""
+    import gzip
+    import shutil
+    import tempfile
+    gold = os.path.join(ROOT, "tests", "golden")
+    try:
+        import numpy as np
+        z = np.load(os.path.join(gold, "chr21_input.npz"))
+        X, Y = z["X"], z["Y"]
+    except Exception as e:
+        return {"skipped": "no golden input: %s" % e}
+    d = tempfile.mkdtemp(prefix="cloops_cli_")
+    try:
+        bed = os.path.join(d, "chr21.bedpe.gz")
+        with gzip.open(bed, "wt") as fh:
+            for x, y in zip(X.tolist(), Y.tolist()):
+                fh.write("chr21\t%d\t%d\tchr21\t%d\t%d\tid\t1\t+\t-\n" % (x, x, y, y))
+        env = dict(os.environ)
+        env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+        walls = []
+        for rep in range(2):                              # (the second run has the page cache and the GPU context warm)
+            out = os.path.join(d, "run%d" % rep)
+            t0 = time.perf_counter()
+            p = subprocess.run([sys.executable, "-m", "cloops_amd", "-f", bed, "-o", out, "-m", "1"], env=env, cwd=d,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+            walls.append(time.perf_counter() - t0)
+            if p.returncode != 0:
+                return {"error": p.stdout.decode("utf-8", "replace")[-400:]}
+        got = open(os.path.join(d, "run1.loop")).read()
+        want_path = os.path.join(gold, "chr21_v2.loop")
+        same = os.path.exists(want_path) and got == open(want_path).read()
+        return {"workload": "chr21 example (99 674 PETs), -m 1: BASELINE.json configs[0]", "wall_s": min(walls), "first_wall_s": walls[0],
+                "loop_rows": max(0, got.count("\n") - 1), "loop_file_identical_to_golden": bool(same),
+                "reference_wall_s": 9.8, "reference_source": "BASELINE.md section 2 (the reference, converted copy, one core, build container)",
+                "note": "whole command as a child process: interpreter start + parse + upload + sweep + significance + .loop"}
+    except Exception as e:
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 # ---- CPU baseline: the C oracle, one host process per chromosome (the reference's own shape, cLoops/pipe.py:117) ----

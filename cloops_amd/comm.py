@@ -98,6 +98,21 @@ def rccl_versions():
     return int(b.value), int(l.value)
 
 
+STALE_ID_SKEW_S = 120.0
+
+
+def _process_start_time():
+    """wall-clock start of this process (from /proc; now, if that cannot be read)"""
+    try:
+        with open("/proc/self/stat") as fh:
+            ticks = float(fh.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as fh:
+            up = float(fh.read().split()[0])
+        return time.time() - (up - ticks / os.sysconf("SC_CLK_TCK"))
+    except Exception:
+        return time.time()
+
+
 def exchange_id(rank, world, make_id, tag=None, timeout=300.0, directory=ID_DIR):
     """rank 0 makes the id (make_id() -> bytes) and publishes it; every rank returns the same bytes.  The file name carries
     default_tag(), which names this launcher instance and this communicator: whatever is found under it was written for it."""
@@ -105,6 +120,10 @@ def exchange_id(rank, world, make_id, tag=None, timeout=300.0, directory=ID_DIR)
         return make_id()
     path = id_path(tag, directory)
     if rank == 0:
+        try:
+            os.remove(path)                                # a file an earlier launch under the same tag left behind (it died between
+        except OSError:                                    # publishing and the unlink behind its first barrier)
+            pass
         blob = make_id()
         tmp = path + ".tmp%d" % os.getpid()
         with open(tmp, "wb") as fh:
@@ -112,11 +131,15 @@ def exchange_id(rank, world, make_id, tag=None, timeout=300.0, directory=ID_DIR)
         os.replace(tmp, path)                              # atomic: readers see nothing or all of it
         return blob
     t0 = time.time()
+    # a file much older than THIS process cannot be for it (launchers whose ranks are children of a long-lived parent -- a shell
+    # loop, a notebook -- give two successive launches the same tag): the window is generous because ranks may start seconds apart
+    oldest = _process_start_time() - STALE_ID_SKEW_S
     while True:
         try:
             with open(path, "rb") as fh:
                 blob = fh.read()
-            if len(blob) == ID_BYTES:
+                fresh = os.fstat(fh.fileno()).st_mtime >= oldest
+            if len(blob) == ID_BYTES and fresh:
                 return blob
         except (IOError, OSError):
             pass
@@ -165,11 +188,15 @@ class Comm(object):
         return cls(rank, world, local if device is None else device)
 
     def close(self):
+        """frees the communicator and its page-locked buffers -- views handed out by gather_tables(copy=False) die with them"""
         for k in ("_pin_send", "_pin_recv"):
             buf = getattr(self, k, None)
             if buf is not None:
                 self._lib.cl_comm_host_free(ctypes.c_void_p(buf[0]))
                 setattr(self, k, None)
+        for p in getattr(self, "_retired", []):
+            self._lib.cl_comm_host_free(ctypes.c_void_p(p))
+        self._retired = []
         if getattr(self, "_h", None):
             self._lib.cl_comm_destroy(self._h)
             self._h = None
@@ -179,7 +206,10 @@ class Comm(object):
         buf = getattr(self, which, None)
         if buf is None or buf[1] < nbytes:
             if buf is not None:
-                self._lib.cl_comm_host_free(ctypes.c_void_p(buf[0]))
+                # views of the old buffer may still be out (gather_tables(copy=False)): it is kept until close()
+                if not hasattr(self, "_retired"):
+                    self._retired = []
+                self._retired.append(buf[0])
             want = int(nbytes + nbytes // 4 + 4096)
             p = self._lib.cl_comm_host_alloc(want)
             if not p:
@@ -210,7 +240,8 @@ class Comm(object):
     def gather_tables(self, table, dst=None, copy=True):
         """variable-length int32 [K_r, C] tables from every rank -> list of per-rank arrays (on `dst` only when given; the
         other ranks get empty tables).  `table` may be a list of tables (their concatenation).  Two collectives: the row
-        counts, then the rows padded to the longest table."""
+        counts, then the rows padded to the longest table.  copy=False hands out VIEWS of the communicator's page-locked
+        receive buffer: the next gather overwrites them, close() frees them.)"""
         tabs = [np.asarray(t) for t in table] if isinstance(table, (list, tuple)) else [np.asarray(table)]
         if not tabs or any(t.ndim != 2 for t in tabs) or len({t.shape[1] for t in tabs}) > 1:
             raise ValueError("tables must be a non-empty list of [K, C] arrays with one C")

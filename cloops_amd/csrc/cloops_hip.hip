@@ -3252,10 +3252,27 @@ extern "C" int cl_cluster(cl_chrom* c, int variant, int32_t eps, int32_t min_pts
     return finish_wait(c, n_clusters, max_label);
 }
 
+// A run that fails half-way (allocation, a HIP error between two launches) must not leave state behind that a later run would
+// trust: the count cache it may have marked valid before its words were written, the tickets of the in-kernel scans and the
+// superblock sums of the list kernels (all "zero between kernels").
+struct RunGuard {
+    cl_chrom* c; bool armed = true;
+    explicit RunGuard(cl_chrom* cc) : c(cc) {}
+    ~RunGuard()
+    {
+        if (!armed) return;
+        c->rc.valid = false;
+        c->l_sup_dirty = true;
+        if (c->counters.p) (void)hipMemsetAsync(c->counters.as<int>() + CTR_TICKET_A, 0, 8, c->stream);
+        (void)hipGetLastError();
+    }
+};
+
 static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, int32_t* labels_out)
 {
     int rc;
     GridParams g;
+    RunGuard guard(c);
 #ifdef CLOOPS_DEVEL
     // developer build: host time of the enqueue, by section (CLOOPS_TRACE_ENQ=<ms> prints the calls above that)
     static const double trace_ms = getenv("CLOOPS_TRACE_ENQ") ? atof(getenv("CLOOPS_TRACE_ENQ")) : -1.0;
@@ -3426,7 +3443,9 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
                        c->chainhead.as<int>(), rows ? c->slot[c->cur].labels.as<int>() : (int*)nullptr, c->slot[c->cur].slab.as<int>(), t);
     }
     HIP_TRY(hipGetLastError());
-    return finish_enqueue(c, g.S + 2, c->w_dM ? c->w_dM : strip + g.S, labels_out);
+    rc = finish_enqueue(c, g.S + 2, c->w_dM ? c->w_dM : strip + g.S, labels_out);
+    guard.armed = rc != CL_OK;
+    return rc;
 }
 
 

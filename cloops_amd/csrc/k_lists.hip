@@ -1299,23 +1299,33 @@ k_emit_records_w(GridParams g, const int* __restrict__ lcnt, const unsigned long
                 return w == 0 ? ((p >= pbeg) & (q >= qlo)) : w == 1 ? ((p < pend) & (q <= qhi)) : w == 2 ? ((p < pbeg) & (q <= qhi)) : ((p < pend2) & (q <= qhi));
             };
             auto acc = [&](int w, int p) { return w == 2 ? p >= plo : (w == 3 ? p <= phi : true); };
+            // one round: 64 cores of walk w -> true if the walk goes on behind them
+            auto round = [&](int w, bool in, int2 p, int r) {
+                const bool ok = in && more(w, p.x, p.y);
+                const int rv = (ok && acc(w, p.y)) ? r : -1;
+                unsigned long long pending = __ballot(rv >= 0);
+                while (pending) {
+                    const int R = __builtin_amdgcn_readlane(rv, __ffsll((long long)pending) - 1);
+                    pending &= ~__ballot(rv == R);
+                    see(R);
+                }
+                return __ballot(ok) == ~0ull;
+            };
+            // the first rounds of all four walks in flight together (the kernel is a handful of waves deep in dependent loads)
+            int2 p0[4]; int r0[4]; bool in0[4];
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                bool on = true;
-                for (int rnd = 0; on; ++rnd) {
+                const int j = w == 0 ? start[w] - lane : start[w] + lane;
+                in0[w] = j >= 0 && j < C;
+                p0[w] = in0[w] ? cpair[j] : make_int2(0, 0); r0[w] = in0[w] ? croot[j] : -1;
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                bool on = round(w, in0[w], p0[w], r0[w]);
+                for (int rnd = 1; on; ++rnd) {
                     const int j = w == 0 ? start[w] - lane - 64 * rnd : start[w] + lane + 64 * rnd;
                     const bool in = j >= 0 && j < C;
-                    const int2 p = in ? cpair[j] : make_int2(0, 0);
-                    const int r = in ? croot[j] : -1;
-                    const bool ok = in && more(w, p.x, p.y);
-                    const int rv = (ok && acc(w, p.y)) ? r : -1;
-                    unsigned long long pending = __ballot(rv >= 0);
-                    while (pending) {
-                        const int R = __builtin_amdgcn_readlane(rv, __ffsll((long long)pending) - 1);
-                        pending &= ~__ballot(rv == R);
-                        see(R);
-                    }
-                    on = __ballot(ok) == ~0ull;
+                    on = round(w, in, in ? cpair[j] : make_int2(0, 0), in ? croot[j] : -1);
                 }
             }
             if (lane == 0) {

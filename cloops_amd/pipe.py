@@ -91,7 +91,7 @@ STREAMS = _StreamPool()
 
 
 def _make_chrom(X, Y, device):
-    """a resident chromosome on one of the device's shared streams; -> (chromosome, pool slot)"""
+    """a resident chromosome on one of the device's shared streams (its close() also gives the stream's slot back) -> chromosome"""
     stream, slot = STREAMS.pick(device, len(X))
     try:
         ch = api.Chromosome(X, Y, device=device, stream=stream) if stream else api.Chromosome(X, Y, device=device)

@@ -217,3 +217,32 @@ def test_dist_stats_cut_sources(jd, flip):
                 sumlog = st["sumx"][g] + st["xshift"] * len(a)
                 assert abs(sumlog - np.log2(a).sum()) < 1e-6 * max(1.0, np.log2(a).sum())
     ch.close()
+
+
+def test_two_workers_on_one_device(monkeypatch):
+    """the multi-device dispatch of runDBSCAN / runSweepFast (cLoops/pipe.py:117: one worker per chromosome group) with what one GPU can
+    exercise of it: CLOOPS_DEVICES=0,0 = two workers (host threads, LPT shares of the chromosomes) on device 0 -- same result
+    as the single-worker form.  (RCCL refuses two ranks on one device: world > 1 stays untested until a multi-GPU node exists.)"""
+    from cloops_amd.synth import synth_chrom
+    chroms = {}
+    for k, (n, L) in enumerate(((60000, 40000000), (45000, 30000000), (30000, 20000000), (20000, 15000000))):
+        chroms["chr%d-chr%d" % (k + 1, k + 1)] = synth_chrom(n, L, 50 + k)
+
+    def run_all():
+        pipe.CACHE.clear()
+        fs = [pipe.CACHE.put_arrays(name, X, Y) for name, (X, Y) in chroms.items()]
+        one = pipe.runDBSCAN(fs, 2000, 5, cut=0)
+        sweep = pipe.runSweepFast(fs, [1000, 2000], [6, 4], cut=0)
+        pipe.CACHE.clear()
+        return one, sweep
+
+    monkeypatch.delenv("CLOOPS_DEVICES", raising=False)
+    (dI1, dS1, dis1, dss1), (sI1, cut1, cuts1, steps1) = run_all()
+    monkeypatch.setenv("CLOOPS_DEVICES", "0,0")
+    assert pipe._devices() == [0, 0]
+    (dI2, dS2, dis2, dss2), (sI2, cut2, cuts2, steps2) = run_all()
+    assert list(dI1) == list(dI2) and all(dI1[k]["records"] == dI2[k]["records"] for k in dI1)
+    assert dS1 == dS2 and dis1 == dis2 and dss1 == dss2
+    assert cut1 == cut2 and cuts1 == cuts2
+    assert [(s["n_inter"], s["n_self"], s.get("cut_out")) for s in steps1] == [(s["n_inter"], s["n_self"], s.get("cut_out")) for s in steps2]
+    assert list(sI1) == list(sI2) and all(np.array_equal(sI1[k]["boxes"], sI2[k]["boxes"]) for k in sI1)
