@@ -264,10 +264,13 @@ def main(argv=None):
 
     def one_sweep(log_k2):
         dataI, cut, cuts, steps = pipe.runSweepFast(fs, eps_list, minpts_list, cut=0, variant=VARIANT, allsum=allsum,
-                                                    probe=probe if (log_k2 and rank == 0) else None)
-        if use_dist:
-            # the path's final exchange (cLoops/pipe.py:119-127 merges its workers' results): all candidate tables
-            # (to rank 0, where the reference's parent process merges them; the other ranks do not copy everybody's rows back)
+                                                    probe=probe if (log_k2 and rank == 0) else None, finish_device=comm is not None)
+        if comm is not None:
+            # the path's final exchange (cLoops/pipe.py:119-127 merges its workers' results): the candidate tables go to rank 0 from
+            # where cl_cand_finish_device left them -- exact sizes over RCCL, one device-to-host copy at the root, none elsewhere
+            tabs = comm.gather_device([v["dev_rows"] for v in dataI.values()], [v["n_rows"] for v in dataI.values()], dst=0, copy=False)
+            ncand = sum(len(t) for t in tabs)
+        elif use_dist:
             rows = [v["boxes"] for v in dataI.values() if len(v["boxes"])]
             rows = rows if rows else np.zeros((0, 4), np.int32)
             tabs = comm.gather_tables(rows, dst=0, copy=False) if comm is not None else gather_tables(rows, device=tdev, dst=0, copy=False)
@@ -580,15 +583,19 @@ def scaling_proxy(pipe, lpt_assign, fs, sizes, steps, nranks, one_gpu_sweep_s, r
         for _ in range(len(steps) + 1):
             c1.allsum(vec)
         t_ar = time.perf_counter() - t0
-        rows = tables if tables else np.zeros((0, 4), np.int32)
-        c1.gather_tables(rows, dst=0, copy=False)
+        # the gather: the candidate tables of the whole genome where a sweep's dedup leaves them (device memory of the 23 resident
+        # handles) -> one page-locked buffer at the root (cl_comm_gather_device; at world size 1 every table is a direct
+        # device-to-host copy, a real root receives the other ranks' rows over xGMI into a device buffer first)
+        dres = pipe.runSweepFast(fs, eps, mps, cut=0, variant=VARIANT, forced_cuts=forced, finish_device=True)[0]
+        ptrs, nrows = [v["dev_rows"] for v in dres.values()], [v["n_rows"] for v in dres.values()]
+        c1.gather_device(ptrs, nrows, dst=0, copy=False)
         t0 = time.perf_counter()
-        ncand = sum(len(t) for t in c1.gather_tables(rows, dst=0, copy=False))
+        ncand = sum(len(t) for t in c1.gather_device(ptrs, nrows, dst=0, copy=False))
         t_g = time.perf_counter() - t0
         c1.close()
         out["exchanges_world1"] = {"allreduce_calls": len(steps) + 1, "allreduce_total_s": t_ar, "gather_rows": int(ncand), "gather_s": t_g,
                                    "rccl": c1.rccl_loaded,
-                                   "note": "through libcloops_comm.so on ONE rank: host staging + RCCL call + stream synchronisation, without the xGMI hops of a real ring"}
+                                   "note": "through libcloops_comm.so on ONE rank: the all-reduce with host staging + RCCL call + stream synchronisation, the gather device-resident (cl_comm_gather_device); without the xGMI hops of a real ring"}
         out["predicted_sweep_s"] = sum_of_max + t_ar + t_g
         out["predicted_speedup"] = one_gpu_sweep_s / out["predicted_sweep_s"]
     except Exception as e:                                   # (no RCCL on this box: the compute terms stand alone)

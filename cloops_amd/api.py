@@ -192,6 +192,13 @@ class Chromosome(object):
         _lib.check(self._lib.cl_cand_finish(self._h, int(final_cut), buf.ctypes.data_as(ctypes.c_void_p), int(capacity), ctypes.byref(k)))
         return buf[: int(k.value)].copy()
 
+    def cand_finish_device(self, final_cut):
+        """the same, leaving the boxes on the device -> (device pointer, rows); valid until the handle's next sweep finishes
+        (cl_cand_finish_device: what comm.Comm.gather_device sends to the merging rank)"""
+        ptr, k = ctypes.c_void_p(), ctypes.c_int64(0)
+        _lib.check(self._lib.cl_cand_finish_device(self._h, int(final_cut), ctypes.byref(ptr), ctypes.byref(k)))
+        return (ptr.value or 0), int(k.value)
+
     def set_sort_index(self, mode=1):
         """rows kept sorted by the in-strip coordinate, every eps' layout from a 2-pass strip sort of that order:
         0 = built at the handle's second sort (default), 1 = at the first, -1 = never (cl_set_sort_index)"""

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libcloops_comm.so")
 SYMBOLS = ("cl_comm_last_error", "cl_comm_rccl_version", "cl_comm_unique_id", "cl_comm_init", "cl_comm_destroy", "cl_comm_rank", "cl_comm_world",
            "cl_comm_allreduce_f64", "cl_comm_allreduce_max_f64", "cl_comm_allgather_i32", "cl_comm_gather_i32", "cl_comm_barrier",
-           "cl_comm_host_alloc", "cl_comm_host_free", "cl_comm_gather_i32_pinned")
+           "cl_comm_host_alloc", "cl_comm_host_free", "cl_comm_gather_i32_pinned", "cl_comm_gather_device", "cl_comm_allreduce_f64_device")
 ID_BYTES = 128
 ID_DIR = "/tmp"
 _lib = None
@@ -77,6 +77,8 @@ def load():
     lib.cl_comm_host_free.restype = None
     lib.cl_comm_host_free.argtypes = [vp]
     lib.cl_comm_gather_i32_pinned.argtypes = [vp, vp, i64, ctypes.c_int, vp]
+    lib.cl_comm_gather_device.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int, vp, i64, vp]
+    lib.cl_comm_allreduce_f64_device.argtypes = [vp, vp, i64, vp]
     _lib = lib
     return lib
 
@@ -236,6 +238,41 @@ class Comm(object):
 
     def make_allsum(self):
         return self.allsum
+
+    def gather_device(self, ptrs, rows, cols=4, dst=0, copy=True):
+        """DEVICE-RESIDENT tables (api.Chromosome.cand_finish_device: pointer + rows, one per chromosome of this rank) to rank
+        `dst`: exact sizes, ranks in order, one device-to-host copy at `dst` (cl_comm_gather_device) -> list of per-rank int32
+        [K_r, cols] arrays on `dst` (empty tables elsewhere).  copy=False: views of the communicator's page-locked buffer."""
+        keep = [(int(p), int(k)) for p, k in zip(ptrs, rows) if int(k) > 0]
+        nt = len(keep)
+        tp = (ctypes.c_void_p * max(nt, 1))(*[p for p, _ in keep])
+        tr = (ctypes.c_int64 * max(nt, 1))(*[k for _, k in keep])
+        per = (ctypes.c_int64 * self.world)()
+        mine = sum(k for _, k in keep)
+        # (the receive buffer must exist before the counts are known on this rank: sized by a first exchange of the counts when it
+        #  is too small -- the library all-gathers them again, a few microseconds)
+        recv = self.rank == dst
+        need_rows = mine if self.world == 1 else None
+        if need_rows is None:
+            cnt = np.zeros(self.world, dtype=np.int32)
+            _check(self._lib.cl_comm_allgather_i32(self._h, np.asarray([mine], np.int32).ctypes.data_as(ctypes.c_void_p), 1, cnt.ctypes.data_as(ctypes.c_void_p)))
+            need_rows = int(cnt.astype(np.int64).sum())
+        out = self._pinned("_pin_recv", max(need_rows, 1) * cols * 4) if recv else None
+        outp = out.ctypes.data_as(ctypes.c_void_p) if recv else None
+        _check(self._lib.cl_comm_gather_device(self._h, tp, tr, nt, int(cols), int(dst), outp, int(need_rows), per))
+        if not recv:
+            return [np.zeros((0, cols), np.int32) for _ in range(self.world)]
+        res, at = [], 0
+        for r in range(self.world):
+            k = int(per[r])
+            v = out[at * cols:(at + k) * cols].reshape(k, cols)
+            res.append(v.copy() if copy else v)
+            at += k
+        return res
+
+    def allsum_device(self, dev_ptr, n, stream=None):
+        """element-wise sum over the ranks of n float64 in place in DEVICE memory (cl_comm_allreduce_f64_device)"""
+        _check(self._lib.cl_comm_allreduce_f64_device(self._h, ctypes.c_void_p(dev_ptr), int(n), ctypes.c_void_p(stream)))
 
     def gather_tables(self, table, dst=None, copy=True):
         """variable-length int32 [K_r, C] tables from every rank -> list of per-rank arrays (on `dst` only when given; the

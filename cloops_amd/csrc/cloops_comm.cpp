@@ -181,6 +181,90 @@ extern "C" int cl_comm_gather_i32(cl_comm* c, const int32_t* hin, int64_t n, int
     return gather_i32(c, hin, n, root, hout);
 }
 
+// ---- device-resident exchanges ------------------------------------------------------------------------------------
+extern "C" int cl_comm_allreduce_f64_device(cl_comm* c, double* dev, int64_t n, void* stream)
+{
+    if (!c || (n > 0 && !dev) || n < 0) return cfail("cl_comm_allreduce_f64_device", "bad arguments");
+    if (n == 0) return 0;
+    HIPC(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    NCC(ncclAllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, c->comm, st));
+    if (!stream) HIPC(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int cl_comm_gather_device(cl_comm* c, const int32_t* const* tabs, const int64_t* rows, int32_t ntab, int32_t cols, int root,
+                                     int32_t* pinned_out, int64_t cap_rows, int64_t* rank_rows)
+{
+    if (!c || ntab < 0 || cols <= 0 || root < 0 || root >= c->world || !rank_rows || (ntab > 0 && (!tabs || !rows)))
+        return cfail("cl_comm_gather_device", "bad arguments");
+    HIPC(hipSetDevice(c->device));
+    long long mine = 0;
+    for (int k = 0; k < ntab; ++k) { if (rows[k] < 0 || (rows[k] > 0 && !tabs[k])) return cfail("cl_comm_gather_device", "bad table"); mine += rows[k]; }
+    // the row counts of all ranks (two int32 halves per rank: a 200 M-PET genome stays far below 2^31 rows, a larger one may not)
+    int32_t cnt[2] = {(int32_t)(mine & 0x7fffffff), (int32_t)(mine >> 31)};
+    {
+        const size_t in_bytes = 8, out_bytes = in_bytes * (size_t)c->world;
+        int rc = ensure(c, out_bytes + 64, 256 + out_bytes);
+        if (rc) return rc;
+        memcpy(c->pin, cnt, in_bytes);
+        HIPC(hipMemcpyAsync(c->dev, c->pin, in_bytes, hipMemcpyHostToDevice, c->stream));
+        NCC(ncclAllGather(c->dev, (char*)c->dev + 256, 2, ncclInt32, c->comm, c->stream));
+        HIPC(hipMemcpyAsync((char*)c->pin + 64, (char*)c->dev + 256, out_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+        const int32_t* all = (const int32_t*)((char*)c->pin + 64);
+        for (int r = 0; r < c->world; ++r) rank_rows[r] = (long long)all[2 * r] + ((long long)all[2 * r + 1] << 31);
+    }
+    long long total = 0;
+    for (int r = 0; r < c->world; ++r) total += rank_rows[r];
+    const size_t row_bytes = (size_t)cols * 4;
+    if (c->rank == root) {
+        if (total > cap_rows) return cfail("cl_comm_gather_device", "pinned_out too small");
+        if (total > 0 && !pinned_out) return cfail("cl_comm_gather_device", "null receive buffer");
+        if (c->world == 1) {
+            // one rank: every table goes straight to its place in the caller's page-locked buffer
+            size_t at = 0;
+            for (int k = 0; k < ntab; ++k)
+                if (rows[k] > 0) { HIPC(hipMemcpyAsync((char*)pinned_out + at, tabs[k], (size_t)rows[k] * row_bytes, hipMemcpyDeviceToHost, c->stream)); at += (size_t)rows[k] * row_bytes; }
+            HIPC(hipStreamSynchronize(c->stream));
+            return 0;
+        }
+        int rc = ensure(c, 0, (size_t)total * row_bytes + 256);
+        if (rc) return rc;
+        char* stage = (char*)c->dev;
+        size_t at = 0;
+        NCC(ncclGroupStart());
+        for (int r = 0; r < c->world; ++r) {
+            const size_t nb = (size_t)rank_rows[r] * row_bytes;
+            if (r == root) {
+                size_t a2 = at;
+                for (int k = 0; k < ntab; ++k)
+                    if (rows[k] > 0) { HIPC(hipMemcpyAsync(stage + a2, tabs[k], (size_t)rows[k] * row_bytes, hipMemcpyDeviceToDevice, c->stream)); a2 += (size_t)rows[k] * row_bytes; }
+            } else if (nb > 0) {
+                NCC(ncclRecv(stage + at, (size_t)rank_rows[r] * cols, ncclInt32, r, c->comm, c->stream));
+            }
+            at += nb;
+        }
+        NCC(ncclGroupEnd());
+        if (total > 0) HIPC(hipMemcpyAsync(pinned_out, stage, (size_t)total * row_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+    } else {
+        // (one message per rank: its tables are packed device-to-device first, so that the root posts ONE receive per rank)
+        if (mine > 0) {
+            int rc = ensure(c, 0, (size_t)mine * row_bytes + 256);
+            if (rc) return rc;
+            size_t at = 0;
+            for (int k = 0; k < ntab; ++k)
+                if (rows[k] > 0) { HIPC(hipMemcpyAsync((char*)c->dev + at, tabs[k], (size_t)rows[k] * row_bytes, hipMemcpyDeviceToDevice, c->stream)); at += (size_t)rows[k] * row_bytes; }
+            NCC(ncclGroupStart());
+            NCC(ncclSend(c->dev, (size_t)mine * cols, ncclInt32, root, c->comm, c->stream));
+            NCC(ncclGroupEnd());
+        }
+        HIPC(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
 extern "C" int cl_comm_barrier(cl_comm* c)
 {
     // everything this process has enqueued on the device is done, then all ranks meet

@@ -605,10 +605,41 @@ extern "C" int cl_cand_append(cl_chrom* c, int32_t step, int64_t* n_inter, int64
     return CL_OK;
 }
 
+// combineTwice + filterClusterByDis over the chromosome's candidate buffer -> the surviving boxes in c->cand_out (device), *kept of them
+static int cand_finish_core(cl_chrom* c, int32_t final_cut, long long* kept_out);
+
 extern "C" int cl_cand_finish(cl_chrom* c, int32_t final_cut, int32_t* boxes_out, int64_t capacity, int64_t* n_out)
 {
     if (!c || !n_out) return fail(CL_ERR_ARG, "cl_cand_finish: null argument");
     *n_out = 0;
+    long long kept = 0;
+    int rc = cand_finish_core(c, final_cut, &kept);
+    if (rc) return rc;
+    *n_out = kept;
+    if (kept > capacity) return fail(CL_ERR_ARG, "cl_cand_finish: boxes_out too small");
+    if (kept > 0) {
+        if (!boxes_out) return fail(CL_ERR_ARG, "cl_cand_finish: boxes_out is null");
+        HIP_TRY(hipMemcpyAsync(boxes_out, c->cand_out.p, (size_t)kept * 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return CL_OK;
+}
+
+extern "C" int cl_cand_finish_device(cl_chrom* c, int32_t final_cut, const int32_t** dev_rows_out, int64_t* n_out)
+{
+    if (!c || !n_out || !dev_rows_out) return fail(CL_ERR_ARG, "cl_cand_finish_device: null argument");
+    *n_out = 0; *dev_rows_out = nullptr;
+    long long kept = 0;
+    int rc = cand_finish_core(c, final_cut, &kept);
+    if (rc) return rc;
+    *n_out = kept;
+    *dev_rows_out = kept > 0 ? (const int32_t*)c->cand_out.p : nullptr;      // valid until the handle's next sweep finishes (or it is destroyed)
+    return CL_OK;
+}
+
+static int cand_finish_core(cl_chrom* c, int32_t final_cut, long long* kept_out)
+{
+    *kept_out = 0;
     const long long N = c->cand_n;
     if (N == 0) return CL_OK;
     if (c->enq != c->deq) return fail(CL_ERR_ARG, "cl_cand_finish: asynchronous runs still in flight");
@@ -681,14 +712,7 @@ extern "C" int cl_cand_finish(cl_chrom* c, int32_t final_cut, int32_t* boxes_out
     HIP_TRY(hipMemcpyAsync(&tail[1], bcount + nb - 1, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     CF_MARK();
-    const long long kept = (long long)tail[0] + tail[1];
-    *n_out = kept;
-    if (kept > capacity) return fail(CL_ERR_ARG, "cl_cand_finish: boxes_out too small");
-    if (kept > 0) {
-        if (!boxes_out) return fail(CL_ERR_ARG, "cl_cand_finish: boxes_out is null");
-        HIP_TRY(hipMemcpyAsync(boxes_out, c->cand_out.p, (size_t)kept * 16, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
+    *kept_out = (long long)tail[0] + tail[1];
     return CL_OK;
 }
 

@@ -556,7 +556,7 @@ def _lib_logbins():
 CUT_RECHECK_MARGIN = 1e-6
 
 
-def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, allsum=None, probe=None, forced_cuts=None):
+def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, allsum=None, probe=None, forced_cuts=None, finish_device=False):
     """runSweep with the per-step statistics reduced on the GPUs: neither labels nor distance
     lists come back to the host -- per chromosome only the K-row cluster table, a few sums, and
     the 256-bin histograms of an exact radix select for the median (all additive over chromosomes
@@ -575,15 +575,19 @@ def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, 
     of its work, the estimate included) -- bench.py replays the genome-wide chain on one emulated rank's share of the
     chromosomes with it.
 
+    `finish_device`: the candidate tables stay on the device ({"f": f, "dev_rows": pointer, "n_rows": k, "boxes": None} per
+    chromosome, valid until the handle's next sweep finishes): a multi-rank run hands them to comm.Comm.gather_device, which sends
+    exact sizes to the merging rank without a detour through the host (cLoops/pipe.py:119-127 merges in the parent).
+
     returns (dataI {key: {"f": f, "boxes": int32[k,4]}} of the local chromosomes, cut, cuts, steps)."""
     variant = variant or DBSCAN_VARIANT
     gsum = allsum if allsum is not None else (lambda a: a)
     devs = _devices()
     with CACHE.pinned(fs, devs) as res_all:
-        return _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gsum, probe, forced_cuts)
+        return _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gsum, probe, forced_cuts, finish_device)
 
 
-def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gsum, probe=None, forced_cuts=None):
+def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gsum, probe=None, forced_cuts=None, finish_device=False):
     cuts = [cut]
     steps = []
     live = [(f, r) for f, r in zip(fs, res_all) if len(r.d)]
@@ -756,6 +760,9 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
         def finish(fr):
             f, r = fr
             with r.lock:
+                if finish_device:
+                    ptr, k = r.chrom.cand_finish_device(final_cut)
+                    return r.key, {"f": f, "boxes": None, "dev_rows": ptr, "n_rows": k}
                 b = r.chrom.cand_finish(final_cut, appended[f])
             return r.key, {"f": f, "boxes": b}                # int32 [k, 4] rows (minX, maxX, minY, maxY), append order
 

@@ -63,6 +63,20 @@ void* cl_comm_host_alloc(int64_t bytes);
 void cl_comm_host_free(void* p);
 int cl_comm_gather_i32_pinned(cl_comm* c, const int32_t* pinned_in, int64_t n, int root, int32_t* pinned_out);
 
+/* DEVICE-RESIDENT exchanges (exact-size send / receive of the loop tables, statistics reduced where the kernels
+ * left them).
+ * cl_comm_gather_device: every rank hands `ntab` int32 tables of rows[k] x cols that live in ITS device memory (the candidate
+ * tables cl_cand_finish_device left there); `root` receives all of them -- ranks in order, a rank's tables in the order given,
+ * exact sizes (row counts all-gathered first, then grouped ncclSend / ncclRecv; the root's own tables are device-to-device
+ * copies) -- and copies the whole once to `pinned_out` (page-locked, cap_rows rows); rank_rows_out[world] = rows per rank
+ * (every rank gets the counts).  The sending ranks touch neither host memory nor PCIe.
+ * cl_comm_allreduce_f64_device: element-wise sum over the ranks of n float64 IN PLACE in device memory (the buffer the step's
+ * last kernel wrote), on `stream` (the caller's; NULL = the communicator's own) -- no host staging; the caller copies the
+ * result out once. */
+int cl_comm_gather_device(cl_comm* c, const int32_t* const* dev_tables, const int64_t* rows, int32_t ntab, int32_t cols, int root,
+                          int32_t* pinned_out, int64_t cap_rows, int64_t* rank_rows_out);
+int cl_comm_allreduce_f64_device(cl_comm* c, double* dev_inout, int64_t n, void* stream);
+
 /* hipDeviceSynchronize() of this rank's device, then a barrier over all ranks (an all-reduce of one element) */
 int cl_comm_barrier(cl_comm* c);
 

@@ -235,6 +235,11 @@ int cl_cluster_step_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts
 int cl_step_result(cl_chrom* c, int64_t* n_inter, int64_t* n_self, cl_dsummary* out);
 int cl_cand_append(cl_chrom* c, int32_t step, int64_t* n_inter, int64_t* n_self);
 int cl_cand_finish(cl_chrom* c, int32_t final_cut, int32_t* boxes_out, int64_t capacity, int64_t* n_out);
+/* The same, leaving the surviving boxes ON THE DEVICE: *dev_rows_out = n_out rows of {minX, maxX, minY, maxY} int32 in device
+ * memory of the handle (valid until its next sweep finishes or it is destroyed) -- what cl_comm_gather_device
+ * (include/cloops_comm.h) sends to the rank that merges the ranks' tables (cLoops/pipe.py:119-127 merges in the parent),
+ * without a detour through the host on the sending ranks. */
+int cl_cand_finish_device(cl_chrom* c, int32_t final_cut, const int32_t** dev_rows_out, int64_t* n_out);
 
 /* The cluster table of a run goes to pinned host memory at its end (cl_boxes_host / cl_get_boxes); enabled = 0
  * skips that copy for the following runs (callers that only use cl_cand_append / the distance statistics). */

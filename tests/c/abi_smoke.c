@@ -75,6 +75,24 @@ int main(void)
         free(lab2);
         cl_chrom_destroy(d);
     }
+    {
+        /* a sweep step + the candidate table left on the device (cl_cand_finish_device: what cl_comm_gather_device sends) next to the
+           host form: the same rows */
+        int64_t ni = 0, ns = 0, k_host = 0, k_dev = 0;
+        const int32_t* dev_rows = NULL;
+        cl_dsummary* sm = malloc(sizeof *sm);
+        if (!sm) return 14;
+        CHECK(cl_cand_reset(c));
+        CHECK(cl_cluster_step_async(c, CL_VARIANT_CDBSCAN2, 2000, 5, 0, 0, -1));
+        CHECK(cl_wait(c, &nc, &ml));
+        CHECK(cl_step_result(c, &ni, &ns, sm));
+        int32_t* hb = malloc((size_t)(ni + 1) * 16);
+        CHECK(cl_cand_finish(c, 0, hb, ni, &k_host));
+        CHECK(cl_cand_finish_device(c, 0, &dev_rows, &k_dev));
+        if (k_host != k_dev || (k_dev > 0 && !dev_rows)) { fprintf(stderr, "cand_finish_device: %lld rows, host form %lld\n", (long long)k_dev, (long long)k_host); return 15; }
+        printf("sweep step: %lld inter-ligation boxes, %lld kept (host and device forms)\n", (long long)ni, (long long)k_dev);
+        free(hb); free(sm);
+    }
     if (cl_cluster(c, 7, 2000, 5, 0, lab, &nc, &ml) != CL_ERR_ARG) return 8;          /* unknown variant */
     if (cl_cluster(c, CL_VARIANT_CDBSCAN2, 0, 5, 0, lab, &nc, &ml) != CL_ERR_ARG) return 9;   /* eps = 0 */
     cl_chrom_destroy(c);

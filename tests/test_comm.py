@@ -64,6 +64,41 @@ def test_collectives_at_world_one():
         c.close()
 
 
+@pytest.mark.gpu
+def test_device_resident_exchanges_at_world_one():
+    """cl_comm_gather_device / cl_comm_allreduce_f64_device: the candidate tables go to the merging rank from where
+    cl_cand_finish_device left them, the statistics are reduced in device memory -- at world size 1 (one MI355X per box)"""
+    import ctypes
+    from cloops_amd import api, pipe
+    from cloops_amd.synth import synth_chrom
+    pipe.CACHE.clear()
+    fs = [pipe.CACHE.put_arrays("chr%d-chr%d" % (k, k), *synth_chrom(n, 30000000, 60 + k)) for k, n in enumerate((90000, 60000, 30000), 1)]
+    c = comm.Comm(0, 1, 0)
+    try:
+        host = pipe.runSweepFast(fs, [1000, 2000], [6, 4], cut=0)[0]
+        dev = pipe.runSweepFast(fs, [1000, 2000], [6, 4], cut=0, finish_device=True)[0]
+        assert list(host) == list(dev) and all(v["boxes"] is None and v["n_rows"] == len(host[k]["boxes"]) for k, v in dev.items())
+        out = c.gather_device([v["dev_rows"] for v in dev.values()], [v["n_rows"] for v in dev.values()], dst=0)
+        assert len(out) == 1 and np.array_equal(out[0], np.concatenate([host[k]["boxes"] for k in host]))
+        assert c.gather_device([], [], dst=0)[0].shape == (0, 4)
+        # the all-reduce in place in device memory: a double buffer of the HIP runtime's own
+        hip = ctypes.CDLL("libamdhip64.so")
+        ptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(8 * 1000)) == 0
+        try:
+            a = np.linspace(-3.0, 5.0, 1000)
+            assert hip.hipMemcpy(ptr, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(8000), 1) == 0
+            c.allsum_device(ptr.value, 1000)
+            b = np.zeros(1000)
+            assert hip.hipMemcpy(b.ctypes.data_as(ctypes.c_void_p), ptr, ctypes.c_size_t(8000), 2) == 0
+            assert np.array_equal(a, b)
+        finally:
+            hip.hipFree(ptr)
+    finally:
+        c.close()
+        pipe.CACHE.clear()
+
+
 # ---- the Python side of Comm at world size > 1, over a stand-in for libcloops_comm.so ---------------------------------
 class _Hub(object):
     """what RCCL does, in one process: every rank deposits its buffer, a barrier, everybody reads what it needs"""

@@ -1,14 +1,28 @@
-import os, sys, time
+"""Developer tool: the device-resident gather at world size 1 (cl_comm_gather_device) against one plain device-to-host copy of the
+same bytes.  python tools/gather_probe.py"""
+import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch, torch.distributed as dist
-os.environ.setdefault("MASTER_ADDR","127.0.0.1"); os.environ.setdefault("MASTER_PORT","29544"); os.environ.setdefault("RANK","0"); os.environ.setdefault("WORLD_SIZE","1")
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", device_id=torch.device("cuda",0))
-from cloops_amd.dist import gather_tables
-tab = np.random.randint(0, 1<<28, (78806,5)).astype(np.int32)
-dev = torch.device("cuda",0)
-for it in range(5):
-    torch.cuda.synchronize(); t=time.perf_counter(); out = gather_tables(tab, device=dev); torch.cuda.synchronize(); print("gather", round((time.perf_counter()-t)*1e3,3),"ms")
-for it in range(3):
-    t=time.perf_counter(); dist.barrier(); torch.cuda.synchronize(); print("barrier", round((time.perf_counter()-t)*1e3,3),"ms")
-dist.destroy_process_group()
+import numpy as np
+from cloops_amd import pipe, comm
+from cloops_amd.synth import synth_chrom, chrom_sizes
+pipe.CACHE.clear()
+fs = []
+for ci, (name, length, n) in enumerate(chrom_sizes(int(sys.argv[1]) if len(sys.argv) > 1 else 100000000)):
+    X, Y = synth_chrom(n, length, 3000 + ci)
+    fs.append(pipe.CACHE.put_arrays("%s-%s" % (name, name), X, Y))
+c = comm.Comm(0, 1, 0)
+d = pipe.runSweepFast(fs, [5000, 7500], [50, 30], cut=0, finish_device=True)[0]
+ptrs, rows = [v["dev_rows"] for v in d.values()], [v["n_rows"] for v in d.values()]
+tot = sum(rows)
+for k in range(4):
+    t0 = time.perf_counter()
+    out = c.gather_device(ptrs, rows, dst=0, copy=False)
+    print("gather_device: %d rows (%.1f MB) in %.2f ms" % (len(out[0]), tot * 16 / 1e6, 1e3 * (time.perf_counter() - t0)))
+hip = ctypes.CDLL("libamdhip64.so")
+dev, host = ctypes.c_void_p(), ctypes.c_void_p()
+hip.hipMalloc(ctypes.byref(dev), ctypes.c_size_t(tot * 16)); hip.hipHostMalloc(ctypes.byref(host), ctypes.c_size_t(tot * 16), 0)
+for k in range(3):
+    t0 = time.perf_counter()
+    hip.hipMemcpy(host, dev, ctypes.c_size_t(tot * 16), 2)
+    print("one hipMemcpy D2H of the same bytes: %.2f ms" % (1e3 * (time.perf_counter() - t0)))
+c.close()

@@ -1,0 +1,7 @@
+import sys, os, json, io, contextlib
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+import cloops_amd.pipe as p
+p.SWEEP_STREAMS = int(sys.argv[1])
+import bench
+sys.argv = ["bench.py", "--steps", "6", "--warmup", "1", "--no-cpu-baseline", "--no-with-labels", "--no-secondary", "--proxy-ranks", "0"]
+bench.main()
