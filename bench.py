@@ -492,33 +492,63 @@ def roofline_block(replay, n_probe):
 
 def with_labels_sweep(pipe, fs, steps, pets_per_sweep, reps=2):
     """SURVEY.md 8d(1)'s end point on the headline workload: the same 12 runs (the chain's own eps, minPts, cut) over the same
-    23 resident chromosomes, every run landing ROW-ALIGNED labels and its cluster table in pinned host memory (what
-    cLoops/pipe.py:70-102 consumes) -- the row-order label scatter and 0.8 GB of labels over PCIe per run that the sweep's
-    own form (statistics and candidates on the device) never pays.  All chromosomes of a run are enqueued, then collected."""
+    23 resident chromosomes, every run landing its labels and its cluster table in pinned host memory (what
+    cLoops/pipe.py:70-102 consumes) -- which the sweep's own form (statistics and candidates on the device) never pays.
+    Two forms: the labels as the reference holds them, CLUSTERED points only (`.labels` is a dict of them, cDBSCAN2.py:186-191): one
+    (row, label) pair per labelled PET, written by the label kernel straight into page-locked memory (cl_cluster_pairs_async) -- the
+    figure; and row-aligned int32 labels of every PET (`row_aligned`: the row-order scatter and 0.8 GB over PCIe per run).
+    All chromosomes of a run are enqueued, then collected."""
     res = [pipe.CACHE.get(f) for f in fs]
     res.sort(key=lambda r: -len(r.d))
-    for r in res:
-        r.chrom.set_device_labels(True)
 
-    def sweep():
+    # the cuts are given (the chain of the timed sweeps), so consecutive runs are independent: a chromosome has two result slots, and
+    # run k + 1 of every chromosome is enqueued before run k is collected -- its kernels execute while run k's labels cross PCIe
+    def sweep_pairs():
         nlab = 0
-        for st in steps:
+        for k, st in enumerate(steps):
+            for r in res:
+                r.chrom.cluster_pairs_async(VARIANT, st["eps"], st["minPts"], st["cut_in"], want_boxes=True)
+            if k > 0:
+                for r in res:
+                    nlab += int(r.chrom.wait_pairs(defer=True)[1].shape[0])      # (their copies run side by side ...)
+                for r in res:
+                    r.chrom.pairs_sync()                                          # (... and are all on the host here)
+        for r in res:
+            nlab += int(r.chrom.wait_pairs(defer=True)[1].shape[0])
+        for r in res:
+            r.chrom.pairs_sync()
+        return nlab
+
+    def sweep_rows():
+        nlab = 0
+        for k, st in enumerate(steps):
             for r in res:
                 r.chrom.cluster_async(VARIANT, st["eps"], st["minPts"], st["cut_in"], want_labels=True, want_boxes=True)
-            for r in res:
-                out = r.chrom.wait()
-                nlab += int(out.labels.shape[0])
+            if k > 0:
+                for r in res:
+                    nlab += int(r.chrom.wait().labels.shape[0])
+        for r in res:
+            nlab += int(r.chrom.wait().labels.shape[0])
         return nlab
-    sweep()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        nlab = sweep()
-    dt = (time.perf_counter() - t0) / reps
+
+    def timed(fn):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            k = fn()
+        return (time.perf_counter() - t0) / reps, k
+    dt, nlab = timed(sweep_pairs)
+    for r in res:
+        r.chrom.set_device_labels(True)
+    dt_rows, nrows = timed(sweep_rows)
     for r in res:
         r.chrom.set_device_labels(False)
-    return {"sweep_wall_s": dt, "value": pets_per_sweep / dt, "unit": "PETs/s", "runs": len(steps), "labels_to_host_per_sweep": nlab,
-            "end_point": "row-aligned int32 labels of every PET + the cluster table of every run in pinned host memory "
-                         "(SURVEY.md 8d(1)); cuts = the chain of the timed sweeps; no statistics / candidate work on the device"}
+    return {"sweep_wall_s": dt, "value": pets_per_sweep / dt, "unit": "PETs/s", "runs": len(steps), "labelled_pets_to_host_per_sweep": nlab,
+            "bytes_to_host_per_sweep": 8 * nlab,
+            "end_point": "(row, label) int32 pairs of every CLUSTERED PET (the reference's `.labels` holds nothing else) + the cluster table of every run in "
+                         "pinned host memory (SURVEY.md 8d(1)); cuts = the chain of the timed sweeps; no statistics / candidate work on the device",
+            "row_aligned": {"sweep_wall_s": dt_rows, "value": pets_per_sweep / dt_rows, "labels_to_host_per_sweep": nrows, "bytes_to_host_per_sweep": 4 * nrows,
+                            "end_point": "row-aligned int32 labels of EVERY PET (-1 = not clustered) + the cluster table of every run"}}
 
 
 def scaling_proxy(pipe, lpt_assign, fs, sizes, steps, nranks, one_gpu_sweep_s, reps=2):

@@ -120,6 +120,10 @@ class Chromosome(object):
             if p:
                 self._lib.cl_host_free(ctypes.c_void_p(p))
                 self._pinned[k] = None
+        for k, p in enumerate(getattr(self, "_pin_pairs", None) or []):
+            if p:
+                self._lib.cl_host_free(ctypes.c_void_p(p))
+                self._pin_pairs[k] = None
 
     def __del__(self):
         try:
@@ -257,6 +261,41 @@ class Chromosome(object):
                                               labels.ctypes.data_as(ctypes.c_void_p) if want_labels else None))
         self._inflight.append((labels, bool(want_boxes)))
         self._enq += 1
+
+    def cluster_pairs_async(self, variant, eps, minPts, cut=0, want_boxes=True):
+        """Enqueue a run whose labels come back the way the reference holds them -- clustered PETs only (cDBSCAN2.py:186-191): one
+        (row, label) pair per labelled PET in a page-locked buffer (cl_cluster_pairs_async); pair with wait_pairs()."""
+        v = VARIANTS[variant]
+        self.set_table_export(want_boxes)
+        which = self._enq & 1
+        if getattr(self, "_pin_pairs", None) is None:
+            self._pin_pairs, self._pin_pairs_arr = [None, None], [None, None]
+        if self._pin_pairs[which] is None:
+            p = self._lib.cl_host_alloc(max(8, self.n * 8))
+            if not p:
+                raise MemoryError("cl_host_alloc(%d) failed" % (self.n * 8))
+            self._pin_pairs[which] = p
+            self._pin_pairs_arr[which] = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_int32)), shape=(self.n, 2))
+        buf = self._pin_pairs_arr[which]
+        _lib.check(self._lib.cl_cluster_pairs_async(self._h, v, int(eps), int(minPts), int(cut), buf.ctypes.data_as(ctypes.c_void_p), self.n))
+        self._inflight.append((buf, bool(want_boxes)))
+        self._enq += 1
+
+    def wait_pairs(self, copy=False, defer=False):
+        """completes the oldest run enqueued by cluster_pairs_async -> (ClusterResult with labels None, pairs int32 [K, 2]: row, label).
+        defer=True: the pairs are still crossing PCIe when this returns -- call pairs_sync() before reading them (a loop over many
+        chromosomes waits for all of them first: their copies then run side by side)"""
+        buf, exported = self._inflight.pop(0)
+        nc, ml = ctypes.c_int32(0), ctypes.c_int32(-1)
+        self._lib.cl_set_pairs_defer(self._h, 1 if defer else 0)
+        _lib.check(self._lib.cl_wait(self._h, ctypes.byref(nc), ctypes.byref(ml)))
+        k = int(self._lib.cl_last_n_labelled(self._h))
+        pairs = buf[:k].copy() if copy else buf[:k]
+        boxes = self._boxes(ml.value, copy) if exported else None
+        return ClusterResult(None, nc.value, ml.value, boxes, self.timing() if self._profiling else None), pairs
+
+    def pairs_sync(self):
+        _lib.check(self._lib.cl_pairs_sync(self._h))
 
     def wait(self, copy=False):
         """Complete the oldest in-flight run -> ClusterResult (labels / boxes are VIEWS of pinned

@@ -131,6 +131,9 @@ struct cl_chrom {
     int run_level = 0;                // traversal level of the run being enqueued (run_sort_and_count decides: level 4 needs the count cache's tables)
     const int* w_dM = nullptr;        // device: PETs that entered DBSCAN in the run being enqueued
     bool run_rows = true;             // the run being enqueued produces row-aligned labels
+    int2* pairs_out = nullptr;        // cl_cluster_pairs_async: (row, label) of every labelled PET, written by the label kernel straight into
+    long long pairs_cap = 0;          // the caller's page-locked buffer (its count: header word 6)
+    bool pairs_defer = false, pairs_copy_pending = false;      // cl_set_pairs_defer / cl_pairs_sync
     bool l4_make_base = false;        // level 4: the run makes the words of its eps -- K2 on the base layout, launched behind the band query
     bool l4_cut = false;              // level 4: the run has a cut (the per-strip tables of k_cut_strips apply)
     bool l4_band = false;             // ... and re-uses counts under another cut (the band's words are fresh: c->cnt, by run position)
@@ -164,6 +167,8 @@ struct cl_chrom {
         size_t h_boxes_cap = 0;
         int32_t* labels_out = nullptr;
         DevBuf slab;                  // labels in sorted order (rotated variants)
+        DevBuf pairs;                 // cl_cluster_pairs_async: (row, label) of the labelled PETs on the device (copied out by cl_wait: their number is
+        int2* pairs_host = nullptr;   //   only known when the run has completed)
         bool exported = true;         // the table rows were stored to h_boxes
         bool step_valid = false;      // the run carried the sweep-step tail (classification, candidate append, distance summary)
         bool host_written = false;    // ... and its last kernel stored header + step output in pinned host memory itself
@@ -265,7 +270,7 @@ int lists_scatter_root(cl_chrom* c, int nm, const ListRun& L);
 int lists_border(cl_chrom* c, const GridParams& g, int nm, const ListRun& L);
 int lists_emit_records(cl_chrom* c, const GridParams& g, int nm, const ListRun& L);
 int lists_scatter_owner(cl_chrom* c, int nm, const ListRun& L);
-int lists_final(cl_chrom* c, const GridParams& g, int nm, const ListRun& L, bool rows);
+int lists_final(cl_chrom* c, const GridParams& g, int nm, const ListRun& L, bool rows, int* pair_count);
 
 // kernels of k_sweep.hip that the step tail (finish_enqueue) launches
 __global__ void __launch_bounds__(256)

@@ -1864,7 +1864,7 @@ __global__ void k_root_labels_bits_l(GridParams g, const int* __restrict__ rootl
 {
     const int ids = wboff[nblkw];                        // total number of ids handed out
     if (blockIdx.x == 0 && threadIdx.x == 0) {          // k_pack_header rides along (nothing behind this kernel raises a flag)
-        hdr[0] = ids; hdr[1] = counters[CTR_OVERFLOW]; hdr[2] = d_M[0]; hdr[3] = 0; hdr[4] = -1; hdr[5] = 0;
+        hdr[0] = ids; hdr[1] = counters[CTR_OVERFLOW]; hdr[2] = d_M[0]; hdr[3] = 0; hdr[4] = -1; hdr[5] = 0; hdr[6] = 0;      // (6: labelled PETs handed out as pairs)
     }
     const int K = counters[CTR_NROOT];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
@@ -1960,7 +1960,7 @@ static void free_chrom(cl_chrom* c)
     (void)hipSetDevice(c->device);
     DevBuf* bufs[] = {&c->keys_in, &c->keys_out, &c->vals_in, &c->vals_out, &c->sort_tmp, &c->scan_tmp, &c->qb_key, &c->qb_val, &c->sv, &c->sa,
                       &c->strip, &c->cnt, &c->parent, &c->root, &c->head, &c->headidx, &c->cellfirst, &c->compkey,
-                      &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->slot[0].d_step, &c->slot[1].d_step, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
+                      &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->slot[0].d_step, &c->slot[1].d_step, &c->slot[0].pairs, &c->slot[1].pairs, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
                       &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out, &c->dhist,
                       &c->rc_cnt, &c->rc_pre, &c->rc_poff, &c->rc_dpre, &c->rc_D, &c->rc_blen, &c->rootlist, &c->cflag8, &c->blk_tmp,
                       &c->l_mask, &c->l_rank, &c->l_blk, &c->l_cstrip, &c->l_wpos, &c->l_wenc, &c->l_dist, &c->l_aux, &c->l_tab, &c->l_fix, &c->bkey};
@@ -3096,6 +3096,19 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
     }
 #endif
     const int K = sl.h_hdr[0];
+    if (sl.pairs_host) {
+        // the (row, label) pairs of a cl_cluster_pairs_async run: their number is in the header that has just arrived
+        int2* dst = sl.pairs_host;
+        sl.pairs_host = nullptr;
+        const long long kp = sl.h_hdr[6];
+        if (kp > 0 && sl.h_hdr[1] == 0) {
+            HIP_TRY(hipMemcpyAsync(dst, sl.pairs.p, (size_t)kp * 8, hipMemcpyDeviceToHost, c->aux_stream));
+            // (cl_set_pairs_defer: the caller completes the copy with cl_pairs_sync -- a loop over many handles then has all their
+            //  copies in flight together instead of one engine's worth at a time)
+            if (c->pairs_defer) c->pairs_copy_pending = true;
+            else HIP_TRY(hipStreamSynchronize(c->aux_stream));
+        }
+    }
     if (sl.h_hdr[1] != 0)
         return fail(CL_ERR_HIP, sl.h_hdr[1] == 8 ? "internal: the number of PETs that passed the cut differs from the host's count"
                                 : sl.h_hdr[1] == 4 ? "internal: strip longer than the hybrid sort accepts"
@@ -3187,6 +3200,35 @@ extern "C" int cl_cluster_async(cl_chrom* c, int variant, int32_t eps, int32_t m
     HIP_TRY(hipSetDevice(c->device));
     if (variant == CL_VARIANT_BLOCK) return run_block(c, eps, min_pts, cut, labels_out);
     return run_rotated(c, variant, eps, min_pts, cut, labels_out);
+}
+
+extern "C" int cl_cluster_pairs_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut, int32_t* pinned_pairs_out, int64_t capacity_pairs)
+{
+    if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
+    if (!pinned_pairs_out || capacity_pairs <= 0) return fail(CL_ERR_ARG, "cl_cluster_pairs_async: no pair buffer");
+    if (variant != CL_VARIANT_CDBSCAN1 && variant != CL_VARIANT_CDBSCAN2) return fail(CL_ERR_ARG, "cl_cluster_pairs_async: rotated variants only");
+    if (c->traversal < 3 || min_pts < 2 || min_pts > 128) return fail(CL_ERR_ARG, "cl_cluster_pairs_async: needs the list form of the run (traversal level >= 3, minPts 2 .. 128)");
+    c->pairs_out = (int2*)pinned_pairs_out;
+    c->pairs_cap = capacity_pairs;
+    const int rc = cl_cluster_async(c, variant, eps, min_pts, cut, nullptr);
+    c->pairs_out = nullptr; c->pairs_cap = 0;
+    return rc;
+}
+extern "C" void cl_set_pairs_defer(cl_chrom* c, int enabled) { if (c) c->pairs_defer = enabled != 0; }
+extern "C" int cl_pairs_sync(cl_chrom* c)
+{
+    if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
+    if (c->pairs_copy_pending) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->aux_stream));
+        c->pairs_copy_pending = false;
+    }
+    return CL_OK;
+}
+extern "C" int64_t cl_last_n_labelled(const cl_chrom* c)
+{
+    if (!c || !c->have_result || c->last_slot < 0) return -1;
+    return c->slot[c->last_slot].h_hdr[6];
 }
 
 extern "C" int cl_cluster_step_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut, int32_t step, int64_t fine_lo)
@@ -3316,11 +3358,11 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     c->init_nclr = nw + 1;
     // row-aligned labels only when somebody reads them: k_final_labels then writes the label (or -1) of every PET that
     // entered DBSCAN and only the rows removed by the cut filter need the -1 fill
-    const bool rows = labels_out != nullptr || c->device_labels;
+    const bool rows = labels_out != nullptr || c->device_labels || c->pairs_out != nullptr;
     // how far the run works on lists (k_lists.hip; cl_set_traversal): 0 = tile kernels over every PET, 1 = K3 on the core list,
     // 2 = + the border rule on the walker list, 3 = + labels / table / distance list from the lists (only labelled PETs are
     // written: the row-aligned array is filled with -1 first)
-    if (rows && (cut > 0 || (wide == 0 && c->traversal >= 3))) HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
+    if (rows && !c->pairs_out && (cut > 0 || (wide == 0 && c->traversal >= 3))) HIP_TRY(hipMemsetAsync(c->slot[c->cur].labels.p, 0xFF, (size_t)n * 4, c->stream));
     c->run_rows = rows;
     const int trav_saved = c->traversal;
     if (wide != 0) c->traversal = 0;                    // (developer tile shapes: the tile kernels)
@@ -3336,7 +3378,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     ENQ_MARK();
     {
         cl_chrom::Slot& sl = c->slot[c->cur];
-        sl.rows_valid = rows; sl.sorted_src = g.swap != 0; sl.k7_sv = c->w_sv; sl.k7_v0 = g.V0; sl.k7_lcnt = nullptr;
+        sl.rows_valid = rows && !c->pairs_out; sl.sorted_src = g.swap != 0; sl.k7_sv = c->w_sv; sl.k7_v0 = g.V0; sl.k7_lcnt = nullptr;
         // variant 2 hands an id only to a live cluster, which has >= minPts members (cDBSCAN2.py:180-185): K <= n / minPts;
         // variant 1 numbers every component, dropped ones included (cDBSCAN.py:136-152): K <= n
         sl.kmax = (variant == CL_VARIANT_CDBSCAN2 && minPts >= 1) ? n / minPts + 1 : n;
@@ -3433,7 +3475,9 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
                        c->hdr.as<int>() + 16 * c->cur, c->w_dM ? c->w_dM : (const int*)(strip + g.S));
     c->hdr_packed = true;
     if (level >= 3) {
-        if ((rc = lists_final(c, g, nm, L, rows))) return rc;
+        c->slot[c->cur].pairs_host = c->pairs_out;
+        if (c->pairs_out && (rc = c->slot[c->cur].pairs.ensure((size_t)std::max<long long>(c->pairs_cap, 1) * 8))) return rc;
+        if ((rc = lists_final(c, g, nm, L, rows, c->hdr.as<int>() + 16 * c->cur + 6))) return rc;
         cl_chrom::Slot& sl = c->slot[c->cur];
         sl.k7_lcnt = L.lcnt; sl.k7_sv = c->l_dist.as<int>();      // the distance statistics read the run's lists (K7Src::sorted == 2)
     } else {

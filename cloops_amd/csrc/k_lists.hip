@@ -1356,7 +1356,9 @@ __global__ void __launch_bounds__(BIGTPB)
 k_final_lists(GridParams g, const int* __restrict__ lcnt, const int2* __restrict__ cpair, const int* __restrict__ cpos,
               const int* __restrict__ croot, const int2* __restrict__ wpair, const int* __restrict__ wpos,
               const int* __restrict__ wowner, const int* __restrict__ rlabel, const u32* __restrict__ srow,
-              int* __restrict__ labels, int* __restrict__ llab, int* __restrict__ ldist, Table t)
+              int* __restrict__ labels, int* __restrict__ llab, int* __restrict__ ldist, Table t,
+              int2* __restrict__ pairs /* or null: (row, label) of every labelled item (compact, unordered; cl_wait copies pair_count of them out) */, int pairs_cap,
+              int* __restrict__ pair_count)
 {
     __shared__ TableLds h;
     table_lds_init(h);
@@ -1368,8 +1370,8 @@ k_final_lists(GridParams g, const int* __restrict__ lcnt, const int2* __restrict
         idx[ch] = (blockIdx.x * LF_CHUNKS + ch) * BIGTPB + threadIdx.x;
         const int k = idx[ch];
         own[ch] = -1; pos[ch] = 0; pr[ch] = make_int2(0, 0);
-        if (k < C) { own[ch] = croot[k]; pr[ch] = cpair[k]; pos[ch] = labels ? cpos[k] : 0; }
-        else if (k < L) { own[ch] = owner_root(wowner[k - C]); pr[ch] = wpair[k - C]; pos[ch] = labels ? wpos[k - C] : 0; }
+        if (k < C) { own[ch] = croot[k]; pr[ch] = cpair[k]; pos[ch] = (labels || pairs) ? cpos[k] : 0; }
+        else if (k < L) { own[ch] = owner_root(wowner[k - C]); pr[ch] = wpair[k - C]; pos[ch] = (labels || pairs) ? wpos[k - C] : 0; }
     }
 #pragma unroll
     for (int ch = 0; ch < LF_CHUNKS; ++ch) lab[ch] = own[ch] >= 0 ? rlabel[own[ch]] : -1;
@@ -1388,6 +1390,34 @@ k_final_lists(GridParams g, const int* __restrict__ lcnt, const int2* __restrict
                 const int a = g.swap ? qq : pp, v = g.swap ? pp : qq;
                 x[ch] = (v - a) / 2; y[ch] = (v + a) / 2;
             }
+        }
+    }
+    if (pairs) {
+        // the reference's `.labels` holds clustered points only (cDBSCAN2.py:186-191): (row, label) pairs of the labelled items,
+        // compacted -- ONE counter bump per workgroup (a bump per wave put 120 k same-address atomics with a return value into a
+        // chr1 run), 8 contiguous bytes per lane.  (Written straight into page-locked host memory the kernel ran at 20 GB/s of
+        // PCIe and held the compute stream.)
+        __shared__ int l_pc[LF_CHUNKS * (BIGTPB / 64)];
+        __shared__ int l_pbase;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        unsigned long long bals[LF_CHUNKS];
+#pragma unroll
+        for (int ch = 0; ch < LF_CHUNKS; ++ch) {
+            bals[ch] = __ballot(lab[ch] >= 0);
+            if (lane == 0) l_pc[ch * (BIGTPB / 64) + wv] = __popcll(bals[ch]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int k = 0; k < LF_CHUNKS * (BIGTPB / 64); ++k) { const int v = l_pc[k]; l_pc[k] = tot; tot += v; }      // (exclusive, in place)
+            l_pbase = tot ? atomicAdd(pair_count, tot) : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ch = 0; ch < LF_CHUNKS; ++ch) {
+            if (lab[ch] < 0) continue;
+            const int at = l_pbase + l_pc[ch * (BIGTPB / 64) + wv] + lane_rank(bals[ch]);
+            if (at < pairs_cap) pairs[at] = make_int2((int)srow[pos[ch]], lab[ch]);
         }
     }
 #pragma unroll
@@ -1614,12 +1644,13 @@ int lists_scatter_owner(cl_chrom* c, int nm, const ListRun& L)
     return CL_OK;
 }
 
-int lists_final(cl_chrom* c, const GridParams& g, int nm, const ListRun& L, bool rows)
+int lists_final(cl_chrom* c, const GridParams& g, int nm, const ListRun& L, bool rows, int* pair_count)
 {
     cl_chrom::Slot& sl = c->slot[c->cur];
     hipLaunchKernelGGL(k_final_lists, dim3(nblocks(nm, BIGTPB * LF_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, L.lcnt, (const int2*)L.cpair, (const int*)L.cpos,
                        (const int*)croot_of(c), (const int2*)L.wpair, (const int*)L.wpos, (const int*)c->owner.as<int>(), (const int*)c->chainhead.as<int>(),
-                       (const u32*)c->srow, rows ? sl.labels.as<int>() : (int*)nullptr, sl.slab.as<int>(), c->l_dist.as<int>(), make_table(c));
+                       (const u32*)c->srow, (rows && !c->pairs_out) ? sl.labels.as<int>() : (int*)nullptr, sl.slab.as<int>(), c->l_dist.as<int>(), make_table(c),
+                       c->pairs_out ? sl.pairs.as<int2>() : (int2*)nullptr, (int)std::min<long long>(c->pairs_cap, INT_MAX), pair_count);
     HIP_TRY(hipGetLastError());
     return CL_OK;
 }
@@ -1686,7 +1717,7 @@ extern "C" int cl_debug_time_lists(cl_chrom* c, int which, int reps, float* ms_o
                                    c->lo.as<int>(), L2.pstrip, L2.cmask, L2.cgrank, L2.cstrip, bb.sup, 2, (int*)nullptr);
                 HIP_TRY(hipMemsetAsync(c->counters.p, 0, 64, c->stream));
                 if ((rc = lists_union_flatten(c, g, nm, L2))) return rc;
-            } else { if ((rc = lists_final(c, g, nm, L2, false))) return rc; }
+            } else { if ((rc = lists_final(c, g, nm, L2, false, c->counters.as<int>() + 40))) return rc; }
         } else return fail(CL_ERR_ARG, "cl_debug_time_lists: kernel not supported on its own");
     }
     HIP_TRY(hipEventRecord(e1, c->stream));

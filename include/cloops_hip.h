@@ -226,6 +226,22 @@ const int32_t* cl_labels_device(const cl_chrom* c);
  * cl_cand_reset starts a new sweep.
  */
 int cl_cand_reset(cl_chrom* c);
+/* The labels of a run as the reference holds them: cDBSCAN(mat, eps, minPts).labels is a dict of the CLUSTERED points only
+ * (cDBSCAN2.py:186-191, cDBSCAN.py:143-152).  Like cl_cluster_async, but instead of n row-aligned labels the run leaves one
+ * (row, label) int32 pair per labelled PET, in no particular order, written by its last kernel straight into
+ * `pinned_pairs_out` (page-locked host memory: cl_host_alloc; capacity_pairs pairs -- n always suffices); after cl_wait
+ * cl_last_n_labelled(c) says how many.  A sweep that wants labels on the host every run moves 8 bytes per clustered PET
+ * over PCIe instead of 4 bytes per PET.  Rotated variants at traversal level >= 3 and minPts 2 .. 128 only (CL_ERR_ARG
+ * otherwise). */
+int cl_cluster_pairs_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut, int32_t* pinned_pairs_out,
+                           int64_t capacity_pairs);
+int64_t cl_last_n_labelled(const cl_chrom* c);
+/* cl_set_pairs_defer(c, 1): cl_wait of a pairs run returns with the copy of the pairs to the host still in flight (their number
+ * is known: cl_last_n_labelled); cl_pairs_sync(c) completes it.  A host that collects many chromosomes waits for all of them
+ * first and syncs afterwards, so that their copies cross PCIe side by side. */
+void cl_set_pairs_defer(cl_chrom* c, int enabled);
+int cl_pairs_sync(cl_chrom* c);
+
 /* One step of a sweep in ONE asynchronous call: cl_cluster_async(labels_out = NULL) followed, in the run's own stream,
  * by what cl_cand_append and cl_dist_summary do for that run (same `cut`).  After cl_wait the results are on the host:
  * cl_step_result copies them out without touching the GPU.  One step in flight per chromosome.  `fine_lo` >= 0 (a guess

@@ -73,3 +73,35 @@ def test_sweep_step_statistics_from_the_lists():
             assert st["cut_out"] == c
     finally:
         pipe.CACHE.clear()
+
+
+@pytest.mark.parametrize("variant", ["v2", "v1"])
+def test_pairs_form_equals_row_aligned_labels(variant):
+    """cl_cluster_pairs_async: the labels as the reference holds them -- (row, label) of the clustered points only
+    (cDBSCAN2.py:186-191) -- reassemble to exactly the row-aligned labels of cl_cluster, run after run on two result slots"""
+    X, Y = synth_chrom(N, 46709983, 37)
+    ref = api.Chromosome(X, Y)
+    ch = api.Chromosome(X, Y)
+    try:
+        pending = []
+        for eps, m, cut in ((2000, 5, 0), (5000, 20, 0), (5000, 10, 3000), (5000, 10, 4500)):
+            ch.cluster_pairs_async(variant, eps, m, cut)
+            pending.append((eps, m, cut))
+            if len(pending) == 2:
+                e0, m0, c0 = pending.pop(0)
+                res, pairs = ch.wait_pairs(copy=True)
+                want = ref.cluster(variant, e0, m0, c0)
+                got = np.full(len(X), -1, np.int32)
+                got[pairs[:, 0]] = pairs[:, 1]
+                assert len(np.unique(pairs[:, 0])) == len(pairs) == int((want.labels >= 0).sum())
+                assert np.array_equal(got, want.labels) and res.n_clusters == want.n_clusters
+        while pending:
+            e0, m0, c0 = pending.pop(0)
+            res, pairs = ch.wait_pairs(copy=True)
+            want = ref.cluster(variant, e0, m0, c0)
+            got = np.full(len(X), -1, np.int32)
+            got[pairs[:, 0]] = pairs[:, 1]
+            assert np.array_equal(got, want.labels)
+    finally:
+        ch.close()
+        ref.close()
