@@ -106,7 +106,7 @@ struct cl_chrom {
     // only if q - eps < max(the two cuts): every later run with a minPts of the set takes the words of the PETs beyond that
     // band as they are (k_cut_copy<true> carries them through its compaction) and runs K2 on the band alone.  Results are
     // identical with the cache switched off (cl_set_count_reuse); cLoops/pipe.py:247-250 walks minPts inside eps, descending.
-    struct CountCache { bool valid = false; bool base_space = false /* level 4: words by base position, hints in base positions (k_lists.hip) */; int layout = -1, eps = 0, thr = 0 /* q threshold of the run's cut, 0 = none */, cap = 0; u32 tmask[4] = {0, 0, 0, 0} /* the minPts values the words serve, bit t - 1 */; } rc;
+    struct CountCache { bool valid = false; bool cut_on_base = false /* made on the base layout by a run under a cut: the PETs within eps above thr counted removed neighbours -- every run under a cut re-queries its band */; bool base_space = false /* level 4: words by base position, hints in base positions (k_lists.hip) */; int layout = -1, eps = 0, thr = 0 /* q threshold of the run's cut, 0 = none */, cap = 0; u32 tmask[4] = {0, 0, 0, 0} /* the minPts values the words serve, bit t - 1 */; } rc;
     DevBuf rc_cnt, rc_pre, rc_poff, rc_dpre, rc_D, rc_blen;   // the words in the sorted order of the run that made them; per strip: PETs its cut removed
                                       // from the strip / from all strips up to and including it
     bool reuse_counts = true;         // cl_set_count_reuse

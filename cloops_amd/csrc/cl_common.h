@@ -78,6 +78,8 @@ struct GridParams {
                   //   count a non-core PET's word holds is only as exact as those tests need: for every t of the set,
                   //   stored >= t  <=>  count >= t (an upper bound of the count otherwise; <= 1 still means "nothing within eps")
     int tgap;     //   the widest gap of that set: max over c in [1, minPts) of (smallest served minPts above c) - c
+    int qmin;     // K2 (clustering form): PETs with q below it get no word (level 4: the words of an eps are made on the base layout by a run
+                  //   under a cut -- the PETs its cut removes are in the cut band of every run that could ever read their words)
     int peps;     // 1 << rbits.  The kernels never see p itself but its ORDER-PRESERVING re-encoding
                   //   sp = strip << rbits | (p mod eps)   (the strip and remainder fields of the sort key):
                   //   strip(p) = sp >> rbits (no division), and |p_j - p_i| <= eps  <=>  |sp_j - sp_i| <= peps

@@ -2504,6 +2504,7 @@ static int make_grid(cl_chrom* c, int variant, int eps, int minPts, int cut, Gri
     for (auto& w : g->tmask) w = 0;
     if (minPts >= 1 && minPts <= 128) g->tmask[(minPts - 1) >> 5] = 1u << ((minPts - 1) & 31);      // a one-off run serves its own minPts
     g->tgap = minPts - 1;
+    g->qmin = INT_MIN;
 #ifdef CLOOPS_DEVEL
     // developer build only (-DCLOOPS_DEVEL): ablation knobs that can change results; never in the shipped library
     { const char* e = getenv("CLOOPS_DBG"); g->dbg = e ? atoi(e) : 0; }
@@ -2714,7 +2715,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
         if (cacheable) {
             const bool serves = c->rc.valid && c->rc.layout == layout && c->rc.eps == g.eps && g.minPts <= c->rc.cap &&
                                 ((c->rc.tmask[m1 >> 5] >> (m1 & 31)) & 1u) && c->rc.base_space == want4;
-            if (serves && thr_new == c->rc.thr) rcmode = RC_SAME;
+            if (serves && thr_new == c->rc.thr && !(c->rc.cut_on_base && thr_new != 0)) rcmode = RC_SAME;
             else if (serves && !on_base && (long long)g.S <= 8LL * n) rcmode = RC_REMAP;      // (the band kernel works strip by strip)
             else rcmode = RC_MAKE;
             if ((rc = c->rc_cnt.ensure((size_t)n * 4)) || (rc = c->rc_pre.ensure(((size_t)g.S + 2) * 4)) ||
@@ -2729,6 +2730,7 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
         }
         if (rcmode == RC_MAKE) {
             c->rc.valid = true; c->rc.layout = layout; c->rc.eps = g.eps; c->rc.thr = thr_new; c->rc.cap = g.minPts; c->rc.base_space = want4;
+            c->rc.cut_on_base = false;
             // the minPts values these words will be asked about: the announced ones up to this run's (cl_set_count_thresholds), or
             // everything from the announced floor up (cl_set_count_floor), and this run's own
             for (int k = 0; k < 4; ++k) c->rc.tmask[k] = 0;
@@ -2759,7 +2761,10 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
                 HIP_TRY(hipMemsetAsync(c->rc_pre.p, 0, ((size_t)g.S + 2) * 4, c->stream));
                 HIP_TRY(hipMemsetAsync(c->rc_poff.p, 0, ((size_t)g.S + 2) * 4, c->stream));
                 c->l4_make_base = true;                      // (launched in the region-query bracket, below)
-                c->rc.thr = 0;
+                // (the PETs this run's cut removes get no word: a later run under a smaller cut finds them in its cut band, which
+                //  reaches up to the larger of the two thresholds + eps)
+                c->rc.thr = thr_new;
+                c->rc.cut_on_base = true;
                 c->w_cnt = c->rc_cnt.as<int>();
                 rcmode = RC_REMAP;
                 c->last_k2_mode_make = true;
@@ -2842,9 +2847,10 @@ static int run_sort_and_count(cl_chrom* c, const GridParams& g, bool exact)
         // level 4: the words of the eps, on the base layout itself (every row), whatever this run's cut is
         GridParams g0 = gk;
         g0.cut = 0;
+        g0.qmin = c->rc.thr;
         rc = cl_launch_region(c->stream, g0, n, n, false, c->bq.as<int>() + SORT_PAD, c->bsp.as<int>() + SORT_PAD, c->bstrip.as<int>(), c->btile.as<int>(),
                               c->rc_cnt.as<int>());
-        c->slot[c->cur].n_queried = n;
+        c->slot[c->cur].n_queried = c->run_m;             // (the PETs that got a word: those the cut keeps)
     } else if (!k2_skip && !k2_band && !SKIP(256)) {
         rc = cl_launch_region(c->stream, gk, n, c->run_m, exact, c->w_sv, c->w_sa, c->w_strip, c->w_tile, c->w_cnt);
         c->slot[c->cur].n_queried = c->run_m;

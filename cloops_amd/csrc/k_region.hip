@@ -345,7 +345,7 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         const int tix = (int)threadIdx.x + u * K2F_TPB;
         const int2 me = p_me[u], rr = p_rr[u], ll = p_ll[u];
         const int pbeg = me.y & nmask;
-        const bool valid = t0 + tix < M;
+        const bool valid = (t0 + tix < M) & (me.x >= g.qmin);
         // the (minPts-1)-th next / previous PET is in the same strip and within eps in q (unsigned add: a sentinel q wraps harmlessly)
         const bool core = ((rr.y < pbeg + peps) & (rr.x <= (int)((unsigned)me.x + (unsigned)eps))) | ((ll.y >= pbeg) & (ll.x >= me.x - eps));
         if (valid & core) cnt[t0 + tix] = minPts;

@@ -59,6 +59,8 @@ def test_dense_chain_like_mode3(variant):
         # traversal level 4 makes the words of an eps on the base layout itself (threshold 0) also when the making run has a cut: the
         # second run at (10, 3000) re-uses them under "another" cut (band query) instead of as they are
         modes[10] = 2
+        # ... and a run without a cut cannot take words made under a cut as they are (the PETs below that cut got none): (5000, 20, 0)
+        # behind the chain of cuts still can (the words of eps 5000 were made at cut 0); nothing else changes in this sequence
     # (5000, 12, 4000): the words of (5000, 10, 3000) have cap 10 < 12 -> a new set with cap 12, floor 12 ... then 50 > 12
     _check_seq(X, Y, variant, 20, seq, oracle_at=(1, 3, 7, 11, 14, 16), modes=modes)
 

@@ -48,11 +48,17 @@ def test_level4_makes_no_copy_for_reusing_runs():
     ch.set_count_thresholds([5, 10, 20])
     try:
         modes = []
-        for eps, m, cut in ((5000, 20, 3000), (5000, 10, 3500), (5000, 5, 0), (5000, 10, 2000)):
+        runs = ((5000, 20, 3000),      # makes the words of the eps: on the base layout (PETs below its cut skipped) + its own cut band
+                (5000, 10, 3500),      # re-uses them: band query only
+                (5000, 10, 3000),      # the making run's cut again: still a band query (its band counted removed neighbours)
+                (7500, 20, 0),         # another eps, no cut: the query on the base layout
+                (7500, 10, 0),         # same layout, no cut: the words as they are
+                (7500, 5, 2000))       # a cut on top of them: band query
+        for eps, m, cut in runs:
             got = ch.cluster("v2", eps, m, cut)
             modes.append(ch.last_region_mode())
             assert np.array_equal(got.labels, _want("v2", X, Y, eps, m, cut)), (eps, m, cut)
-        assert modes == [0, 2, 1, 2], modes
+        assert modes == [0, 2, 2, 0, 1, 2], modes
     finally:
         ch.close()
 
