@@ -1,6 +1,6 @@
 #!/bin/bash
 # developer tool (build container): compile the kernel sources of a COMMIT (default HEAD) into cloops_amd/libcloops_hip_devel.so, the
-# "B" slot of tools/ab_bench.sh / scratch/sweep_modes.py (CLOOPS_DEVEL_LIB=1), so that the working tree (A) and the commit (B) can be
+# "B" slot of tools/ab_bench.sh (CLOOPS_DEVEL_LIB=1), so that the working tree (A) and the commit (B) can be
 # timed on one box.  usage: bash tools/build_head_as_b.sh [commit]
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
