@@ -755,11 +755,12 @@ __device__ __forceinline__ int lower_bound_pairs(const int2* __restrict__ pv, in
 template <int NT, int HALO>
 __global__ void __launch_bounds__(256)
 k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __restrict__ cpair, const int* __restrict__ chainid,
-          const int* __restrict__ cstrip, const int* __restrict__ cend, int* parent)
+          const int* __restrict__ cstrip, const int* __restrict__ cend, int* parent, int* __restrict__ cskip)
 {
     constexpr int WIN = NT + HALO;
     __shared__ int2 lw[WIN];
     __shared__ int lx[WIN];
+    __shared__ int lend[WIN];                            // last core of the staged core's chain
     const int C = lcnt[0];
     const int tile = ltile_of_block(blockIdx.x);
     const int t0 = tile * NT;
@@ -769,7 +770,13 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
         const int gi = base + k;
         const bool in = gi >= 0 && gi < C;
         lw[k] = in ? cpair[gi] : (gi < 0 ? make_int2(0, INT_MIN) : make_int2(INT_MAX, INT_MAX));
-        lx[k] = in ? chainid[gi] : -1;
+        const int ch = in ? chainid[gi] : -1;
+        lx[k] = ch;
+        // where a walk that has met this core may go on: behind its chain (all cores of a chain are one component).  k_border_*
+        // walks the same way: cskip[c] = the first core behind c's chain, written here by the tile that owns c
+        const int ce = in ? cend[ch] : -1;
+        lend[k] = ce;
+        if (in && k >= HALO) cskip[gi] = ce + 1;
     }
     __syncthreads();
     const int wbeg = max(base, 0);
@@ -817,7 +824,9 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
                         uf_unite(parent, A, B);            // more chains than slots: unite right away
                     }
                 };
-                if (tb >= wbeg && b - tb <= 2047) {
+                if (L_ABL(1 << 17)) tb = b;              // (ablation: neither search nor walk)
+                if (tb >= b) { }
+                else if (tb >= wbeg && b - tb <= 2047) {
                     // the window is staged.  Once a chain has been touched the walk jumps behind its last core (cend): a window
                     // covered by one chain costs one candidate instead of all of them.
                     const int len = b - tb;
@@ -826,13 +835,14 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
                     else if (len <= 63) j = lds_lower_bound8<6>(w, tb, b, qlo);
                     else if (len <= 255) j = lds_lower_bound8<8>(w, tb, b, qlo);
                     else j = lds_lower_bound8<11>(w, tb, b, qlo);
+                    if (L_ABL(1 << 16)) j = b;           // (ablation: the search without the walk)
                     while (j < b) {
 #ifdef CLOOPS_DEVEL
                         ++st_it;
 #endif
-                        int2 cv[4]; int bv[4];
+                        int2 cv[4]; int bv[4], ev[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { const int idx = min(j + k, b - 1); cv[k] = lw[idx - base]; bv[k] = lx[idx - base]; }
+                        for (int k = 0; k < 4; ++k) { const int idx = min(j + k, b - 1); cv[k] = lw[idx - base]; bv[k] = lx[idx - base]; ev[k] = lend[idx - base]; }
                         int next = j + 4;
                         bool stop = false;
 #pragma unroll
@@ -841,12 +851,11 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
                             if (cv[k].x > qhi) { stop = true; next = b; continue; }
                             if (cv[k].y >= T) {
                                 touch(bv[k]);
-                                // (a short window is cheaper walked through: touch() passes over a chain it has seen)
-                                if (len > 24) {
+                                if (len > 8 || L_ABL(1 << 15)) {
 #ifdef CLOOPS_DEVEL
                                     ++st_jump;
 #endif
-                                    stop = true; next = cend[bv[k]] + 1;      // (> j + k: the chain holds this core)
+                                    stop = true; next = ev[k] + 1;      // (> j + k: the chain holds this core)
                                 }
                             }
                         }
@@ -896,6 +905,8 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
         }
 #ifdef CLOOPS_DEVEL
         LSTAT(12, in ? 1 : 0); LSTAT(13, st_it); LSTAT(14, st_touch); LSTAT(15, st_un); LSTAT(16, st_glb); LSTAT(17, st_jump);
+        { int mx = st_it; for (int o2 = 32; o2 > 0; o2 >>= 1) mx = max(mx, __shfl_down(mx, o2)); if (lane == 0 && LSTAT_ON) { atomicAdd(&g_lstat[18], (unsigned long long)mx); atomicAdd(&g_lstat[19], 1ull); }
+          if (LSTAT_ON && st_it > 2) atomicAdd(&g_lstat[20], 1ull); if (LSTAT_ON && st_it > 4) atomicAdd(&g_lstat[21], 1ull); if (LSTAT_ON && st_it > 8) atomicAdd(&g_lstat[22], 1ull); }
 #else
         (void)st_un;
 #endif
@@ -910,8 +921,8 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
 // both arrive as ckey[c] (k_make_lists); two-level reduce-by-key as in k_flatten (cloops_hip.hip)
 __global__ void __launch_bounds__(BIGTPB)
 k_flatten_c(const int* __restrict__ lcnt, const int* __restrict__ chainid, const int* __restrict__ parent, const int* __restrict__ ckey,
-            const int* __restrict__ cend, int* __restrict__ croot, int* __restrict__ cskip, int* __restrict__ compkey,
-            int* __restrict__ ncore, int* __restrict__ rootlist, int* __restrict__ counters)
+            int* __restrict__ croot, int* __restrict__ compkey,
+            int* __restrict__ ncore, int* __restrict__ rootlist, int* __restrict__ counters, int abl)
 {
     __shared__ int hkey[AGG_H], hmin[AGG_H], hcnt[AGG_H];
     __shared__ int l_nroot, l_rootbase;
@@ -930,19 +941,11 @@ k_flatten_c(const int* __restrict__ lcnt, const int* __restrict__ chainid, const
         key[e] = in[e] ? ckey[ii[e]] : INT_MAX;
     }
     {
-        // cskip[c] = the first core behind c's chain: a walk that has found one core of a chain within reach needs no other
-        // (k_border_w; all cores of a chain share the root)
-        int ce[FLAT_PER];
-#pragma unroll
-        for (int e = 0; e < FLAT_PER; ++e) ce[e] = in[e] ? cend[x[e]] : 0;
-#pragma unroll
-        for (int e = 0; e < FLAT_PER; ++e) if (in[e]) cskip[ii[e]] = ce[e] + 1;
-    }
-    {
         // the union kernel has completed (kernel boundary = coherent): plain loads, all walks of the thread step together
         bool todo = false;
 #pragma unroll
         for (int e = 0; e < FLAT_PER; ++e) todo |= in[e];
+        if (abl & (1 << 21)) todo = false;
         while (todo) {
             int p[FLAT_PER];
 #pragma unroll
@@ -971,6 +974,7 @@ k_flatten_c(const int* __restrict__ lcnt, const int* __restrict__ chainid, const
             if (isroot) myslot[e] = wbase + lane_rank(rb);
         }
     }
+    if (!(abl & (1 << 20)))
 #pragma unroll
     for (int e = 0; e < FLAT_PER; ++e) {
         const unsigned long long pending = __ballot(r[e] >= 0);
@@ -987,10 +991,25 @@ k_flatten_c(const int* __restrict__ lcnt, const int* __restrict__ chainid, const
                     if (sl >= 0) { atomicMin(&hmin[sl], mk); atomicAdd(&hcnt[sl], __popcll(m)); }
                     else { atomicMin(&compkey[R], mk); atomicAdd(&ncore[R], __popcll(m)); }
                 }
-            } else if (r[e] >= 0) {
-                const int sl = agg_slot(hkey, r[e]);
-                if (sl >= 0) { if (key[e] != INT_MAX) atomicMin(&hmin[sl], key[e]); atomicAdd(&hcnt[sl], 1); }
-                else { if (key[e] != INT_MAX) atomicMin(&compkey[r[e]], key[e]); atomicAdd(&ncore[r[e]], 1); }
+            } else {
+                // cores follow each other in layout order: the cores of a component come in RUNS (chains; neighbouring chains of a
+                // cluster).  A run of equal roots is reduced inside the wave (segmented min over six shuffles, the length from
+                // the head flags) and its last lane alone goes to the table -- a handful of LDS atomics per wave instead of 64 pairs
+                const int rv = r[e];
+                const int prev = __shfl_up(rv, 1);
+                const unsigned long long hb = __ballot(lane == 0 || prev != rv);
+                const int start = 63 - __clzll((long long)(hb & (~0ull >> (63 - lane))));
+                const unsigned long long above = lane == 63 ? 0ull : (hb & (~0ull << (lane + 1)));
+                const int end = above ? __ffsll((long long)above) - 2 : 63;
+                int mk = key[e];
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(mk, d); if (lane - d >= start) mk = min(mk, v); }
+                if (lane == end && rv >= 0) {
+                    const int cntv = end - start + 1;
+                    const int sl = agg_slot(hkey, rv);
+                    if (sl >= 0) { if (mk != INT_MAX) atomicMin(&hmin[sl], mk); atomicAdd(&hcnt[sl], cntv); }
+                    else { if (mk != INT_MAX) atomicMin(&compkey[rv], mk); atomicAdd(&ncore[rv], cntv); }
+                }
             }
         }
     }
@@ -1233,6 +1252,226 @@ k_border_w(GridParams g, int ntiles, int npos, const int* __restrict__ lcnt,
                 pending &= ~m;
             }
         }
+    }
+}
+
+// ---- k_border_q: variant 2's border rule with the long walks set aside -------------------------------------------
+// k_border_w pays, per wave, the LONGEST of its 64 walkers' walks (2.3-3.8 steps per walker on average, 15-25 for the slowest
+// lane: a walker whose q window one strip away lies beside a cluster it is not adjacent to passes all of that cluster's
+// cores).  Here a walk stops after `kcap` steps; a walker with a walk left over puts itself -- record, where its walks go
+// on, the components seen so far -- into a queue in the part of the staging arrays the tile's cores leave free (cores +
+// walkers of a tile <= its positions: room for at least 4 of 9 walkers; who finds it full finishes in place), and afterwards
+// every queued walker gets BQ_G lanes that test BQ_G candidates per step (a ballot finds the first one that ends the window or
+// is within reach): the slow walks become a few steps of a few waves instead of holding up every wave.  Same results as
+// k_border_w<.., false>.
+__device__ __forceinline__ void see4(int r, int& r0, int& r1, int& r2, int& r3, int* counters)
+{
+    if ((r == r0) | (r == r1) | (r == r2) | (r == r3)) return;
+    if (r0 < 0) r0 = r; else if (r1 < 0) r1 = r; else if (r2 < 0) r2 = r; else if (r3 < 0) r3 = r;
+    else atomicExch(&counters[CTR_OVERFLOW], 1);          // (beyond the geometric bound: the run fails loudly)
+}
+
+template <int NT, int HC, int BQ_G>
+__global__ void __launch_bounds__(256)
+k_border_q(GridParams g, int ntiles, int npos, int kcap, const int* __restrict__ lcnt,
+           const unsigned long long* __restrict__ cmask, const int* __restrict__ cgrank, const int* __restrict__ wgrank,
+           const int2* __restrict__ cpair, const int* __restrict__ croot, const int* __restrict__ cskip,
+           const int* __restrict__ cstrip, const int2* __restrict__ wpair, const int* __restrict__ wpos,
+           const int* __restrict__ wenc, const int* __restrict__ compkey, const int* __restrict__ ncore,
+           int* __restrict__ wowner, int* __restrict__ bsize, int* __restrict__ usize, int* __restrict__ clist, int* __restrict__ counters)
+{
+    constexpr int WIN = NT + 2 * HC;
+    __shared__ int2 lw[WIN];
+    __shared__ int2 lx[WIN];                             // (root, first core behind the chain)
+    __shared__ int l_nq;
+    const int C = lcnt[0];
+    const int tile = ltile_of_block(blockIdx.x);
+    const int t0 = tile * NT;
+    if (tile >= ntiles || t0 >= npos) return;
+    const int g0 = t0 >> 6, g1 = (t0 + NT) >> 6;
+    const int w0 = wgrank[g0], w1 = wgrank[g1];
+    if (w0 == w1) return;
+    const int clo = max(cgrank[g0] - HC, 0), chi = min(cgrank[g1] + HC, C);
+    if (threadIdx.x == 0) l_nq = 0;
+    for (int k = threadIdx.x; k < chi - clo; k += 256) { lw[k] = cpair[clo + k]; lx[k] = make_int2(croot[clo + k], cskip[clo + k]); }
+    __syncthreads();
+    const int qbase = (chi - clo + 1) & ~1;              // queue entry e: lw / lx [qbase + 2 e, + 2) = 8 ints
+    const int qcap = (WIN - qbase) >> 1;
+    const int lane = threadIdx.x & 63;
+    // the walker's place in the output, its owner and the counts per owning component (release rule of variant 2): as k_border_w
+    auto finish = [&](bool act, int h, int r0, int r1, int r2, int r3) {
+        int kk[4], nn[4];
+        const int rr[4] = {r0, r1, r2, r3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int r = act ? rr[k] : -1; kk[k] = r >= 0 ? compkey[r] : INT_MAX; nn[k] = r >= 0 ? ncore[r] : 0; }
+        int o = act ? rr[0] : -1, bestk = kk[0], nco = nn[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (kk[k] < bestk) { bestk = kk[k]; o = rr[k]; nco = nn[k]; }
+        const bool contested = act && r1 >= 0;
+        if (act) wowner[h] = o < 0 ? -1 : (contested ? (o | OWNER_CONTESTED) : o);
+        const bool cnt_me = act && o >= 0 && nco < g.minPts;
+        {
+            const bool want = cnt_me && contested;
+            const unsigned long long wb = __ballot(want);
+            if (wb) {
+                const int firstl = __ffsll((long long)wb) - 1;
+                int lbase = 0;
+                if (lane == firstl) lbase = atomicAdd(&counters[CTR_NFLAG], __popcll(wb));
+                lbase = __builtin_amdgcn_readlane(lbase, firstl);
+                if (want) clist[lbase + lane_rank(wb)] = h;
+            }
+        }
+        unsigned long long pending = __ballot(cnt_me);
+        while (pending) {
+            const int leader = __ffsll((long long)pending) - 1;
+            const int O = __builtin_amdgcn_readlane(o, leader);
+            const unsigned long long m = __ballot(cnt_me && o == O);
+            const unsigned long long mu = __ballot(cnt_me && o == O && !contested);
+            if (lane == leader) {
+                atomicAdd(&bsize[O], __popcll(m));
+                if (mu) atomicAdd(&usize[O], __popcll(mu));
+            }
+            pending &= ~m;
+        }
+    };
+    // ---- pass 0: every walker, walks of at most kcap steps ----
+#pragma unroll 1
+    for (int i0 = 0; i0 < w1 - w0; i0 += 256) {
+        const int h = w0 + i0 + (int)threadIdx.x;
+        bool act = h < w1;
+        int ja = -1, jb = -1, r0 = -1, r1 = -1, r2 = -1, r3 = -1;
+        int2 me = make_int2(0, 0);
+        {
+            int pos = 0, enc = 0;
+            if (act) { me = wpair[h]; pos = wpos[h]; enc = wenc[h]; }
+            const bool hinted = (unsigned)enc != LH_NONE;
+            const int pa = hinted ? pos - (int)((unsigned)enc & 0xffffu) : pos, pb = hinted ? pos + (int)((unsigned)enc >> 16) : pos;
+            const int gr0 = cgrank[pos >> 6], gr1 = cgrank[pa >> 6], gr2 = cgrank[pb >> 6];
+            const unsigned long long gm0 = cmask[pos >> 6], gm1 = cmask[pa >> 6], gm2 = cmask[pb >> 6];
+            const int c1 = gr0 + __popcll(gm0 & low_mask(pos & 63));
+            ja = gr1 + __popcll(gm1 & low_mask(pa & 63));
+            jb = gr2 + __popcll(gm2 & low_mask(pb & 63));
+            if (act && !hinted) {
+                // no hints (minPts outside 2..128, pile-ups, hints that left their fields): the cores-only strip table
+                const int s = me.y >> g.rbits, qlo = me.x - g.eps;
+                ja = s > 0 ? lower_bound_pairs(cpair, cstrip[s - 1], cstrip[s], qlo) : C;
+                jb = lower_bound_pairs(cpair, cstrip[s + 1], cstrip[min(s + 2, g.S)], qlo);
+            }
+            if (act) {
+                // own strip: the nearest core on either side stands for all of its side (same strip, q inside one eps: one component)
+                const int qlo = me.x - g.eps, qhi = me.x + g.eps;
+                const int pbeg = me.y & ~(g.peps - 1), pend = pbeg + g.peps;
+                const int jl = max(c1 - 1, 0), jr = max(min(c1, C - 1), 0);
+                int2 pl, pr; int rl, rrt;
+                if (jl >= clo && jr < chi) { pl = lw[jl - clo]; pr = lw[jr - clo]; rl = lx[jl - clo].x; rrt = lx[jr - clo].x; }
+                else { pl = cpair[jl]; pr = cpair[jr]; rl = croot[jl]; rrt = croot[jr]; }
+                if (c1 > 0 && (pl.y >= pbeg) & (pl.x >= qlo)) see4(rl, r0, r1, r2, r3, counters);
+                if (c1 < C && (pr.y < pend) & (pr.x <= qhi)) see4(rrt, r0, r1, r2, r3, counters);
+            } else { ja = -1; jb = -1; }
+        }
+        const int qhi = me.x + g.eps;
+        const int pbeg = me.y & ~(g.peps - 1), pend2 = pbeg + 2 * g.peps;
+        const int plo = me.y - g.peps, phi = me.y + g.peps;
+        // a walk of at most `cap` steps from core j on: -1 = the window is exhausted, else the core to go on from
+        auto walk = [&](int j, int pcap, bool below, int cap) -> int {
+            if (j < 0) return -1;
+            int it = 0;
+            while (j < C) {
+                if (it >= cap) return j;
+                ++it;
+                const bool in0 = j >= clo && j + 1 < chi;
+                int2 p0, p1, x0, x1;
+                if (in0) { p0 = lw[j - clo]; p1 = lw[j + 1 - clo]; x0 = lx[j - clo]; x1 = lx[j + 1 - clo]; }
+                else {
+                    const int j1 = min(j + 1, C - 1);
+                    p0 = cpair[j]; p1 = cpair[j1]; x0 = make_int2(croot[j], cskip[j]); x1 = make_int2(croot[j1], cskip[j1]);
+                    if (j + 1 >= C) p1 = make_int2(INT_MAX, INT_MAX);
+                }
+                if (!((p0.y < pcap) & (p0.x <= qhi))) return -1;
+                if (below ? p0.y >= plo : p0.y <= phi) { see4(x0.x, r0, r1, r2, r3, counters); j = x0.y; continue; }
+                if (!((p1.y < pcap) & (p1.x <= qhi))) return -1;
+                if (below ? p1.y >= plo : p1.y <= phi) { see4(x1.x, r0, r1, r2, r3, counters); j = x1.y; continue; }
+                j += 2;
+            }
+            return -1;
+        };
+        int cap = kcap;
+#pragma unroll 1
+        for (int round = 0; round < 2; ++round) {
+            ja = walk(ja, pbeg, true, cap);
+            jb = walk(jb, pend2, false, cap);
+            const bool left = (ja >= 0) | (jb >= 0);
+            if (!__any(left)) break;
+            // (round 0 only: the second round leaves nothing over)
+            const bool want = left && r3 < 0;
+            const unsigned long long wb = __ballot(want);
+            int slot = INT_MAX;
+            if (wb) {
+                const int firstl = __ffsll((long long)wb) - 1;
+                int lbase = 0;
+                if (lane == firstl) lbase = atomicAdd(&l_nq, __popcll(wb));
+                lbase = __builtin_amdgcn_readlane(lbase, firstl);
+                if (want) slot = lbase + lane_rank(wb);
+            }
+            if (slot < qcap) {
+                lw[qbase + 2 * slot] = make_int2(h, me.x); lw[qbase + 2 * slot + 1] = make_int2(me.y, ja);
+                lx[qbase + 2 * slot] = make_int2(jb, r0); lx[qbase + 2 * slot + 1] = make_int2(r1, r2);
+                act = false; ja = -1; jb = -1;
+            }
+            cap = INT_MAX;                               // (no room in the queue, or four components already: finish in place)
+        }
+        finish(act, h, r0, r1, r2, r3);
+    }
+    __syncthreads();
+    // ---- pass 1: the queued walkers, BQ_G lanes each ----
+    const int nq = min(l_nq, qcap);
+    const int gl = lane & (BQ_G - 1), gsh = lane & ~(BQ_G - 1);
+    constexpr unsigned GM = BQ_G >= 32 ? 0xffffffffu : ((1u << (BQ_G & 31)) - 1u);
+#pragma unroll 1
+    for (int e0 = 0; e0 < nq; e0 += 256 / BQ_G) {
+        const int e = e0 + ((int)threadIdx.x / BQ_G);
+        const bool live = e < nq;
+        int h = 0, ja = -1, jb = -1, r0 = -1, r1 = -1, r2 = -1, r3 = -1;
+        int2 me = make_int2(0, 0);
+        if (live) {
+            const int2 e0v = lw[qbase + 2 * e], e1v = lw[qbase + 2 * e + 1], e2v = lx[qbase + 2 * e], e3v = lx[qbase + 2 * e + 1];
+            h = e0v.x; me = make_int2(e0v.y, e1v.x); ja = e1v.y; jb = e2v.x; r0 = e2v.y; r1 = e3v.x; r2 = e3v.y;
+        }
+        const int qhi = me.x + g.eps;
+        const int pbeg = me.y & ~(g.peps - 1), pend2 = pbeg + 2 * g.peps;
+        const int plo = me.y - g.peps, phi = me.y + g.peps;
+        // the group's lanes hold the same walker: one candidate per lane and step, the first that ends the window or lies within
+        // reach decides (every lane of the group takes the same decision)
+        auto gwalk = [&](int j, int pcap, bool below) {
+            while (true) {
+                const bool go = j >= 0 && j < C;
+                if (!__any(go)) break;
+                const int idx = j + gl;
+                int2 p = make_int2(INT_MAX, INT_MAX);
+                if (go && idx < C) { if (idx >= clo && idx < chi) p = lw[idx - clo]; else p = cpair[idx]; }
+                const bool inw = (p.y < pcap) & (p.x <= qhi);
+                const bool hit = inw & (below ? p.y >= plo : p.y <= phi);
+                const unsigned gstop = (unsigned)(__ballot(go && (!inw | hit)) >> gsh) & GM;
+                const unsigned ghit = (unsigned)(__ballot(go && hit) >> gsh) & GM;
+                if (go) {
+                    if (!gstop) j += BQ_G;
+                    else {
+                        const int f = __ffs((int)gstop) - 1;
+                        if (!((ghit >> f) & 1u)) j = -1;
+                        else {
+                            const int jj = j + f;
+                            int2 x;
+                            if (jj >= clo && jj < chi) x = lx[jj - clo]; else x = make_int2(croot[jj], cskip[jj]);
+                            see4(x.x, r0, r1, r2, r3, counters);
+                            j = x.y;
+                        }
+                    }
+                }
+            }
+        };
+        gwalk(ja, pbeg, true);
+        gwalk(jb, pend2, false);
+        finish(live && gl == 0, h, r0, r1, r2, r3);
     }
 }
 
@@ -1589,13 +1828,13 @@ int lists_union_flatten(cl_chrom* c, const GridParams& g, int nm, const ListRun&
     // the union walk looks one strip back, i.e. about one strip's cores in front of the core: the halo follows the mean strip population
     if ((long long)c->n > 80LL * g.S)
         hipLaunchKernelGGL((k_union_c<UNT, 512>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, g, nt, L.lcnt, (const int2*)L.cpair, (const int*)c->chainflag.as<int>(),
-                           (const int*)L.cstrip, (const int*)c->lo.as<int>(), c->parent.as<int>());
+                           (const int*)L.cstrip, (const int*)c->lo.as<int>(), c->parent.as<int>(), c->cellfirst.as<int>() /* cskip: the cell minima are in the keys */);
     else
         hipLaunchKernelGGL((k_union_c<UNT, 128>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, g, nt, L.lcnt, (const int2*)L.cpair, (const int*)c->chainflag.as<int>(),
-                           (const int*)L.cstrip, (const int*)c->lo.as<int>(), c->parent.as<int>());
+                           (const int*)L.cstrip, (const int*)c->lo.as<int>(), c->parent.as<int>(), c->cellfirst.as<int>() /* cskip: the cell minima are in the keys */);
     hipLaunchKernelGGL(k_flatten_c, dim3(nblocks(nm, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, L.lcnt, (const int*)c->chainflag.as<int>(),
-                       (const int*)c->parent.as<int>(), (const int*)L.ckey, (const int*)c->lo.as<int>(), croot_of(c), c->cellfirst.as<int>() /* cskip: the cell minima are in the keys */,
-                       c->compkey.as<int>(), c->ncore.as<int>(), c->rootlist.as<int>(), c->counters.as<int>());
+                       (const int*)c->parent.as<int>(), (const int*)L.ckey, croot_of(c),
+                       c->compkey.as<int>(), c->ncore.as<int>(), c->rootlist.as<int>(), c->counters.as<int>(), (int)g.dbg2);
     HIP_TRY(hipGetLastError());
     return CL_OK;
 }
@@ -1609,15 +1848,30 @@ int lists_scatter_root(cl_chrom* c, int nm, const ListRun& L)
 
 int lists_border(cl_chrom* c, const GridParams& g, int nm, const ListRun& L)
 {
-    constexpr int BNT = 2048, BHC = 256;
+    constexpr int BNT = 2048, BHC = 256, BHQ = 254;      // (k_border_q: 4 bytes of LDS for its queue counter, still four workgroups per CU)
     const int nt = nblocks(L.npos, BNT);
     (void)nm;
 #define LB_ARGS g, nt, L.npos, L.lcnt, L.cmask, L.cgrank, L.wgrank, (const int2*)L.cpair, (const int*)croot_of(c), (const int*)c->cellfirst.as<int>(),    \
                 (const int*)L.ckey, (const int*)L.cstrip, (const int2*)L.wpair, (const int*)L.wpos, (const int*)L.wenc, (const int*)c->compkey.as<int>(),                    \
                 (const int*)c->ncore.as<int>(), c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->chainflag.as<int>() /* clist: the chain ids are dead */,  \
                 c->counters.as<int>()
+    int kcap = 2, bqg = 16;
+    bool queued = true;
+#ifdef CLOOPS_DEVEL
+    { const char* e = getenv("CLOOPS_BCAP"); if (e) kcap = atoi(e); queued = kcap > 0; e = getenv("CLOOPS_BQG"); if (e) bqg = atoi(e); }
+#endif
     if (g.variant == CL_VARIANT_CDBSCAN1) hipLaunchKernelGGL((k_border_w<BNT, BHC, true>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LB_ARGS);
-    else hipLaunchKernelGGL((k_border_w<BNT, BHC, false>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LB_ARGS);
+    else if (!queued) hipLaunchKernelGGL((k_border_w<BNT, BHC, false>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LB_ARGS);
+#define LBQ_ARGS g, nt, L.npos, kcap, L.lcnt, L.cmask, L.cgrank, L.wgrank, (const int2*)L.cpair, (const int*)croot_of(c), (const int*)c->cellfirst.as<int>(),           \
+                 (const int*)L.cstrip, (const int2*)L.wpair, (const int*)L.wpos, (const int*)L.wenc, (const int*)c->compkey.as<int>(), (const int*)c->ncore.as<int>(),        \
+                 c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->chainflag.as<int>(), c->counters.as<int>()
+#ifdef CLOOPS_DEVEL
+    else if (bqg == 8) hipLaunchKernelGGL((k_border_q<BNT, BHQ, 8>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LBQ_ARGS);
+    else if (bqg == 32) hipLaunchKernelGGL((k_border_q<BNT, BHQ, 32>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LBQ_ARGS);
+#endif
+    else hipLaunchKernelGGL((k_border_q<BNT, BHQ, 16>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LBQ_ARGS);
+    (void)bqg;
+#undef LBQ_ARGS
 #undef LB_ARGS
     HIP_TRY(hipGetLastError());
     return CL_OK;

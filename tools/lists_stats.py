@@ -25,3 +25,4 @@ for eps, m, cut in settings:
         eps, m, cut, v[10], v[8], v[9], v[0], v[1], v[1] / max(1, v[0]), v[2], v[3] / max(1, v[0]), v[4] / max(1, v[0]), v[5] / max(1, v[0]), v[6] / max(1, v[7])))
     print("      union: cores %d walk rounds %.2f touches %.3f unites %.4f global-path %.4f jumps %.3f (per core)" % (
         v[12], v[13] / max(1, v[12]), v[14] / max(1, v[12]), v[15] / max(1, v[12]), v[16] / max(1, v[12]), v[17] / max(1, v[12])))
+    print("      union: per wave max rounds %.1f; cores with > 2 / 4 / 8 rounds: %.3f %.3f %.3f" % (v[18] / max(1, v[19]), v[20] / max(1, v[12]), v[21] / max(1, v[12]), v[22] / max(1, v[12])))
