@@ -26,6 +26,8 @@ static inline int bits_for(unsigned v) { int b = 0; while (v) { ++b; v >>= 1; } 
 
 
 #define K7_BLOCKS 2048           // workgroups (= fixed partial sums) of the K7 reductions: 8 waves per SIMD (512 left the loads
+#define K7_STEP_BLOCKS 256       // ... of the sweep step's k7_summary: 1024 threads each (every workgroup ends with up to 5 888 atomics into the two
+#define K7_STEP_THREADS 1024      //     histograms -- 2048 x 256 threads: 67 us per chr1 step, 256 x 1024: 47 us)
 #define K7_LOGBINS 3840          // 30 octaves x 128: bin = floor(log2 d) * 128 + the next 7 bits of d (monotone in d)
 #define K7_FINE 2048
 #define K7_XSHIFT 11.0           // sums are taken over x = log2|d| - K7_XSHIFT (less cancellation in sum x^2 - (sum x)^2 / n)

@@ -3035,10 +3035,17 @@ int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* labels_ou
         src.sorted = sl.sorted_src ? (sl.k7_lcnt ? 2 : 1) : 0; src.n = n; src.M = 0; src.v0 = sl.k7_v0; src.dM = sl.k7_lcnt ? sl.k7_lcnt : d_M;
         src.X = c->d_x; src.Y = c->d_y; src.labels = sl.labels.as<int>(); src.sv = sl.k7_sv; src.slab = sl.slab.as<int>();
         src.dh = k7_hist_for(c, c->pending_cut);
-        if (!SKIP(16)) hipLaunchKernelGGL(k7_summary, dim3(K7_BLOCKS), dim3(TPB), 0, c->stream, src, c->pending_cut, cls, parts, lh,
+        int k7b = K7_STEP_BLOCKS;
+#ifdef CLOOPS_DEVEL
+        int k7t = K7_STEP_THREADS;
+        { const char* e = getenv("CLOOPS_K7B"); if (e) k7b = std::max(1, std::min(atoi(e), K7_BLOCKS)); e = getenv("CLOOPS_K7T"); if (e) k7t = atoi(e); }
+#else
+        const int k7t = K7_STEP_THREADS;
+#endif
+        if (!SKIP(16)) hipLaunchKernelGGL(k7_summary, dim3(k7b), dim3(k7t), 0, c->stream, src, c->pending_cut, cls, parts, lh,
                            (unsigned)c->pending_fine_lo, c->pending_fine_lo >= 0 ? lh + K7_LOGBINS : (unsigned long long*)nullptr);
         static_assert((16 + sizeof(K7Part)) % 8 == 0, "step output in 8-byte words");
-        hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, (const K7Part*)parts, K7_BLOCKS, (K7Part*)(ds + 16),
+        hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, (const K7Part*)parts, k7b, (K7Part*)(ds + 16),
                            (const int*)bcount, nb, (long long*)ds, (const unsigned long long*)ds, (int)(out_bytes / 8),
                            (unsigned long long*)sl.h_step, (const int*)dh, sl.h_hdr);
         sl.host_written = labels_out == nullptr;        // nothing left for the copy stream

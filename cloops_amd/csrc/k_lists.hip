@@ -573,6 +573,10 @@ k_make_lists_q(GridParams g, int npos, int bandq, const int* __restrict__ bq, co
     const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
     const int t0 = blk * LT;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // A tile is a chain of dependent round trips (masks -> keys / hints; tile sums -> places -> stores), and a chromosome is eight
+    // rounds of resident workgroups: the loads are issued as early as their addresses are known -- q and sp of every position
+    // with the masks (nearly every 64-byte line holds a listed PET anyway), keys / hints and the rows of the boundary cells as
+    // soon as the masks are there, and only then the sums in front of the tile, whose barrier nothing else waits for.
     unsigned long long cbv[8], wbv[8];
     int cgv[8], wgv[8], q[8], sp[8], aux[8];
 #pragma unroll
@@ -580,36 +584,8 @@ k_make_lists_q(GridParams g, int npos, int bandq, const int* __restrict__ bq, co
         const int gidx = (t0 >> 6) + u * 4 + wv;
         cbv[u] = cmask[gidx]; wbv[u] = wmask[gidx];
         cgv[u] = cgloc[gidx]; wgv[u] = wgloc[gidx];
-    }
-    int cbase, wbase;
-    {
-        // cores / walkers in front of this tile: the 16-tile superblocks in front of its own + the tiles of its own in front of it
-        const int sb = blk >> 4;
-        int pc = 0, pw_ = 0;
-        for (int k = threadIdx.x; k < sb; k += 256) { const unsigned long long v = sup[k]; pc += (int)(unsigned)v; pw_ += (int)(unsigned)(v >> 32); }
-        if (threadIdx.x < 16) { const int k = sb * 16 + (int)threadIdx.x; if (k < blk) { pc += bsum[k]; pw_ += bsum[nblk + 1 + k]; } }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { pc += __shfl_down(pc, o); pw_ += __shfl_down(pw_, o); }
-        if (lane == 0) { l_red[0][wv] = pc; l_red[1][wv] = pw_; }
-        __syncthreads();
-        cbase = l_red[0][0] + l_red[0][1] + l_red[0][2] + l_red[0][3];
-        wbase = l_red[1][0] + l_red[1][1] + l_red[1][2] + l_red[1][3];
-    }
-    if (blk == nblk - 1 && threadIdx.x == 0) {
-        const int C = cbase + bsum[blk], W = wbase + bsum[nblk + 1 + blk];
-        lcnt[0] = C; lcnt[1] = W;
-        cgrank[nblk * LG] = C; wgrank[nblk * LG] = W;
-#ifdef CLOOPS_DEVEL
-        if (LSTAT_ON) { atomicAdd(&g_lstat[8], (unsigned long long)C); atomicAdd(&g_lstat[9], (unsigned long long)W); atomicAdd(&g_lstat[11], 1ull); }
-#endif
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
         const int b = t0 + u * 256 + (int)threadIdx.x;
-        const bool any = ((cbv[u] | wbv[u]) >> lane) & 1ull;
-        q[u] = any ? bq[b] : 0; sp[u] = any ? bsp[b] : 0;
-        cgv[u] += cbase; wgv[u] += wbase;
-        if (lane == 0) { const int gidx = (t0 >> 6) + u * 4 + wv; cgrank[gidx] = cgv[u]; wgrank[gidx] = wgv[u]; }
+        q[u] = b < npos ? bq[b] : 0; sp[u] = b < npos ? bsp[b] : 0;
     }
     {
         // a core's key: variant 1 its input row (the component's start point is its smallest-row core, cDBSCAN.py:134-137);
@@ -642,6 +618,33 @@ k_make_lists_q(GridParams g, int npos, int bandq, const int* __restrict__ bq, co
             if (isw) aux[u] = (int)lh_pack(aux[u], 0, 0);
         }
     }
+    int cbase, wbase;
+    {
+        // cores / walkers in front of this tile: the 16-tile superblocks in front of its own + the tiles of its own in front of it
+        const int sb = blk >> 4;
+        int pc = 0, pw_ = 0;
+        for (int k = threadIdx.x; k < sb; k += 256) { const unsigned long long v = sup[k]; pc += (int)(unsigned)v; pw_ += (int)(unsigned)(v >> 32); }
+        if (threadIdx.x < 16) { const int k = sb * 16 + (int)threadIdx.x; if (k < blk) { pc += bsum[k]; pw_ += bsum[nblk + 1 + k]; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { pc += __shfl_down(pc, o); pw_ += __shfl_down(pw_, o); }
+        if (lane == 0) { l_red[0][wv] = pc; l_red[1][wv] = pw_; }
+        __syncthreads();
+        cbase = l_red[0][0] + l_red[0][1] + l_red[0][2] + l_red[0][3];
+        wbase = l_red[1][0] + l_red[1][1] + l_red[1][2] + l_red[1][3];
+    }
+    if (blk == nblk - 1 && threadIdx.x == 0) {
+        const int C = cbase + bsum[blk], W = wbase + bsum[nblk + 1 + blk];
+        lcnt[0] = C; lcnt[1] = W;
+        cgrank[nblk * LG] = C; wgrank[nblk * LG] = W;
+#ifdef CLOOPS_DEVEL
+        if (LSTAT_ON) { atomicAdd(&g_lstat[8], (unsigned long long)C); atomicAdd(&g_lstat[9], (unsigned long long)W); atomicAdd(&g_lstat[11], 1ull); }
+#endif
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        cgv[u] += cbase; wgv[u] += wbase;
+        if (lane == 0) { const int gidx = (t0 >> 6) + u * 4 + wv; cgrank[gidx] = cgv[u]; wgrank[gidx] = wgv[u]; }
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int b = t0 + u * 256 + (int)threadIdx.x;
@@ -664,12 +667,12 @@ k_make_lists_q(GridParams g, int npos, int bandq, const int* __restrict__ bq, co
 // ------------------------------------------------------------------------------------------
 // Inside a strip every pair is within eps in the strip coordinate, so cores whose q gaps are <= eps form a CHAIN -- on the core
 // array a contiguous run.  chainid[c] = index of the chain's first core (its head: the union-find node of all its cores);
-// cend[head] = index of its last core.  Every component root is a chain head: the per-root accumulators are reset here.
+// cskip[c] = a core behind c from which a walk that has met c goes on (see below).  Every component root is a chain head: the per-root accumulators are reset here.
 #define CH_PER 4
 __global__ void __launch_bounds__(256)
 k_chain_c(GridParams g, const int* __restrict__ lcnt, const int2* __restrict__ cpair, int* __restrict__ chainid,
           int* __restrict__ parent, int* __restrict__ compkey, int* __restrict__ ncore, int* __restrict__ bsize,
-          int* __restrict__ usize, int* __restrict__ state, int* __restrict__ cend,
+          int* __restrict__ usize, int* __restrict__ state, int* __restrict__ cskip,
           const int* __restrict__ strip_start, const unsigned long long* __restrict__ cmask, const int* __restrict__ cgrank,
           int* __restrict__ cstrip, int* __restrict__ sup, int nsup2, int* __restrict__ ckey_prune /* or null */)
 {
@@ -703,6 +706,10 @@ k_chain_c(GridParams g, const int* __restrict__ lcnt, const int2* __restrict__ c
         const bool open = in && (c == 0 || (pv[e].y & nmask) != p0 || pv[e].x < me[e].x - g.eps);
         const bool last = in && (c + 1 >= C || (nx[e].y & nmask) != p0 || nx[e].x > me[e].x + g.eps);
         const unsigned long long ob = __ballot(open);
+        // cskip[c]: where a walk that has met core c may go on -- behind the chain's last core, or at the wave's end if the chain
+        // runs on (any core of the chain behind c will do: the walks meet the chain again and skip again)
+        const unsigned long long lb = __ballot(last) & (~0ull << lane);
+        const int skip = (c - lane) + (lb ? __ffsll((long long)lb) : 64);
         const unsigned long long upto = ob & ((2ull << lane) - 1ull);
         int head = upto ? (c - lane) + 63 - __clzll((long long)upto) : -1;
         if (__any(in && !upto)) {
@@ -722,7 +729,7 @@ k_chain_c(GridParams g, const int* __restrict__ lcnt, const int2* __restrict__ c
         if (in) {
             chainid[c] = head;
             if (head == c) { parent[c] = c; compkey[c] = INT_MAX; ncore[c] = 0; bsize[c] = 0; usize[c] = 0; state[c] = ST_LIVE; }
-            if (last) cend[head] = c;
+            cskip[c] = skip;
             // variant 2, keys by cell (level 4): of a cell's cores only the first carries the cell to k_flatten_c (two cores of one
             // cell are always one component) -- the others cost it neither an atomic nor a compare
             if (ckey_prune && c > 0 && (pv[e].y & nmask) == p0 && div_eps(g, pv[e].x) == div_eps(g, me[e].x)) ckey_prune[c] = INT_MAX;
@@ -755,12 +762,12 @@ __device__ __forceinline__ int lower_bound_pairs(const int2* __restrict__ pv, in
 template <int NT, int HALO>
 __global__ void __launch_bounds__(256)
 k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __restrict__ cpair, const int* __restrict__ chainid,
-          const int* __restrict__ cstrip, const int* __restrict__ cend, int* parent, int* __restrict__ cskip)
+          const int* __restrict__ cstrip, const int* __restrict__ cskip, int* parent)
 {
     constexpr int WIN = NT + HALO;
     __shared__ int2 lw[WIN];
     __shared__ int lx[WIN];
-    __shared__ int lend[WIN];                            // last core of the staged core's chain
+    __shared__ int lend[WIN];                            // where a walk goes on behind the staged core's chain (k_chain_c)
     const int C = lcnt[0];
     const int tile = ltile_of_block(blockIdx.x);
     const int t0 = tile * NT;
@@ -770,13 +777,8 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
         const int gi = base + k;
         const bool in = gi >= 0 && gi < C;
         lw[k] = in ? cpair[gi] : (gi < 0 ? make_int2(0, INT_MIN) : make_int2(INT_MAX, INT_MAX));
-        const int ch = in ? chainid[gi] : -1;
-        lx[k] = ch;
-        // where a walk that has met this core may go on: behind its chain (all cores of a chain are one component).  k_border_*
-        // walks the same way: cskip[c] = the first core behind c's chain, written here by the tile that owns c
-        const int ce = in ? cend[ch] : -1;
-        lend[k] = ce;
-        if (in && k >= HALO) cskip[gi] = ce + 1;
+        lx[k] = in ? chainid[gi] : -1;
+        lend[k] = in ? cskip[gi] : 0;
     }
     __syncthreads();
     const int wbeg = max(base, 0);
@@ -827,7 +829,7 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
                 if (L_ABL(1 << 17)) tb = b;              // (ablation: neither search nor walk)
                 if (tb >= b) { }
                 else if (tb >= wbeg && b - tb <= 2047) {
-                    // the window is staged.  Once a chain has been touched the walk jumps behind its last core (cend): a window
+                    // the window is staged.  Once a chain has been touched the walk jumps behind it (cskip, k_chain_c): a window
                     // covered by one chain costs one candidate instead of all of them.
                     const int len = b - tb;
                     int j;
@@ -836,30 +838,30 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
                     else if (len <= 255) j = lds_lower_bound8<8>(w, tb, b, qlo);
                     else j = lds_lower_bound8<11>(w, tb, b, qlo);
                     if (L_ABL(1 << 16)) j = b;           // (ablation: the search without the walk)
+                    // four candidates per round; the first that ends the window (q beyond it) or lies within reach decides: the
+                    // walk stops, or notes the chain and goes on behind it
                     while (j < b) {
 #ifdef CLOOPS_DEVEL
                         ++st_it;
 #endif
-                        int2 cv[4]; int bv[4], ev[4];
+                        int2 cv[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { const int idx = min(j + k, b - 1); cv[k] = lw[idx - base]; bv[k] = lx[idx - base]; ev[k] = lend[idx - base]; }
-                        int next = j + 4;
-                        bool stop = false;
+                        for (int k = 0; k < 4; ++k) cv[k] = lw[min(j + k, b - 1) - base];
+                        int f = 4; bool fh = false;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            if (stop || j + k >= b) continue;
-                            if (cv[k].x > qhi) { stop = true; next = b; continue; }
-                            if (cv[k].y >= T) {
-                                touch(bv[k]);
-                                if (len > 8 || L_ABL(1 << 15)) {
-#ifdef CLOOPS_DEVEL
-                                    ++st_jump;
-#endif
-                                    stop = true; next = ev[k] + 1;      // (> j + k: the chain holds this core)
-                                }
-                            }
+                        for (int k = 3; k >= 0; --k) {
+                            const bool bey = (j + k >= b) | (cv[k].x > qhi);
+                            const bool hit = cv[k].y >= T;
+                            if (bey | hit) { f = k; fh = hit & !bey; }
                         }
-                        j = next;
+                        if (f == 4) { j += 4; continue; }
+                        if (!fh) break;
+                        const int idx = j + f - base;
+                        touch(lx[idx]);
+#ifdef CLOOPS_DEVEL
+                        ++st_jump;
+#endif
+                        j = lend[idx];                     // (> j + f)
                     }
                 } else {
 #ifdef CLOOPS_DEVEL
@@ -880,7 +882,7 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
                             if (cv[e].y >= T) {
                                 touch(bv[e]);
                                 stop = true;
-                                next = cend[bv[e]] + 1;
+                                next = cskip[min(k + e, b - 1)];
                             }
                         }
                         k = next;
@@ -1739,7 +1741,7 @@ int lists_build(cl_chrom* c, const GridParams& g, int nm, ListRun* out)
     // chains (the core count is only known on the device: the grids are sized by the PETs of the run)
     hipLaunchKernelGGL(k_chain_c, dim3(nblocks(nm, 256 * CH_PER)), dim3(256), 0, c->stream, g, L.lcnt, (const int2*)L.cpair, c->chainflag.as<int>(),
                        c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
-                       c->lo.as<int>(), (const int*)c->w_strip, L.cmask, L.cgrank, L.cstrip, b.sup, b.nsup2, (int*)nullptr);
+                       c->cellfirst.as<int>() /* cskip */, (const int*)c->w_strip, L.cmask, L.cgrank, L.cstrip, b.sup, b.nsup2, (int*)nullptr);
     L.npos = nm; L.pstrip = c->w_strip;
     *out = L;
     HIP_TRY(hipGetLastError());
@@ -1800,7 +1802,7 @@ int lists_build_base(cl_chrom* c, const GridParams& g, int nm, ListRun* out)
 #undef LMQ_ARGS
     hipLaunchKernelGGL(k_chain_c, dim3(nblocks(nm, 256 * CH_PER)), dim3(256), 0, c->stream, g, L.lcnt, (const int2*)L.cpair, c->chainflag.as<int>(),
                        c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
-                       c->lo.as<int>(), L.pstrip, L.cmask, L.cgrank, L.cstrip, b.sup, std::max(nsup_ints, b.nsup2), v2 ? L.ckey : (int*)nullptr);
+                       c->cellfirst.as<int>() /* cskip */, L.pstrip, L.cmask, L.cgrank, L.cstrip, b.sup, std::max(nsup_ints, b.nsup2), v2 ? L.ckey : (int*)nullptr);
     *out = L;
     HIP_TRY(hipGetLastError());
     c->l_sup_dirty = false;
@@ -1828,10 +1830,10 @@ int lists_union_flatten(cl_chrom* c, const GridParams& g, int nm, const ListRun&
     // the union walk looks one strip back, i.e. about one strip's cores in front of the core: the halo follows the mean strip population
     if ((long long)c->n > 80LL * g.S)
         hipLaunchKernelGGL((k_union_c<UNT, 512>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, g, nt, L.lcnt, (const int2*)L.cpair, (const int*)c->chainflag.as<int>(),
-                           (const int*)L.cstrip, (const int*)c->lo.as<int>(), c->parent.as<int>(), c->cellfirst.as<int>() /* cskip: the cell minima are in the keys */);
+                           (const int*)L.cstrip, (const int*)c->cellfirst.as<int>() /* cskip: the cell minima are in the keys */, c->parent.as<int>());
     else
         hipLaunchKernelGGL((k_union_c<UNT, 128>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, g, nt, L.lcnt, (const int2*)L.cpair, (const int*)c->chainflag.as<int>(),
-                           (const int*)L.cstrip, (const int*)c->lo.as<int>(), c->parent.as<int>(), c->cellfirst.as<int>() /* cskip: the cell minima are in the keys */);
+                           (const int*)L.cstrip, (const int*)c->cellfirst.as<int>() /* cskip: the cell minima are in the keys */, c->parent.as<int>());
     hipLaunchKernelGGL(k_flatten_c, dim3(nblocks(nm, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, L.lcnt, (const int*)c->chainflag.as<int>(),
                        (const int*)c->parent.as<int>(), (const int*)L.ckey, croot_of(c),
                        c->compkey.as<int>(), c->ncore.as<int>(), c->rootlist.as<int>(), c->counters.as<int>(), (int)g.dbg2);
@@ -1968,7 +1970,7 @@ extern "C" int cl_debug_time_lists(cl_chrom* c, int which, int reps, float* ms_o
                 ListBufs bb; if ((rc = list_bufs(c, g, c->run_level == 4 ? (int)c->n : nm, &bb))) return rc;
                 hipLaunchKernelGGL(k_chain_c, dim3(nblocks(nm, 256 * CH_PER)), dim3(256), 0, c->stream, g, L2.lcnt, (const int2*)L2.cpair, c->chainflag.as<int>(),
                                    c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
-                                   c->lo.as<int>(), L2.pstrip, L2.cmask, L2.cgrank, L2.cstrip, bb.sup, 2, (int*)nullptr);
+                                   c->cellfirst.as<int>(), L2.pstrip, L2.cmask, L2.cgrank, L2.cstrip, bb.sup, 2, (int*)nullptr);
                 HIP_TRY(hipMemsetAsync(c->counters.p, 0, 64, c->stream));
                 if ((rc = lists_union_flatten(c, g, nm, L2))) return rc;
             } else { if ((rc = lists_final(c, g, nm, L2, false, c->counters.as<int>() + 40))) return rc; }

@@ -155,7 +155,7 @@ k7_reduce_parts(const K7Part* __restrict__ parts, int nparts, K7Part* out, const
 
 // one pass: counts, sum x and sum x^2 (x = log2|d| - K7_XSHIFT over d != 0) for both groups, and the log-binned
 // histogram of the self group's |d| (first level of the exact median)
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(1024)
 k7_summary(K7Src s, int cut, const signed char* __restrict__ cls, K7Part* __restrict__ parts, unsigned long long* __restrict__ loghist,
            unsigned fine_lo, unsigned long long* __restrict__ fine /* or null: exact histogram of the self group's fine_lo <= |d| < fine_lo + 2048 */)
 {
@@ -179,8 +179,8 @@ k7_summary(K7Src s, int cut, const signed char* __restrict__ cls, K7Part* __rest
             }
         }
     });
-    __shared__ double s_d[4][TPB / 64];
-    __shared__ long long s_n[4][TPB / 64];
+    __shared__ double s_d[4][16];
+    __shared__ long long s_n[4][16];
     for (int g = 0; g < 2; ++g)
         for (int o = 32; o > 0; o >>= 1) {
             sx[g] += __shfl_down(sx[g], o); sxx[g] += __shfl_down(sxx[g], o);
@@ -196,7 +196,7 @@ k7_summary(K7Src s, int cut, const signed char* __restrict__ cls, K7Part* __rest
         K7Part p;
         for (int g = 0; g < 2; ++g) {
             double a = 0, b = 0; long long c = 0, d = 0;
-            for (int w = 0; w < TPB / 64; ++w) { a += s_d[g][w]; b += s_d[2 + g][w]; c += s_n[g][w]; d += s_n[2 + g][w]; }
+            for (int w = 0; w < (int)blockDim.x / 64; ++w) { a += s_d[g][w]; b += s_d[2 + g][w]; c += s_n[g][w]; d += s_n[2 + g][w]; }
             p.sx[g] = a; p.sxx[g] = b; p.n_all[g] = c; p.n_pos[g] = d;
         }
         parts[blockIdx.x] = p;
