@@ -1478,10 +1478,10 @@ k_border_q(GridParams g, int ntiles, int npos, int kcap, const int* __restrict__
 }
 
 // ---- variant 2 release rule (cDBSCAN2.py:180-183): the records of the contested walkers --------------------------
-// The contested walkers that k_border_w listed (walkers of components that are not live on their cores alone), one WAVE each.
+// The contested walkers that k_border_* listed (walkers of components that are not live on their cores alone), 16 lanes each.
 // Only one whose first-come owner is UNCERTAIN can change hands (k_resolve_release walks a record's components in key order
 // and a live one ends the walk): most listed walkers leave after that test.  The others collect their adjacent components:
-// four walks over the core array (own strip downwards / upwards, one strip below, one above), 64 cores per round, every
+// four walks over the core array (own strip downwards / upwards, one strip below, one above), 16 cores per round, every
 // DISTINCT root looked at once.
 __global__ void __launch_bounds__(TPB)
 k_emit_records_w(GridParams g, const int* __restrict__ lcnt, const unsigned long long* __restrict__ cmask,
@@ -1497,35 +1497,45 @@ k_emit_records_w(GridParams g, const int* __restrict__ lcnt, const unsigned long
     const int lane = threadIdx.x & 63;
     const int nwaves = gridDim.x * (TPB / 64);
     const int wave = blockIdx.x * (TPB / 64) + (int)(threadIdx.x >> 6);
+    constexpr int EG = 16;                                // lanes per walker
+    const int gl = lane & (EG - 1), gsh = lane & ~(EG - 1), grp = lane / EG;
     for (int k0 = 0; k0 < nlist; k0 += 64 * nwaves) {
         const int kl = k0 + lane * nwaves + wave;
         const int ci = kl < nlist ? clist[kl] : -1;
         const int co = ci >= 0 ? wowner[ci] : -1;
         unsigned long long todo = __ballot(ci >= 0 && state[owner_root(co) >= 0 ? owner_root(co) : 0] == ST_UNKNOWN && co >= 0);
         while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const int h = __builtin_amdgcn_readlane(ci, src);                // (wave-uniform from here on)
-            const int2 me = wpair[h];
-            const int pos = wpos[h], enc = wenc[h];
+            // the wave's next 64 / EG walkers, one per group of EG lanes (every lane of a group holds the same walker and takes the
+            // same decisions; the kernel is a handful of dependent round trips per walker -- four of them side by side)
+            int src = -1;
+#pragma unroll
+            for (int gi = 0; gi < 64 / EG; ++gi) {
+                if (todo) { if (grp == gi) src = __ffsll((long long)todo) - 1; todo &= todo - 1; }
+            }
+            const bool act = src >= 0;
+            const int h = __shfl(ci, act ? src : 0);
+            const int2 me = act ? wpair[h] : make_int2(0, 0);
+            const int pos = act ? wpos[h] : 0, enc = act ? wenc[h] : (int)LH_NONE;
             const int qlo = me.x - g.eps, qhi = me.x + g.eps;
             const int pbeg = me.y & ~(g.peps - 1), pend = pbeg + g.peps, pend2 = pend + g.peps;
             const int plo = me.y - g.peps, phi = me.y + g.peps;
-            const int c1 = core_rank(cmask, cgrank, pos);
-            int ca, cb;
-            if ((unsigned)enc != LH_NONE) {
-                ca = core_rank(cmask, cgrank, pos - (int)((unsigned)enc & 0xffffu));
-                cb = core_rank(cmask, cgrank, pos + (int)((unsigned)enc >> 16));
-            } else {
-                const int s = me.y >> g.rbits;
-                ca = s > 0 ? lower_bound_pairs(cpair, cstrip[s - 1], cstrip[s], qlo) : C;
-                cb = lower_bound_pairs(cpair, cstrip[s + 1], cstrip[min(s + 2, g.S)], qlo);
+            int c1 = 0, ca = C, cb = C;
+            if (act) {
+                c1 = core_rank(cmask, cgrank, pos);
+                if ((unsigned)enc != LH_NONE) {
+                    ca = core_rank(cmask, cgrank, pos - (int)((unsigned)enc & 0xffffu));
+                    cb = core_rank(cmask, cgrank, pos + (int)((unsigned)enc >> 16));
+                } else {
+                    const int s = me.y >> g.rbits;
+                    ca = s > 0 ? lower_bound_pairs(cpair, cstrip[s - 1], cstrip[s], qlo) : C;
+                    cb = lower_bound_pairs(cpair, cstrip[s + 1], cstrip[min(s + 2, g.S)], qlo);
+                }
             }
             int rr[4] = {-1, -1, -1, -1};
             int kk[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
             int nr = 0;
             bool any_u = false, overflow = false;
-            auto see = [&](int r) {                                          // (every lane keeps the same list)
+            auto see = [&](int r) {                                          // (every lane of the group keeps the same list)
                 for (int q = 0; q < 4; ++q) if (rr[q] == r) return;
                 if (nr == 4) { overflow = true; return; }
                 const int key = compkey[r];
@@ -1540,36 +1550,36 @@ k_emit_records_w(GridParams g, const int* __restrict__ lcnt, const unsigned long
                 return w == 0 ? ((p >= pbeg) & (q >= qlo)) : w == 1 ? ((p < pend) & (q <= qhi)) : w == 2 ? ((p < pbeg) & (q <= qhi)) : ((p < pend2) & (q <= qhi));
             };
             auto acc = [&](int w, int p) { return w == 2 ? p >= plo : (w == 3 ? p <= phi : true); };
-            // one round: 64 cores of walk w -> true if the walk goes on behind them
-            auto round = [&](int w, bool in, int2 p, int r) {
-                const bool ok = in && more(w, p.x, p.y);
+            // one round: EG cores of walk w -> true if the group's walk goes on behind them
+            auto round = [&](int w, bool on, bool in, int2 p, int r) {
+                const bool ok = on && in && more(w, p.x, p.y);
                 const int rv = (ok && acc(w, p.y)) ? r : -1;
-                unsigned long long pending = __ballot(rv >= 0);
-                while (pending) {
-                    const int R = __builtin_amdgcn_readlane(rv, __ffsll((long long)pending) - 1);
-                    pending &= ~__ballot(rv == R);
-                    see(R);
+                unsigned pending = (unsigned)(__ballot(rv >= 0) >> gsh) & 0xffffu;
+                while (__any(pending != 0u)) {
+                    const int R = __shfl(rv, gsh + (pending ? __ffs((int)pending) - 1 : 0));
+                    const unsigned same = (unsigned)(__ballot(pending != 0u && rv == R) >> gsh) & 0xffffu;
+                    if (pending) { see(R); pending &= ~same; }
                 }
-                return __ballot(ok) == ~0ull;
+                return on && ((unsigned)(__ballot(ok) >> gsh) & 0xffffu) == 0xffffu;
             };
-            // the first rounds of all four walks in flight together (the kernel is a handful of waves deep in dependent loads)
+            // the first rounds of all four walks in flight together
             int2 p0[4]; int r0[4]; bool in0[4];
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const int j = w == 0 ? start[w] - lane : start[w] + lane;
-                in0[w] = j >= 0 && j < C;
+                const int j = w == 0 ? start[w] - gl : start[w] + gl;
+                in0[w] = act && j >= 0 && j < C;
                 p0[w] = in0[w] ? cpair[j] : make_int2(0, 0); r0[w] = in0[w] ? croot[j] : -1;
             }
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                bool on = round(w, in0[w], p0[w], r0[w]);
-                for (int rnd = 1; on; ++rnd) {
-                    const int j = w == 0 ? start[w] - lane - 64 * rnd : start[w] + lane + 64 * rnd;
-                    const bool in = j >= 0 && j < C;
-                    on = round(w, in, in ? cpair[j] : make_int2(0, 0), in ? croot[j] : -1);
+                bool on = round(w, act, in0[w], p0[w], r0[w]);
+                for (int rnd = 1; __any(on); ++rnd) {
+                    const int j = w == 0 ? start[w] - gl - EG * rnd : start[w] + gl + EG * rnd;
+                    const bool in = on && j >= 0 && j < C;
+                    on = round(w, on, in, in ? cpair[j] : make_int2(0, 0), in ? croot[j] : -1);
                 }
             }
-            if (lane == 0) {
+            if (act && gl == 0) {
                 if (overflow) atomicExch(&counters[CTR_OVERFLOW], 1);
                 if (any_u) {
                     const int idx = atomicAdd(&counters[CTR_NREC], 1);
