@@ -228,6 +228,12 @@ class Chromosome(object):
         arr = (ctypes.c_int32 * max(1, len(vals)))(*vals)
         self._lib.cl_set_count_thresholds(self._h, arr, len(vals))
 
+    def set_eps_list(self, eps_list):
+        """the eps values that will be asked for (cl_set_eps_list): with a common divisor the layouts come from one fine sort; empty = unknown"""
+        vals = [int(e) for e in eps_list]
+        arr = (ctypes.c_int32 * max(1, len(vals)))(*vals)
+        self._lib.cl_set_eps_list(self._h, arr, len(vals))
+
     def last_region_mode(self):
         """0 = the last enqueued run did a full region query, 1 = re-used the kept words, 2 = re-used them outside the cut band"""
         return int(self._lib.cl_last_region_mode(self._h))

@@ -25,6 +25,7 @@ __device__ __forceinline__ int je_minus(const int* __restrict__ cstart, int j) {
 static inline int bits_for(unsigned v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 
 
+#define CL_FINE_KMAX 8           // most runs per strip a layout is merged from (cl_set_eps_list)
 #define K7_BLOCKS 2048           // workgroups (= fixed partial sums) of the K7 reductions: 8 waves per SIMD (512 left the loads
 #define K7_STEP_BLOCKS 256       // ... of the sweep step's k7_summary: 1024 threads each (every workgroup ends with up to 5 888 atomics into the two
 #define K7_STEP_THREADS 1024      //     histograms -- 2048 x 256 threads: 67 us per chr1 step, 256 x 1024: 47 us)
@@ -85,6 +86,11 @@ struct cl_chrom {
     DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, scan_tmp;
     DevBuf qb_key, qb_val;            // the q index (k_make_qkeys): rows sorted by q, persistent
     int qindex_layout = -1;           // layout the q index was built for (-1: none)
+    // the fine layout (cl_set_eps_list): rows sorted by (strip of width fine_w, q) once; the layout of an eps = k fine_w is a per-strip merge of it
+    DevBuf fq, fsp, frow, fstrip;
+    int fine_w = 0;                   // announced common divisor of the sweep's eps values (0: none)
+    int fine_valid_w = 0, fine_layout = -1;       // what the fine buffers hold
+    GridParams fine_g;
     int sort_index_mode = 0;          // cl_set_sort_index: 0 = build at the second sort, 1 = at the first, -1 = never
     long long n_sorts = 0;            // layouts sorted on this handle so far
     DevBuf sv, sa, strip, cnt, parent, root, head, headidx, cellfirst, compkey, ncore, bsize, owner, state;

@@ -287,6 +287,55 @@ struct SplitOut {                                       // output iterator: valu
     __host__ __device__ __forceinline__ bool operator<(const SplitOut& o) const { return q < o.q; }
 };
 
+// ------------------------------------------------------------------------------------------
+// A layout from the FINE layout (cl_set_eps_list).  The eps values of a sweep usually share a large divisor w (Hi-C mode 3:
+// 5000 / 7500 / 10000 -> 2500), and the strips of every eps start at the same origin: a strip of width eps = k w is k
+// consecutive strips of width w.  With the rows sorted ONCE by (fine strip, q) -- the same 2-pass strip sort of the q index --
+// the layout of an eps is no sort at all: a strip's PETs are one contiguous segment of the fine layout, made of k runs that are
+// each in (q, row) order, and every PET finds its place inside the segment by k - 1 bisections of the other runs (its
+// neighbours in the wave bisect the same few hundred entries: the loads stay in L1 / L2).  Same permutation as the sort, bit
+// for bit (composite order (q, row) = the stable order of the q index).  One pass of 12 B/PET in, 12 B/PET out instead of two
+// radix passes + histogram + the sort's own resets.
+// ------------------------------------------------------------------------------------------
+__global__ void k_strips_from_fine(int S, int s0, int k, int F, int f0, const int* __restrict__ fstrip, int n, int* __restrict__ strip_start)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > S + 1) return;
+    const long long f = (long long)k * ((long long)s + s0) - f0;
+    strip_start[s] = s >= S ? n : fstrip[(int)std::min<long long>(std::max<long long>(f, 0), F)];
+}
+__global__ void __launch_bounds__(256)
+k_layout_from_fine(int n, GridParams g, GridParams gf, int k, const int* __restrict__ fq, const int* __restrict__ fsp, const u32* __restrict__ frow,
+                   const int* __restrict__ fstrip, int* __restrict__ dq, int* __restrict__ dsp, u32* __restrict__ drow, int* __restrict__ dtile)
+{
+    const int i = blockIdx.x * 256 + (int)threadIdx.x;
+    if (i >= n) return;
+    const int q = fq[i], spf = fsp[i];
+    const u32 row = frow[i];
+    const int f = spf >> gf.rbits;                       // fine strip: row of the fine table
+    const int fabs = f + gf.s0;                          // (>= 0: strips count from the common origin A0)
+    const int sabs = fabs / k, r = fabs - sabs * k;      // the strip of width eps and the PET's run inside it
+    const int fbase = sabs * k - gf.s0;                  // table row of the strip's first run (< 0: runs in front of the chromosome's first strip)
+    int dst = fstrip[max(fbase, 0)] + (i - fstrip[f]);
+    for (int rr = 0; rr < k; ++rr) {
+        const int ff = fbase + rr;
+        if (rr == r || ff < 0 || ff >= gf.S) continue;
+        int lo = fstrip[ff], hi = fstrip[ff + 1];
+        const int b0 = lo;
+        while (lo < hi) {                                 // entries of run rr in front of (q, row)
+            const int mid = (lo + hi) >> 1;
+            const int qy = fq[mid];
+            const bool less = qy < q || (qy == q && frow[mid] < row);
+            lo = less ? mid + 1 : lo; hi = less ? hi : mid;
+        }
+        dst += lo - b0;
+    }
+    dq[dst] = q;
+    dsp[dst] = ((sabs - g.s0) << g.rbits) | (r * gf.eps + (spf & (gf.peps - 1)));
+    drow[dst] = row;
+    if ((dst & 255) == 0) dtile[dst >> 8] = min(sabs - g.s0, g.S);
+}
+
 // tile_s0 (optional): strip of every 256th sorted PET (what k_decode_sp leaves, for a layout that was not decoded)
 __global__ void k_strip_table32(const u32* __restrict__ skeys, int n, int S, int shift, int* __restrict__ strip_start, int* __restrict__ tile_s0 = nullptr)
 {
@@ -1963,7 +2012,8 @@ static void free_chrom(cl_chrom* c)
                       &c->ncore, &c->bsize, &c->owner, &c->state, &c->flag, &c->rankscan, &c->slot[0].labels, &c->slot[0].table, &c->slot[1].labels, &c->slot[1].table, &c->slot[0].slab, &c->slot[1].slab, &c->slot[0].d_step, &c->slot[1].d_step, &c->slot[0].pairs, &c->slot[1].pairs, &c->hdr, &c->k7_cls, &c->k7_parts, &c->sig_tx, &c->sig_ty, &c->sig_tmp, &c->sig_sorttmp, &c->sig_m, &c->sig_win, &c->sig_out,
                       &c->ulist, &c->lo, &c->hi, &c->recs, &c->counters, &c->chainflag, &c->chainhead, &c->usize, &c->b_cstart, &c->b_ckey, &c->b_nb, &c->b_cx, &c->b_cy, &c->tile_s0, &c->bq, &c->bsp, &c->brow, &c->bstrip, &c->btile, &c->sel_tmp, &c->cand_box, &c->cand_step, &c->cand_keep, &c->cand_out, &c->dhist,
                       &c->rc_cnt, &c->rc_pre, &c->rc_poff, &c->rc_dpre, &c->rc_D, &c->rc_blen, &c->rootlist, &c->cflag8, &c->blk_tmp,
-                      &c->l_mask, &c->l_rank, &c->l_blk, &c->l_cstrip, &c->l_wpos, &c->l_wenc, &c->l_dist, &c->l_aux, &c->l_tab, &c->l_fix, &c->bkey};
+                      &c->l_mask, &c->l_rank, &c->l_blk, &c->l_cstrip, &c->l_wpos, &c->l_wenc, &c->l_dist, &c->l_aux, &c->l_tab, &c->l_fix, &c->bkey,
+                      &c->fq, &c->fsp, &c->frow, &c->fstrip};
     for (DevBuf* b : bufs) b->release();
     c->arena.release();                                  // (after its slices have been dropped)
     if (c->own_xy) { if (c->d_x) (void)hipFree(c->d_x); if (c->d_y) (void)hipFree(c->d_y); }
@@ -1993,6 +2043,24 @@ extern "C" void cl_set_count_floor(cl_chrom* c, int32_t min_pts)
     c->count_floor = min_pts > 0 ? min_pts : 0;
     for (auto& w : c->count_tmask) w = 0;
 }
+extern "C" void cl_set_eps_list(cl_chrom* c, const int32_t* eps, int32_t n)
+{
+    if (!c) return;
+    long long gcd = 0, mx = 0;
+    int distinct = 0;
+    for (int k = 0; eps && k < n; ++k) {
+        if (eps[k] <= 0) { gcd = 0; distinct = 0; break; }
+        bool seen = false;
+        for (int j = 0; j < k; ++j) seen |= eps[j] == eps[k];
+        distinct += seen ? 0 : 1;
+        long long a = eps[k], b = gcd;
+        while (b) { const long long t = a % b; a = b; b = t; }
+        gcd = a; mx = std::max<long long>(mx, eps[k]);
+    }
+    // worth a layout of its own: several eps values, strips of the common width not absurdly narrow, at most CL_FINE_KMAX runs per strip
+    c->fine_w = (distinct >= 2 && gcd >= 16 && mx / gcd <= CL_FINE_KMAX) ? (int)gcd : 0;
+}
+
 extern "C" void cl_set_count_thresholds(cl_chrom* c, const int32_t* min_pts, int32_t n)
 {
     if (!c) return;
@@ -2393,6 +2461,7 @@ __global__ void k_store_m(int S, const int* __restrict__ sloc, const int* __rest
         {&c->ulist, n * 4}, {&c->lo, n * 4}, {&c->hi, n * 4}, {&c->recs, n * sizeof(Rec)}, \
         {&c->chainflag, n * 4}, {&c->chainhead, n * 4}, {&c->usize, n * 4}, {&c->tile_s0, (n / 256 + 2) * 4}, \
         {&c->bq, (n + 2 * SORT_PAD) * 4}, {&c->bsp, (n + 2 * SORT_PAD) * 4}, {&c->brow, n * 4}, {&c->btile, (n / 256 + 2) * 4}, \
+        {&c->fq, n * 4}, {&c->fsp, n * 4}, {&c->frow, n * 4}, \
         {&c->qb_key, n * 4}, {&c->qb_val, n * 8}, {&c->k7_cls, n + 16}, {&c->rc_cnt, n * 4}, {&c->rootlist, n * 4}, {&c->cflag8, n + 16}, \
         {&c->slot[0].d_step, 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8 + K7_BLOCKS * sizeof(K7Part)}, \
         {&c->slot[1].d_step, 16 + sizeof(K7Part) + K7_LOGBINS * 8 + K7_FINE * 8 + K7_BLOCKS * sizeof(K7Part)}, \
@@ -2478,7 +2547,7 @@ int ensure_workspace(cl_chrom* c, int S)
     if (!c->arena.p) (void)reserve_workspace(c);
     const cl_chrom::Slot* other = &c->slot[1 - c->cur];
     for (const Want& w : wants) if (w.b != &other->labels && w.b != &other->table && w.b != &other->slab && w.b != &c->slot[0].d_step && w.b != &c->slot[1].d_step && w.b != &c->bq && w.b != &c->bsp && w.b != &c->brow && w.b != &c->btile && w.b != &c->qb_key &&
-                                    w.b != &c->qb_val && w.b != &c->k7_cls && w.b != &c->rc_cnt && w.b != &c->rootlist && w.b != &c->cflag8 && (rc = w.b->ensure(w.bytes))) return rc;
+                                    w.b != &c->qb_val && w.b != &c->fq && w.b != &c->fsp && w.b != &c->frow && w.b != &c->k7_cls && w.b != &c->rc_cnt && w.b != &c->rootlist && w.b != &c->cflag8 && (rc = w.b->ensure(w.bytes))) return rc;
     if ((rc = c->strip.ensure(((size_t)S + 2) * 4)) || (rc = c->counters.ensure(256))) return rc;      // (counters: allocated at upload)
     if (c->sv.fresh || c->sa.fresh) {
         // sentinel pads around the sorted arrays (k_region_core stages its windows without bounds checks)
@@ -2608,16 +2677,47 @@ static int sort_layout(cl_chrom* c, const GridParams& g, int* dsv, int* dsa, u32
             // every row is in the layout: keys and values are made inside the first radix pass, the last one writes the layout
             ev_record(c, 1);
             u32* rows = drow ? drow : k32_in;
-            const auto kin = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), SpKeyOfIndex{c->qb_key.as<u32>(), c->qb_val.as<u64>(), g});
-            const auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), SpValOfIndex{c->qb_key.as<u32>(), c->qb_val.as<u64>()});
-            size_t need = 0;
-            hipError_t e = rocprim::radix_sort_pairs<SortConfig>(nullptr, need, kin, (u32*)dsa, vin, SplitOut{dsv, rows}, (size_t)n, g.rbits, g.rbits + strip_bits, c->stream);
-            if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs(strips) size query", hipGetErrorString(e));
-            if (need > c->sort_tmp.bytes && (rc = c->sort_tmp.ensure(need))) return rc;
-            size_t tb = c->sort_tmp.bytes;
-            e = rocprim::radix_sort_pairs<SortConfig>(c->sort_tmp.p, tb, kin, (u32*)dsa, vin, SplitOut{dsv, rows}, (size_t)n, g.rbits, g.rbits + strip_bits, c->stream);
-            if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs(strips)", hipGetErrorString(e));
-            LAUNCH(k_strip_table32, g.S + 2, (const u32*)dsa, n, g.S, g.rbits, dstrip, dtile);
+            auto strip_sort = [&](const GridParams& gx, int* osa, int* osv, u32* orow, int* ostrip, int* otile) -> int {
+                const int sbits = std::max(1, bits_for((unsigned)gx.S));
+                const auto kin = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), SpKeyOfIndex{c->qb_key.as<u32>(), c->qb_val.as<u64>(), gx});
+                const auto vin = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), SpValOfIndex{c->qb_key.as<u32>(), c->qb_val.as<u64>()});
+                size_t need = 0;
+                hipError_t e = rocprim::radix_sort_pairs<SortConfig>(nullptr, need, kin, (u32*)osa, vin, SplitOut{osv, orow}, (size_t)n, gx.rbits, gx.rbits + sbits, c->stream);
+                if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs(strips) size query", hipGetErrorString(e));
+                int rc2;
+                if (need > c->sort_tmp.bytes && (rc2 = c->sort_tmp.ensure(need))) return rc2;
+                size_t tb = c->sort_tmp.bytes;
+                e = rocprim::radix_sort_pairs<SortConfig>(c->sort_tmp.p, tb, kin, (u32*)osa, vin, SplitOut{osv, orow}, (size_t)n, gx.rbits, gx.rbits + sbits, c->stream);
+                if (e != hipSuccess) return fail(CL_ERR_HIP, "radix_sort_pairs(strips)", hipGetErrorString(e));
+                LAUNCH(k_strip_table32, gx.S + 2, (const u32*)osa, n, gx.S, gx.rbits, ostrip, otile);
+                return CL_OK;
+            };
+            const int fw = c->fine_w;
+            if (fw > 0 && g.eps % fw == 0 && g.eps / fw <= CL_FINE_KMAX) {
+                // the eps values of the sweep share the divisor fw (cl_set_eps_list): the layout comes from the fine one
+                if (c->fine_valid_w != fw || c->fine_layout != layout) {
+                    GridParams gf;
+                    if (make_grid(c, g.variant, fw, 1, 0, &gf) != CL_OK) c->fine_w = 0;      // (too many strips of that width: sort as before)
+                    else {
+                        gf.dbg = g.dbg; gf.dbg2 = g.dbg2;
+                        if ((rc = c->fq.ensure((size_t)n * 4)) || (rc = c->fsp.ensure((size_t)n * 4)) || (rc = c->frow.ensure((size_t)n * 4)) ||
+                            (rc = c->fstrip.ensure(((size_t)gf.S + 2) * 4))) return rc;
+                        if ((rc = strip_sort(gf, c->fsp.as<int>(), c->fq.as<int>(), c->frow.as<u32>(), c->fstrip.as<int>(), (int*)nullptr))) return rc;
+                        c->fine_g = gf; c->fine_valid_w = fw; c->fine_layout = layout;
+                    }
+                }
+                if (c->fine_w > 0) {
+                    const GridParams& gf = c->fine_g;
+                    const int k = g.eps / fw;
+                    LAUNCH(k_strips_from_fine, g.S + 2, g.S, g.s0, k, gf.S, gf.s0, (const int*)c->fstrip.as<int>(), n, dstrip);
+                    hipLaunchKernelGGL(k_layout_from_fine, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, g, gf, k, (const int*)c->fq.as<int>(),
+                                       (const int*)c->fsp.as<int>(), (const u32*)c->frow.as<u32>(), (const int*)c->fstrip.as<int>(), dsv, dsa, rows, dtile);
+                    HIP_TRY(hipGetLastError());
+                    c->srow = rows;
+                    return CL_OK;
+                }
+            }
+            if ((rc = strip_sort(g, dsa, dsv, rows, dstrip, dtile))) return rc;
             c->srow = rows;
             return CL_OK;
         }

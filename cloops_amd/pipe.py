@@ -607,6 +607,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
             r.chrom.set_count_thresholds(sorted(set(int(m) for m in minPts)))
             if len(set(eps)) > 1:
                 r.chrom.set_sort_index(1)                    # several layouts are coming: the q index pays from the first one on
+                r.chrom.set_eps_list(sorted(set(int(e) for e in eps)))      # ... and, if the values share a divisor, one fine sort serves all of them
         step_no = 0
         # where the summary should look for the next median (see _select_kth).  The first step has no earlier median to go by:
         # it counts the distances 1 .. 2048 exactly (self-ligation distances are a few hundred bp: ests.py's cut model) and falls
@@ -777,6 +778,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
             # the announced minPts list belongs to this sweep: a later one-off run on the handle serves its own minPts only
             try:
                 r.chrom.set_count_thresholds([])
+                r.chrom.set_eps_list([])
             except Exception:
                 pass
         for r in held:

@@ -303,6 +303,11 @@ void cl_set_sort_index(cl_chrom* c, int mode);
  * repeat the first run's minPts re-use its words.
  * cl_last_region_mode: what the last enqueued run did -- 0 full region query, 1 words re-used as they were (same
  * cut), 2 words carried through the compaction + region query on the band. */
+/* cl_set_eps_list: the eps values the caller will ask for (the outer loop of cLoops/pipe.py:241-281; the sweep driver knows its
+ * list).  When they share a divisor w >= 16 with max(eps) / w <= 8 (Hi-C mode 3: 5000 / 7500 / 10000 -> 2500) the handle sorts its
+ * rows once by strips of width w; the layout of every announced eps is then a per-strip merge of that order (a strip of width
+ * k w = k consecutive strips of width w) instead of a sort -- the same permutation, bit for bit.  n = 0 forgets the list. */
+void cl_set_eps_list(cl_chrom* c, const int32_t* eps, int32_t n);
 void cl_set_count_reuse(cl_chrom* c, int enabled);
 void cl_set_count_floor(cl_chrom* c, int32_t min_pts);
 void cl_set_count_thresholds(cl_chrom* c, const int32_t* min_pts, int32_t n);

@@ -39,6 +39,9 @@ class FakeChromosome(object):
     def set_count_thresholds(self, min_pts_list):
         pass
 
+    def set_eps_list(self, eps_list):
+        pass
+
     def set_sort_index(self, mode=1):
         pass
 

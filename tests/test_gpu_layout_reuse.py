@@ -89,3 +89,47 @@ def test_sort_index_modes_agree(variant, reuse):
             assert np.array_equal(rs[2].labels, want)
     for h in hs:
         h.close()
+
+
+@pytest.mark.parametrize("variant", ["v2", "v1"])
+def test_layouts_from_the_fine_layout(variant):
+    """cl_set_eps_list: the eps values share a divisor -- every layout is merged from ONE sort by strips of that width (2, 3, 4 and
+    1 runs per strip, revisits, a value outside the list in between), and the labels equal a handle that sorts every layout and
+    the oracle"""
+    X, Y = synth_chrom(400000, 9000000, 21)
+    a = api.Chromosome(X, Y)
+    b = api.Chromosome(X, Y)
+    a.set_sort_index(1)
+    b.set_sort_index(1)
+    a.set_eps_list([1500, 3000, 4500, 6000])
+    runs = [(3000, 8, 0), (3000, 6, 2500), (4500, 8, 2700), (6000, 10, 0), (1500, 5, 0), (2000, 6, 1000), (4500, 6, 0), (3000, 8, 3100)]
+    for k, (eps, m, cut) in enumerate(runs):
+        ra = a.cluster(variant, eps, m, cut)
+        rb = b.cluster(variant, eps, m, cut)
+        assert np.array_equal(ra.labels, rb.labels), (variant, eps, m, cut)
+        assert ra.n_clusters == rb.n_clusters and np.array_equal(ra.boxes, rb.boxes)
+        if k in (1, 2, 3):
+            want = oracle.single_dbscan(variant, X, Y, eps, m, cut)["labels"]
+            assert np.array_equal(ra.labels, want), (variant, eps, m, cut)
+    # a list without a useful divisor, and more runs per strip than the merge takes: plain sorts, same results
+    for lst in ([1000, 1007], [500, 6000]):
+        a.set_eps_list(lst)
+        for eps in lst:
+            ra, rb = a.cluster(variant, eps, 6, 900), b.cluster(variant, eps, 6, 900)
+            assert np.array_equal(ra.labels, rb.labels), (variant, lst, eps)
+    a.set_eps_list([])
+    a.close()
+    b.close()
+
+
+def test_fine_layout_on_chr21_edges():
+    """real data (ragged strips, empty strips, pile-ups at the chromosome's ends) through the merged layouts"""
+    X, Y = G.chr21_xy()
+    a = api.Chromosome(X, Y)
+    a.set_sort_index(1)
+    a.set_eps_list([750, 1500, 2250])
+    for eps, m, cut in [(750, 5, 0), (1500, 5, 4601), (2250, 4, 0), (1500, 3, 0)]:
+        got = a.cluster("v2", eps, m, cut).labels
+        want = oracle.single_dbscan("v2", X, Y, eps, m, cut)["labels"]
+        assert np.array_equal(got, want), (eps, m, cut)
+    a.close()
