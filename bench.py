@@ -396,6 +396,7 @@ def k2_replay(chrom, settings, served, passes=3):
     for key, on in [kv for kv in (("reuse", True), ("full", False)) if only in (None, "", kv[0])]:
         chrom.set_count_reuse(on)
         chrom.set_count_thresholds(served if on else [])
+        chrom.set_eps_list(sorted(set(ep for ep, _, _ in settings)) if on else [])     # (as the sweep driver announces it)
         rows = []
         for p in range(passes + 1):                     # (pass 0 warms the handle up: allocations, the q index)
             for ep, m, cut in settings:
@@ -407,6 +408,7 @@ def k2_replay(chrom, settings, served, passes=3):
         out[key] = rows
     chrom.set_count_reuse(True)
     chrom.set_count_thresholds(served)
+    chrom.set_eps_list([])
     chrom.set_profiling(False)
     if only:
         out["full" if only == "reuse" else "reuse"] = out[only]

@@ -304,36 +304,91 @@ __global__ void k_strips_from_fine(int S, int s0, int k, int F, int f0, const in
     const long long f = (long long)k * ((long long)s + s0) - f0;
     strip_start[s] = s >= S ? n : fstrip[(int)std::min<long long>(std::max<long long>(f, 0), F)];
 }
+#define LFF_T 1024               // PETs of the fine layout per workgroup
+#define LFF_CAP 4096             // staged entries: the strips a tile's PETs belong to, whole (a tile + one strip on either side)
 __global__ void __launch_bounds__(256)
 k_layout_from_fine(int n, GridParams g, GridParams gf, int k, const int* __restrict__ fq, const int* __restrict__ fsp, const u32* __restrict__ frow,
                    const int* __restrict__ fstrip, int* __restrict__ dq, int* __restrict__ dsp, u32* __restrict__ drow, int* __restrict__ dtile)
 {
-    const int i = blockIdx.x * 256 + (int)threadIdx.x;
-    if (i >= n) return;
-    const int q = fq[i], spf = fsp[i];
-    const u32 row = frow[i];
-    const int f = spf >> gf.rbits;                       // fine strip: row of the fine table
-    const int fabs = f + gf.s0;                          // (>= 0: strips count from the common origin A0)
-    const int sabs = fabs / k, r = fabs - sabs * k;      // the strip of width eps and the PET's run inside it
-    const int fbase = sabs * k - gf.s0;                  // table row of the strip's first run (< 0: runs in front of the chromosome's first strip)
-    int dst = fstrip[max(fbase, 0)] + (i - fstrip[f]);
-    for (int rr = 0; rr < k; ++rr) {
-        const int ff = fbase + rr;
-        if (rr == r || ff < 0 || ff >= gf.S) continue;
-        int lo = fstrip[ff], hi = fstrip[ff + 1];
-        const int b0 = lo;
-        while (lo < hi) {                                 // entries of run rr in front of (q, row)
-            const int mid = (lo + hi) >> 1;
-            const int qy = fq[mid];
-            const bool less = qy < q || (qy == q && frow[mid] < row);
-            lo = less ? mid + 1 : lo; hi = less ? hi : mid;
-        }
-        dst += lo - b0;
+    __shared__ int lq[LFF_CAP];
+    __shared__ u32 lr[LFF_CAP];
+    const int t0 = blockIdx.x * LFF_T, t1 = min(n, t0 + LFF_T);
+    if (t0 >= n) return;
+    // the strips (of width eps) the tile's first and last PET belong to are contiguous in the fine layout: [a, b) holds every run
+    // any PET of the tile has to be ranked in
+    const int sb_first = (((fsp[t0] >> gf.rbits) + gf.s0) / k) * k - gf.s0, sb_last = (((fsp[t1 - 1] >> gf.rbits) + gf.s0) / k) * k - gf.s0;
+    const int a = fstrip[max(sb_first, 0)], b = fstrip[min(sb_last + k, gf.S)];
+    const bool staged = b - a <= LFF_CAP;                 // (a pile-up strip longer than the staging area: bisections in global memory)
+    if (staged) for (int j = threadIdx.x; j < b - a; j += 256) { lq[j] = fq[a + j]; lr[j] = frow[a + j]; }
+    __syncthreads();
+    // four PETs per thread, their searches side by side (every probe is a dependent round trip: four chains in flight)
+    constexpr int E = LFF_T / 256;
+    int q[E], spf[E], fbase[E], r[E], dst[E];
+    u32 row[E];
+    bool in[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = t0 + e * 256 + (int)threadIdx.x;
+        in[e] = i < t1;
+        const int ic = in[e] ? i : t0;
+        if (staged) { q[e] = lq[ic - a]; row[e] = lr[ic - a]; } else { q[e] = fq[ic]; row[e] = frow[ic]; }
+        spf[e] = fsp[ic];
     }
-    dq[dst] = q;
-    dsp[dst] = ((sabs - g.s0) << g.rbits) | (r * gf.eps + (spf & (gf.peps - 1)));
-    drow[dst] = row;
-    if ((dst & 255) == 0) dtile[dst >> 8] = min(sabs - g.s0, g.S);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = t0 + e * 256 + (int)threadIdx.x;
+        const int f = spf[e] >> gf.rbits;                // fine strip: row of the fine table
+        const int fabs = f + gf.s0;                      // (>= 0: strips count from the common origin A0)
+        const int sabs = fabs / k;                       // the strip of width eps ...
+        r[e] = fabs - sabs * k;                          // ... and the PET's run inside it
+        fbase[e] = sabs * k - gf.s0;                     // table row of the strip's first run (< 0: runs in front of the chromosome's first strip)
+        dst[e] = in[e] ? fstrip[max(fbase[e], 0)] + (i - fstrip[f]) : 0;
+    }
+    for (int rr = 0; rr < k; ++rr) {
+        int lo[E], hi[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int ff = fbase[e] + rr;
+            const bool on = in[e] && rr != r[e] && ff >= 0 && ff < gf.S;
+            lo[e] = on ? fstrip[ff] : 0; hi[e] = on ? fstrip[ff + 1] : 0;
+            dst[e] -= lo[e];
+        }
+        if (staged) {
+            bool any = true;
+            while (any) {                                 // entries of run rr in front of (q, row)
+                any = false;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const bool go = lo[e] < hi[e];
+                    const int mid = go ? (lo[e] + hi[e]) >> 1 : a;
+                    const int qy = lq[mid - a];
+                    const bool less = qy < q[e] || (qy == q[e] && lr[mid - a] < row[e]);
+                    lo[e] = (go && less) ? mid + 1 : lo[e]; hi[e] = (go && !less) ? mid : hi[e];
+                    any |= lo[e] < hi[e];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                while (lo[e] < hi[e]) {
+                    const int mid = (lo[e] + hi[e]) >> 1;
+                    const int qy = fq[mid];
+                    const bool less = qy < q[e] || (qy == q[e] && frow[mid] < row[e]);
+                    lo[e] = less ? mid + 1 : lo[e]; hi[e] = less ? hi[e] : mid;
+                }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) dst[e] += lo[e];
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (!in[e]) continue;
+        const int sabs = (fbase[e] + gf.s0) / k;
+        dq[dst[e]] = q[e];
+        dsp[dst[e]] = ((sabs - g.s0) << g.rbits) | (r[e] * gf.eps + (spf[e] & (gf.peps - 1)));
+        drow[dst[e]] = row[e];
+        if ((dst[e] & 255) == 0) dtile[dst[e] >> 8] = min(sabs - g.s0, g.S);
+    }
 }
 
 // tile_s0 (optional): strip of every 256th sorted PET (what k_decode_sp leaves, for a layout that was not decoded)
@@ -2710,7 +2765,7 @@ static int sort_layout(cl_chrom* c, const GridParams& g, int* dsv, int* dsa, u32
                     const GridParams& gf = c->fine_g;
                     const int k = g.eps / fw;
                     LAUNCH(k_strips_from_fine, g.S + 2, g.S, g.s0, k, gf.S, gf.s0, (const int*)c->fstrip.as<int>(), n, dstrip);
-                    hipLaunchKernelGGL(k_layout_from_fine, dim3(nblocks(n, 256)), dim3(256), 0, c->stream, n, g, gf, k, (const int*)c->fq.as<int>(),
+                    hipLaunchKernelGGL(k_layout_from_fine, dim3(nblocks(n, LFF_T)), dim3(256), 0, c->stream, n, g, gf, k, (const int*)c->fq.as<int>(),
                                        (const int*)c->fsp.as<int>(), (const u32*)c->frow.as<u32>(), (const int*)c->fstrip.as<int>(), dsv, dsa, rows, dtile);
                     HIP_TRY(hipGetLastError());
                     c->srow = rows;
