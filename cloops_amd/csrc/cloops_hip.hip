@@ -344,7 +344,12 @@ k_layout_from_fine(int n, GridParams g, GridParams gf, int k, const int* __restr
         fbase[e] = sabs * k - gf.s0;                     // table row of the strip's first run (< 0: runs in front of the chromosome's first strip)
         dst[e] = in[e] ? fstrip[max(fbase[e], 0)] + (i - fstrip[f]) : 0;
     }
-    for (int rr = 0; rr < k; ++rr) {
+#ifdef CLOOPS_DEVEL
+    const int kk_abl = (g.dbg2 & (1 << 12)) ? 0 : k;      // (ablation: no searches)
+#else
+    const int kk_abl = k;
+#endif
+    for (int rr = 0; rr < kk_abl; ++rr) {
         int lo[E], hi[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -383,6 +388,9 @@ k_layout_from_fine(int n, GridParams g, GridParams gf, int k, const int* __restr
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         if (!in[e]) continue;
+#ifdef CLOOPS_DEVEL
+        if (g.dbg2 & (1 << 13)) { if (dst[e] == 0x7fffffff) dq[0] = 1; continue; }      // (ablation: no stores)
+#endif
         const int sabs = (fbase[e] + gf.s0) / k;
         dq[dst[e]] = q[e];
         dsp[dst[e]] = ((sabs - g.s0) << g.rbits) | (r[e] * gf.eps + (spf[e] & (gf.peps - 1)));
