@@ -546,6 +546,7 @@ SWEEP_THREADS = 8
 #: Measured on the 200 M-PET mode-3 sweep: 0.212 s against 0.208 s -- the serial order (largest chromosome first) is worth more
 #: than the 2 ms of host time the 23 enqueues take, so it stays off.
 PARALLEL_ENQUEUE = False
+STEP_TRACE = None        # developer hook (tools/step_gap.py): a list -> (step, t of the last wait that returned, t of the next step's first enqueue)
 
 
 def _lib_logbins():
@@ -628,6 +629,8 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                 # and the host-side collection runs on the pool
                 def enqueue(fr):
                     f, r = fr
+                    if STEP_TRACE is not None and fr is by_size[0]:
+                        STEP_TRACE.append((this_step, "enqueue", time.perf_counter()))
                     r.lock.acquire()
                     try:
                         r.chrom.step_async(variant, ep, m, step_cut, this_step, fine_lo)
@@ -653,6 +656,8 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                     f, r = fr
                     try:
                         res = r.chrom.wait()
+                        if STEP_TRACE is not None:
+                            STEP_TRACE.append((this_step, "waited", time.perf_counter()))
                         if probe is not None:
                             probe(f, ep, m, step_cut, res)
                         # the run carried its own tail on the device: the table classified (pipe.py:83-97), its
@@ -670,8 +675,9 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                 loghist = np.zeros(_lib_logbins(), dtype=np.int64)
                 fine = np.zeros(2048, dtype=np.int64)
                 xshift = 0.0
-                hists, fines = [], []
-                for f, r, nI, ndS, nin, s1 in _pmap(pool, collect, live):
+                # (results are taken in file order AS THEY ARRIVE: the sums of the chromosomes that finished early are done while
+                #  the others still run -- behind the step's last wait only that chromosome's share is left)
+                for f, r, nI, ndS, nin, s1 in (pool.map(collect, live) if (pool is not None and len(live) > 1) else map(collect, live)):
                     nS += ndS
                     n_in += nin
                     if nI == 0:                               # runDBSCAN skips such chromosomes entirely (pipe.py:121-122)
@@ -682,19 +688,18 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                     for gg in (0, 1):
                         for kk in ("n_all", "n_pos", "sumx", "sumxx"):
                             tot[kk][gg] += s1[kk][gg]
-                    hists.append(s1["loghist"])
+                    loghist += s1["loghist"]                  # (integer histograms: exact in any order)
                     if s1.get("fine") is not None:
-                        fines.append(s1["fine"])
+                        fine += s1["fine"]
                     xshift = s1["xshift"]
-                # (integer histograms: one reduction over the stack instead of an add per chromosome)
-                if hists:
-                    loghist += np.add.reduce(hists)
-                if fines:
-                    fine += np.add.reduce(fines)
+                if STEP_TRACE is not None:
+                    STEP_TRACE.append((this_step, "collected", time.perf_counter()))
                 # the genome-wide statistics: everything is additive over chromosomes and ranks -- two small exchanges per
                 # step (one integer vector, one float vector), then the histograms of the median's refinement
                 gi = np.concatenate([np.asarray([nI_tot, nS, n_in, len(used)] + tot["n_all"] + tot["n_pos"], dtype=np.int64), loghist, fine])
                 gf = np.asarray(tot["sumx"] + tot["sumxx"] + [xshift if used else 0.0, 1.0 if used else 0.0], dtype=np.float64)
+                if STEP_TRACE is not None:
+                    STEP_TRACE.append((this_step, "reduced", time.perf_counter()))
                 if allsum is not None:
                     # ONE exchange per step: the counts ride as float64 next to the sums (every count and every sum of counts
                     # stays far below 2^53, so they come back exact)
@@ -705,6 +710,8 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                 steps.append(st)
                 st["wall_s"] = time.perf_counter() - t_step0   # enqueue .. statistics of this rank on the host (+ the exchange); the cut follows
                 rng.__exit__(None, None, None)
+                if STEP_TRACE is not None:
+                    STEP_TRACE.append((this_step, "stats", time.perf_counter()))
                 if int(g[3]) == 0:                            # pipe.py:251-255
                     if log:
                         log("ERROR: no inter-ligation PETs detected for eps %s minPts %s,can't model the distance cutoff,continue anyway" % (ep, m))
@@ -745,6 +752,8 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                     st["frags"] = int(frags)
                     cuts.append(cut_2)
                     cut = cut_2                               # pipe.py:274
+                    if STEP_TRACE is not None:
+                        STEP_TRACE.append((this_step, "cut", time.perf_counter()))
                 elif forced_cuts is not None and forced_cuts[this_step] is not None:
                     cut = int(forced_cuts[this_step])
                     cuts.append(cut)
