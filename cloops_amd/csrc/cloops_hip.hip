@@ -293,8 +293,8 @@ struct SplitOut {                                       // output iterator: valu
 // consecutive strips of width w.  With the rows sorted ONCE by (fine strip, q) -- the same 2-pass strip sort of the q index --
 // the layout of an eps is no sort at all: a strip's PETs are one contiguous segment of the fine layout, made of k runs that are
 // each in (q, row) order, and every PET finds its place inside the segment by k - 1 bisections of the other runs (its
-// neighbours in the wave bisect the same few hundred entries: the loads stay in L1 / L2).  Same permutation as the sort, bit
-// for bit (composite order (q, row) = the stable order of the q index).  One pass of 12 B/PET in, 12 B/PET out instead of two
+// neighbours in the wave search the same few hundred entries, staged in LDS).  The same order as the sort's except among equal
+// distances of one strip (by run instead of by input row: no kernel reads that order).  One pass of 12 B/PET in, 12 B/PET out instead of two
 // radix passes + histogram + the sort's own resets.
 // ------------------------------------------------------------------------------------------
 __global__ void k_strips_from_fine(int S, int s0, int k, int F, int f0, const int* __restrict__ fstrip, int n, int* __restrict__ strip_start)
@@ -311,15 +311,14 @@ k_layout_from_fine(int n, GridParams g, GridParams gf, int k, const int* __restr
                    const int* __restrict__ fstrip, int* __restrict__ dq, int* __restrict__ dsp, u32* __restrict__ drow, int* __restrict__ dtile)
 {
     __shared__ int lq[LFF_CAP];
-    __shared__ u32 lr[LFF_CAP];
     const int t0 = blockIdx.x * LFF_T, t1 = min(n, t0 + LFF_T);
     if (t0 >= n) return;
     // the strips (of width eps) the tile's first and last PET belong to are contiguous in the fine layout: [a, b) holds every run
     // any PET of the tile has to be ranked in
     const int sb_first = (((fsp[t0] >> gf.rbits) + gf.s0) / k) * k - gf.s0, sb_last = (((fsp[t1 - 1] >> gf.rbits) + gf.s0) / k) * k - gf.s0;
     const int a = fstrip[max(sb_first, 0)], b = fstrip[min(sb_last + k, gf.S)];
-    const bool staged = b - a <= LFF_CAP;                 // (a pile-up strip longer than the staging area: bisections in global memory)
-    if (staged) for (int j = threadIdx.x; j < b - a; j += 256) { lq[j] = fq[a + j]; lr[j] = frow[a + j]; }
+    const bool staged = b - a <= LFF_CAP;                 // (a pile-up strip longer than the staging area: searches in global memory)
+    if (staged) for (int j = threadIdx.x; j < b - a; j += 256) lq[j] = fq[a + j];
     __syncthreads();
     // four PETs per thread, their searches side by side (every probe is a dependent round trip: four chains in flight)
     constexpr int E = LFF_T / 256;
@@ -331,8 +330,7 @@ k_layout_from_fine(int n, GridParams g, GridParams gf, int k, const int* __restr
         const int i = t0 + e * 256 + (int)threadIdx.x;
         in[e] = i < t1;
         const int ic = in[e] ? i : t0;
-        if (staged) { q[e] = lq[ic - a]; row[e] = lr[ic - a]; } else { q[e] = fq[ic]; row[e] = frow[ic]; }
-        spf[e] = fsp[ic];
+        q[e] = fq[ic]; row[e] = frow[ic]; spf[e] = fsp[ic];
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -349,41 +347,45 @@ k_layout_from_fine(int n, GridParams g, GridParams gf, int k, const int* __restr
 #else
     const int kk_abl = k;
 #endif
+    // Order inside a strip: q, ties by run, then by the place inside the run -- a PET's place = its place in its own run + the
+    // entries with q' <= q of every run in front of its own + those with q' < q of every run behind (one compare per probe:
+    // q' < q + 1 resp. q' < q).  Equal distances are not in input-row order as behind the sort; nothing reads that order.
     for (int rr = 0; rr < kk_abl; ++rr) {
-        int lo[E], hi[E];
+        int lo[E], len[E], key[E], pos[E];
+        int nmax = 0;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int ff = fbase[e] + rr;
             const bool on = in[e] && rr != r[e] && ff >= 0 && ff < gf.S;
-            lo[e] = on ? fstrip[ff] : 0; hi[e] = on ? fstrip[ff + 1] : 0;
-            dst[e] -= lo[e];
+            lo[e] = on ? fstrip[ff] : 0; len[e] = on ? fstrip[ff + 1] - lo[e] : 0;
+            key[e] = q[e] + (rr < r[e] ? 1 : 0);
+            pos[e] = 0;
+            nmax = max(nmax, len[e]);
         }
+        nmax = wave_max_i(nmax);
+        int nsteps = 0;
+        while ((1 << nsteps) <= nmax) ++nsteps;          // (wave-uniform)
         if (staged) {
-            bool any = true;
-            while (any) {                                 // entries of run rr in front of (q, row)
-                any = false;
+            for (int step = nsteps > 0 ? 1 << (nsteps - 1) : 0; step >= 1; step >>= 1) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    const bool go = lo[e] < hi[e];
-                    const int mid = go ? (lo[e] + hi[e]) >> 1 : a;
-                    const int qy = lq[mid - a];
-                    const bool less = qy < q[e] || (qy == q[e] && lr[mid - a] < row[e]);
-                    lo[e] = (go && less) ? mid + 1 : lo[e]; hi[e] = (go && !less) ? mid : hi[e];
-                    any |= lo[e] < hi[e];
+                    const int p = pos[e] + step - 1;
+                    const int v = lq[lo[e] - a + min(p, max(len[e] - 1, 0))];
+                    pos[e] = (p < len[e] && v < key[e]) ? pos[e] + step : pos[e];
                 }
             }
         } else {
+            for (int step = nsteps > 0 ? 1 << (nsteps - 1) : 0; step >= 1; step >>= 1) {
 #pragma unroll
-            for (int e = 0; e < E; ++e)
-                while (lo[e] < hi[e]) {
-                    const int mid = (lo[e] + hi[e]) >> 1;
-                    const int qy = fq[mid];
-                    const bool less = qy < q[e] || (qy == q[e] && frow[mid] < row[e]);
-                    lo[e] = less ? mid + 1 : lo[e]; hi[e] = less ? hi[e] : mid;
+                for (int e = 0; e < E; ++e) {
+                    const int p = pos[e] + step - 1;
+                    const int v = fq[lo[e] + min(p, max(len[e] - 1, 0))];
+                    pos[e] = (p < len[e] && v < key[e]) ? pos[e] + step : pos[e];
                 }
+            }
         }
 #pragma unroll
-        for (int e = 0; e < E; ++e) dst[e] += lo[e];
+        for (int e = 0; e < E; ++e) dst[e] += pos[e];
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) {

@@ -306,7 +306,8 @@ void cl_set_sort_index(cl_chrom* c, int mode);
 /* cl_set_eps_list: the eps values the caller will ask for (the outer loop of cLoops/pipe.py:241-281; the sweep driver knows its
  * list).  When they share a divisor w >= 16 with max(eps) / w <= 8 (Hi-C mode 3: 5000 / 7500 / 10000 -> 2500) the handle sorts its
  * rows once by strips of width w; the layout of every announced eps is then a per-strip merge of that order (a strip of width
- * k w = k consecutive strips of width w) instead of a sort -- the same permutation, bit for bit.  n = 0 forgets the list. */
+ * k w = k consecutive strips of width w) instead of a sort -- the same (strip, distance) order; PETs of one strip at EQUAL distance
+ * follow each other by run instead of by input row, an order no result depends on.  n = 0 forgets the list. */
 void cl_set_eps_list(cl_chrom* c, const int32_t* eps, int32_t n);
 void cl_set_count_reuse(cl_chrom* c, int enabled);
 void cl_set_count_floor(cl_chrom* c, int32_t min_pts);
