@@ -1397,30 +1397,55 @@ k_border_q(GridParams g, int ntiles, int npos, int kcap, const int* __restrict__
             }
             return -1;
         };
-        int cap = kcap;
+        // kcap steps of both walks as straight-line predicated code (the walks' branches cost a wave more scalar instructions --
+        // exec-mask bookkeeping -- than vector ones): a lane whose walk is over, or whose candidates are not staged, idles
+        bool ovf = false;
+        auto seep = [&](bool on, int r) {
+            const bool add = on & !((r == r0) | (r == r1) | (r == r2) | (r == r3));
+            const bool s0 = add & (r0 < 0), s1 = add & !s0 & (r1 < 0), s2 = add & !s0 & !s1 & (r2 < 0), s3 = add & !s0 & !s1 & !s2 & (r3 < 0);
+            ovf |= add & !s0 & !s1 & !s2 & !s3;
+            r0 = s0 ? r : r0; r1 = s1 ? r : r1; r2 = s2 ? r : r2; r3 = s3 ? r : r3;
+        };
+        auto pstep = [&](int& j, bool& on, int pcap, bool below) {
+            const bool go = on & (j >= clo) & (j + 1 < chi);
+            const int k0 = go ? j - clo : 0;
+            const int2 p0 = lw[k0], p1 = lw[k0 + 1], x0 = lx[k0], x1 = lx[k0 + 1];
+            const bool w0 = (p0.y < pcap) & (p0.x <= qhi), h0 = w0 & (below ? p0.y >= plo : p0.y <= phi);
+            const bool w1 = (p1.y < pcap) & (p1.x <= qhi), h1 = w1 & (below ? p1.y >= plo : p1.y <= phi);
+            const bool hit0 = go & h0, hit1 = go & w0 & !h0 & h1;
+            const bool fin = go & (!w0 | (!h0 & !w1));
+            seep(hit0 | hit1, hit0 ? x0.x : x1.x);
+            j = hit0 ? x0.y : (hit1 ? x1.y : (go ? j + 2 : j));
+            on = on & !fin & (j < C);
+        };
+        bool ona = act & (ja >= 0) & (ja < C), onb = act & (jb >= 0) & (jb < C);
 #pragma unroll 1
-        for (int round = 0; round < 2; ++round) {
-            ja = walk(ja, pbeg, true, cap);
-            jb = walk(jb, pend2, false, cap);
-            const bool left = (ja >= 0) | (jb >= 0);
-            if (!__any(left)) break;
-            // (round 0 only: the second round leaves nothing over)
-            const bool want = left && r3 < 0;
-            const unsigned long long wb = __ballot(want);
-            int slot = INT_MAX;
-            if (wb) {
-                const int firstl = __ffsll((long long)wb) - 1;
-                int lbase = 0;
-                if (lane == firstl) lbase = atomicAdd(&l_nq, __popcll(wb));
-                lbase = __builtin_amdgcn_readlane(lbase, firstl);
-                if (want) slot = lbase + lane_rank(wb);
+        for (int it = 0; it < kcap; ++it) { pstep(ja, ona, pbeg, true); pstep(jb, onb, pend2, false); }
+        if (ovf) atomicExch(&counters[CTR_OVERFLOW], 1);
+        ja = ona ? ja : -1; jb = onb ? jb : -1;
+        {
+            const bool left = ona | onb;
+            if (__any(left)) {
+                const bool want = left && r3 < 0;
+                const unsigned long long wb = __ballot(want);
+                int slot = INT_MAX;
+                if (wb) {
+                    const int firstl = __ffsll((long long)wb) - 1;
+                    int lbase = 0;
+                    if (lane == firstl) lbase = atomicAdd(&l_nq, __popcll(wb));
+                    lbase = __builtin_amdgcn_readlane(lbase, firstl);
+                    if (want) slot = lbase + lane_rank(wb);
+                }
+                if (slot < qcap) {
+                    lw[qbase + 2 * slot] = make_int2(h, me.x); lw[qbase + 2 * slot + 1] = make_int2(me.y, ja);
+                    lx[qbase + 2 * slot] = make_int2(jb, r0); lx[qbase + 2 * slot + 1] = make_int2(r1, r2);
+                    act = false;
+                } else if (left) {
+                    // (no room in the queue, or four components already: finish in place)
+                    ja = walk(ja, pbeg, true, INT_MAX);
+                    jb = walk(jb, pend2, false, INT_MAX);
+                }
             }
-            if (slot < qcap) {
-                lw[qbase + 2 * slot] = make_int2(h, me.x); lw[qbase + 2 * slot + 1] = make_int2(me.y, ja);
-                lx[qbase + 2 * slot] = make_int2(jb, r0); lx[qbase + 2 * slot + 1] = make_int2(r1, r2);
-                act = false; ja = -1; jb = -1;
-            }
-            cap = INT_MAX;                               // (no room in the queue, or four components already: finish in place)
         }
         finish(act, h, r0, r1, r2, r3);
     }
