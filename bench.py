@@ -416,16 +416,17 @@ def k2_replay(chrom, settings, served, passes=3):
 
 
 def roofline_block(replay, n_probe):
-    """The region query (K2) on the probe chromosome, AMORTISED over the runs of an eps the way the sweep executes it:
-    the first run of an eps does the whole query (k_region_core, its counts kept exact from the smallest minPts of the
-    sweep up), the three that follow take the kept words of every PET outside their cut band through the cut compaction
-    (k_cut_copy<true>: what that costs beyond the plain compaction = the difference of the two sort-phase brackets,
-    run by run against the pass without re-use) and query the band only (k_region_core<.., band>).
-      achieved = sum over the 12 runs of SURVEY 8d's algorithmic bytes N * 12 + (S + 2) * 4
-                 / sum over the 12 runs of (K2 launch time + carry cost)
-    K2 is the only kernel between its two events; the bracket around an EMPTY kernel (event packets + dispatch gap,
-    calibrated by the library) is taken out of every launch -- rocprofv3's kernel duration has no such term
-    (profiles/README.md).  `full_query` = the same figure with every run doing its own full query (rounds 1-3)."""
+    """The region query (K2) on the probe chromosome, three ways:
+      frac / achieved   AMORTISED over the runs of an eps the way the sweep executes it: the first run of an eps queries the whole
+                        base layout (k_region_core, counts bracketed for the sweep's minPts list), every run under a cut queries its
+                        cut band only (k_band, a kernel of its own between its own pair of events) and reads every other PET's word
+                        in place: sum over the 12 runs of SURVEY 8d's algorithmic bytes N * 12 + (S + 2) * 4 / sum over the 12 runs
+                        of (k_region_core time + k_band time).  (Traversal levels <= 3 carry the words through the cut compaction
+                        instead: that cost = the difference of the sort-phase brackets against the pass without re-use.)
+      per_launch        the k_region_core launches that executed, each against the algorithmic bytes of the PETs it covered
+      full_query        every run its own full query (cl_set_count_reuse(0)): the per-launch figure of rounds 1-3
+    K2 is the only kernel between its two events; the bracket around an EMPTY kernel (event packets + dispatch gap, calibrated by
+    the library) is taken out of every launch -- rocprofv3's kernel duration has no such term (profiles/README.md)."""
     rows, full = replay["reuse"], replay["full"]
 
     def net(tm):
