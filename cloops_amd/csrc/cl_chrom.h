@@ -145,6 +145,7 @@ struct cl_chrom {
     bool l4_make_base = false;        // level 4: the run makes the words of its eps -- K2 on the base layout, launched behind the band query
     bool l4_cut = false;              // level 4: the run has a cut (the per-strip tables of k_cut_strips apply)
     bool l4_band = false;             // ... and re-uses counts under another cut (the band's words are fresh: c->cnt, by run position)
+    bool fuse_chains = true;          // the chains of a run are made inside k_union_c (false: k_chain_c, a kernel of its own -- developer A/B)
     bool l_sup_dirty = false;         // k_classify's superblock sums may be non-zero (a run that failed between k_classify and k_chain_c)
     GridParams dbg_g{}; int dbg_nm = 0;   // the last rotated run's grid and size (developer build: kernels timed on their own)
     int traversal = 4;                // cl_set_traversal: 0 = tile kernels over every PET (rounds 1-4), 1 = K3 on the core list,

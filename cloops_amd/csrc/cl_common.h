@@ -52,7 +52,7 @@ static inline int fail(int code, const char* what, const char* detail = nullptr)
 #define TPB 256
 
 enum { ST_LIVE = 0, ST_DEAD = 1, ST_UNKNOWN = 2 };          // variant-2 release state of a component
-enum { CTR_NU = 0, CTR_NREC = 1, CTR_OVERFLOW = 2, CTR_NROOT = 3, CTR_NFLAG = 4 };         // device counters
+enum { CTR_NU = 0, CTR_NREC = 1, CTR_OVERFLOW = 2, CTR_NROOT = 3, CTR_NFLAG = 4, CTR_NOVF = 5 };         // device counters
 enum { CTR_TICKET_A = 50, CTR_TICKET_B = 51 };          // "last workgroup" tickets of the in-kernel scans: zero between kernels, never cleared with the counters
 
 struct GridParams {

@@ -567,7 +567,8 @@ k_make_lists_q(GridParams g, int npos, int bandq, const int* __restrict__ bq, co
                const unsigned long long* __restrict__ cmask, const unsigned long long* __restrict__ wmask, const int* __restrict__ cgloc,
                const int* __restrict__ wgloc, const int* __restrict__ bsum, const unsigned long long* __restrict__ sup,
                int* __restrict__ cgrank, int* __restrict__ wgrank, int2* __restrict__ cpair, int* __restrict__ cpos,
-               int* __restrict__ ckey, int2* __restrict__ wpair, int* __restrict__ wpos, int* __restrict__ wenc, int* __restrict__ lcnt)
+               int* __restrict__ ckey, int2* __restrict__ wpair, int* __restrict__ wpos, int* __restrict__ wenc, int* __restrict__ lcnt,
+               int* __restrict__ parent /* or null: every core its own union-find node (the fused k_union_c needs that before it starts) */)
 {
     __shared__ int l_red[2][4];
     const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
@@ -655,6 +656,7 @@ k_make_lists_q(GridParams g, int npos, int bandq, const int* __restrict__ bq, co
             const int dst = cgv[u] + __popcll(cb & low_mask(lane));
             cpair[dst] = make_int2(q[u], sp[u]); ckey[dst] = aux[u];
             if (cpos) cpos[dst] = b;                     // (only a run with row-aligned labels needs a core's position)
+            if (parent) parent[dst] = dst;
         } else if (isw) {
             const int dst = wgv[u] + __popcll(wb & low_mask(lane));
             wpair[dst] = make_int2(q[u], sp[u]); wpos[dst] = b; wenc[dst] = aux[u];
@@ -759,31 +761,107 @@ __device__ __forceinline__ int lower_bound_pairs(const int2* __restrict__ pv, in
     return lo;
 }
 
-template <int NT, int HALO>
+// FUSE: the chains are made HERE, from the staged pairs (no k_chain_c, no chain ids / skips read back): open flags by one compare
+// with the predecessor in LDS, the head of a core's chain = the nearest open flag at or in front of it (ballots per 64 staged
+// cores, the chunks' masks in LDS; a chain that began in front of the staged range: one look-back by the first wave, 64 cores per
+// round), where a walk goes on behind a chain = the next open flag.  The tile's own cores get their chain id, skip and per-head
+// resets written; parent[c] = c was set for every core by k_prep_c (another tile may unite with a head before its own tile runs).
+// A core whose window is not staged (a strip population beyond the halo) would need chain ids of other tiles: it is listed and
+// k_union_overflow takes it behind this kernel.
+struct HeadReset { int* compkey; int* ncore; int* bsize; int* usize; int* state; };
+template <int NT, int HALO, bool FUSE>
 __global__ void __launch_bounds__(256)
-k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __restrict__ cpair, const int* __restrict__ chainid,
-          const int* __restrict__ cstrip, const int* __restrict__ cskip, int* parent)
+k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __restrict__ cpair, int* chainid,
+          const int* __restrict__ cstrip, int* cskip, int* parent, HeadReset hr, int* __restrict__ ckey_prune /* or null */,
+          int* __restrict__ ovlist, int* __restrict__ counters)
 {
     constexpr int WIN = NT + HALO;
+    constexpr int NCH = WIN / 64;
     __shared__ int2 lw[WIN];
     __shared__ int lx[WIN];
-    __shared__ int lend[WIN];                            // where a walk goes on behind the staged core's chain (k_chain_c)
+    __shared__ int lend[WIN];                            // where a walk goes on behind the staged core's chain
+    __shared__ unsigned long long l_ob[FUSE ? NCH : 1];
+    __shared__ int l_found;
     const int C = lcnt[0];
     const int tile = ltile_of_block(blockIdx.x);
     const int t0 = tile * NT;
     if (tile >= ntiles || t0 >= C) return;
     const int base = t0 - HALO;
+    const int lane = threadIdx.x & 63;
+    const int nmask = ~(g.peps - 1);
+    if (FUSE && threadIdx.x == 0) l_found = -1;
     for (int k = threadIdx.x; k < WIN; k += 256) {
         const int gi = base + k;
         const bool in = gi >= 0 && gi < C;
-        lw[k] = in ? cpair[gi] : (gi < 0 ? make_int2(0, INT_MIN) : make_int2(INT_MAX, INT_MAX));
-        lx[k] = in ? chainid[gi] : -1;
-        lend[k] = in ? cskip[gi] : 0;
+        const int2 me = in ? cpair[gi] : (gi < 0 ? make_int2(0, INT_MIN) : make_int2(INT_MAX, INT_MAX));
+        lw[k] = me;
+        if (!FUSE) { lx[k] = in ? chainid[gi] : -1; lend[k] = in ? cskip[gi] : 0; }
+        else {
+            // does the staged core open a chain?  (entries in front of core 0 never do, entries behind the last core always.)  The
+            // predecessor's pair comes from the lane in front; the first lane of a wave reads it
+            int2 pv = make_int2(__shfl_up(me.x, 1), __shfl_up(me.y, 1));
+            if (lane == 0 && gi > 0 && gi < C) pv = cpair[gi - 1];
+            const bool o = gi <= 0 ? gi == 0 : (gi >= C || (pv.y & nmask) != (me.y & nmask) || pv.x < me.x - g.eps);
+            const unsigned long long ob = __ballot(o);
+            if (lane == 0) l_ob[k >> 6] = ob;
+        }
     }
     __syncthreads();
+    if (FUSE) {
+        if (threadIdx.x < 64 && base > 0 && !(l_ob[0] & 1ull)) {
+            // the chain of the first staged cores opened in front of the staged range: look back, 64 cores per round (core 0 opens a
+            // chain: the loop ends)
+            int found = -1;
+            for (int k0 = base - 64; found < 0; k0 -= 64) {
+                const int j = k0 + lane;
+                bool o = false;
+                if (j >= 0) {
+                    const int2 a = cpair[j];
+                    const int2 b = j > 0 ? cpair[j - 1] : make_int2(0, INT_MIN);
+                    o = j == 0 || (b.y & nmask) != (a.y & nmask) || b.x < a.x - g.eps;
+                }
+                const unsigned long long bal = __ballot(o);
+                if (bal) found = k0 + 63 - __clzll((long long)bal);
+            }
+            if (lane == 0) l_found = found;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < WIN; k += 256) {
+            const int ch = k >> 6, gi = base + k;
+            const unsigned long long ob = l_ob[ch];
+            const unsigned long long upto = ob & (~0ull >> (63 - lane));
+            int head;
+            if (upto) head = base + ch * 64 + 63 - __clzll((long long)upto);
+            else {
+                head = l_found;
+                for (int c2 = ch - 1; c2 >= 0; --c2) { const unsigned long long o2 = l_ob[c2]; if (o2) { head = base + c2 * 64 + 63 - __clzll((long long)o2); break; } }
+            }
+            const unsigned long long above = lane == 63 ? 0ull : (ob & (~0ull << (lane + 1)));
+            int skip;
+            if (above) skip = base + ch * 64 + __ffsll((long long)above) - 1;
+            else {
+                skip = base + WIN;                       // (the chain runs on behind the staged range: any core of it behind this one will do)
+                for (int c2 = ch + 1; c2 < NCH; ++c2) { const unsigned long long o2 = l_ob[c2]; if (o2) { skip = base + c2 * 64 + __ffsll((long long)o2) - 1; break; } }
+            }
+            const bool in = gi >= 0 && gi < C;
+            lx[k] = in ? head : -1;
+            lend[k] = in ? min(skip, C) : 0;
+            if (in && k >= HALO) {
+                chainid[gi] = head;
+                cskip[gi] = min(skip, C);
+                if (head == gi) { hr.compkey[gi] = INT_MAX; hr.ncore[gi] = 0; hr.bsize[gi] = 0; hr.usize[gi] = 0; hr.state[gi] = ST_LIVE; }
+                // variant 2, keys by cell (level 4): of a cell's cores only the first carries the cell to k_flatten_c (two cores of one
+                // cell are always one component) -- the others cost it neither an atomic nor a compare
+                if (ckey_prune && gi > 0) {
+                    const int2 me = lw[k], pv = lw[k - 1];
+                    if ((pv.y & nmask) == (me.y & nmask) && div_eps(g, pv.x) == div_eps(g, me.x)) ckey_prune[gi] = INT_MAX;
+                }
+            }
+        }
+        __syncthreads();
+    }
     const int wbeg = max(base, 0);
     LdsPairs w; w.a = lw; w.base = base;
-    const int lane = threadIdx.x & 63;
     constexpr int PER = NT / 256;
     // (one copy of the body: unrolled over the thread's cores the kernel was 80 KB of code -- more than the instruction cache two CUs share)
 #pragma unroll 1
@@ -863,6 +941,9 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
 #endif
                         j = lend[idx];                     // (> j + f)
                     }
+                } else if (FUSE) {
+                    // (chain ids of other tiles are not there yet: k_union_overflow)
+                    ovlist[atomicAdd(&counters[CTR_NOVF], 1)] = i;
                 } else {
 #ifdef CLOOPS_DEVEL
                     ++st_glb;
@@ -912,6 +993,50 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
 #else
         (void)st_un;
 #endif
+    }
+}
+
+// what has to be in place before the fused k_union_c: every core its own union-find node (a tile may unite with a head of another
+// tile before that tile has run), the cores-only strip table, and k_classify's superblock sums back at zero for the next run
+__global__ void k_prep_c(GridParams g, const int* __restrict__ lcnt, const int* __restrict__ strip_start,
+                         const unsigned long long* __restrict__ cmask, const int* __restrict__ cgrank, int* __restrict__ cstrip,
+                         int* __restrict__ sup, int nsup2, int* __restrict__ parent /* or null: k_make_lists_q has done it */)
+{
+    const int C = lcnt[0];
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (parent && u < C) parent[u] = u;
+    if (u <= g.S + 1) {
+        const int M = strip_start[g.S];
+        const int p = u <= g.S ? strip_start[u] : M;
+        cstrip[u] = p < M ? core_rank(cmask, cgrank, p) : C;
+    }
+    if (u < nsup2) sup[u] = 0;
+}
+// the cores k_union_c<.., true> could not serve from its staged range (their strip below begins in front of it): the same walk
+// over global memory, chain ids and skips of every tile in place by now
+__global__ void k_union_overflow(GridParams g, const int* __restrict__ counters, const int* __restrict__ ovlist, const int2* __restrict__ cpair,
+                                 const int* __restrict__ chainid, const int* __restrict__ cstrip, const int* __restrict__ cskip, int* parent)
+{
+    const int nov = counters[CTR_NOVF];
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nov; t += gridDim.x * blockDim.x) {
+        const int i = ovlist[t];
+        const int2 me = cpair[i];
+        const int A = chainid[i];
+        const int s = me.y >> g.rbits;
+        if (s <= 0) continue;
+        const int tb = cstrip[s - 1], b = cstrip[s];
+        const int qlo = me.x - g.eps, qhi = me.x + g.eps, T = me.y - g.peps;
+        int k = lower_bound_pairs(cpair, tb, b, qlo);
+        int lastB = -1;
+        while (k < b) {
+            const int2 cv = cpair[k];
+            if (cv.x > qhi) break;
+            if (cv.y >= T) {
+                const int B = chainid[k];
+                if (B != lastB) { uf_unite(parent, A, B); lastB = B; }
+                k = cskip[k];
+            } else ++k;
+        }
     }
 }
 
@@ -1760,6 +1885,16 @@ static void list_views(cl_chrom* c, const ListBufs& b, ListRun* L)
     L->wpos = c->l_wpos.as<int>(); L->wenc = c->l_wenc.as<int>(); L->cstrip = c->l_cstrip.as<int>();
 }
 
+static inline void fuse_knob(cl_chrom* c)
+{
+#ifdef CLOOPS_DEVEL
+    const char* e = getenv("CLOOPS_FUSE");               // 0: k_chain_c + k_union_c<.., false> (the chains as a kernel of their own)
+    if (e) c->fuse_chains = atoi(e) != 0;
+#else
+    (void)c;
+#endif
+}
+
 int lists_build(cl_chrom* c, const GridParams& g, int nm, ListRun* out)
 {
     ListBufs b;
@@ -1774,6 +1909,11 @@ int lists_build(cl_chrom* c, const GridParams& g, int nm, ListRun* out)
     launch_classify(c, g, nblk, b);
     launch_make_lists(c, g, nblk, b, L);
     // chains (the core count is only known on the device: the grids are sized by the PETs of the run)
+    fuse_knob(c);
+    if (c->fuse_chains)
+        hipLaunchKernelGGL(k_prep_c, dim3(nblocks(std::max(std::max(nm, g.S + 2), b.nsup2))), dim3(TPB), 0, c->stream, g, (const int*)L.lcnt, (const int*)c->w_strip,
+                           (const unsigned long long*)L.cmask, (const int*)L.cgrank, L.cstrip, b.sup, b.nsup2, c->parent.as<int>());
+    else
     hipLaunchKernelGGL(k_chain_c, dim3(nblocks(nm, 256 * CH_PER)), dim3(256), 0, c->stream, g, L.lcnt, (const int2*)L.cpair, c->chainflag.as<int>(),
                        c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                        c->cellfirst.as<int>() /* cskip */, (const int*)c->w_strip, L.cmask, L.cgrank, L.cstrip, b.sup, b.nsup2, (int*)nullptr);
@@ -1797,6 +1937,7 @@ int lists_base_keys(cl_chrom* c, const GridParams& g)
 
 int lists_build_base(cl_chrom* c, const GridParams& g, int nm, ListRun* out)
 {
+    fuse_knob(c);
     const int n = (int)c->n;
     ListBufs b;
     int rc = list_bufs(c, g, n, &b);
@@ -1825,7 +1966,7 @@ int lists_build_base(cl_chrom* c, const GridParams& g, int nm, ListRun* out)
 #undef LCQ_ARGS
 #define LMQ_ARGS g, n, bandq, bq, bsp, brow, (const int*)c->bkey.as<int>(), (const int2*)c->l_fix.as<int2>(), words, band, (const unsigned long long*)b.cmask,                  \
                  (const unsigned long long*)b.wmask, (const int*)b.cgloc, (const int*)b.wgloc, (const int*)b.bsum, (const unsigned long long*)sup64, b.cgrank, b.wgrank, L.cpair,  \
-                 c->run_rows ? L.cpos : (int*)nullptr, L.ckey, L.wpair, L.wpos, L.wenc, b.lcnt
+                 c->run_rows ? L.cpos : (int*)nullptr, L.ckey, L.wpair, L.wpos, L.wenc, b.lcnt, c->fuse_chains ? c->parent.as<int>() : (int*)nullptr
     if (v2) {
         if (!c->l4_cut) hipLaunchKernelGGL((k_make_lists_q<true, false, false>), dim3(nblk), dim3(256), 0, c->stream, LMQ_ARGS);
         else if (c->l4_band) hipLaunchKernelGGL((k_make_lists_q<true, true, true>), dim3(nblk), dim3(256), 0, c->stream, LMQ_ARGS);
@@ -1835,6 +1976,11 @@ int lists_build_base(cl_chrom* c, const GridParams& g, int nm, ListRun* out)
         else hipLaunchKernelGGL((k_make_lists_q<false, false, false>), dim3(nblk), dim3(256), 0, c->stream, LMQ_ARGS);
     }
 #undef LMQ_ARGS
+    fuse_knob(c);
+    if (c->fuse_chains)
+        hipLaunchKernelGGL(k_prep_c, dim3(nblocks(std::max(g.S + 2, std::max(nsup_ints, b.nsup2)))), dim3(TPB), 0, c->stream, g, (const int*)L.lcnt,
+                           (const int*)L.pstrip, (const unsigned long long*)L.cmask, (const int*)L.cgrank, L.cstrip, b.sup, std::max(nsup_ints, b.nsup2), (int*)nullptr);
+    else
     hipLaunchKernelGGL(k_chain_c, dim3(nblocks(nm, 256 * CH_PER)), dim3(256), 0, c->stream, g, L.lcnt, (const int2*)L.cpair, c->chainflag.as<int>(),
                        c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                        c->cellfirst.as<int>() /* cskip */, L.pstrip, L.cmask, L.cgrank, L.cstrip, b.sup, std::max(nsup_ints, b.nsup2), v2 ? L.ckey : (int*)nullptr);
@@ -1863,12 +2009,20 @@ int lists_union_flatten(cl_chrom* c, const GridParams& g, int nm, const ListRun&
     constexpr int UNT = 1024;
     const int nt = nblocks(nm, UNT);
     // the union walk looks one strip back, i.e. about one strip's cores in front of the core: the halo follows the mean strip population
-    if ((long long)c->n > 80LL * g.S)
-        hipLaunchKernelGGL((k_union_c<UNT, 512>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, g, nt, L.lcnt, (const int2*)L.cpair, (const int*)c->chainflag.as<int>(),
-                           (const int*)L.cstrip, (const int*)c->cellfirst.as<int>() /* cskip: the cell minima are in the keys */, c->parent.as<int>());
-    else
-        hipLaunchKernelGGL((k_union_c<UNT, 128>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, g, nt, L.lcnt, (const int2*)L.cpair, (const int*)c->chainflag.as<int>(),
-                           (const int*)L.cstrip, (const int*)c->cellfirst.as<int>() /* cskip: the cell minima are in the keys */, c->parent.as<int>());
+    const HeadReset hr{c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>()};
+    int* prune = (c->run_level >= 4 && g.variant == CL_VARIANT_CDBSCAN2) ? L.ckey : (int*)nullptr;
+#define LU_ARGS g, nt, L.lcnt, (const int2*)L.cpair, c->chainflag.as<int>(), (const int*)L.cstrip, c->cellfirst.as<int>() /* cskip: the cell minima are in the keys */, \
+                c->parent.as<int>(), hr, prune, c->ulist.as<int>() /* the overflow list: free until k_mark_uncertain_l */, c->counters.as<int>()
+    if (c->fuse_chains) {
+        if ((long long)c->n > 80LL * g.S) hipLaunchKernelGGL((k_union_c<UNT, 512, true>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LU_ARGS);
+        else hipLaunchKernelGGL((k_union_c<UNT, 128, true>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LU_ARGS);
+        hipLaunchKernelGGL(k_union_overflow, dim3(64), dim3(256), 0, c->stream, g, (const int*)c->counters.as<int>(), (const int*)c->ulist.as<int>(), (const int2*)L.cpair,
+                           (const int*)c->chainflag.as<int>(), (const int*)L.cstrip, (const int*)c->cellfirst.as<int>(), c->parent.as<int>());
+    } else {
+        if ((long long)c->n > 80LL * g.S) hipLaunchKernelGGL((k_union_c<UNT, 512, false>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LU_ARGS);
+        else hipLaunchKernelGGL((k_union_c<UNT, 128, false>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LU_ARGS);
+    }
+#undef LU_ARGS
     hipLaunchKernelGGL(k_flatten_c, dim3(nblocks(nm, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, L.lcnt, (const int*)c->chainflag.as<int>(),
                        (const int*)c->parent.as<int>(), (const int*)L.ckey, croot_of(c),
                        c->compkey.as<int>(), c->ncore.as<int>(), c->rootlist.as<int>(), c->counters.as<int>(), (int)g.dbg2);
@@ -1990,7 +2144,7 @@ extern "C" int cl_debug_time_lists(cl_chrom* c, int which, int reps, float* ms_o
                 hipLaunchKernelGGL((k_make_lists_q<true, true, true>), dim3(nb4), dim3(256), 0, c->stream, g, n, bandq, bq, bsp, (const u32*)c->brow.as<u32>(), (const int*)c->bkey.as<int>(),
                                    (const int2*)c->l_fix.as<int2>(), (const int*)c->rc_cnt.as<int>(), (const int*)c->cnt.as<int>(), (const unsigned long long*)bb.cmask,
                                    (const unsigned long long*)bb.wmask, (const int*)bb.cgloc, (const int*)bb.wgloc, (const int*)bb.bsum, (const unsigned long long*)sup64, bb.cgrank, bb.wgrank,
-                                   L.cpair, (int*)nullptr, L.ckey, L.wpair, L.wpos, L.wenc, bb.lcnt);
+                                   L.cpair, (int*)nullptr, L.ckey, L.wpair, L.wpos, L.wenc, bb.lcnt, (int*)nullptr);
             }
         } else if (which == 4 || which == 3 || which == 5) {
             // k_border_w / k_union_c + k_flatten_c / k_final_lists of the last run once more (their inputs are in place; the per-component
@@ -2003,6 +2157,11 @@ extern "C" int cl_debug_time_lists(cl_chrom* c, int which, int reps, float* ms_o
             else if (which == 3) {
                 // (the chain kernel resets the forest and the per-head accumulators first -- timed with it)
                 ListBufs bb; if ((rc = list_bufs(c, g, c->run_level == 4 ? (int)c->n : nm, &bb))) return rc;
+                fuse_knob(c);
+                if (c->fuse_chains)
+                    hipLaunchKernelGGL(k_prep_c, dim3(nblocks(std::max(nm, g.S + 2))), dim3(TPB), 0, c->stream, g, (const int*)L2.lcnt, (const int*)L2.pstrip,
+                                       (const unsigned long long*)L2.cmask, (const int*)L2.cgrank, L2.cstrip, bb.sup, 2, c->parent.as<int>());
+                else
                 hipLaunchKernelGGL(k_chain_c, dim3(nblocks(nm, 256 * CH_PER)), dim3(256), 0, c->stream, g, L2.lcnt, (const int2*)L2.cpair, c->chainflag.as<int>(),
                                    c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                                    c->cellfirst.as<int>(), L2.pstrip, L2.cmask, L2.cgrank, L2.cstrip, bb.sup, 2, (int*)nullptr);
