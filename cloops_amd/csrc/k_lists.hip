@@ -2006,7 +2006,7 @@ static int* croot_of(cl_chrom* c) { return c->run_level >= 2 ? c->root.as<int>()
 
 int lists_union_flatten(cl_chrom* c, const GridParams& g, int nm, const ListRun& L)
 {
-    constexpr int UNT = 1024;
+    constexpr int UNT = 512;
     const int nt = nblocks(nm, UNT);
     // the union walk looks one strip back, i.e. about one strip's cores in front of the core: the halo follows the mean strip population
     const HeadReset hr{c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>()};
