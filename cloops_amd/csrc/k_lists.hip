@@ -1046,6 +1046,9 @@ __global__ void k_union_overflow(GridParams g, const int* __restrict__ counters,
 //   variant 1: key = smallest input row of a core = the component's start point (cDBSCAN.py:134-137)
 //   variant 2: key = smallest cellfirst over the cells holding its cores (cDBSCAN2.py:117-140)
 // both arrive as ckey[c] (k_make_lists); two-level reduce-by-key as in k_flatten (cloops_hip.hip)
+#ifndef FLC_PER
+#define FLC_PER 4          // cores per thread of k_flatten_c
+#endif
 __global__ void __launch_bounds__(BIGTPB)
 k_flatten_c(const int* __restrict__ lcnt, const int* __restrict__ chainid, const int* __restrict__ parent, const int* __restrict__ ckey,
             int* __restrict__ croot, int* __restrict__ compkey,
@@ -1057,12 +1060,12 @@ k_flatten_c(const int* __restrict__ lcnt, const int* __restrict__ chainid, const
     if (threadIdx.x == 0) l_nroot = 0;
     __syncthreads();
     const int C = lcnt[0];
-    if ((int)blockIdx.x * BIGTPB * FLAT_PER >= C) return;
-    int ii[FLAT_PER], r[FLAT_PER], key[FLAT_PER], x[FLAT_PER];
-    bool in[FLAT_PER];
+    if ((int)blockIdx.x * BIGTPB * FLC_PER >= C) return;
+    int ii[FLC_PER], r[FLC_PER], key[FLC_PER], x[FLC_PER];
+    bool in[FLC_PER];
 #pragma unroll
-    for (int e = 0; e < FLAT_PER; ++e) {
-        ii[e] = (blockIdx.x * FLAT_PER + e) * BIGTPB + (int)threadIdx.x;
+    for (int e = 0; e < FLC_PER; ++e) {
+        ii[e] = (blockIdx.x * FLC_PER + e) * BIGTPB + (int)threadIdx.x;
         in[e] = ii[e] < C;
         x[e] = in[e] ? chainid[ii[e]] : -1;
         key[e] = in[e] ? ckey[ii[e]] : INT_MAX;
@@ -1071,26 +1074,26 @@ k_flatten_c(const int* __restrict__ lcnt, const int* __restrict__ chainid, const
         // the union kernel has completed (kernel boundary = coherent): plain loads, all walks of the thread step together
         bool todo = false;
 #pragma unroll
-        for (int e = 0; e < FLAT_PER; ++e) todo |= in[e];
+        for (int e = 0; e < FLC_PER; ++e) todo |= in[e];
         if (abl & (1 << 21)) todo = false;
         while (todo) {
-            int p[FLAT_PER];
+            int p[FLC_PER];
 #pragma unroll
-            for (int e = 0; e < FLAT_PER; ++e) p[e] = in[e] ? parent[x[e]] : -1;
+            for (int e = 0; e < FLC_PER; ++e) p[e] = in[e] ? parent[x[e]] : -1;
             todo = false;
 #pragma unroll
-            for (int e = 0; e < FLAT_PER; ++e) { todo |= in[e] && p[e] != x[e]; x[e] = in[e] ? p[e] : x[e]; }
+            for (int e = 0; e < FLC_PER; ++e) { todo |= in[e] && p[e] != x[e]; x[e] = in[e] ? p[e] : x[e]; }
         }
     }
 #pragma unroll
-    for (int e = 0; e < FLAT_PER; ++e) {
+    for (int e = 0; e < FLC_PER; ++e) {
         r[e] = in[e] ? x[e] : -1;
         if (in[e]) croot[ii[e]] = r[e];
     }
     const int lane = threadIdx.x & 63;
-    int myslot[FLAT_PER];
+    int myslot[FLC_PER];
 #pragma unroll
-    for (int e = 0; e < FLAT_PER; ++e) {
+    for (int e = 0; e < FLC_PER; ++e) {
         myslot[e] = -1;
         const bool isroot = r[e] == ii[e] && r[e] >= 0;
         const unsigned long long rb = __ballot(isroot);
@@ -1103,7 +1106,7 @@ k_flatten_c(const int* __restrict__ lcnt, const int* __restrict__ chainid, const
     }
     if (!(abl & (1 << 20)))
 #pragma unroll
-    for (int e = 0; e < FLAT_PER; ++e) {
+    for (int e = 0; e < FLC_PER; ++e) {
         const unsigned long long pending = __ballot(r[e] >= 0);
         if (pending) {
             const int leader = __ffsll((long long)pending) - 1;
@@ -1148,7 +1151,7 @@ k_flatten_c(const int* __restrict__ lcnt, const int* __restrict__ chainid, const
     if (threadIdx.x == 0) l_rootbase = l_nroot ? atomicAdd(&counters[CTR_NROOT], l_nroot) : 0;
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < FLAT_PER; ++e) if (myslot[e] >= 0) rootlist[l_rootbase + myslot[e]] = ii[e];
+    for (int e = 0; e < FLC_PER; ++e) if (myslot[e] >= 0) rootlist[l_rootbase + myslot[e]] = ii[e];
 }
 
 // interop with the tile kernels (cl_set_traversal levels 1 and 2): the lists' results at their positions of the layout
@@ -1752,7 +1755,9 @@ k_emit_records_w(GridParams g, const int* __restrict__ lcnt, const unsigned long
 // distance statistics K7 read: d = q + V0; noise never entered a list); labels[row] = label only for labelled items (the
 // caller has filled the array with -1: .labels of the reference holds clustered points only, cDBSCAN2.py:186-191); the
 // cluster table {minX, maxX, minY, maxY, count} by the two-level reduce-by-key of cl_table.h (pipe.py:78-102).
+#ifndef LF_CHUNKS
 #define LF_CHUNKS 4
+#endif
 __global__ void __launch_bounds__(BIGTPB)
 k_final_lists(GridParams g, const int* __restrict__ lcnt, const int2* __restrict__ cpair, const int* __restrict__ cpos,
               const int* __restrict__ croot, const int2* __restrict__ wpair, const int* __restrict__ wpos,
@@ -2023,7 +2028,7 @@ int lists_union_flatten(cl_chrom* c, const GridParams& g, int nm, const ListRun&
         else hipLaunchKernelGGL((k_union_c<UNT, 128, false>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LU_ARGS);
     }
 #undef LU_ARGS
-    hipLaunchKernelGGL(k_flatten_c, dim3(nblocks(nm, BIGTPB * FLAT_PER)), dim3(BIGTPB), 0, c->stream, L.lcnt, (const int*)c->chainflag.as<int>(),
+    hipLaunchKernelGGL(k_flatten_c, dim3(nblocks(nm, BIGTPB * FLC_PER)), dim3(BIGTPB), 0, c->stream, L.lcnt, (const int*)c->chainflag.as<int>(),
                        (const int*)c->parent.as<int>(), (const int*)L.ckey, croot_of(c),
                        c->compkey.as<int>(), c->ncore.as<int>(), c->rootlist.as<int>(), c->counters.as<int>(), (int)g.dbg2);
     HIP_TRY(hipGetLastError());
@@ -2039,28 +2044,28 @@ int lists_scatter_root(cl_chrom* c, int nm, const ListRun& L)
 
 int lists_border(cl_chrom* c, const GridParams& g, int nm, const ListRun& L)
 {
-    constexpr int BNT = 2048, BHC = 256, BHQ = 254;      // (k_border_q: 4 bytes of LDS for its queue counter, still four workgroups per CU)
-    const int nt = nblocks(L.npos, BNT);
+    constexpr int BNT = 2048, BHC = 256, BNQ = 1024, BHQ = 254;      // (k_border_q: 1024-position tiles, six workgroups per CU -- 106 us against 110 for 2048 and 147 for 512 on the chr1 replay)
     (void)nm;
-#define LB_ARGS g, nt, L.npos, L.lcnt, L.cmask, L.cgrank, L.wgrank, (const int2*)L.cpair, (const int*)croot_of(c), (const int*)c->cellfirst.as<int>(),    \
-                (const int*)L.ckey, (const int*)L.cstrip, (const int2*)L.wpair, (const int*)L.wpos, (const int*)L.wenc, (const int*)c->compkey.as<int>(),                    \
-                (const int*)c->ncore.as<int>(), c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->chainflag.as<int>() /* clist: the chain ids are dead */,  \
-                c->counters.as<int>()
     int kcap = 2, bqg = 16;
     bool queued = true;
 #ifdef CLOOPS_DEVEL
     { const char* e = getenv("CLOOPS_BCAP"); if (e) kcap = atoi(e); queued = kcap > 0; e = getenv("CLOOPS_BQG"); if (e) bqg = atoi(e); }
 #endif
+    const int nt = nblocks(L.npos, (g.variant == CL_VARIANT_CDBSCAN1 || !queued) ? BNT : BNQ);
+#define LB_ARGS g, nt, L.npos, L.lcnt, L.cmask, L.cgrank, L.wgrank, (const int2*)L.cpair, (const int*)croot_of(c), (const int*)c->cellfirst.as<int>(),    \
+                (const int*)L.ckey, (const int*)L.cstrip, (const int2*)L.wpair, (const int*)L.wpos, (const int*)L.wenc, (const int*)c->compkey.as<int>(),                    \
+                (const int*)c->ncore.as<int>(), c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->chainflag.as<int>() /* clist: the chain ids are dead */,  \
+                c->counters.as<int>()
     if (g.variant == CL_VARIANT_CDBSCAN1) hipLaunchKernelGGL((k_border_w<BNT, BHC, true>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LB_ARGS);
     else if (!queued) hipLaunchKernelGGL((k_border_w<BNT, BHC, false>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LB_ARGS);
 #define LBQ_ARGS g, nt, L.npos, kcap, L.lcnt, L.cmask, L.cgrank, L.wgrank, (const int2*)L.cpair, (const int*)croot_of(c), (const int*)c->cellfirst.as<int>(),           \
                  (const int*)L.cstrip, (const int2*)L.wpair, (const int*)L.wpos, (const int*)L.wenc, (const int*)c->compkey.as<int>(), (const int*)c->ncore.as<int>(),        \
                  c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->chainflag.as<int>(), c->counters.as<int>()
 #ifdef CLOOPS_DEVEL
-    else if (bqg == 8) hipLaunchKernelGGL((k_border_q<BNT, BHQ, 8>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LBQ_ARGS);
-    else if (bqg == 32) hipLaunchKernelGGL((k_border_q<BNT, BHQ, 32>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LBQ_ARGS);
+    else if (bqg == 8) hipLaunchKernelGGL((k_border_q<BNQ, BHQ, 8>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LBQ_ARGS);
+    else if (bqg == 32) hipLaunchKernelGGL((k_border_q<BNQ, BHQ, 32>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LBQ_ARGS);
 #endif
-    else hipLaunchKernelGGL((k_border_q<BNT, BHQ, 16>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LBQ_ARGS);
+    else hipLaunchKernelGGL((k_border_q<BNQ, BHQ, 16>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LBQ_ARGS);
     (void)bqg;
 #undef LBQ_ARGS
 #undef LB_ARGS
