@@ -16,13 +16,19 @@
 //                 arrays in sorted order; the rank index cgrank[g] = cores in front of 64-PET group g (with the core bit mask:
 //                 any POSITION of the layout -> index into the core array in two loads, so K2's window hints stay usable);
 //                 the cores-only strip table.
-//   k_chain_c     cores of one strip within eps in q form a chain = a contiguous run of the core array: chain head per core
-//                 (a ballot inside the wave, one look-back per wave), the chain's last core, per-head resets.
-//   k_union_c     cross-strip core-core edges by lock-free union-find on the chain heads; tiles of the CORE array with a
-//                 left halo (the window one strip below holds cores only: nothing to step over).
+//   k_classify_q / k_make_lists_q   the same two passes straight over the BASE layout of the eps (traversal level 4: no compacted copy
+//                 of the layout per run; a PET is in the run if q >= the cut's threshold, its word comes from the count cache of the
+//                 eps or, inside the cut band, from k_band).
+//   k_prep_c      the cores-only strip table; k_classify's sums back to zero.
+//   k_union_c     cores of one strip within eps in q form a chain = a contiguous run of the core array, and chains are the nodes
+//                 of the union-find: tiles of the CORE array with a left halo make their chains in LDS (open flags while staging,
+//                 heads and skips by ballots), then the cross-strip core-core edges by lock-free hooking on the chain heads (the
+//                 window one strip below holds cores only: nothing to step over).  k_chain_c: the chains as a kernel of their
+//                 own (developer A/B).  k_union_overflow: cores whose window is not staged.
 //   k_flatten_c   root per core, component key / core count per root, the root list.
-//   k_border_w    the border rule (R1 / R2) for the walkers; the cores around a tile's position range are
-//                 a contiguous slice of the core array, staged once; a walker's windows start at rank(K2 hint).
+//   k_border_q    variant 2's border rule for the walkers; the cores around a tile's position range are a contiguous slice of the
+//                 core array, staged once; a walker's windows start at rank(K2 hint); walks capped at two steps, the long ones
+//                 queued in LDS and finished by 16 lanes each.  k_border_w: variant 1 (needs every core neighbour).
 //   k_emit_records_w, k_final_lists: the release records of variant 2 and labels / cluster table / distance list from the
 //                 two lists.
 //
