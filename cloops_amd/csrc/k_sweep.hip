@@ -2,6 +2,7 @@
 // loops of a sweep: combineTwice / filterClusterByDis, cLoops/pipe.py:130-174), K8 (interval counts of the significance
 // step, cLoops/cModel.py) -- kernels and their C entry points.
 #include "cl_chrom.h"
+#include "cl_log2_tab.h"
 
 // ==========================================================================================
 // K7: distance statistics of one step (the inputs of cLoops/ests.py:36-61, estIntSelCutFrag)
@@ -31,6 +32,27 @@ __global__ void k7_classify(const int* __restrict__ hdr, Table t, signed char* _
 //   rows    input-row order (variants that only produce row-order labels)
                                  // of a 66-element sequential loop per thread uncovered: 177 us -> see DESIGN.md)
 
+// log2 of an integer distance 1 <= d < 2^31, to the last bit or two of a double: d = 2^e m, m in [1, 2) exact; the top 7 bits of m
+// pick an interval with centre c; r = m / c - 1 (one FMA with the tabulated reciprocal, |r| < 2^-8); log2 d = e + log2 c + log2(1 + r)
+// with six terms of the series -- a third of the instructions of the library's general-purpose log2 (k7_summary takes one per
+// clustered PET).  rcp / lg: the tables of cl_log2_tab.h, in LDS.
+#ifndef K7_LIBM_LOG2
+#define K7_LIBM_LOG2 0             // 1: the library's log2 (A/B)
+#endif
+__device__ __forceinline__ double k7_log2(unsigned d, const double* __restrict__ rcp, const double* __restrict__ lg)
+{
+    const int e = 31 - __clz((int)d);
+    const unsigned k = ((d << (31 - e)) >> 24) & 127u;
+    const double m = __hiloint2double((int)(0x3ff00000u | (((d << (31 - e)) & 0x7fffffffu) >> 11)), (int)(d << (31 - e) << 21));
+    const double r = fma(m, rcp[k], -1.0);
+    double p = -0.24044917348149393;                                  // -1 / (6 ln 2)
+    p = fma(p, r, 0.28853900817779268);                               //  1 / (5 ln 2)
+    p = fma(p, r, -0.36067376022224085);                              // -1 / (4 ln 2)
+    p = fma(p, r, 0.48089834696298783);                               //  1 / (3 ln 2)
+    p = fma(p, r, -0.72134752044448170);                              // -1 / (2 ln 2)
+    p = fma(p, r, 1.4426950408889634);                                //  1 / ln 2
+    return ((double)e + lg[k]) + p * r;
+}
 __device__ __forceinline__ int k7_logbin(unsigned d)      // d >= 1
 {
     const int e = 31 - __clz((int)d);
@@ -161,6 +183,8 @@ k7_summary(K7Src s, int cut, const signed char* __restrict__ cls, K7Part* __rest
 {
     __shared__ unsigned int h[K7_LOGBINS];
     __shared__ unsigned int hf[K7_FINE];
+    __shared__ double l_rcp[128], l_lg[128];
+    if (threadIdx.x < 128) { l_rcp[threadIdx.x] = K7_RCP[threadIdx.x]; l_lg[threadIdx.x] = K7_LOG[threadIdx.x]; }
     for (int k = threadIdx.x; k < K7_LOGBINS; k += blockDim.x) h[k] = 0u;
     for (int k = threadIdx.x; k < K7_FINE; k += blockDim.x) hf[k] = 0u;
     __syncthreads();
@@ -170,7 +194,7 @@ k7_summary(K7Src s, int cut, const signed char* __restrict__ cls, K7Part* __rest
     k7_for_each(s, cut, cls, [&](int g, int ad, int w) {                  // w PETs of this group and distance
         na[g] += w;
         if (ad > 0) {
-            const double x = log2((double)ad) - K7_XSHIFT, wx = (double)w * x;
+            const double x = (K7_LIBM_LOG2 ? log2((double)ad) : k7_log2((unsigned)ad, l_rcp, l_lg)) - K7_XSHIFT, wx = (double)w * x;
             np_[g] += w; sx[g] += wx; sxx[g] += wx * x;
             if (g == 1) {
                 atomicAdd(&h[k7_logbin((unsigned)ad)], (unsigned)w);
