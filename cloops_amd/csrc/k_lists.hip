@@ -457,8 +457,20 @@ k_base_keys(GridParams g, int npos, const int* __restrict__ bq, const int* __res
                 const unsigned long long o2 = l_chead[k2];
                 if (o2) { pos[u] = t0 + 64 * k2 + 63 - __clzll((long long)o2); break; }
             }
-        if (pos[u] >= t0) atomicMin(&lmin[pos[u] - t0], (int)row[u]);
         if (i == min(t0 + LT, npos) - 1) l_hlast = pos[u];
+    }
+    // a cell's PETs sit in neighbouring lanes: the wave is cut into runs of one cell, a run is reduced over its lanes (segmented
+    // shuffles) and its first lane alone goes to the cell's slot -- one LDS atomic per cell and wave instead of one per PET on one address
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int prev = __shfl_up(pos[u], 1);
+        const unsigned long long B = __ballot(lane == 0 || prev != pos[u]);
+        const unsigned long long rest = lane == 63 ? 0ull : (B >> (lane + 1));
+        const int nb = rest ? lane + __ffsll((long long)rest) : 64;        // first lane behind this lane's run
+        int m = pos[u] >= t0 ? (int)row[u] : INT_MAX;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int a = __shfl_down(m, d); if (lane + d < nb) m = min(m, a); }
+        if (((B >> lane) & 1ull) && pos[u] >= t0) atomicMin(&lmin[pos[u] - t0], m);
     }
     __syncthreads();
     const int tend = t0 + LT;
