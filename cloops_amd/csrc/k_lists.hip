@@ -1936,10 +1936,14 @@ int lists_build(cl_chrom* c, const GridParams& g, int nm, ListRun* out)
     if (c->fuse_chains)
         hipLaunchKernelGGL(k_prep_c, dim3(nblocks(std::max(std::max(nm, g.S + 2), b.nsup2))), dim3(TPB), 0, c->stream, g, (const int*)L.lcnt, (const int*)c->w_strip,
                            (const unsigned long long*)L.cmask, (const int*)L.cgrank, L.cstrip, b.sup, b.nsup2, c->parent.as<int>());
+#ifdef CLOOPS_DEVEL
     else
     hipLaunchKernelGGL(k_chain_c, dim3(nblocks(nm, 256 * CH_PER)), dim3(256), 0, c->stream, g, L.lcnt, (const int2*)L.cpair, c->chainflag.as<int>(),
                        c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                        c->cellfirst.as<int>() /* cskip */, (const int*)c->w_strip, L.cmask, L.cgrank, L.cstrip, b.sup, b.nsup2, (int*)nullptr);
+#else
+    { }
+#endif
     L.npos = nm; L.pstrip = c->w_strip;
     *out = L;
     HIP_TRY(hipGetLastError());
@@ -2003,10 +2007,14 @@ int lists_build_base(cl_chrom* c, const GridParams& g, int nm, ListRun* out)
     if (c->fuse_chains)
         hipLaunchKernelGGL(k_prep_c, dim3(nblocks(std::max(g.S + 2, std::max(nsup_ints, b.nsup2)))), dim3(TPB), 0, c->stream, g, (const int*)L.lcnt,
                            (const int*)L.pstrip, (const unsigned long long*)L.cmask, (const int*)L.cgrank, L.cstrip, b.sup, std::max(nsup_ints, b.nsup2), (int*)nullptr);
+#ifdef CLOOPS_DEVEL
     else
     hipLaunchKernelGGL(k_chain_c, dim3(nblocks(nm, 256 * CH_PER)), dim3(256), 0, c->stream, g, L.lcnt, (const int2*)L.cpair, c->chainflag.as<int>(),
                        c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                        c->cellfirst.as<int>() /* cskip */, L.pstrip, L.cmask, L.cgrank, L.cstrip, b.sup, std::max(nsup_ints, b.nsup2), v2 ? L.ckey : (int*)nullptr);
+#else
+    { }
+#endif
     *out = L;
     HIP_TRY(hipGetLastError());
     c->l_sup_dirty = false;
@@ -2041,10 +2049,13 @@ int lists_union_flatten(cl_chrom* c, const GridParams& g, int nm, const ListRun&
         else hipLaunchKernelGGL((k_union_c<UNT, 128, true>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LU_ARGS);
         hipLaunchKernelGGL(k_union_overflow, dim3(64), dim3(256), 0, c->stream, g, (const int*)c->counters.as<int>(), (const int*)c->ulist.as<int>(), (const int2*)L.cpair,
                            (const int*)c->chainflag.as<int>(), (const int*)L.cstrip, (const int*)c->cellfirst.as<int>(), c->parent.as<int>());
-    } else {
+    }
+#ifdef CLOOPS_DEVEL
+    else {
         if ((long long)c->n > 80LL * g.S) hipLaunchKernelGGL((k_union_c<UNT, 512, false>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LU_ARGS);
         else hipLaunchKernelGGL((k_union_c<UNT, 128, false>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LU_ARGS);
     }
+#endif
 #undef LU_ARGS
     hipLaunchKernelGGL(k_flatten_c, dim3(nblocks(nm, BIGTPB * FLC_PER)), dim3(BIGTPB), 0, c->stream, L.lcnt, (const int*)c->chainflag.as<int>(),
                        (const int*)c->parent.as<int>(), (const int*)L.ckey, croot_of(c),
@@ -2075,7 +2086,9 @@ int lists_border(cl_chrom* c, const GridParams& g, int nm, const ListRun& L)
                 (const int*)c->ncore.as<int>(), c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->chainflag.as<int>() /* clist: the chain ids are dead */,  \
                 c->counters.as<int>()
     if (g.variant == CL_VARIANT_CDBSCAN1) hipLaunchKernelGGL((k_border_w<BNT, BHC, true>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LB_ARGS);
+#ifdef CLOOPS_DEVEL
     else if (!queued) hipLaunchKernelGGL((k_border_w<BNT, BHC, false>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LB_ARGS);
+#endif
 #define LBQ_ARGS g, nt, L.npos, kcap, L.lcnt, L.cmask, L.cgrank, L.wgrank, (const int2*)L.cpair, (const int*)croot_of(c), (const int*)c->cellfirst.as<int>(),           \
                  (const int*)L.cstrip, (const int2*)L.wpair, (const int*)L.wpos, (const int*)L.wenc, (const int*)c->compkey.as<int>(), (const int*)c->ncore.as<int>(),        \
                  c->owner.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->chainflag.as<int>(), c->counters.as<int>()
@@ -2184,10 +2197,14 @@ extern "C" int cl_debug_time_lists(cl_chrom* c, int which, int reps, float* ms_o
                 if (c->fuse_chains)
                     hipLaunchKernelGGL(k_prep_c, dim3(nblocks(std::max(nm, g.S + 2))), dim3(TPB), 0, c->stream, g, (const int*)L2.lcnt, (const int*)L2.pstrip,
                                        (const unsigned long long*)L2.cmask, (const int*)L2.cgrank, L2.cstrip, bb.sup, 2, c->parent.as<int>());
+#ifdef CLOOPS_DEVEL
                 else
                 hipLaunchKernelGGL(k_chain_c, dim3(nblocks(nm, 256 * CH_PER)), dim3(256), 0, c->stream, g, L2.lcnt, (const int2*)L2.cpair, c->chainflag.as<int>(),
                                    c->parent.as<int>(), c->compkey.as<int>(), c->ncore.as<int>(), c->bsize.as<int>(), c->usize.as<int>(), c->state.as<int>(),
                                    c->cellfirst.as<int>(), L2.pstrip, L2.cmask, L2.cgrank, L2.cstrip, bb.sup, 2, (int*)nullptr);
+#else
+    { }
+#endif
                 HIP_TRY(hipMemsetAsync(c->counters.p, 0, 64, c->stream));
                 if ((rc = lists_union_flatten(c, g, nm, L2))) return rc;
             } else { if ((rc = lists_final(c, g, nm, L2, false, c->counters.as<int>() + 40))) return rc; }

@@ -76,6 +76,28 @@ int main(void)
         cl_chrom_destroy(d);
     }
     {
+        /* the outer loop of cLoops/pipe.py:241-281 from C: the eps list announced (cl_set_eps_list), both layouts merged from one fine
+           sort -- labels equal to a handle that sorts every layout */
+        const int32_t eps_list[2] = {1000, 2000};
+        cl_chrom* d = NULL;
+        CHECK(cl_chrom_create(0, NULL, x, y, n, 0, &d));
+        cl_set_sort_index(c, 1);
+        cl_set_eps_list(c, eps_list, 2);
+        int32_t* lab2 = malloc((size_t)n * sizeof *lab2);
+        if (!lab2) return 20;
+        for (int r = 0; r < 2; ++r) {
+            int32_t nc2 = 0, ml2 = -1;
+            CHECK(cl_cluster(c, CL_VARIANT_CDBSCAN2, eps_list[r], 5, 300, lab, &nc, &ml));
+            CHECK(cl_cluster(d, CL_VARIANT_CDBSCAN2, eps_list[r], 5, 300, lab2, &nc2, &ml2));
+            if (nc != nc2 || ml != ml2) return 21;
+            for (int64_t i = 0; i < n; ++i) if (lab[i] != lab2[i]) { fprintf(stderr, "eps %d: label of row %lld differs\n", eps_list[r], (long long)i); return 22; }
+        }
+        cl_set_eps_list(c, NULL, 0);
+        printf("eps list: 2 layouts from one fine sort, labels equal\n");
+        free(lab2);
+        cl_chrom_destroy(d);
+    }
+    {
         /* a sweep step + the candidate table left on the device (cl_cand_finish_device: what cl_comm_gather_device sends) next to the
            host form: the same rows */
         int64_t ni = 0, ns = 0, k_host = 0, k_dev = 0;
