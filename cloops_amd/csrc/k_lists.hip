@@ -1047,13 +1047,23 @@ __global__ void k_union_overflow(GridParams g, const int* __restrict__ counters,
         int k = lower_bound_pairs(cpair, tb, b, qlo);
         int lastB = -1;
         while (k < b) {
-            const int2 cv = cpair[k];
-            if (cv.x > qhi) break;
-            if (cv.y >= T) {
-                const int B = chainid[k];
-                if (B != lastB) { uf_unite(parent, A, B); lastB = B; }
-                k = cskip[k];
-            } else ++k;
+            // (eight candidates per round, their loads in flight together: a window beside a cluster the core is not adjacent to is a
+            //  long run of misses, and every one of them would be a round trip to L2)
+            int2 cv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cv[e] = cpair[min(k + e, b - 1)];
+            int f = 8; bool fh = false;
+#pragma unroll
+            for (int e = 7; e >= 0; --e) {
+                const bool bey = (k + e >= b) | (cv[e].x > qhi);
+                const bool hit = cv[e].y >= T;
+                if (bey | hit) { f = e; fh = hit & !bey; }
+            }
+            if (f == 8) { k += 8; continue; }
+            if (!fh) break;
+            const int B = chainid[k + f];
+            if (B != lastB) { uf_unite(parent, A, B); lastB = B; }
+            k = cskip[k + f];
         }
     }
 }
@@ -2047,7 +2057,7 @@ int lists_union_flatten(cl_chrom* c, const GridParams& g, int nm, const ListRun&
     if (c->fuse_chains) {
         if ((long long)c->n > 80LL * g.S) hipLaunchKernelGGL((k_union_c<UNT, 512, true>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LU_ARGS);
         else hipLaunchKernelGGL((k_union_c<UNT, 128, true>), dim3(ltile_grid(nt)), dim3(256), 0, c->stream, LU_ARGS);
-        hipLaunchKernelGGL(k_union_overflow, dim3(64), dim3(256), 0, c->stream, g, (const int*)c->counters.as<int>(), (const int*)c->ulist.as<int>(), (const int2*)L.cpair,
+        hipLaunchKernelGGL(k_union_overflow, dim3(1024), dim3(256), 0, c->stream, g, (const int*)c->counters.as<int>(), (const int*)c->ulist.as<int>(), (const int2*)L.cpair,
                            (const int*)c->chainflag.as<int>(), (const int*)L.cstrip, (const int*)c->cellfirst.as<int>(), c->parent.as<int>());
     }
 #ifdef CLOOPS_DEVEL
