@@ -228,6 +228,10 @@ class Chromosome(object):
         arr = (ctypes.c_int32 * max(1, len(vals)))(*vals)
         self._lib.cl_set_count_thresholds(self._h, arr, len(vals))
 
+    def set_stream(self, stream):
+        """move the idle handle to another caller-made / library-made stream of its device (cl_chrom_set_stream)"""
+        _lib.check(self._lib.cl_chrom_set_stream(self._h, ctypes.c_void_p(stream)))
+
     def set_eps_list(self, eps_list):
         """the eps values that will be asked for (cl_set_eps_list): with a common divisor the layouts come from one fine sort; empty = unknown"""
         vals = [int(e) for e in eps_list]

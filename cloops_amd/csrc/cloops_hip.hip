@@ -2108,6 +2108,19 @@ extern "C" void cl_set_count_floor(cl_chrom* c, int32_t min_pts)
     c->count_floor = min_pts > 0 ? min_pts : 0;
     for (auto& w : c->count_tmask) w = 0;
 }
+extern "C" int cl_chrom_set_stream(cl_chrom* c, void* stream)
+{
+    if (!c || !stream || c->own_stream) return fail(CL_ERR_ARG, "cl_chrom_set_stream: needs a handle on a caller's stream and a stream");
+    if (c->slot[0].pending || c->slot[1].pending) return fail(CL_ERR_ARG, "cl_chrom_set_stream: a run is in flight");
+    if ((hipStream_t)stream == c->stream) return CL_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));             // (everything the handle enqueued there is done: the new stream starts clean)
+    c->stream = (hipStream_t)stream;
+    c->shared_copy = nullptr;                             // the copy stream belongs to the compute stream: looked up again when needed
+    c->copy_mode = library_made_stream(c->stream) ? 2 : 1;
+    return CL_OK;
+}
+
 extern "C" void cl_set_eps_list(cl_chrom* c, const int32_t* eps, int32_t n)
 {
     if (!c) return;

@@ -87,6 +87,34 @@ class _StreamPool(object):
             slot[1] -= max(1, int(n))
 
 
+    def rebalance(self, chroms):
+        """`chroms` = the idle handles of one sweep [(chromosome made by _make_chrom, n PETs)]: dealt again over their device's
+        shared streams, largest first (LPT).  A handle is bound to a stream when it is uploaded -- in arrival order, before anyone
+        knows which chromosomes a sweep will take: chr1 .. chrX of a 200 M genome arrive as 72 / 63 / 65 M PETs on the three
+        streams, and a step lasts as long as its fullest stream."""
+        if SWEEP_STREAMS <= 0:
+            return
+        by_dev = {}
+        for ch, n in chroms:
+            slot = getattr(ch.close, "slot", None)
+            if slot is not None:
+                by_dev.setdefault(ch.device, []).append((ch, max(1, int(n)), slot))
+        with self._lock:
+            for dev, items in by_dev.items():
+                slots = self._by_dev.get(dev, [])
+                if len(slots) < 2:
+                    continue
+                load = {id(s): 0 for s in slots}
+                for ch, n, slot in sorted(items, key=lambda t: -t[1]):
+                    best = min(slots, key=lambda s: load[id(s)])
+                    load[id(best)] += n
+                    if best is not slot:
+                        ch.set_stream(best[0])
+                        slot[1] -= n
+                        best[1] += n
+                        ch.close.slot = best
+
+
 STREAMS = _StreamPool()
 
 
@@ -601,6 +629,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
     for r in held:
         r.sweep_lock.acquire()
     try:
+        STREAMS.rebalance([(r.chrom, len(r.d)) for _, r in live])
         for f, r in live:
             r.chrom.cand_reset()
             # the region query of the first run at an eps serves the later runs at that eps (their minPts are smaller: the

@@ -332,6 +332,11 @@ void cl_set_traversal(cl_chrom* c, int level);
  * device instead of one per chromosome: how many kernels run side by side is then the application's choice, not a
  * property of how the runtime maps dozens of streams onto its hardware queues.  Destroy a stream after its handles. */
 void* cl_stream_create(int device);
+/* cl_chrom_set_stream: move an idle handle (no run in flight) that was created on a caller's / library-made stream to another
+ * stream of the same device -- the sweep driver balances its chromosomes over its shared streams when a sweep starts (a handle is
+ * bound to a stream when it is uploaded, long before the set of chromosomes of a sweep is known).  Waits for the handle's old
+ * stream.  CL_ERR_ARG for a handle with a stream of its own (stream == NULL at creation) or a NULL stream. */
+int cl_chrom_set_stream(cl_chrom* c, void* stream);
 void cl_stream_destroy(void* stream);
 
 /* Page-locked host memory for result buffers (labels_out / boxes_out / counts_out): D2H

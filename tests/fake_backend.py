@@ -42,6 +42,9 @@ class FakeChromosome(object):
     def set_eps_list(self, eps_list):
         pass
 
+    def set_stream(self, stream):
+        pass
+
     def set_sort_index(self, mode=1):
         pass
 

@@ -246,3 +246,41 @@ def test_two_workers_on_one_device(monkeypatch):
     assert cut1 == cut2 and cuts1 == cuts2
     assert [(s["n_inter"], s["n_self"], s.get("cut_out")) for s in steps1] == [(s["n_inter"], s["n_self"], s.get("cut_out")) for s in steps2]
     assert list(sI1) == list(sI2) and all(np.array_equal(sI1[k]["boxes"], sI2[k]["boxes"]) for k in sI1)
+
+
+def test_handle_moves_between_shared_streams():
+    """cl_chrom_set_stream: an idle handle made on one shared stream clusters the same on another; a handle with a stream of its own
+    refuses; the sweep driver's LPT re-deal (pipe.STREAMS.rebalance) leaves the results of a sweep untouched"""
+    from cloops_amd import api, pipe, _lib
+    from cloops_amd.synth import synth_chrom
+    lib = _lib.load()
+    s1, s2 = lib.cl_stream_create(0), lib.cl_stream_create(0)
+    X, Y = synth_chrom(120000, 3000000, 4)
+    a = api.Chromosome(X, Y, stream=s1)
+    want = a.cluster("v2", 2000, 5, 0).labels.copy()
+    a.set_stream(s2)
+    assert np.array_equal(a.cluster("v2", 2000, 5, 300).labels, api.Chromosome(X, Y).cluster("v2", 2000, 5, 300).labels)
+    a.set_stream(s1)
+    assert np.array_equal(a.cluster("v2", 2000, 5, 0).labels, want)
+    own = api.Chromosome(X, Y)
+    with pytest.raises(Exception):
+        own.set_stream(s1)
+    a.close()
+    own.close()
+    # residents uploaded smallest first land unevenly on the shared streams; the sweep deals them again and gives the same chain
+    parts = [synth_chrom(n, 4000000, 50 + k) for k, n in enumerate((20000, 30000, 50000, 90000, 160000))]
+    fs = [pipe.CACHE.put_arrays("rb%d-rb%d" % (k, k), x, y) for k, (x, y) in enumerate(parts)]
+    try:
+        d1, cut1, cuts1, _ = pipe.runSweepFast(fs, [2000, 3000], [8, 5], cut=0)
+        keep = pipe.STREAMS.rebalance
+        pipe.STREAMS.rebalance = lambda chroms: None
+        try:
+            d2, cut2, cuts2, _ = pipe.runSweepFast(fs, [2000, 3000], [8, 5], cut=0)
+        finally:
+            pipe.STREAMS.rebalance = keep
+        assert cut1 == cut2 and cuts1 == cuts2 and list(d1) == list(d2)
+        for k in d1:
+            assert np.array_equal(d1[k]["boxes"], d2[k]["boxes"])
+    finally:
+        for f in fs:
+            pipe.CACHE.drop(f)
