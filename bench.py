@@ -554,7 +554,7 @@ def with_labels_sweep(pipe, fs, steps, pets_per_sweep, reps=2):
                             "end_point": "row-aligned int32 labels of EVERY PET (-1 = not clustered) + the cluster table of every run"}}
 
 
-def scaling_proxy(pipe, lpt_assign, fs, sizes, steps, nranks, one_gpu_sweep_s, reps=2):
+def scaling_proxy(pipe, lpt_assign, fs, sizes, steps, nranks, one_gpu_sweep_s, reps=3):
     """Single-GPU evidence for the N-GPU claim.  Every rank's LPT share of `nranks` is swept ALONE on this GPU, replaying the
     genome-wide chain (the cuts a real run all-reduces), and timed step by step.  A real run meets after every step (the cut
     is a genome-wide estimate: one all-reduce per run), so what bounds it is the SUM over the steps of the slowest rank's
@@ -585,18 +585,21 @@ def scaling_proxy(pipe, lpt_assign, fs, sizes, steps, nranks, one_gpu_sweep_s, r
         fr = [copies[f] for f in fr]
         try:
             pipe.runSweepFast(fr, eps, mps, cut=0, variant=VARIANT, forced_cuts=forced)
-            acc, tot = np.zeros(len(steps)), 0.0
+            # the FASTEST of `reps` sweeps: a share is 14-19 ms of wall clock, and one hiccup of the host (a page fault, a thread
+            # that wakes late) in one of two sweeps used to move the slowest rank -- the figure the prediction is built on -- by 20 %
+            acc, tot = None, None
             for _ in range(reps):
                 t0 = time.perf_counter()
                 res = pipe.runSweepFast(fr, eps, mps, cut=0, variant=VARIANT, forced_cuts=forced)
-                tot += time.perf_counter() - t0
-                acc += np.asarray([st["wall_s"] for st in res[3]])
+                t = time.perf_counter() - t0
+                if tot is None or t < tot:
+                    tot, acc = t, np.asarray([st["wall_s"] for st in res[3]])
             tables += [v["boxes"] for v in res[0].values() if len(v["boxes"])]
         finally:
             for name in fr:
                 pipe.CACHE.drop(name)
-        dt = tot / reps
-        walls.append(list(acc / reps)); tails.append(max(dt - float(acc.sum()) / reps, 0.0))       # tail: candidate dedup + tables to the host
+        dt = tot
+        walls.append(list(acc)); tails.append(max(dt - float(acc.sum()), 0.0))                     # tail: candidate dedup + tables to the host
         per.append({"rank": r, "chromosomes": [sizes[ci][0] for ci in sorted(share)], "pets": int(sum(sizes[ci][2] for ci in share)),
                     "sweep_wall_s": dt, "steps_wall_s": [round(x, 6) for x in walls[-1]]})
     mk = max(p["sweep_wall_s"] for p in per)
@@ -604,7 +607,7 @@ def scaling_proxy(pipe, lpt_assign, fs, sizes, steps, nranks, one_gpu_sweep_s, r
     out = {"ranks": nranks, "per_rank": per, "makespan_s": mk, "sum_over_steps_of_slowest_rank_s": sum_of_max, "one_gpu_sweep_s": one_gpu_sweep_s,
            "implied_speedup": one_gpu_sweep_s / mk if mk > 0 else None, "implied_efficiency": one_gpu_sweep_s / mk / nranks if mk > 0 else None,
            "lpt_balance": max(p["pets"] for p in per) / (sum(p["pets"] for p in per) / float(nranks)),
-           "note": "each rank's share timed ALONE on one MI355X with the genome-wide cut chain forced (runSweepFast(forced_cuts)); makespan_s = the slowest "
+           "note": "each rank's share timed ALONE on one MI355X with the genome-wide cut chain forced (runSweepFast(forced_cuts)), the fastest of 3 sweeps; makespan_s = the slowest "
                    "rank's whole sweep (no meeting between the steps: a lower bound); sum_over_steps_of_slowest_rank_s = with the per-step meeting a real run has; "
                    "every share runs on handles of its own (made for the proxy, as a rank would make them), not on the handles of the 23-chromosome sweep"}
     try:
