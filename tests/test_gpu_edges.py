@@ -195,3 +195,27 @@ def test_failed_arena_reservation_is_harmless():
             assert np.array_equal(got.labels, want), v
     finally:
         ch.close()
+
+
+def test_walkers_beside_clusters_they_do_not_touch():
+    """the border rule's queue (k_border_q): pairs of sparse PETs whose windows one strip away run along dense clusters they are
+    NOT adjacent to -- nearly every walker has a walk left over after the capped steps, more than the queue of a tile holds
+    (the rest finishes in place) -- next to walkers that are adjacent to two and three clusters (contested: release records)"""
+    rng = np.random.default_rng(11)
+    eps = 1000
+    parts = []
+    for k in range(40):
+        c = 200000 + 6000 * k                                   # dense diagonal blobs: cores
+        parts.append(np.stack([c + rng.integers(-150, 151, 700), c + 9000 + rng.integers(-150, 151, 700)], 1))
+        # walkers in pairs, one strip further along the diagonal (X + Y larger by ~1.2-1.9 eps), same distance range: inside the q
+        # window of the blob's strip but out of reach of its cores -- and some just within reach
+        m = 400
+        bx = c + rng.integers(-150, 151, m) + rng.integers(600, 950, m)
+        by = bx + 9000 + rng.integers(-300, 301, m)
+        parts.append(np.stack([bx, by], 1))
+        parts.append(np.stack([bx + rng.integers(1, 40, m), by + rng.integers(1, 40, m)], 1))
+    P = np.concatenate(parts)
+    P = P[rng.permutation(len(P))]
+    for minPts in (30, 8):
+        run_all(P[:, 0], P[:, 1], eps, minPts, variants=["v2", "v1"])
+        run_all(P[:, 0], P[:, 1], eps, minPts, cut=8800, variants=["v2"])
