@@ -1,12 +1,13 @@
-// cl_band.h -- K2 on the cut band (count cache of the handle, cl_chrom::rc), as device code that rides inside k_cut_copy.
+// cl_band.h -- K2 on the cut band (count cache of the handle, cl_chrom::rc), as device code: the kernel k_band of traversal level 4
+// (words and hints in base positions, BASEOUT) and, at levels <= 3, a part of k_cut_copy.
 //
 // A run that re-uses the K2 words of an earlier run of its eps has to redo the region query (cDBSCAN.py:186-205,
 // cDBSCAN2.py:333-334) only for the PETs whose neighbourhood the two cuts treat differently: q < bandq = the larger cut +
 // eps.  The sorted order inside a strip is q, so those are the FIRST blen[s].x kept PETs of every strip, and everything
 // within eps of them lies among the first blen[s].y (q < bandq + eps) of the strips s-1, s, s+1 -- a few per cent of the
 // chromosome, a handful of PETs per strip.  That little work is pure latency (table row -> strip prefixes -> a few LDS
-// searches -> one store per PET), so it does not get a launch of its own: the first workgroups of the run's compaction
-// kernel do it while the others stream the copy, reading the prefixes straight from the BASE layout (the kept PETs of strip
+// searches -> one store per PET).  At levels <= 3 it does not get a launch of its own: the first workgroups of the run's compaction
+// kernel do it while the others stream the copy (level 4 copies nothing: k_band, 17-35 us), reading the prefixes straight from the BASE layout (the kept PETs of strip
 // s start at src0[s] there) and writing the words at the PETs' places in the new one (new strip start + position).
 //
 // One WAVE takes KB_SB consecutive strips (their table rows live in its lanes, the offsets come from shuffles -- no
