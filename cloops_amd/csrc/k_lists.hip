@@ -1854,6 +1854,7 @@ k_final_lists(GridParams g, const int* __restrict__ lcnt, const int2* __restrict
             if (at < pairs_cap) pairs[at] = make_int2((int)srow[pos[ch]], lab[ch]);
         }
     }
+    if (L_ABL(1 << 10)) return;                             // (ablation: no cluster table)
 #pragma unroll
     for (int ch = 0; ch < LF_CHUNKS; ++ch) table_accumulate(t, h, lab[ch], x[ch], y[ch]);
     table_flush(t, h);
