@@ -1857,6 +1857,7 @@ k_final_lists(GridParams g, const int* __restrict__ lcnt, const int2* __restrict
     if (L_ABL(1 << 10)) return;                             // (ablation: no cluster table)
 #pragma unroll
     for (int ch = 0; ch < LF_CHUNKS; ++ch) table_accumulate(t, h, lab[ch], x[ch], y[ch]);
+    if (L_ABL(1 << 9)) return;                              // (ablation: the table stays in LDS)
     table_flush(t, h);
 }
 
