@@ -139,8 +139,8 @@ struct cl_chrom {
     int run_level = 0;                // traversal level of the run being enqueued (run_sort_and_count decides: level 4 needs the count cache's tables)
     const int* w_dM = nullptr;        // device: PETs that entered DBSCAN in the run being enqueued
     bool run_rows = true;             // the run being enqueued produces row-aligned labels
-    int2* pairs_out = nullptr;        // cl_cluster_pairs_async: (row, label) of every labelled PET, written by the label kernel straight into
-    long long pairs_cap = 0;          // the caller's page-locked buffer (its count: header word 6)
+    int2* pairs_out = nullptr;        // cl_cluster_pairs_async: (row, label) of every labelled PET, staged by the label kernel in the slot's
+    long long pairs_cap = 0;          // device buffer and copied by cl_wait into the caller's page-locked buffer (their count: header word 6)
     bool pairs_defer = false, pairs_copy_pending = false;      // cl_set_pairs_defer / cl_pairs_sync
     bool l4_make_base = false;        // level 4: the run makes the words of its eps -- K2 on the base layout, launched behind the band query
     bool l4_cut = false;              // level 4: the run has a cut (the per-strip tables of k_cut_strips apply)
@@ -178,6 +178,7 @@ struct cl_chrom {
         DevBuf slab;                  // labels in sorted order (rotated variants)
         DevBuf pairs;                 // cl_cluster_pairs_async: (row, label) of the labelled PETs on the device (copied out by cl_wait: their number is
         int2* pairs_host = nullptr;   //   only known when the run has completed)
+        long long pairs_host_cap = 0; //   the caller's capacity (pairs): cl_wait refuses a run that labelled more
         bool exported = true;         // the table rows were stored to h_boxes
         bool step_valid = false;      // the run carried the sweep-step tail (classification, candidate append, distance summary)
         bool host_written = false;    // ... and its last kernel stored header + step output in pinned host memory itself

@@ -80,6 +80,7 @@ struct GridParams {
     int tgap;     //   the widest gap of that set: max over c in [1, minPts) of (smallest served minPts above c) - c
     int qmin;     // K2 (clustering form): PETs with q below it get no word (level 4: the words of an eps are made on the base layout by a run
                   //   under a cut -- the PETs its cut removes are in the cut band of every run that could ever read their words)
+    int qtop;     // the largest in-strip coordinate q of the chromosome (k_region_keys packs q into 28 bits of a sorted 64-bit key)
     int peps;     // 1 << rbits.  The kernels never see p itself but its ORDER-PRESERVING re-encoding
                   //   sp = strip << rbits | (p mod eps)   (the strip and remainder fields of the sort key):
                   //   strip(p) = sp >> rbits (no division), and |p_j - p_i| <= eps  <=>  |sp_j - sp_i| <= peps

@@ -2680,6 +2680,7 @@ static int make_grid(cl_chrom* c, int variant, int eps, int minPts, int cut, Gri
     const int qmin = g->swap ? c->st.amin : c->st.vmin, qmax = g->swap ? c->st.amax : c->st.vmax;
     (void)qmin;
     g->qbits = std::max(1, bits_for((unsigned)((long long)qmax - g->V0)));
+    g->qtop = (int)std::min<long long>((long long)qmax - g->V0, INT_MAX);
     g->rbits = bits_for((unsigned)(eps - 1));
     g->peps = 1 << g->rbits;
     // the strip coordinate lives in the kernels as sp = strip << rbits | remainder (GridParams): sp + peps must stay an int
@@ -3292,6 +3293,10 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
         int2* dst = sl.pairs_host;
         sl.pairs_host = nullptr;
         const long long kp = sl.h_hdr[6];
+        // the kernel clamps its stores at the capacity but keeps counting: a run that labelled more PETs than the caller's
+        // buffer holds is an argument error, nothing is copied (the staging buffer holds `capacity` pairs, not kp)
+        if (kp > sl.pairs_host_cap)
+            return fail(CL_ERR_ARG, "cl_cluster_pairs_async: the run labelled more PETs than capacity_pairs (n always suffices)");
         if (kp > 0 && sl.h_hdr[1] == 0) {
             HIP_TRY(hipMemcpyAsync(dst, sl.pairs.p, (size_t)kp * 8, hipMemcpyDeviceToHost, c->aux_stream));
             // (cl_set_pairs_defer: the caller completes the copy with cl_pairs_sync -- a loop over many handles then has all their
@@ -3419,7 +3424,7 @@ extern "C" int cl_pairs_sync(cl_chrom* c)
 extern "C" int64_t cl_last_n_labelled(const cl_chrom* c)
 {
     if (!c || !c->have_result || c->last_slot < 0) return -1;
-    return c->slot[c->last_slot].h_hdr[6];
+    return c->slot[c->last_slot].h_hdr[6];               // (may exceed the capacity of a run cl_wait refused with CL_ERR_ARG)
 }
 
 extern "C" int cl_cluster_step_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut, int32_t step, int64_t fine_lo)
@@ -3667,6 +3672,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     c->hdr_packed = true;
     if (level >= 3) {
         c->slot[c->cur].pairs_host = c->pairs_out;
+        c->slot[c->cur].pairs_host_cap = c->pairs_cap;
         if (c->pairs_out && (rc = c->slot[c->cur].pairs.ensure((size_t)std::max<long long>(c->pairs_cap, 1) * 8))) return rc;
         if ((rc = lists_final(c, g, nm, L, rows, c->hdr.as<int>() + 16 * c->cur + 6))) return rc;
         cl_chrom::Slot& sl = c->slot[c->cur];

@@ -629,6 +629,381 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
 }
 
 // ------------------------------------------------------------------------------------------
+// K2, sorted-key form (round 6): the clustering form for the DENSE shapes, re-decomposed so that
+//   (1) a search probe is ONE 8-byte LDS read at an immediate offset, one 64-bit compare and a select: the window is staged as
+//       ONE sorted array of 64-bit keys  strip_rel << 52 | q << 24 | cum  (strip_rel = strip - (s0 - 2), clamped to 0 .. 4095;
+//       q < 2^28: the host checks qtop + eps + 1 < 2^28) -- sorted order (strip, q) IS the order of the keys, so "first PET of
+//       strip t with q >= x" is a plain lower bound of the key (t, x), whichever strip the probes run through;
+//   (2) the candidates of the neighbour strips are not touched at all for most PETs: `cum` holds two RUNNING CLASS COUNTERS over
+//       the window order (12 bits each: how many staged entries in front have r = p mod eps >= eps/3 resp. >= 2 eps/3), so for a q
+//       window [ja, ka) of strip s-1 the number of its PETs in every third of the strip is a difference of two reads.  One strip
+//       below a candidate is a neighbour iff r_j >= r_i: every PET of a HIGHER third is one, every PET of a lower third is not,
+//       only the PETs of the query's own third are uncertain (one strip above: mirrored).  That gives count in [low, up] with
+//       up - low = a third of the two windows; if no served minPts lies in (low, up] the word is settled (cDBSCAN.py:186-205
+//       needs the count only against minPts; cDBSCAN2.py:333-334 likewise) -- on chr1 of the 200 M genome 3-9 % of the PETs are
+//       left for candidate walks instead of 20-31 %;
+//   (3) the in-strip remainders r are not staged: the walks of those few PETs read sp from global memory (L2 hits: the tile has
+//       just streamed it).
+// Everything else (tile / halo shapes, strip-table slice, phase 0, per-wave lists, deferred walks by the workgroup, the word
+// and its hints, the global-memory continuation for pile-ups) is k_region_core's.
+// ------------------------------------------------------------------------------------------
+typedef unsigned long long u64k;
+#define K2K_RELMAX 4095
+#define K2K_HCAP 63           // the upper ends of the neighbour windows are searched 6 steps deep
+
+// first index of [pos, pos + 2^K - 1] whose key is >= key (pos + 2^K - 1 if none of the probed ones is)
+template <int K>
+__device__ __forceinline__ int k2k_first_ge(const u64k* __restrict__ w, int pos, u64k key)
+{
+    // (the position runs in BYTES: a probe is ds_read_b64 at an immediate offset, v_cmp_lt_u64, v_add, v_cndmask -- no address shift)
+    int p8 = pos * 8;
+#pragma unroll
+    for (int step = 1 << (K - 1); step >= 1; step >>= 1) {
+        const u64k v = *reinterpret_cast<const u64k*>(reinterpret_cast<const char*>(w) + p8 + (step - 1) * 8);
+        p8 = v >= key ? p8 : p8 + step * 8;
+    }
+    return p8 >> 3;
+}
+template <int K>
+__device__ __forceinline__ int k2k_first_ge_clamped(const u64k* __restrict__ w, int pos, int last, u64k key)
+{
+    int p8 = pos * 8;
+    const int last8 = last * 8;
+#pragma unroll
+    for (int step = 1 << (K - 1); step >= 1; step >>= 1) {
+        const u64k v = *reinterpret_cast<const u64k*>(reinterpret_cast<const char*>(w) + min(p8 + (step - 1) * 8, last8));
+        p8 = v >= key ? p8 : p8 + step * 8;
+    }
+    return p8 >> 3;
+}
+// inclusive prefix sum over the 64 lanes of a wave on the DPP network
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v)
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+template <int U, int HALO, bool TAIL>
+__global__ void __launch_bounds__(K2F_TPB, HALO >= 1024 ? 5 : 7)      // (the LDS holds seven / five workgroups per CU: the registers must too)
+k_region_keys(GridParams g, int ntiles, const int* __restrict__ sv, const int* __restrict__ sa,
+              const int* __restrict__ strip_start, const int* __restrict__ tile_s0, int* __restrict__ cnt)
+{
+    constexpr int TILE = K2F_TPB * U, WIN = TILE + 2 * HALO, NV = WIN / 4;
+    constexpr int FULL = NV / K2F_TPB;                                   // int4 staging slots per thread
+    constexpr int NSEG = FULL * (K2F_TPB / 64);                         // 256-entry segments of the window, one per (slot, wave)
+    constexpr int RUN = (2048 / TILE) > 0 ? (2048 / TILE) : 1;
+    static_assert(HALO % 4 == 0 && HALO >= 128 && TILE + HALO + K2F_SLACK <= SORT_PAD && TILE % 256 == 0 && NV % K2F_TPB == 0, "window shape");
+    static_assert(WIN + K2F_SLACK < (int)K2H_MASK && WIN + K2F_SLACK < 4096 && K2F_SLACK > K2K_HCAP && NSEG <= 64 && TILE <= 1024, "field widths");
+    __shared__ __attribute__((aligned(16))) u64k lw[WIN + K2F_SLACK];   // sorted keys, window index = sorted index - (t0 - HALO)
+    __shared__ int l_st[K2F_NS + 4];
+    __shared__ unsigned int l_list[TILE];
+    __shared__ unsigned char l_next[128];
+    unsigned int* l_seg = l_list;                                        // segment totals of the counter scan (read before the lists exist)
+    const int xcd = blockIdx.x & 7, kseq = blockIdx.x >> 3;
+    const int tile = ((kseq / RUN) * 8 + xcd) * RUN + (kseq % RUN);
+    if (tile >= ntiles) return;
+    const int t0 = tile * TILE;
+    int s0 = 0;
+    if (TAIL) { s0 = tile_s0[t0 >> 8]; if (s0 >= g.S) return; }
+    const int M = strip_start[g.S];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int eps = g.eps, peps = g.peps, minPts = g.minPts;
+    {
+        const int4* __restrict__ gq = reinterpret_cast<const int4*>(sv + (t0 - HALO));
+        const int4* __restrict__ gp = reinterpret_cast<const int4*>(sa + (t0 - HALO));
+        int4 qv[FULL], pv[FULL];
+#pragma unroll
+        for (int u = 0; u < FULL; ++u) { qv[u] = gq[threadIdx.x + u * K2F_TPB]; pv[u] = gp[threadIdx.x + u * K2F_TPB]; }
+        if (!TAIL) { s0 = tile_s0[t0 >> 8]; if (s0 >= g.S) return; }
+        const int st = strip_start[min(max(s0 - 1 + (int)threadIdx.x, 0), g.S)];
+        // class counters: running counts of r >= t1 (bits 0..11) and r >= t2 (bits 12..23) over the window order
+        const int t1 = (eps + 2) / 3, t2 = (2 * eps + 2) / 3, rmask = peps - 1;
+        unsigned cx[FULL][4], tot[FULL];
+#pragma unroll
+        for (int u = 0; u < FULL; ++u) {
+            const int ps[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w};
+            unsigned run = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = ps[k] & rmask;
+                cx[u][k] = run;
+                run += (r >= t1 ? 1u : 0u) + (r >= t2 ? 0x1000u : 0u);
+            }
+            tot[u] = wave_incl_scan(run);
+            if (lane == 63) l_seg[u * (K2F_TPB / 64) + wv] = tot[u];
+            tot[u] -= run;                              // exclusive inside the (slot, wave) segment
+        }
+        l_st[threadIdx.x] = st;
+        if (threadIdx.x < 4) l_st[K2F_NS + threadIdx.x] = 0;
+        if (threadIdx.x < 128) {
+            const int v = (int)threadIdx.x, wi = v >> 5;
+            int nx = 255;
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                const u32 x = k == wi ? (g.tmask[k] & (~0u << (v & 31))) : (k > wi ? g.tmask[k] : 0u);
+                if (x) nx = k * 32 + __ffs(x);
+            }
+            l_next[v] = (unsigned char)nx;
+        }
+        __syncthreads();
+        // the segments in front of mine: one read per lane, a wave scan, a read-lane per slot
+        const unsigned sg = lane < NSEG ? l_seg[lane] : 0u;
+        const unsigned sgi = wave_incl_scan(sg);
+        const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)sgi, 63);
+        const int wvu = __builtin_amdgcn_readfirstlane(wv);
+        const int sbase = s0 - 2;
+        const bool nearM = t0 - HALO + WIN > M;        // rows behind M (a filtered tail) carry strip S: they are in no strip
+        int4* l4 = reinterpret_cast<int4*>(lw);
+#pragma unroll
+        for (int u = 0; u < FULL; ++u) {
+            const unsigned segbase = (unsigned)__builtin_amdgcn_readlane((int)(sgi - sg), u * (K2F_TPB / 64) + wvu);
+            const unsigned base = segbase + tot[u];
+            const int slot = (int)threadIdx.x + u * K2F_TPB;
+            const int qs[4] = {qv[u].x, qv[u].y, qv[u].z, qv[u].w};
+            const int ps[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w};
+            unsigned lo[4], hi[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int rel = min(max((ps[k] >> g.rbits) - sbase, 0), K2K_RELMAX);
+                if (nearM && t0 - HALO + 4 * slot + k >= M) rel = K2K_RELMAX;
+                const unsigned q = min((unsigned)qs[k], 0x0fffffffu);
+                lo[k] = (q << 24) | (base + cx[u][k]);
+                hi[k] = ((unsigned)rel << 20) | (q >> 8);
+            }
+            l4[2 * slot] = make_int4((int)lo[0], (int)hi[0], (int)lo[1], (int)hi[1]);
+            l4[2 * slot + 1] = make_int4((int)lo[2], (int)hi[2], (int)lo[3], (int)hi[3]);
+        }
+        if (threadIdx.x < K2F_SLACK) lw[WIN + threadIdx.x] = ((u64k)0xffffffffu << 32) | 0xff000000u | total;
+    }
+    __syncthreads();
+    K2_ABL(32);
+    const int m1 = minPts - 1;
+    const u64k E24 = (u64k)(unsigned)eps << 24, STRIP1 = 1ull << 52;
+    const u64k KMASK = ~(u64k)0xffffffu;                // (strip_rel, q) of a key
+    unsigned int* my_list = l_list + wv * (64 * U);
+    int nh = 0;
+    // ---- phase 0: the (minPts-1)-th next / previous PET is in the same strip and within eps in q -> core -------------------
+    u64k p_me[U], p_rr[U], p_ll[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int li = HALO + (int)threadIdx.x + u * K2F_TPB;
+        p_me[u] = lw[li]; p_rr[u] = lw[li + m1]; p_ll[u] = lw[li - m1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int tix = (int)threadIdx.x + u * K2F_TPB;
+        const u64k me = p_me[u] & KMASK;
+        const int qi = (int)((unsigned)(me >> 24) & 0x0fffffffu);
+        const bool valid = (t0 + tix < M) & (qi >= g.qmin);
+        // (a key of a later strip is above (rel, q + eps) whatever its q: q + eps < 2^28; one of an earlier strip, raised by eps, stays below)
+        const bool core = (p_rr[u] < me + E24 + (1ull << 24)) | (p_ll[u] + E24 >= me);
+        if (valid & core) cnt[t0 + tix] = minPts;
+        const bool hard = valid & !core;
+        const unsigned long long bal = __ballot(hard);
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        if (hard) my_list[nh + before] = (unsigned)tix;
+        nh += __popcll(bal);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    K2_ABL(64);
+    // ---- phase 1: own strip = an index difference of two bounded searches ---------------------------------------------------
+    int n2 = 0;
+    for (int h0 = 0; h0 < nh; h0 += 64) {
+        const int h = h0 + lane;
+        const bool act = h < nh;
+        const int tix = act ? (int)my_list[h] : 0, li = HALO + tix;
+        const u64k me = lw[li] & KMASK;
+        const unsigned qi = (unsigned)(me >> 24) & 0x0fffffffu;
+        const u64k keyL = me - ((u64k)min(qi, (unsigned)eps) << 24), keyH = me + E24 + (1ull << 24);
+        int lo, hi;
+        if (m1 <= 4) { lo = k2k_first_ge<2>(lw, li - 3, keyL); hi = k2k_first_ge<2>(lw, li + 1, keyH); }
+        else if (m1 <= 8) { lo = k2k_first_ge<3>(lw, li - 7, keyL); hi = k2k_first_ge<3>(lw, li + 1, keyH); }
+        else if (m1 <= 32) { lo = k2k_first_ge<5>(lw, li - 31, keyL); hi = k2k_first_ge<5>(lw, li + 1, keyH); }
+        else if (m1 <= 64) { lo = k2k_first_ge<6>(lw, li - 63, keyL); hi = k2k_first_ge<6>(lw, li + 1, keyH); }
+        else { lo = k2k_first_ge<7>(lw, li - 127, keyL); hi = k2k_first_ge<7>(lw, li + 1, keyH); }
+        const int c = hi - lo;
+        const bool need = act & (c < minPts);
+        if (act & !need) cnt[t0 + tix] = c;
+        const unsigned long long bal = __ballot(need);
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        if (need) my_list[n2 + before] = (unsigned)tix | ((unsigned)c << 16);
+        n2 += __popcll(bal);
+    }
+    K2_ABL(128);
+    // ---- phase 2: the q windows [ja, ka) of strip s-1 and [jb, kb) of strip s+1, their class counts, the bracket -----------
+    const int off = HALO - t0;
+    const int wlo = max(t0 - HALO, 0) + off, whi = min(t0 - HALO + WIN, M) + off;
+    const int last = WIN + K2F_SLACK - 1;
+    auto emit = [&](int tix, int li, int c, int hja, int hjb) {
+        int outv = c;
+        if (c < minPts) {
+            unsigned enc = 0x80000000u | ((unsigned)c << K2W_CSHIFT);
+            enc |= (hja >= 0) ? ((unsigned)(li - hja) | ((unsigned)(hjb - li) << K2H_BITS)) : K2H_NONE;
+            outv = (int)enc;
+        }
+        cnt[t0 + tix] = outv;
+    };
+    // the candidates of both windows one by one (their strip coordinates from global memory: window index + t0 - HALO)
+    auto walk = [&](int c, int tix, int ja, int na, int jb, int nb) {
+        const int pi = sa[t0 + tix], plo = pi - peps, phi = pi + peps;
+        const int* __restrict__ ga = sa + (t0 - HALO) + ja;
+        const int* __restrict__ gb = sa + (t0 - HALO) + jb;
+        for (int j = 0; (j < na) & (c < minPts); j += 4) {
+            int v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = ga[j + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c += ((j + k < na) & (v[k] >= plo)) ? 1 : 0;       // one strip below: sp can only be too low
+        }
+        for (int j = 0; (j < nb) & (c < minPts); j += 4) {
+            int v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = gb[j + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c += ((j + k < nb) & (v[k] <= phi)) ? 1 : 0;       // one strip above: only too high
+        }
+        return c;
+    };
+    int n3 = 0;
+    for (int h = lane; h < n2; h += 64) {
+        const unsigned ent = my_list[h];
+        const int tix = (int)(ent & 0xffffu), li = HALO + tix;
+        int c = (int)(ent >> 16);
+        const u64k me = lw[li] & KMASK;
+        const unsigned qi = (unsigned)(me >> 24) & 0x0fffffffu;
+        const int rel = (int)(me >> 52);
+        const bool far = rel >= K2K_RELMAX - 1;           // the clamp of strip_rel: the keys do not tell this PET's strips apart
+        const int kk = far ? (sa[t0 + tix] >> g.rbits) - s0 : rel - 2;
+        const int kc = min(kk, K2F_NS);
+        int tb = l_st[kc], b = l_st[kc + 1], e = l_st[kc + 2], te = l_st[kc + 3];
+        asm volatile("" : "+v"(tb), "+v"(b), "+v"(e), "+v"(te));      // (four LDS reads: keeps the compiler from merging them with the rare global loads below into FLAT loads)
+        if (kk + 3 >= K2F_NS) {
+            const int s = kk + s0;
+            tb = strip_start[max(s - 1, 0)]; b = strip_start[s]; e = strip_start[s + 1]; te = strip_start[min(s + 2, g.S)];
+        }
+        const int gtb0 = tb, gte0 = te;
+        tb += off; e += off; te += off;
+        const u64k dq = (u64k)min(qi, (unsigned)eps) << 24;
+        const u64k keyAL = me - STRIP1 - dq, keyAH = me - STRIP1 + E24 + (1ull << 24);
+        const u64k keyBL = me + STRIP1 - dq, keyBH = me + STRIP1 + E24 + (1ull << 24);
+        bool okA = (tb >= wlo) & !far, okB = (te <= whi) & !far;
+        if (__any(!(okA & okB))) {
+            // a neighbour strip that sticks out of the staged range is clipped to it when the staged part provably holds the q window
+            const u64k f = lw[wlo], l = lw[whi - 1];
+            if (!okA & !far) { okA = (f >= (me & ~((1ull << 52) - 1ull)) - STRIP1) & (f < keyAL); tb = wlo; }
+            if (!okB & !far) { okB = (l >= keyBH) & (l < (me & ~((1ull << 52) - 1ull)) + 2 * STRIP1); te = whi; }
+        }
+        const int longest = max(b + off - tb, te - e);
+        int hja = -1, hjb = -1;
+        bool deferred = false;
+        if (okA & okB) {
+            int ja, jb;
+            if (!__any(longest > 31)) { ja = k2k_first_ge<5>(lw, tb, keyAL); jb = k2k_first_ge<5>(lw, e, keyBL); }
+            else if (!__any(longest > 127)) { ja = k2k_first_ge<7>(lw, tb, keyAL); jb = k2k_first_ge_clamped<7>(lw, e, last, keyBL); }
+            else if (!__any(longest > 255)) { ja = k2k_first_ge_clamped<8>(lw, tb, last, keyAL); jb = k2k_first_ge_clamped<8>(lw, e, last, keyBL); }
+            else if (!__any(longest > 511)) { ja = k2k_first_ge_clamped<9>(lw, tb, last, keyAL); jb = k2k_first_ge_clamped<9>(lw, e, last, keyBL); }
+            else if (!__any(longest > 1023)) { ja = k2k_first_ge_clamped<10>(lw, tb, last, keyAL); jb = k2k_first_ge_clamped<10>(lw, e, last, keyBL); }
+            else { ja = k2k_first_ge_clamped<12>(lw, tb, last, keyAL); jb = k2k_first_ge_clamped<12>(lw, e, last, keyBL); }
+            const int ka = k2k_first_ge<6>(lw, ja, keyAH), kb = k2k_first_ge<6>(lw, jb, keyBH);
+            hja = ja; hjb = jb;
+            K2_ABL(512);
+            const int na = ka - ja, nb = kb - jb;
+            // class counts of both windows and the query's own third (its increment of the running counters)
+            const unsigned cja = (unsigned)lw[ja], cka = (unsigned)lw[ka], cjb = (unsigned)lw[jb], ckb = (unsigned)lw[kb];
+            const unsigned inc = ((unsigned)lw[li + 1] - (unsigned)lw[li]) & 0xffffffu;
+            const unsigned dA = (cka - cja) & 0xffffffu, dB = (ckb - cjb) & 0xffffffu;
+            const int A1 = (int)(dA & 0xfffu), A2 = (int)(dA >> 12), B1 = (int)(dB & 0xfffu), B2 = (int)(dB >> 12);
+            const bool f1 = (inc & 1u) != 0, f2 = (inc >> 12) != 0;
+            // one strip below: neighbours have r_j >= r_i -- the higher thirds surely, the own third perhaps; one strip above: mirrored
+            const int sureA = f2 ? 0 : (f1 ? A2 : A1), uncA = f2 ? A2 : (f1 ? A1 - A2 : na - A1);
+            const int sureB = f2 ? nb - B2 : (f1 ? nb - B1 : 0), uncB = f2 ? B2 : (f1 ? B1 - B2 : nb - B1);
+            const int low = c + sureA + sureB, up = low + uncA + uncB;
+            const bool capped = (na >= K2K_HCAP) | (nb >= K2K_HCAP);
+            // count in [low, up] (up only if both windows were searched to their ends).  Core at every served minPts: done.  No served
+            // minPts in (low, up]: every test reads the same from up as from the count (up <= 1 = isolated: up is a true upper bound).
+            if (low >= minPts) c = low;
+            else if (!capped && up < (int)l_next[low]) c = up;
+            else {
+                const unsigned long long bal = __ballot(true);
+                const int slot = n3 + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                int na2 = na, nb2 = nb;
+                if (capped) {
+                    // a window longer than the shallow search: its true end (clamped to the array: okA / okB say the window ends inside)
+                    if (na >= K2K_HCAP) na2 = k2k_first_ge_clamped<12>(lw, ja, last, keyAH) - ja;
+                    if (nb >= K2K_HCAP) nb2 = k2k_first_ge_clamped<12>(lw, jb, last, keyBH) - jb;
+                }
+                if (2 * slot + 1 < (h - lane) + 64 && na2 < 1024 && nb2 < 1024) {
+                    // (tix 10 bits | c 7 | na 10 ; ja 12 | jb 12 ... nb rides in the spare bits)
+                    my_list[2 * slot] = (unsigned)tix | ((unsigned)c << 10) | ((unsigned)na2 << 17) | ((unsigned)(nb2 & 31) << 27);
+                    my_list[2 * slot + 1] = (unsigned)ja | ((unsigned)jb << 12) | ((unsigned)(nb2 >> 5) << 24);
+                    deferred = true;
+                } else c = walk(c, tix, ja, na2, jb, nb2);
+            }
+        } else {
+            // a neighbour strip reaches outside the staged window (pile-up) or lies beyond the key clamp: global memory
+            const int pi = sa[t0 + tix], qlo = (int)qi - eps, qhi = (int)qi + eps;
+            const int gtb = gtb0, ge = e - off, gte = gte0;
+            if (gtb < b) {
+                const int j = lower_bound_4(sv, gtb, b, qlo);
+                c = k2_count_glb<false, 8>(sv, sa, j, b, qhi, pi, peps, minPts, c);
+            }
+            if (c < minPts && ge < gte) {
+                const int j = lower_bound_4(sv, ge, gte, qlo);
+                c = k2_count_glb<false, 8>(sv, sa, j, gte, qhi, pi, peps, minPts, c);
+            }
+        }
+        n3 += __popcll(__ballot(deferred));
+        if (!deferred) emit(tix, li, c, hja, hjb);
+    }
+    n3 = __builtin_amdgcn_readfirstlane(dpp_reduce_wave(n3, OpMax()));
+    // ---- phase 3: the candidate walks of the deferred PETs, by the whole workgroup as one list --------------------------------
+    if (lane == 0) l_st[K2F_NS + wv] = n3;
+    __syncthreads();
+    const int c0 = l_st[K2F_NS], c1 = c0 + l_st[K2F_NS + 1], c2 = c1 + l_st[K2F_NS + 2];
+    int ntot = c2 + l_st[K2F_NS + 3];
+#ifdef CLOOPS_DEVEL
+    if (g.dbg & 2048) ntot = 0;
+#endif
+    // FOUR lanes per deferred PET: a walk is a chain of round trips to the L2 (the strip coordinates are not staged), a workgroup has a
+    // few tens of deferred PETs for its 256 threads, and what it waits for is the longest chain -- lane k of a quad takes the
+    // candidates 4k .. 4k + 3 of every 16 of both windows (8 loads in flight), the quad adds up
+    for (int gi = (int)threadIdx.x; gi < 4 * ntot; gi += K2F_TPB) {
+        const int ei = gi >> 2, sub = gi & 3;
+        const int w = (ei >= c0) + (ei >= c1) + (ei >= c2);
+        const int h = ei - (w == 0 ? 0 : (w == 1 ? c0 : (w == 2 ? c1 : c2)));
+        const unsigned int* wl = l_list + w * (64 * U);
+        const unsigned e0 = wl[2 * h], e1 = wl[2 * h + 1];
+        const int tix = (int)(e0 & 0x3ffu), li = HALO + tix;
+        const int ja = (int)(e1 & 0xfffu), jb = (int)((e1 >> 12) & 0xfffu);
+        const int na = (int)((e0 >> 17) & 0x3ffu), nb = (int)((e0 >> 27) | ((e1 >> 24) << 5));
+        const int pi = sa[t0 + tix], plo = pi - peps, phi = pi + peps;
+        const int* __restrict__ ga = sa + (t0 - HALO) + ja;
+        const int* __restrict__ gb = sa + (t0 - HALO) + jb;
+        int add = 0;
+#pragma unroll 1
+        for (int j = 4 * sub; (j < na) | (j < nb); j += 16) {
+            int va[4], vb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { va[k] = ga[j + k]; vb[k] = gb[j + k]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) add += (((j + k < na) & (va[k] >= plo)) ? 1 : 0) + (((j + k < nb) & (vb[k] <= phi)) ? 1 : 0);
+        }
+        add += CL_DPP(add, 0xb1, 0xf);                  // quad_perm [1,0,3,2]
+        add += CL_DPP(add, 0x4e, 0xf);                  // quad_perm [2,3,0,1]
+        const int c = min((int)((e0 >> 10) & 0x7fu) + add, minPts);      // (a core PET's word is saturated at minPts)
+        if (sub == 0) emit(tix, li, c, ja, jb);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side: pick the tile shape and launch
 // ------------------------------------------------------------------------------------------
 int cl_launch_region(hipStream_t stream, const GridParams& g, int n, int run_m, bool exact, const int* sv, const int* sa,
@@ -655,6 +1030,25 @@ int cl_launch_region(hipStream_t stream, const GridParams& g, int n, int run_m, 
                 else hipLaunchKernelGGL((k_region_core<UU, HH, false>), dim3(grid), dim3(K2F_TPB), padlds, stream, g, ntiles, \
                                    sv, sa, strip_start, tile_s0, cnt); \
             }
+            // the dense shapes run the sorted-key form when q fits its 28-bit field (q + eps + 1 < 2^28: every human chromosome)
+            bool keys = shape >= 1 && shape <= 2 && (long long)g.qtop + g.eps + 1 < (1LL << 28);
+#ifdef CLOOPS_DEVEL
+            if (getenv("CLOOPS_K2_OLD")) keys = false;
+#endif
+#define K2K_LAUNCH(UU, HH)                                                                                              \
+            {                                                                                                           \
+                const int tile = K2F_TPB * UU, ntiles = nblocks(std::max(1, run_m), tile), run = std::max(1, 2048 / tile); \
+                const int grid = ((ntiles + 8 * run - 1) / (8 * run)) * (8 * run);                                      \
+                if (g.cut > 0) hipLaunchKernelGGL((k_region_keys<UU, HH, true>), dim3(grid), dim3(K2F_TPB), padlds, stream, g, ntiles, \
+                                   sv, sa, strip_start, tile_s0, cnt);                            \
+                else hipLaunchKernelGGL((k_region_keys<UU, HH, false>), dim3(grid), dim3(K2F_TPB), padlds, stream, g, ntiles, \
+                                   sv, sa, strip_start, tile_s0, cnt); \
+            }
+            if (keys) {
+                if (shape == 1) K2K_LAUNCH(4, 512) else K2K_LAUNCH(4, 1024)
+                return CL_OK;
+            }
+#undef K2K_LAUNCH
             // window = tile + 2 * halo entries; shapes keep it a multiple of 1024 (every thread stages whole 16-byte slots)
             switch (shape) {
             case 0: K2F_LAUNCH(3, 128) break;

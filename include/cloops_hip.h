@@ -228,9 +228,10 @@ const int32_t* cl_labels_device(const cl_chrom* c);
 int cl_cand_reset(cl_chrom* c);
 /* The labels of a run as the reference holds them: cDBSCAN(mat, eps, minPts).labels is a dict of the CLUSTERED points only
  * (cDBSCAN2.py:186-191, cDBSCAN.py:143-152).  Like cl_cluster_async, but instead of n row-aligned labels the run leaves one
- * (row, label) int32 pair per labelled PET, in no particular order, written by its last kernel straight into
- * `pinned_pairs_out` (page-locked host memory: cl_host_alloc; capacity_pairs pairs -- n always suffices); after cl_wait
- * cl_last_n_labelled(c) says how many.  A sweep that wants labels on the host every run moves 8 bytes per clustered PET
+ * (row, label) int32 pair per labelled PET, in no particular order: its last kernel stages them in device memory and
+ * cl_wait copies exactly cl_last_n_labelled(c) of them into `pinned_pairs_out` (page-locked host memory: cl_host_alloc;
+ * capacity_pairs pairs -- n always suffices; a run that labels MORE than capacity_pairs PETs makes cl_wait return
+ * CL_ERR_ARG and copies nothing).  A sweep that wants labels on the host every run moves 8 bytes per clustered PET
  * over PCIe instead of 4 bytes per PET.  Rotated variants at traversal level >= 3 and minPts 2 .. 128 only (CL_ERR_ARG
  * otherwise). */
 int cl_cluster_pairs_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut, int32_t* pinned_pairs_out,
