@@ -57,7 +57,13 @@ def load():
         return _lib
     if not os.path.exists(SO_PATH):
         raise ImportError("libcloops_comm.so is missing (%s): build it with `python -m cloops_amd.build`" % SO_PATH)
-    lib = ctypes.CDLL(SO_PATH)
+    _lib = _declare(ctypes.CDLL(SO_PATH))
+    return _lib
+
+
+def _declare(lib):
+    """the prototypes of include/cloops_comm.h on a loaded library (tests load a build of cloops_comm.cpp against a host-memory
+    test double of HIP / RCCL through this, tests/test_comm_fake_world.py)"""
     vp, i64 = ctypes.c_void_p, ctypes.c_int64
     lib.cl_comm_last_error.restype = ctypes.c_char_p
     lib.cl_comm_rccl_version.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
@@ -79,7 +85,6 @@ def load():
     lib.cl_comm_gather_i32_pinned.argtypes = [vp, vp, i64, ctypes.c_int, vp]
     lib.cl_comm_gather_device.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int, vp, i64, vp]
     lib.cl_comm_allreduce_f64_device.argtypes = [vp, vp, i64, vp]
-    _lib = lib
     return lib
 
 

@@ -193,75 +193,115 @@ extern "C" int cl_comm_allreduce_f64_device(cl_comm* c, double* dev, int64_t n, 
     return 0;
 }
 
+// One all-gather of a small int32 record per rank through the communicator's staging buffers (pin: [0, in) send, [64 + ...) receive)
+static int allgather_words(cl_comm* c, const int32_t* mine, int nwords, int32_t* all /* world * nwords */)
+{
+    const size_t in_bytes = (size_t)nwords * 4, out_bytes = in_bytes * (size_t)c->world, pad = 256;
+    int rc = ensure(c, pad + out_bytes, pad + out_bytes);
+    if (rc) return rc;
+    memcpy(c->pin, mine, in_bytes);
+    HIPC(hipMemcpyAsync(c->dev, c->pin, in_bytes, hipMemcpyHostToDevice, c->stream));
+    NCC(ncclAllGather(c->dev, (char*)c->dev + pad, (size_t)nwords, ncclInt32, c->comm, c->stream));
+    HIPC(hipMemcpyAsync((char*)c->pin + pad, (char*)c->dev + pad, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    memcpy(all, (char*)c->pin + pad, out_bytes);
+    return 0;
+}
+
+// The protocol has THREE phases so that no rank can leave another inside RCCL:
+//   1. every rank all-gathers {its row count, and -- the root -- the capacity and presence of its receive buffer}: "pinned_out too
+//      small" / "null receive buffer" are decided by EVERY rank from the same record, before any send or receive is posted;
+//   2. every rank allocates its staging area, then the ranks all-gather one status word: an allocation that failed anywhere makes
+//      every rank return the error together;
+//   3. the tables move (grouped ncclSend / ncclRecv); a failure between ncclGroupStart and ncclGroupEnd still closes the group.
 extern "C" int cl_comm_gather_device(cl_comm* c, const int32_t* const* tabs, const int64_t* rows, int32_t ntab, int32_t cols, int root,
                                      int32_t* pinned_out, int64_t cap_rows, int64_t* rank_rows)
 {
     if (!c || ntab < 0 || cols <= 0 || root < 0 || root >= c->world || !rank_rows || (ntab > 0 && (!tabs || !rows)))
         return cfail("cl_comm_gather_device", "bad arguments");
     HIPC(hipSetDevice(c->device));
+    // a table this rank cannot send is reported through the record (status word), not by leaving before the first collective
     long long mine = 0;
-    for (int k = 0; k < ntab; ++k) { if (rows[k] < 0 || (rows[k] > 0 && !tabs[k])) return cfail("cl_comm_gather_device", "bad table"); mine += rows[k]; }
-    // the row counts of all ranks (two int32 halves per rank: a 200 M-PET genome stays far below 2^31 rows, a larger one may not)
-    int32_t cnt[2] = {(int32_t)(mine & 0x7fffffff), (int32_t)(mine >> 31)};
-    {
-        const size_t in_bytes = 8, out_bytes = in_bytes * (size_t)c->world;
-        int rc = ensure(c, out_bytes + 64, 256 + out_bytes);
-        if (rc) return rc;
-        memcpy(c->pin, cnt, in_bytes);
-        HIPC(hipMemcpyAsync(c->dev, c->pin, in_bytes, hipMemcpyHostToDevice, c->stream));
-        NCC(ncclAllGather(c->dev, (char*)c->dev + 256, 2, ncclInt32, c->comm, c->stream));
-        HIPC(hipMemcpyAsync((char*)c->pin + 64, (char*)c->dev + 256, out_bytes, hipMemcpyDeviceToHost, c->stream));
-        HIPC(hipStreamSynchronize(c->stream));
-        const int32_t* all = (const int32_t*)((char*)c->pin + 64);
-        for (int r = 0; r < c->world; ++r) rank_rows[r] = (long long)all[2 * r] + ((long long)all[2 * r + 1] << 31);
-    }
+    int local_bad = 0;
+    for (int k = 0; k < ntab; ++k) { if (rows[k] < 0 || (rows[k] > 0 && !tabs[k])) { local_bad = 1; break; } mine += rows[k]; }
+    if (local_bad) mine = 0;
+    const bool is_root = c->rank == root;
+    const long long cap = is_root ? std::max<long long>(cap_rows, 0) : 0;
+    // (counts and capacity as two 31-bit halves: a 200 M-PET genome stays far below 2^31 rows, a larger one may not)
+    enum { NW = 6 };
+    int32_t rec[NW] = {(int32_t)(mine & 0x7fffffff), (int32_t)(mine >> 31), (int32_t)(cap & 0x7fffffff), (int32_t)(cap >> 31),
+                       (int32_t)(is_root && pinned_out ? 1 : 0), (int32_t)local_bad};
+    std::string all_s((size_t)c->world * NW * 4, '\0');
+    int32_t* all = (int32_t*)&all_s[0];
+    int rc = allgather_words(c, rec, NW, all);
+    if (rc) return rc;
     long long total = 0;
-    for (int r = 0; r < c->world; ++r) total += rank_rows[r];
-    const size_t row_bytes = (size_t)cols * 4;
-    if (c->rank == root) {
-        if (total > cap_rows) return cfail("cl_comm_gather_device", "pinned_out too small");
-        if (total > 0 && !pinned_out) return cfail("cl_comm_gather_device", "null receive buffer");
-        if (c->world == 1) {
-            // one rank: every table goes straight to its place in the caller's page-locked buffer
-            size_t at = 0;
-            for (int k = 0; k < ntab; ++k)
-                if (rows[k] > 0) { HIPC(hipMemcpyAsync((char*)pinned_out + at, tabs[k], (size_t)rows[k] * row_bytes, hipMemcpyDeviceToHost, c->stream)); at += (size_t)rows[k] * row_bytes; }
-            HIPC(hipStreamSynchronize(c->stream));
-            return 0;
-        }
-        int rc = ensure(c, 0, (size_t)total * row_bytes + 256);
-        if (rc) return rc;
-        char* stage = (char*)c->dev;
-        size_t at = 0;
-        NCC(ncclGroupStart());
-        for (int r = 0; r < c->world; ++r) {
-            const size_t nb = (size_t)rank_rows[r] * row_bytes;
-            if (r == root) {
-                size_t a2 = at;
-                for (int k = 0; k < ntab; ++k)
-                    if (rows[k] > 0) { HIPC(hipMemcpyAsync(stage + a2, tabs[k], (size_t)rows[k] * row_bytes, hipMemcpyDeviceToDevice, c->stream)); a2 += (size_t)rows[k] * row_bytes; }
-            } else if (nb > 0) {
-                NCC(ncclRecv(stage + at, (size_t)rank_rows[r] * cols, ncclInt32, r, c->comm, c->stream));
-            }
-            at += nb;
-        }
-        NCC(ncclGroupEnd());
-        if (total > 0) HIPC(hipMemcpyAsync(pinned_out, stage, (size_t)total * row_bytes, hipMemcpyDeviceToHost, c->stream));
-        HIPC(hipStreamSynchronize(c->stream));
-    } else {
-        // (one message per rank: its tables are packed device-to-device first, so that the root posts ONE receive per rank)
-        if (mine > 0) {
-            int rc = ensure(c, 0, (size_t)mine * row_bytes + 256);
-            if (rc) return rc;
-            size_t at = 0;
-            for (int k = 0; k < ntab; ++k)
-                if (rows[k] > 0) { HIPC(hipMemcpyAsync((char*)c->dev + at, tabs[k], (size_t)rows[k] * row_bytes, hipMemcpyDeviceToDevice, c->stream)); at += (size_t)rows[k] * row_bytes; }
-            NCC(ncclGroupStart());
-            NCC(ncclSend(c->dev, (size_t)mine * cols, ncclInt32, root, c->comm, c->stream));
-            NCC(ncclGroupEnd());
-        }
-        HIPC(hipStreamSynchronize(c->stream));
+    bool any_bad = false;
+    for (int r = 0; r < c->world; ++r) {
+        rank_rows[r] = (long long)all[NW * r] + ((long long)all[NW * r + 1] << 31);
+        total += rank_rows[r];
+        any_bad |= all[NW * r + 5] != 0;
     }
+    const long long root_cap = (long long)all[NW * root + 2] + ((long long)all[NW * root + 3] << 31);
+    const bool root_has_out = all[NW * root + 4] != 0;
+    // phase 1 verdicts: the same on every rank
+    if (any_bad) return cfail("cl_comm_gather_device", "bad table (negative row count or null pointer) on some rank");
+    if (total > root_cap) return cfail("cl_comm_gather_device", "pinned_out too small");
+    if (total > 0 && !root_has_out) return cfail("cl_comm_gather_device", "null receive buffer");
+    const size_t row_bytes = (size_t)cols * 4;
+    if (c->world == 1) {
+        // one rank: every table goes straight to its place in the caller's page-locked buffer
+        size_t at = 0;
+        for (int k = 0; k < ntab; ++k)
+            if (rows[k] > 0) { HIPC(hipMemcpyAsync((char*)pinned_out + at, tabs[k], (size_t)rows[k] * row_bytes, hipMemcpyDeviceToHost, c->stream)); at += (size_t)rows[k] * row_bytes; }
+        HIPC(hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    // phase 2: staging areas, then one status word per rank
+    {
+        const size_t need = is_root ? (size_t)total * row_bytes + 256 : (mine > 0 ? (size_t)mine * row_bytes + 256 : 0);
+        int32_t st = need ? (ensure(c, 0, need + 1024 + (size_t)c->world * 4) != 0) : 0;
+        const std::string keep = g_cerr;
+        std::string sts((size_t)c->world * 4, '\0');
+        rc = allgather_words(c, &st, 1, (int32_t*)&sts[0]);
+        if (rc) return rc;
+        for (int r = 0; r < c->world; ++r)
+            if (((const int32_t*)&sts[0])[r] != 0) {
+                if (st) { g_cerr = keep; return -2; }
+                return cfail("cl_comm_gather_device", "staging allocation failed on another rank");
+            }
+    }
+    // phase 3: the tables.  Device-to-device packing first (plain stream work), then ONLY RCCL calls inside the group; a failure inside
+    // the group is remembered and the group is closed before returning
+    char* stage = (char*)c->dev + 512 + (((size_t)c->world * 4 + 255) / 256) * 256;      // (behind the words allgather_words staged)
+    if (is_root) {
+        size_t at = 0;
+        for (int r = 0; r < root; ++r) at += (size_t)rank_rows[r] * row_bytes;
+        for (int k = 0; k < ntab; ++k)
+            if (rows[k] > 0) { HIPC(hipMemcpyAsync(stage + at, tabs[k], (size_t)rows[k] * row_bytes, hipMemcpyDeviceToDevice, c->stream)); at += (size_t)rows[k] * row_bytes; }
+    } else {
+        size_t at = 0;
+        for (int k = 0; k < ntab; ++k)
+            if (rows[k] > 0) { HIPC(hipMemcpyAsync(stage + at, tabs[k], (size_t)rows[k] * row_bytes, hipMemcpyDeviceToDevice, c->stream)); at += (size_t)rows[k] * row_bytes; }
+    }
+    ncclResult_t bad = ncclSuccess;
+    NCC(ncclGroupStart());
+    if (is_root) {
+        size_t at = 0;
+        for (int r = 0; r < c->world; ++r) {
+            if (r != root && rank_rows[r] > 0 && bad == ncclSuccess)
+                bad = ncclRecv(stage + at, (size_t)rank_rows[r] * cols, ncclInt32, r, c->comm, c->stream);
+            at += (size_t)rank_rows[r] * row_bytes;
+        }
+    } else if (mine > 0) {
+        // (one message per rank: the root posts ONE receive per rank)
+        bad = ncclSend(stage, (size_t)mine * cols, ncclInt32, root, c->comm, c->stream);
+    }
+    const ncclResult_t ge = ncclGroupEnd();
+    if (bad != ncclSuccess) return cfail("ncclSend / ncclRecv", ncclGetErrorString(bad));
+    if (ge != ncclSuccess) return cfail("ncclGroupEnd", ncclGetErrorString(ge));
+    if (is_root && total > 0) HIPC(hipMemcpyAsync(pinned_out, stage, (size_t)total * row_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
     return 0;
 }
 
