@@ -12,11 +12,15 @@ A "step" is one pass of the hot path over the batch: ONE whole 12-run sweep over
 resident in HBM" to "deduplicated, distance-filtered candidate-loop table on the host" (cluster tables cross
 PCIe every run; labels stay on the device -- the sweep never needs them).  `value` = PETs that entered DBSCAN,
 summed over the 12 runs and the K timed sweeps, / wall time; `sweep_wall_s` = ms_per_step / 1000 is the second
-half of the metric.  Every sweep does all of its own work: one sort per (chromosome, eps) -- the sorted order does not
-depend on minPts and a cut only removes rows, so the four minPts runs of an eps start from a stable compaction of
-that layout by their cut (cl_set_layout_reuse; the layout of the previous sweep's last eps never matches the next
-sweep's first) -- and region query, components, borders, cluster table and distance statistics for every run.  The
-first sweep of the process (allocations) is reported separately as `first_sweep_s`.
+half of the metric.  Every timed sweep builds the layout of each of its three eps (a per-strip merge of the handle's fine
+layout: the sorted order does not depend on minPts, and a cut only removes a PREFIX of every strip, so the four minPts
+runs of an eps work on that one layout by index -- nothing is copied), one region query per eps plus the cut band of
+every later run, and components, borders, cluster table and distance statistics for every run.  What a timed sweep
+re-uses from the warm-up is the q index and the fine layout (they depend on the rows only): a real pipe() sweeps a
+dataset once (cLoops/pipe.py:247-275), so the same sweep with every derived order dropped first (cl_chrom_drop_indexes;
+allocations kept) is reported as top-level `cold_sweep_s`, the first sweep of the process (allocations too) as
+`first_sweep_s`, and the sweep that lands labels + tables on the host every run (SURVEY.md 8d(1)'s end point) as
+top-level `with_labels_sweep_s`.
 
 With N > 1 (`--gpus N` spawns N ranks through torch.distributed.run -- only the launcher -- when not already launched by
 it) the 23 chromosomes are LPT-sharded over the ranks (cloops_amd.dist.lpt_assign; chromosomes are independent units,
@@ -66,7 +70,7 @@ def parse_args(argv=None):
                          "23+ cores) instead of the bounded 2-run sample, and check its chain against the GPU's")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-with-labels", action="store_true", help="skip the label-inclusive sweep (labels + tables on the host every run)")
-    ap.add_argument("--proxy-ranks", type=int, default=8, help="single-GPU scaling proxy: time every rank's LPT share of N alone (0 = off)")
+    ap.add_argument("--proxy-ranks", default="2,4,8", help="single-GPU scaling proxy: time every rank's LPT share of N alone, for each N of the list (0 = off)")
     return ap.parse_args(argv)
 
 
@@ -263,13 +267,15 @@ def main(argv=None):
             k2_log.append((ep, m, cut_in, dict(res.timing)))
 
     def one_sweep(log_k2):
+        # the path's final exchange (cLoops/pipe.py:119-127 merges its workers' results): the candidate tables go to rank 0 from
+        # where cl_cand_finish_device left them -- exact sizes over RCCL, one device-to-host copy at the root, none elsewhere; run as
+        # the sweep's device_consumer, i.e. while the handles are still pinned and locked
+        gather = (lambda d: comm.gather_device([v["dev_rows"] for v in d.values()], [v["n_rows"] for v in d.values()], dst=0, copy=False)) if comm is not None else None
         dataI, cut, cuts, steps = pipe.runSweepFast(fs, eps_list, minpts_list, cut=0, variant=VARIANT, allsum=allsum,
-                                                    probe=probe if (log_k2 and rank == 0) else None, finish_device=comm is not None)
+                                                    probe=probe if (log_k2 and rank == 0) else None, finish_device=comm is not None,
+                                                    device_consumer=gather)
         if comm is not None:
-            # the path's final exchange (cLoops/pipe.py:119-127 merges its workers' results): the candidate tables go to rank 0 from
-            # where cl_cand_finish_device left them -- exact sizes over RCCL, one device-to-host copy at the root, none elsewhere
-            tabs = comm.gather_device([v["dev_rows"] for v in dataI.values()], [v["n_rows"] for v in dataI.values()], dst=0, copy=False)
-            ncand = sum(len(t) for t in tabs)
+            ncand = sum(len(t) for t in dataI.gathered)
         elif use_dist:
             rows = [v["boxes"] for v in dataI.values() if len(v["boxes"])]
             rows = rows if rows else np.zeros((0, 4), np.int32)
@@ -342,12 +348,29 @@ def main(argv=None):
             if k2_log:
                 line["roofline"]["in_sweep_avg_launch_ms"] = sum(max(t[3]["ms_region"] - t[3]["ms_bracket"], 1e-6) for t in k2_log) / len(k2_log)
                 line["roofline"]["in_sweep_source"] = "HIP events around K2 on chr1's stream during the last warm-up sweep (same work as a timed one; the event records between the kernels cost a sweep ~7 %, so the timed sweeps run without them)"
-    # single-GPU legs behind the timed region: the label-inclusive form of the same sweep, the scaling proxy
+    # single-GPU legs behind the timed region: the one-dataset sweep, the label-inclusive form of the same sweep, the scaling proxy
     if rank == 0 and world == 1 and on_gpu:
+        # a dataset's ONLY sweep: every handle forgets its q index, fine layout, last layout and cached counts (allocations stay)
+        cold = []
+        for _ in range(2):
+            for f in fs:
+                pipe.CACHE.get(f).chrom.drop_indexes()
+            t0c = time.perf_counter()
+            one_sweep(False)
+            cold.append(time.perf_counter() - t0c)
+        line["cold_sweep_s"] = min(cold)
+        line["cold_sweep_note"] = ("the same sweep with cl_chrom_drop_indexes on every chromosome first (q index 4 radix passes + fine layout 2 passes + "
+                                   "everything a timed sweep does; handles and workspaces allocated): what a dataset swept once pays; best of 2")
         if not args.no_with_labels:
             line["with_labels"] = with_labels_sweep(pipe, fs, steps, pets // max(1, args.steps))
-        if args.proxy_ranks > 1:
-            line["scaling_proxy"] = scaling_proxy(pipe, lpt_assign, fs, sizes, steps, args.proxy_ranks, elapsed / max(1, args.steps))
+            line["with_labels_sweep_s"] = line["with_labels"]["sweep_wall_s"]
+        plist = [int(x) for x in str(args.proxy_ranks).split(",") if x.strip() and int(x) > 1]
+        if plist:
+            # the 1 / 2 / 4 / 8 table north_star asks for, as far as ONE GPU can evidence it: the largest N in full, the others compact
+            prox = {n: scaling_proxy(pipe, lpt_assign, fs, sizes, steps, n, elapsed / max(1, args.steps)) for n in sorted(plist)}
+            top = max(prox)
+            line["scaling_proxy"] = prox[top]
+            line["scaling_proxy"]["by_ranks"] = {str(n): {k: v.get(k) for k in ("makespan_s", "sum_over_steps_of_slowest_rank_s", "predicted_sweep_s", "predicted_speedup", "lpt_balance")} for n, v in prox.items()}
     # the secondary single-eps figure and the CPU baseline: rank 0, single GPU only
     if rank == 0 and world == 1 and on_gpu:
         pipe.CACHE.clear()
@@ -478,7 +501,7 @@ def roofline_block(replay, n_probe):
     n_band = len([r for r in rows if r[4] == 2 or r[3].get("ms_band", 0.0) > 0])
     band_ms = [band(r[3]) if r[3].get("ms_band", 0.0) > 0 else (net(r[3]) if r[4] == 2 else None) for r in rows]
     band_ms = [x for x in band_ms if x is not None]
-    return {"bound": "hbm", "kernel": "k_region_core (once per eps, on the base layout) + k_band (the cut band of every run under a cut)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    return {"bound": "hbm", "kernel": "k_region_keys (the sorted-key region query: once per eps, on the base layout) + k_band (the cut band of every run under a cut)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
             "amortised": True, "launches": len(rows), "runs_with_full_query": n_make, "runs_on_the_band": n_band,
             "probe": "chr1 of the genome (%d PETs) alone on the GPU, the sweep's 12 (eps, minPts, cut) runs in the sweep's order x 3 passes" % n_probe,

@@ -213,7 +213,21 @@ class Chromosome(object):
         identical either way -- cl_set_count_reuse of include/cloops_hip.h)"""
         self._lib.cl_set_count_reuse(self._h, 1 if on else 0)
 
-    def set_traversal(self, level=3):
+    def sweep_plan(self, eps_list, min_pts_list):
+        """announce a sweep `for ep in eps: for m in minPts:` (cLoops/pipe.py:241-281) in one call (cl_sweep_plan): one sort for all
+        layouts, one region query per eps, the cut band only for the later runs.  Two empty lists end the plan."""
+        ev = sorted(set(int(e) for e in eps_list))
+        mv = sorted(set(int(m) for m in min_pts_list))
+        ea = (ctypes.c_int32 * max(len(ev), 1))(*ev)
+        ma = (ctypes.c_int32 * max(len(mv), 1))(*mv)
+        _lib.check(self._lib.cl_sweep_plan(self._h, ea, len(ev), ma, len(mv)))
+
+    def drop_indexes(self):
+        """forget the q index, the fine layout, the last eps' layout and the cached counts (cl_chrom_drop_indexes): the next run
+        sorts like the first run on a fresh dataset, allocations stay"""
+        _lib.check(self._lib.cl_chrom_drop_indexes(self._h))
+
+    def set_traversal(self, level=4):
         """how far a run works on its core / walker lists instead of LDS tiles over every PET: 0 .. 3 (default 3; results
         identical at every level -- cl_set_traversal of include/cloops_hip.h)"""
         self._lib.cl_set_traversal(self._h, int(level))

@@ -2102,6 +2102,19 @@ extern "C" void cl_set_layout_reuse(cl_chrom* c, int enabled) { if (c) { c->reus
 extern "C" void cl_set_count_reuse(cl_chrom* c, int enabled) { if (c) { c->reuse_counts = enabled != 0; c->rc.valid = false; } }
 extern "C" void cl_set_traversal(cl_chrom* c, int level) { if (c) { c->traversal = level < 0 ? 0 : (level > 4 ? 4 : level); c->rc.valid = false; } }
 extern "C" int cl_last_region_mode(const cl_chrom* c) { return c ? c->last_k2_mode : 0; }
+// Forget everything the handle has DERIVED from its rows -- the q index, the fine layout, the base layout of the last eps, the
+// cached neighbour counts -- and keep every allocation: the next run pays what the first run on a freshly uploaded dataset pays
+// for its orders, without the allocations of a new handle (bench.py `cold_sweep_s`: a dataset is swept once, pipe.py:247-275).
+extern "C" int cl_chrom_drop_indexes(cl_chrom* c)
+{
+    if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
+    if (c->slot[0].pending || c->slot[1].pending) return fail(CL_ERR_ARG, "cl_chrom_drop_indexes: a run is in flight");
+    c->qindex_layout = -1;
+    c->fine_valid_w = 0; c->fine_layout = -1;
+    c->base.valid = false;
+    c->rc.valid = false;
+    return CL_OK;
+}
 extern "C" void cl_set_count_floor(cl_chrom* c, int32_t min_pts)
 {
     if (!c) return;
@@ -2148,6 +2161,26 @@ extern "C" void cl_set_count_thresholds(cl_chrom* c, const int32_t* min_pts, int
         if (min_pts[k] >= 2 && min_pts[k] <= 128) c->count_tmask[(min_pts[k] - 1) >> 5] |= 1u << ((min_pts[k] - 1) & 31);
 }
 extern "C" void cl_set_sort_index(cl_chrom* c, int mode) { if (c) c->sort_index_mode = mode > 0 ? 1 : (mode < 0 ? -1 : 0); }
+// One call for a sweep (cLoops/pipe.py:241-281: `for ep in eps: for m in minPts:`): everything the handle can prepare from knowing
+// both lists -- the q index from the first sort on and one fine sort for all layouts (several eps), counts bracketed for the minPts
+// list, layout / count reuse on, the default traversal.  n_eps = n_min_pts = 0 ends the plan (a later one-off run serves itself).
+extern "C" int cl_sweep_plan(cl_chrom* c, const int32_t* eps, int32_t n_eps, const int32_t* min_pts, int32_t n_min_pts)
+{
+    if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
+    if (n_eps < 0 || n_min_pts < 0 || (n_eps > 0 && !eps) || (n_min_pts > 0 && !min_pts)) return fail(CL_ERR_ARG, "cl_sweep_plan: bad lists");
+    for (int k = 0; k < n_eps; ++k) if (eps[k] <= 0) return fail(CL_ERR_ARG, "cl_sweep_plan: eps must be positive");
+    for (int k = 0; k < n_min_pts; ++k) if (min_pts[k] <= 0) return fail(CL_ERR_ARG, "cl_sweep_plan: minPts must be positive");
+    if (c->slot[0].pending || c->slot[1].pending) return fail(CL_ERR_ARG, "cl_sweep_plan: a run is in flight");
+    if (!c->reuse_layout) cl_set_layout_reuse(c, 1);
+    if (!c->reuse_counts) cl_set_count_reuse(c, 1);
+    if (c->traversal != 4) cl_set_traversal(c, 4);
+    cl_set_count_thresholds(c, min_pts, n_min_pts);
+    int distinct = 0;
+    for (int k = 0; k < n_eps; ++k) { bool seen = false; for (int j = 0; j < k; ++j) seen |= eps[j] == eps[k]; distinct += seen ? 0 : 1; }
+    if (distinct > 1) { cl_set_sort_index(c, 1); cl_set_eps_list(c, eps, n_eps); }
+    else cl_set_eps_list(c, nullptr, 0);
+    return CL_OK;
+}
 extern "C" int cl_get_timing(const cl_chrom* c, cl_timing* out)
 {
     if (!c || !out) return fail(CL_ERR_ARG, "cl_get_timing: null argument");

@@ -585,7 +585,13 @@ def _lib_logbins():
 CUT_RECHECK_MARGIN = 1e-6
 
 
-def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, allsum=None, probe=None, forced_cuts=None, finish_device=False):
+class _DataI(dict):
+    """runSweepFast's candidate tables; `.gathered` = what `device_consumer` returned"""
+    gathered = None
+
+
+def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, allsum=None, probe=None, forced_cuts=None, finish_device=False,
+                 device_consumer=None):
     """runSweep with the per-step statistics reduced on the GPUs: neither labels nor distance
     lists come back to the host -- per chromosome only the K-row cluster table, a few sums, and
     the 256-bin histograms of an exact radix select for the median (all additive over chromosomes
@@ -608,15 +614,21 @@ def runSweepFast(fs, eps, minPts, cut=0, max_cut=False, log=None, variant=None, 
     chromosome, valid until the handle's next sweep finishes): a multi-rank run hands them to comm.Comm.gather_device, which sends
     exact sizes to the merging rank without a detour through the host (cLoops/pipe.py:119-127 merges in the parent).
 
+    `device_consumer` (with finish_device): called as device_consumer(dataI) WHILE the residents are still pinned in the cache and
+    the sweep locks are held -- the device pointers cannot be evicted, freed or overwritten by another sweep before it returns; what
+    it returns is `dataI.gathered` (bench.py: the RCCL gather of the tables to the merging rank).  Without a consumer the caller
+    must use the pointers before anything else touches these handles.
+
     returns (dataI {key: {"f": f, "boxes": int32[k,4]}} of the local chromosomes, cut, cuts, steps)."""
     variant = variant or DBSCAN_VARIANT
     gsum = allsum if allsum is not None else (lambda a: a)
     devs = _devices()
     with CACHE.pinned(fs, devs) as res_all:
-        return _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gsum, probe, forced_cuts, finish_device)
+        return _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gsum, probe, forced_cuts, finish_device, device_consumer)
 
 
-def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gsum, probe=None, forced_cuts=None, finish_device=False):
+def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gsum, probe=None, forced_cuts=None, finish_device=False,
+                device_consumer=None):
     cuts = [cut]
     steps = []
     live = [(f, r) for f, r in zip(fs, res_all) if len(r.d)]
@@ -629,15 +641,21 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
     for r in held:
         r.sweep_lock.acquire()
     try:
-        STREAMS.rebalance([(r.chrom, len(r.d)) for _, r in live])
+        # (a synchronous call on a handle -- cluster(), sig_counts() -- holds its r.lock: no stream is swapped under one)
+        for r in held:
+            r.lock.acquire()
+        try:
+            STREAMS.rebalance([(r.chrom, len(r.d)) for _, r in live])
+        finally:
+            for r in held:
+                r.lock.release()
         for f, r in live:
             r.chrom.cand_reset()
             # the region query of the first run at an eps serves the later runs at that eps (their minPts are smaller: the
             # reference sorts them descending, pipe.py:316-320) -- its counts have to tell `count >= m` for every m of the list
-            r.chrom.set_count_thresholds(sorted(set(int(m) for m in minPts)))
-            if len(set(eps)) > 1:
-                r.chrom.set_sort_index(1)                    # several layouts are coming: the q index pays from the first one on
-                r.chrom.set_eps_list(sorted(set(int(e) for e in eps)))      # ... and, if the values share a divisor, one fine sort serves all of them
+            # (cl_sweep_plan: with several eps the q index pays from the first sort on and, if the values share a divisor, one fine
+            #  sort serves all of them; the counts of an eps are bracketed for the whole minPts list)
+            r.chrom.sweep_plan(eps, minPts)
         step_no = 0
         # where the summary should look for the next median (see _select_kth).  The first step has no earlier median to go by:
         # it counts the distances 1 .. 2048 exactly (self-ligation distances are a few hundred bp: ests.py's cut model) and falls
@@ -808,15 +826,16 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
         # key order = first appearance over the steps, file order inside a step: what combineTwice's dict inserts
         # (pipe.py:155-174) and runStat later walks -- `appended` was filled in exactly that order
         res_of = dict(live)
-        dataI = dict(_pmap(pool, finish, [(f, res_of[f]) for f in appended]))
+        dataI = _DataI(_pmap(pool, finish, [(f, res_of[f]) for f in appended]))
+        if finish_device and device_consumer is not None:
+            dataI.gathered = device_consumer(dataI)           # (residents pinned, sweep locks held: the pointers are alive)
     finally:
         if pool is not None:
             pool.shutdown(wait=True)
         for f, r in live:
             # the announced minPts list belongs to this sweep: a later one-off run on the handle serves its own minPts only
             try:
-                r.chrom.set_count_thresholds([])
-                r.chrom.set_eps_list([])
+                r.chrom.sweep_plan([], [])
             except Exception:
                 pass
         for r in held:

@@ -271,6 +271,18 @@ void cl_set_device_labels(cl_chrom* c, int enabled);
 void cl_set_profiling(cl_chrom* c, int enabled);
 int cl_get_timing(const cl_chrom* c, cl_timing* out);
 
+/* ---- A sweep in one call -------------------------------------------------------------------------------------------------
+ * The reference's driver runs `for ep in eps: for m in minPts:` over every chromosome (cLoops/pipe.py:241-281, the lists of a mode:
+ * pipe.py:310-344).  A caller that is about to do the same tells the handle ONCE:
+ *     cl_sweep_plan(c, eps, n_eps, min_pts, n_min_pts);
+ * and then calls cl_cluster / cl_cluster_async / cl_cluster_step_async per (eps, minPts, cut) as before.  With the plan the handle
+ * sorts its rows once for all announced eps (when they share a divisor), keeps the layout of an eps for its runs, makes the
+ * neighbour counts of an eps once -- exact enough for every announced minPts -- and re-queries only the cut band of the later runs.
+ * Results are identical with and without a plan; without one every run pays for itself.  n_eps = n_min_pts = 0 ends the plan.
+ * The cl_set_* entries below are the plan's parts, kept for tests and measurements (each documents what it switches); a caller
+ * needs none of them. */
+int cl_sweep_plan(cl_chrom* c, const int32_t* eps, int32_t n_eps, const int32_t* min_pts, int32_t n_min_pts);
+
 /* Sorted-layout reuse (default: enabled).  The sorted order of a chromosome's PETs depends on eps only (not on
  * minPts; a cut only removes rows), and the sweep of cLoops/pipe.py:241-281 walks eps in its OUTER loop: with reuse
  * enabled the handle keeps the sorted arrays of the last eps and every further run at that eps starts from one
@@ -310,17 +322,23 @@ void cl_set_sort_index(cl_chrom* c, int mode);
  * k w = k consecutive strips of width w) instead of a sort -- the same (strip, distance) order; PETs of one strip at EQUAL distance
  * follow each other by run instead of by input row, an order no result depends on.  n = 0 forgets the list. */
 void cl_set_eps_list(cl_chrom* c, const int32_t* eps, int32_t n);
+/* cl_chrom_drop_indexes: forget every order and count the handle has derived from its rows (q index, fine layout, the layout of the
+ * last eps, cached neighbour counts); allocations stay.  The next run pays what the first run on a fresh dataset pays for its
+ * sorts -- measurements of "one dataset, one sweep" (cLoops/pipe.py:247-275 sweeps a dataset once) without re-uploading. */
+int cl_chrom_drop_indexes(cl_chrom* c);
 void cl_set_count_reuse(cl_chrom* c, int enabled);
 void cl_set_count_floor(cl_chrom* c, int32_t min_pts);
 void cl_set_count_thresholds(cl_chrom* c, const int32_t* min_pts, int32_t n);
 int cl_last_region_mode(const cl_chrom* c);
 
 /* How the part of a rotated run behind the region query (components, border rule, labels) walks the data.  The reference
- * expands clusters from core points only (cDBSCAN2.py:114-192 queryGrid, cDBSCAN.py:155-184 expandCluster); level 3
- * (default) does the same: the run's cores and its non-core PETs that have a neighbour are compacted into two lists
- * right behind the region query and nothing else is touched again.  Levels 0..2 keep the LDS-tile kernels over every PET
- * of the run for the components (0), the border rule (<= 1) and the labels (<= 2): results are identical at every level
- * (the tests compare them). */
+ * expands clusters from core points only (cDBSCAN2.py:114-192 queryGrid, cDBSCAN.py:155-184 expandCluster); levels 3 and 4
+ * do the same: the run's cores and its non-core PETs that have a neighbour are compacted into two lists right behind the
+ * region query and nothing else is touched again -- level 3 from a copy of the layout compacted by the run's cut, level 4
+ * (DEFAULT) straight from the eps' base layout (a cut removes a prefix of every strip: nothing is copied, the count cache
+ * lives in base positions).  Levels 0..2 keep the LDS-tile kernels over every PET of the run for the components (0), the
+ * border rule (<= 1) and the labels (<= 2).  Results are identical at every level (the tests compare all five); values
+ * outside 0..4 are clamped. */
 void cl_set_traversal(cl_chrom* c, int level);
 
 /* A HIP stream for cl_chrom_create(..., stream, ...) made by the library (for callers without a HIP binding of their

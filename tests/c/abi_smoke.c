@@ -115,6 +115,45 @@ int main(void)
         printf("sweep step: %lld inter-ligation boxes, %lld kept (host and device forms)\n", (long long)ni, (long long)k_dev);
         free(hb); free(sm);
     }
+    {
+        /* a whole sweep announced in ONE call (cl_sweep_plan): `for ep in eps: for m in minPts:` of cLoops/pipe.py:241-281 with a
+           moving cut -- labels equal to a handle without any plan, and the plan is what makes the later runs of an eps cheap
+           (region mode 2: words re-used, cut band re-queried) */
+        const int32_t eps_list[2] = {1000, 2000}, mp_list[2] = {8, 4};
+        cl_chrom* d = NULL;
+        CHECK(cl_chrom_create(0, NULL, x, y, n, 0, &d));
+        cl_set_count_reuse(d, 0);
+        CHECK(cl_sweep_plan(c, eps_list, 2, mp_list, 2));
+        int32_t* lab2 = malloc((size_t)n * sizeof *lab2);
+        if (!lab2) return 30;
+        int32_t cut = 0;
+        for (int e = 0; e < 2; ++e) for (int m = 0; m < 2; ++m) {
+            int32_t nc2 = 0, ml2 = -1;
+            CHECK(cl_cluster(c, CL_VARIANT_CDBSCAN2, eps_list[e], mp_list[m], cut, lab, &nc, &ml));
+            if (cl_last_region_mode(c) != (m == 0 ? 0 : 2)) { fprintf(stderr, "plan: run (%d, %d) region mode %d\n", e, m, cl_last_region_mode(c)); return 31; }
+            CHECK(cl_cluster(d, CL_VARIANT_CDBSCAN2, eps_list[e], mp_list[m], cut, lab2, &nc2, &ml2));
+            if (nc != nc2 || ml != ml2) return 32;
+            for (int64_t i = 0; i < n; ++i) if (lab[i] != lab2[i]) { fprintf(stderr, "plan: label of row %lld differs\n", (long long)i); return 33; }
+            cut += 400;
+        }
+        CHECK(cl_sweep_plan(c, NULL, 0, NULL, 0));
+        if (cl_sweep_plan(c, eps_list, -1, mp_list, 2) != CL_ERR_ARG) return 34;
+        printf("sweep plan: 4 runs, labels equal to a handle without a plan\n");
+        free(lab2);
+        cl_chrom_destroy(d);
+    }
+    {
+        /* (row, label) pairs with a buffer that is too small: cl_wait refuses (CL_ERR_ARG), nothing is written beyond the capacity */
+        int32_t* pin = (int32_t*)cl_host_alloc(64 * 8 + 8);
+        if (!pin) return 40;
+        pin[128] = 0x5a5a5a5a;
+        CHECK(cl_cluster_pairs_async(c, CL_VARIANT_CDBSCAN2, 2000, 5, 0, pin, 64));
+        if (cl_wait(c, &nc, &ml) != CL_ERR_ARG) { fprintf(stderr, "pairs: a 64-pair buffer was accepted\n"); return 41; }
+        if (pin[128] != 0x5a5a5a5a) return 42;
+        cl_host_free(pin);
+        CHECK(cl_cluster(c, CL_VARIANT_CDBSCAN2, 2000, 5, 0, lab, &nc, &ml));     /* the handle is still usable */
+        printf("pairs capacity: refused\n");
+    }
     if (cl_cluster(c, 7, 2000, 5, 0, lab, &nc, &ml) != CL_ERR_ARG) return 8;          /* unknown variant */
     if (cl_cluster(c, CL_VARIANT_CDBSCAN2, 0, 5, 0, lab, &nc, &ml) != CL_ERR_ARG) return 9;   /* eps = 0 */
     cl_chrom_destroy(c);

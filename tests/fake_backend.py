@@ -42,6 +42,9 @@ class FakeChromosome(object):
     def set_eps_list(self, eps_list):
         pass
 
+    def sweep_plan(self, eps_list, min_pts_list):
+        pass
+
     def set_stream(self, stream):
         pass
 

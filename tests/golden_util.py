@@ -54,6 +54,19 @@ def synth150k():
     return X.astype(np.int64), Y.astype(np.int64), z
 
 
+def dense400k():
+    """-> (X, Y, npz of label arrays, meta): the headline regime, labels made by the REAL classes (golden/make_golden_dense.py)"""
+    import hashlib
+    from cloops_amd.synth import synth_chrom
+    with open(os.path.join(GOLD, "dense400k_meta.json")) as fh:
+        m = json.load(fh)
+    X, Y = synth_chrom(m["n"], m["length"], m["seed"])
+    assert hashlib.sha1(np.stack([X, Y]).astype(np.int32).tobytes()).hexdigest() == m["input_sha1"], "synthetic generator drifted"
+    return X.astype(np.int64), Y.astype(np.int64), _npz("dense400k_labels.npz"), m
+
+
+DENSE_SETTINGS = ((5000, 50, 0), (7500, 30, 5004), (10000, 20, 6250))
+
 FAMILY_SEEDS = {"adversarial": 0, "plain": 1, "clumpy": 2}
 
 

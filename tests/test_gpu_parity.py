@@ -122,3 +122,27 @@ def test_async_two_in_flight_matches_sync():
         ch.wait(); ch.wait()
     finally:
         ch.close()
+
+
+@pytest.mark.parametrize("variant", ROT)
+def test_dense400k_headline_regime(variant):
+    """labels made by the REAL classes at the headline's density and settings (tests/golden/make_golden_dense.py), through the
+    sweep's own path: both lists announced in one call (cl_sweep_plan), traversal level 4, the runs in the sweep's order -- so
+    that the words of an eps are made by the sorted-key region query under the minPts list and the cut band is re-queried"""
+    X, Y, z, m = G.dense400k()
+    ch = api.Chromosome(X, Y)
+    try:
+        if variant != "block":
+            ch.sweep_plan([5000, 7500, 10000], [50, 40, 30, 20])
+        for eps, minPts, cut in G.DENSE_SETTINGS:
+            key = "%s_%d_%d_%d" % (variant, eps, minPts, cut)
+            res = ch.cluster(variant, eps, minPts, cut)
+            assert np.array_equal(res.labels, z[key]), key
+            assert res.n_clusters == m["runs"][key]["clusters"]
+            if variant != "block":
+                # a later run of the same eps under another cut reads the cached words + its cut band: against the oracle
+                res2 = ch.cluster(variant, eps, 20, cut + 700)
+                assert ch.last_region_mode() == 2
+                assert np.array_equal(res2.labels, oracle.single_dbscan(variant, X, Y, eps, 20, cut + 700)["labels"]), (key, "re-use")
+    finally:
+        ch.close()

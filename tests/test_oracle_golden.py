@@ -50,6 +50,18 @@ def test_synth150k(variant):
         assert np.array_equal(z["%s_%d_%d" % (variant, eps, minPts)], got)
 
 
+@pytest.mark.parametrize("variant", ["v2", "v1", "block"])
+def test_dense400k_headline_regime(variant):
+    """the oracle against the REAL classes at the headline's density and settings (minPts 20-50 on strips of hundreds of PETs:
+    cDBSCAN2.py:194-302 crowded cells / Pareto edge points), cut filter of pipe.py:59-63 in front"""
+    X, Y, z, m = G.dense400k()
+    for eps, minPts, cut in G.DENSE_SETTINGS:
+        key = "%s_%d_%d_%d" % (variant, eps, minPts, cut)
+        got = oracle.single_dbscan(variant, X, Y, eps, minPts, cut)["labels"]
+        assert np.array_equal(got, z[key]), key
+        assert int((got >= 0).sum()) == m["runs"][key]["labelled"]
+
+
 def test_empty_input_behaviour():
     e = np.zeros(0, np.int64)
     assert len(oracle.labels("v2", e, e, 100, 5)) == 0          # cDBSCAN2: {}

@@ -45,7 +45,7 @@ json.dump(out, open("$OUT/pmc_fetch_write_k2replay.json", "w"), indent=1)
 # + the query on the cut band + nothing else) moves beyond a plain k_cut_copy<false>; 2 x warm-up and timed pass -> per run
 def kb(k, what):
     return out[k][what] if k in out else 0.0
-k2s = [k for k in out if "k_region_core" in k]
+k2s = [k for k in out if "k_region_core" in k or "k_region_keys" in k]
 runs = 0
 for k in out:
     if k.startswith("k_final_l"):
@@ -73,18 +73,18 @@ def stats(name):
     return {re.sub(r"\(.*", "", r["Name"]).replace("void ", ""): (int(r["Calls"]), float(r["AverageNs"]) / 1e3) for r in csv.DictReader(open("$OUT/" + name))}
 ru, fu = stats("k2_replay_reuse_kernel_stats.csv"), stats("k2_replay_full_kernel_stats.csv")
 passes = [v for k, v in ru.items() if k.startswith("k_final_l")][0][0] // 12
-core = sum(c * a for k, (c, a) in ru.items() if k.startswith("k_region_core"))
+core = sum(c * a for k, (c, a) in ru.items() if k.startswith(("k_region_core", "k_region_keys")))
 plain = fu["k_cut_copy<false>"][1] if "k_cut_copy<false>" in fu else 0.0
 if "k_band" in ru:                                       # level 4: the band query of every run under a cut, a kernel of its own
     carry = ru["k_band"][0] * ru["k_band"][1]
 else:
     carry = ru["k_cut_copy<true>"][0] * (ru["k_cut_copy<true>"][1] - plain) + ru["k_cut_strips"][0] * (ru["k_cut_strips"][1] - fu["k_cut_strips"][1])
-full = sum(c * a for k, (c, a) in fu.items() if k.startswith("k_region_core"))
+full = sum(c * a for k, (c, a) in fu.items() if k.startswith(("k_region_core", "k_region_keys")))
 x = {"passes": passes, "runs_per_pass": 12, "region_core_us_per_pass": round(core / passes, 1), "carry_us_per_pass": round(carry / passes, 1),
      "amortised_us_per_run": round((core + carry) / passes / 12, 2), "full_query_us_per_run": round(full / passes / 12, 2),
-     "kernels_reuse": {k: ru[k] for k in ru if k.startswith(("k_region_core", "k_cut_copy", "k_cut_strips", "k_band"))},
-     "per_launch_us": {k: ru[k][1] for k in ru if k.startswith("k_region_core")},
-     "kernels_full": {k: fu[k] for k in fu if k.startswith(("k_region_core", "k_cut_copy", "k_cut_strips"))},
+     "kernels_reuse": {k: ru[k] for k in ru if k.startswith(("k_region_core", "k_region_keys", "k_cut_copy", "k_cut_strips", "k_band"))},
+     "per_launch_us": {k: ru[k][1] for k in ru if k.startswith(("k_region_core", "k_region_keys"))},
+     "kernels_full": {k: fu[k] for k in fu if k.startswith(("k_region_core", "k_region_keys", "k_cut_copy", "k_cut_strips"))},
      "source": "k2_replay_reuse_kernel_stats.csv / k2_replay_full_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/k2_replay.py 3 with CLOOPS_REPLAY_ONLY=reuse / full; the first of the four passes is the warm-up)"}
 json.dump(x, open("$OUT/k2_from_rocprof.json", "w"), indent=1)
 print(json.dumps(x))
