@@ -3260,6 +3260,16 @@ int finish_enqueue(cl_chrom* c, int n_strips, const int* d_M, int32_t* labels_ou
         hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, (const K7Part*)parts, k7b, (K7Part*)(ds + 16),
                            (const int*)bcount, nb, (long long*)ds, (const unsigned long long*)ds, (int)(out_bytes / 8),
                            (unsigned long long*)sl.h_step, (const int*)dh, sl.h_hdr);
+#ifdef CLOOPS_DEVEL
+        {
+            // developer probe: the step's last (tiny, idempotent) kernel launched CLOOPS_DUP more times -- what a small launch costs the SWEEP
+            static const int dup = getenv("CLOOPS_DUP") ? atoi(getenv("CLOOPS_DUP")) : 0;
+            for (int k = 0; k < dup; ++k)
+                hipLaunchKernelGGL(k7_reduce_parts, dim3(1), dim3(256), 0, c->stream, (const K7Part*)parts, k7b, (K7Part*)(ds + 16),
+                                   (const int*)bcount, nb, (long long*)ds, (const unsigned long long*)ds, (int)(out_bytes / 8),
+                                   (unsigned long long*)sl.h_step, (const int*)dh, sl.h_hdr);
+        }
+#endif
         sl.host_written = labels_out == nullptr;        // nothing left for the copy stream
         sl.fine_lo = c->pending_fine_lo;
         sl.step_valid = true;
