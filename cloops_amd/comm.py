@@ -43,8 +43,9 @@ def default_tag():
     parent), MASTER_PORT, under torch.distributed.run its run id and restart count, and the number of communicators this
     process has formed before -- neither concurrent launches, nor a restarted worker group of the same agent, nor a second
     communicator of the same ranks meet each other's file"""
-    return "%s_%s_%s_%s_%s_%d" % (os.getppid(), _parent_start(), os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
-                                  os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), _SEQ)
+    nonce = os.environ.get("CLOOPS_COMM_NONCE", "")
+    return "%s_%s_%s_%s_%s_%d%s" % (os.getppid(), _parent_start(), os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                                    os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), _SEQ, ("_" + nonce) if nonce else "")
 
 
 class CommError(RuntimeError):
@@ -106,6 +107,7 @@ def rccl_versions():
 
 
 STALE_ID_SKEW_S = 120.0
+STALE_ID_GRACE_S = 30.0
 
 
 def _process_start_time():
@@ -140,16 +142,28 @@ def exchange_id(rank, world, make_id, tag=None, timeout=300.0, directory=ID_DIR)
     t0 = time.time()
     # a file much older than THIS process cannot be for it (launchers whose ranks are children of a long-lived parent -- a shell
     # loop, a notebook -- give two successive launches the same tag): the window is generous because ranks may start seconds apart
+    # A launcher that exports CLOOPS_COMM_NONCE (any string unique to the launch, the same on every rank) names its file exactly: no
+    # clock is consulted.  Without one the age check applies, and a full-size file that STAYS too old is reported after STALE_ID_GRACE_S
+    # instead of being waited for until the timeout (rank 0 replaces a leftover as the first thing it does: a file still stale after
+    # that long is either a leftover of a launch whose rank 0 never came, or this rank started minutes after rank 0 published).
+    exact = bool(os.environ.get("CLOOPS_COMM_NONCE")) and tag is None
     oldest = _process_start_time() - STALE_ID_SKEW_S
+    stale_since = None
     while True:
         try:
             with open(path, "rb") as fh:
                 blob = fh.read()
-                fresh = os.fstat(fh.fileno()).st_mtime >= oldest
+                fresh = exact or os.fstat(fh.fileno()).st_mtime >= oldest
             if len(blob) == ID_BYTES and fresh:
                 return blob
+            if len(blob) == ID_BYTES:
+                stale_since = stale_since or time.time()
+                if time.time() - stale_since > STALE_ID_GRACE_S:
+                    raise CommError("the id file %s is older than this process by more than %.0f s and rank 0 has not replaced it within %.0f s: a leftover "
+                                    "of an earlier launch under the same tag, or this rank started long after rank 0 -- export CLOOPS_COMM_NONCE=<unique per "
+                                    "launch> on every rank to name the file exactly" % (path, STALE_ID_SKEW_S, STALE_ID_GRACE_S))
         except (IOError, OSError):
-            pass
+            stale_since = None
         if time.time() - t0 > timeout:
             raise CommError("no unique id from rank 0 within %.0f s (%s)" % (timeout, path))
         time.sleep(0.01)

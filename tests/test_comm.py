@@ -236,3 +236,27 @@ def test_id_file_names_one_launcher_instance_and_one_communicator(monkeypatch):
     monkeypatch.setattr(comm, "_parent_start", lambda: "12345")
     assert "12345" in comm.default_tag()
     assert comm.id_path("x", "/d") == "/d/cloops_comm_id_x"
+
+
+def test_stale_id_file_fails_fast_and_a_nonce_names_the_file_exactly(tmp_path, monkeypatch):
+    """a full-size id file much older than this process: reported after the grace period instead of being waited for until the timeout;
+    with CLOOPS_COMM_NONCE in the environment of every rank the file is found by name alone (no clock heuristics)"""
+    import time
+    monkeypatch.delenv("CLOOPS_COMM_NONCE", raising=False)
+    monkeypatch.setattr(comm, "STALE_ID_GRACE_S", 0.3)
+    path = comm.id_path("stale", str(tmp_path))
+    with open(path, "wb") as fh:
+        fh.write(b"x" * comm.ID_BYTES)
+    old = time.time() - 3600
+    os.utime(path, (old, old))
+    t0 = time.time()
+    with pytest.raises(comm.CommError, match="CLOOPS_COMM_NONCE"):
+        comm.exchange_id(1, 2, lambda: b"", tag="stale", timeout=30.0, directory=str(tmp_path))
+    assert time.time() - t0 < 10
+    monkeypatch.setenv("CLOOPS_COMM_NONCE", "launch42")
+    assert "launch42" in comm.default_tag()
+    path2 = comm.id_path(None, str(tmp_path))
+    with open(path2, "wb") as fh:
+        fh.write(b"y" * comm.ID_BYTES)
+    os.utime(path2, (old, old))
+    assert comm.exchange_id(1, 2, lambda: b"", timeout=5.0, directory=str(tmp_path)) == b"y" * comm.ID_BYTES
