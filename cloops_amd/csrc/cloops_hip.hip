@@ -306,20 +306,42 @@ __global__ void k_strips_from_fine(int S, int s0, int k, int F, int f0, const in
 }
 #define LFF_T 1024               // PETs of the fine layout per workgroup
 #define LFF_CAP 4096             // staged entries: the strips a tile's PETs belong to, whole (a tile + one strip on either side)
+#define LFF_NST 127              // rows of the fine strip table staged per tile
+#define LFF_PAD 512              // keys of all ones behind them: unclamped probes of searches up to 9 steps deep
 __global__ void __launch_bounds__(256)
-k_layout_from_fine(int n, GridParams g, GridParams gf, int k, const int* __restrict__ fq, const int* __restrict__ fsp, const u32* __restrict__ frow,
+k_layout_from_fine(int n, GridParams g, GridParams gf, int k, unsigned kmagic, int qb, const int* __restrict__ fq, const int* __restrict__ fsp, const u32* __restrict__ frow,
                    const int* __restrict__ fstrip, int* __restrict__ dq, int* __restrict__ dsp, u32* __restrict__ drow, int* __restrict__ dtile)
 {
-    __shared__ int lq[LFF_CAP];
+    __shared__ int lq[LFF_CAP + LFF_PAD];
     const int t0 = blockIdx.x * LFF_T, t1 = min(n, t0 + LFF_T);
     if (t0 >= n) return;
     // the strips (of width eps) the tile's first and last PET belong to are contiguous in the fine layout: [a, b) holds every run
     // any PET of the tile has to be ranked in
     const int sb_first = (((fsp[t0] >> gf.rbits) + gf.s0) / k) * k - gf.s0, sb_last = (((fsp[t1 - 1] >> gf.rbits) + gf.s0) / k) * k - gf.s0;
-    const int a = fstrip[max(sb_first, 0)], b = fstrip[min(sb_last + k, gf.S)];
+    const int f_first = max(sb_first, 0), f_end = min(sb_last + k, gf.S);
+    const int a = fstrip[f_first], b = fstrip[f_end];
     const bool staged = b - a <= LFF_CAP;                 // (a pile-up strip longer than the staging area: searches in global memory)
-    if (staged) for (int j = threadIdx.x; j < b - a; j += 256) lq[j] = fq[a + j];
+    // Sorted-key form (round 6): the staged runs as ONE sorted array of 32-bit keys  run << qb | q  (run = fine strip - first staged
+    // one; q < 2^qb) -- "entries of run t below x" is then a plain lower bound of the key (t, x) from the run's start: a probe is one
+    // LDS read at an immediate offset, ONE compare and a select, no index clamps (behind the staged entries: LFF_PAD keys of all ones).
+    const bool keyed = staged && qb > 0 && (f_end - f_first) < (1 << (32 - qb)) - 1;
+    // the rows of the fine strip table the tile needs, staged as well (a PET reads 2 + 2 (k - 1) of them: dependent global loads otherwise)
+    __shared__ int lst[LFF_NST + 1];
+    const bool slice = f_end - f_first <= LFF_NST;
+    if (slice) for (int j = threadIdx.x; j <= f_end - f_first; j += 256) lst[j] = fstrip[f_first + j];
+    if (keyed) {
+        // (eight loads of a thread in flight before the first LDS store: a rolled loop is a chain of round trips per tile)
+        for (int j0 = 0; j0 < b - a; j0 += 8 * 256) {
+            int vq[8], vs[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = j0 + u * 256 + (int)threadIdx.x; const bool ok = j < b - a; vq[u] = ok ? fq[a + j] : 0; vs[u] = ok ? fsp[a + j] : 0; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = j0 + u * 256 + (int)threadIdx.x; if (j < b - a) lq[j] = (int)((unsigned)vq[u] | ((unsigned)((vs[u] >> gf.rbits) - f_first) << qb)); }
+        }
+        for (int j = threadIdx.x; j < LFF_PAD; j += 256) lq[b - a + j] = -1;
+    } else if (staged) for (int j = threadIdx.x; j < b - a; j += 256) lq[j] = fq[a + j];
     __syncthreads();
+    auto fst = [&](int f) { return slice ? lst[f - f_first] : fstrip[f]; };      // f in [f_first, f_end]
     // four PETs per thread, their searches side by side (every probe is a dependent round trip: four chains in flight)
     constexpr int E = LFF_T / 256;
     int q[E], spf[E], fbase[E], r[E], dst[E];
@@ -337,10 +359,10 @@ k_layout_from_fine(int n, GridParams g, GridParams gf, int k, const int* __restr
         const int i = t0 + e * 256 + (int)threadIdx.x;
         const int f = spf[e] >> gf.rbits;                // fine strip: row of the fine table
         const int fabs = f + gf.s0;                      // (>= 0: strips count from the common origin A0)
-        const int sabs = fabs / k;                       // the strip of width eps ...
+        const int sabs = k == 1 ? fabs : (int)__umulhi((unsigned)fabs, kmagic);      // the strip of width eps: fabs / k (kmagic = ceil(2^32 / k): exact below 2^29; k = 1 has no 32-bit magic) ...
         r[e] = fabs - sabs * k;                          // ... and the PET's run inside it
         fbase[e] = sabs * k - gf.s0;                     // table row of the strip's first run (< 0: runs in front of the chromosome's first strip)
-        dst[e] = in[e] ? fstrip[max(fbase[e], 0)] + (i - fstrip[f]) : 0;
+        dst[e] = in[e] ? fst(max(fbase[e], 0)) + (i - fst(f)) : 0;
     }
 #ifdef CLOOPS_DEVEL
     const int kk_abl = (g.dbg2 & (1 << 12)) ? 0 : k;      // (ablation: no searches)
@@ -357,7 +379,7 @@ k_layout_from_fine(int n, GridParams g, GridParams gf, int k, const int* __restr
         for (int e = 0; e < E; ++e) {
             const int ff = fbase[e] + rr;
             const bool on = in[e] && rr != r[e] && ff >= 0 && ff < gf.S;
-            lo[e] = on ? fstrip[ff] : 0; len[e] = on ? fstrip[ff + 1] - lo[e] : 0;
+            lo[e] = on ? fst(ff) : 0; len[e] = on ? fst(ff + 1) - lo[e] : 0;
             key[e] = q[e] + (rr < r[e] ? 1 : 0);
             pos[e] = 0;
             nmax = max(nmax, len[e]);
@@ -365,7 +387,34 @@ k_layout_from_fine(int n, GridParams g, GridParams gf, int k, const int* __restr
         nmax = wave_max_i(nmax);
         int nsteps = 0;
         while ((1 << nsteps) <= nmax) ++nsteps;          // (wave-uniform)
-        if (staged) {
+        if (keyed && (1 << nsteps) <= LFF_PAD) {
+            // (positions in BYTES: ds_read_b32 at an immediate offset, v_cmp_lt_u32, v_cndmask, v_add per probe)
+            unsigned tk[E];
+            int p4[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool on = len[e] > 0;
+                tk[e] = on ? ((unsigned)key[e] | ((unsigned)(fbase[e] + rr - f_first) << qb)) : 0u;      // (nothing is below key 0: a run that is not searched)
+                p4[e] = on ? (lo[e] - a) * 4 : 0;
+            }
+            const char* lb = reinterpret_cast<const char*>(lq);
+#define LFF_STEP(ST) _Pragma("unroll") for (int e = 0; e < E; ++e) { const unsigned v = *reinterpret_cast<const unsigned*>(lb + p4[e] + ((ST) - 1) * 4); p4[e] = v < tk[e] ? p4[e] + (ST) * 4 : p4[e]; }
+            switch (nsteps) {
+            case 9: LFF_STEP(256)
+            case 8: LFF_STEP(128)
+            case 7: LFF_STEP(64)
+            case 6: LFF_STEP(32)
+            case 5: LFF_STEP(16)
+            case 4: LFF_STEP(8)
+            case 3: LFF_STEP(4)
+            case 2: LFF_STEP(2)
+            case 1: LFF_STEP(1)
+            default: break;
+            }
+#undef LFF_STEP
+#pragma unroll
+            for (int e = 0; e < E; ++e) pos[e] = len[e] > 0 ? (p4[e] >> 2) - (lo[e] - a) : 0;
+        } else if (staged && !keyed) {
             for (int step = nsteps > 0 ? 1 << (nsteps - 1) : 0; step >= 1; step >>= 1) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
@@ -393,7 +442,7 @@ k_layout_from_fine(int n, GridParams g, GridParams gf, int k, const int* __restr
 #ifdef CLOOPS_DEVEL
         if (g.dbg2 & (1 << 13)) { if (dst[e] == 0x7fffffff) dq[0] = 1; continue; }      // (ablation: no stores)
 #endif
-        const int sabs = (fbase[e] + gf.s0) / k;
+        const int sabs = k == 1 ? fbase[e] + gf.s0 : (int)__umulhi((unsigned)(fbase[e] + gf.s0), kmagic);
         dq[dst[e]] = q[e];
         dsp[dst[e]] = ((sabs - g.s0) << g.rbits) | (r[e] * gf.eps + (spf[e] & (gf.peps - 1)));
         drow[dst[e]] = row[e];
@@ -2822,7 +2871,10 @@ static int sort_layout(cl_chrom* c, const GridParams& g, int* dsv, int* dsa, u32
                     const GridParams& gf = c->fine_g;
                     const int k = g.eps / fw;
                     LAUNCH(k_strips_from_fine, g.S + 2, g.S, g.s0, k, gf.S, gf.s0, (const int*)c->fstrip.as<int>(), n, dstrip);
-                    hipLaunchKernelGGL(k_layout_from_fine, dim3(nblocks(n, LFF_T)), dim3(256), 0, c->stream, n, g, gf, k, (const int*)c->fq.as<int>(),
+                    // (q + 1 -- the tie-break key -- must fit the q field of the sorted keys: qb bits; 0 = the field would leave no room for runs)
+                    int qb = bits_for((unsigned)std::min<long long>((long long)gf.qtop + 1, 0x7fffffffLL));
+                    if (qb > 28) qb = 0;
+                    hipLaunchKernelGGL(k_layout_from_fine, dim3(nblocks(n, LFF_T)), dim3(256), 0, c->stream, n, g, gf, k, (unsigned)(((1ull << 32) + (unsigned)k - 1ull) / (unsigned)k), qb, (const int*)c->fq.as<int>(),
                                        (const int*)c->fsp.as<int>(), (const u32*)c->frow.as<u32>(), (const int*)c->fstrip.as<int>(), dsv, dsa, rows, dtile);
                     HIP_TRY(hipGetLastError());
                     c->srow = rows;
