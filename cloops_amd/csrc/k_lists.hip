@@ -808,20 +808,35 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
     const int lane = threadIdx.x & 63;
     const int nmask = ~(g.peps - 1);
     if (FUSE && threadIdx.x == 0) l_found = -1;
-    for (int k = threadIdx.x; k < WIN; k += 256) {
-        const int gi = base + k;
-        const bool in = gi >= 0 && gi < C;
-        const int2 me = in ? cpair[gi] : (gi < 0 ? make_int2(0, INT_MIN) : make_int2(INT_MAX, INT_MAX));
-        lw[k] = me;
-        if (!FUSE) { lx[k] = in ? chainid[gi] : -1; lend[k] = in ? cskip[gi] : 0; }
-        else {
-            // does the staged core open a chain?  (entries in front of core 0 never do, entries behind the last core always.)  The
-            // predecessor's pair comes from the lane in front; the first lane of a wave reads it
-            int2 pv = make_int2(__shfl_up(me.x, 1), __shfl_up(me.y, 1));
-            if (lane == 0 && gi > 0 && gi < C) pv = cpair[gi - 1];
-            const bool o = gi <= 0 ? gi == 0 : (gi >= C || (pv.y & nmask) != (me.y & nmask) || pv.x < me.x - g.eps);
-            const unsigned long long ob = __ballot(o);
-            if (lane == 0) l_ob[k >> 6] = ob;
+    {
+        // (every load of the thread in flight before the first LDS store: the rolled loop was WIN / 256 dependent round trips per tile)
+        constexpr int SU = (WIN + 255) / 256;
+        static_assert(WIN % 64 == 0, "whole waves in the last staging round");
+        int2 mv[SU], pvl[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int gi = base + u * 256 + (int)threadIdx.x;
+            const bool in = gi >= 0 && gi < C && u * 256 + (int)threadIdx.x < WIN;
+            mv[u] = in ? cpair[gi] : (gi < 0 ? make_int2(0, INT_MIN) : make_int2(INT_MAX, INT_MAX));
+            pvl[u] = (FUSE && lane == 0 && gi > 0 && gi < C) ? cpair[gi - 1] : make_int2(0, 0);      // the first lane of a wave reads its predecessor
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int k = u * 256 + (int)threadIdx.x, gi = base + k;
+            if (k >= WIN) continue;                      // (whole waves: WIN is a multiple of 64)
+            const bool in = gi >= 0 && gi < C;
+            const int2 me = mv[u];
+            lw[k] = me;
+            if (!FUSE) { lx[k] = in ? chainid[gi] : -1; lend[k] = in ? cskip[gi] : 0; }
+            else {
+                // does the staged core open a chain?  (entries in front of core 0 never do, entries behind the last core always.)  The
+                // predecessor's pair comes from the lane in front
+                int2 pv = make_int2(__shfl_up(me.x, 1), __shfl_up(me.y, 1));
+                if (lane == 0 && gi > 0 && gi < C) pv = pvl[u];
+                const bool o = gi <= 0 ? gi == 0 : (gi >= C || (pv.y & nmask) != (me.y & nmask) || pv.x < me.x - g.eps);
+                const unsigned long long ob = __ballot(o);
+                if (lane == 0) l_ob[k >> 6] = ob;
+            }
         }
     }
     __syncthreads();
@@ -1451,7 +1466,22 @@ k_border_q(GridParams g, int ntiles, int npos, int kcap, const int* __restrict__
     if (w0 == w1) return;
     const int clo = max(cgrank[g0] - HC, 0), chi = min(cgrank[g1] + HC, C);
     if (threadIdx.x == 0) l_nq = 0;
-    for (int k = threadIdx.x; k < chi - clo; k += 256) { lw[k] = cpair[clo + k]; lx[k] = make_int2(croot[clo + k], cskip[clo + k]); }
+    {
+        // (every staging load of the thread in flight before the first LDS store: the rolled loop was a chain of round trips per tile)
+        constexpr int SU = (WIN + 255) / 256;
+        int2 pv[SU]; int rv[SU], sv[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int k = u * 256 + (int)threadIdx.x;
+            const bool in = k < chi - clo;
+            pv[u] = in ? cpair[clo + k] : make_int2(0, 0); rv[u] = in ? croot[clo + k] : 0; sv[u] = in ? cskip[clo + k] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int k = u * 256 + (int)threadIdx.x;
+            if (k < chi - clo) { lw[k] = pv[u]; lx[k] = make_int2(rv[u], sv[u]); }
+        }
+    }
     __syncthreads();
     const int qbase = (chi - clo + 1) & ~1;              // queue entry e: lw / lx [qbase + 2 e, + 2) = 8 ints
     const int qcap = (WIN - qbase) >> 1;
