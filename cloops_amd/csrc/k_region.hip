@@ -648,6 +648,21 @@ k_region_core(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
 // and its hints, the global-memory continuation for pile-ups) is k_region_core's.
 // ------------------------------------------------------------------------------------------
 typedef unsigned long long u64k;
+#ifdef CLOOPS_DEVEL
+// developer build, CLOOPS_DBG bit 4096: how often the rare paths of k_region_keys run (tools/fuzz_k2_keys.py prints them): 0 launches, 1 PETs in
+// phase 2, 2 beyond the strip_rel clamp, 3 through global memory, 4 clipped windows, 5 deferred walks, 6 walks in place, 7 capped windows
+__device__ unsigned long long g_k2stat[8];
+extern "C" void cl_debug_k2stats(unsigned long long* out)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k2stat), sizeof(g_k2stat));
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k2stat), z, sizeof(z));
+}
+#define K2STAT(slot, cond) do { if ((g.dbg & 4096) && (cond)) atomicAdd(&g_k2stat[slot], 1ull); } while (0)
+#else
+#define K2STAT(slot, cond) do { } while (0)
+#endif
 #define K2K_RELMAX 4095
 #define K2K_HCAP 63           // the upper ends of the neighbour windows are searched 6 steps deep
 
@@ -782,6 +797,7 @@ k_region_keys(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
     }
     __syncthreads();
     K2_ABL(32);
+    K2STAT(0, threadIdx.x == 0 && blockIdx.x == 0);
     const int m1 = minPts - 1;
     const u64k E24 = (u64k)(unsigned)eps << 24, STRIP1 = 1ull << 52;
     const u64k KMASK = ~(u64k)0xffffffu;                // (strip_rel, q) of a key
@@ -801,7 +817,8 @@ k_region_keys(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         const int qi = (int)((unsigned)(me >> 24) & 0x0fffffffu);
         const bool valid = (t0 + tix < M) & (qi >= g.qmin);
         // (a key of a later strip is above (rel, q + eps) whatever its q: q + eps < 2^28; one of an earlier strip, raised by eps, stays below)
-        const bool core = (p_rr[u] < me + E24 + (1ull << 24)) | (p_ll[u] + E24 >= me);
+        // (a PET at the strip_rel clamp shares its key's strip field with every strip behind it: no key test says "same strip" there)
+        const bool core = ((p_rr[u] < me + E24 + (1ull << 24)) | (p_ll[u] + E24 >= me)) & ((me >> 52) != (u64k)K2K_RELMAX);
         if (valid & core) cnt[t0 + tix] = minPts;
         const bool hard = valid & !core;
         const unsigned long long bal = __ballot(hard);
@@ -829,7 +846,17 @@ k_region_keys(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         else if (m1 <= 32) { lo = k2k_first_ge<5>(lw, li - 31, keyL); hi = k2k_first_ge<5>(lw, li + 1, keyH); }
         else if (m1 <= 64) { lo = k2k_first_ge<6>(lw, li - 63, keyL); hi = k2k_first_ge<6>(lw, li + 1, keyH); }
         else { lo = k2k_first_ge<7>(lw, li - 127, keyL); hi = k2k_first_ge<7>(lw, li + 1, keyH); }
-        const int c = hi - lo;
+        int c = hi - lo;
+        const bool clamped = act & ((me >> 52) == (u64k)K2K_RELMAX);
+        if (__any(clamped)) {
+            // at the strip_rel clamp (a window that spans more than 4 000 strips: a gap in the data) the own strip comes from the strip
+            // table and global memory
+            if (clamped) {
+                const int st = sa[t0 + tix] >> g.rbits;
+                const int b = strip_start[st], e = strip_start[st + 1];
+                c = lower_bound_4(sv, b, e, (int)qi + eps + 1) - lower_bound_4(sv, b, e, (int)qi - eps);
+            }
+        }
         const bool need = act & (c < minPts);
         if (act & !need) cnt[t0 + tix] = c;
         const unsigned long long bal = __ballot(need);
@@ -881,6 +908,7 @@ k_region_keys(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         const unsigned qi = (unsigned)(me >> 24) & 0x0fffffffu;
         const int rel = (int)(me >> 52);
         const bool far = rel >= K2K_RELMAX - 1;           // the clamp of strip_rel: the keys do not tell this PET's strips apart
+        K2STAT(1, true); K2STAT(2, far);
         const int kk = far ? (sa[t0 + tix] >> g.rbits) - s0 : rel - 2;
         const int kc = min(kk, K2F_NS);
         int tb = l_st[kc], b = l_st[kc + 1], e = l_st[kc + 2], te = l_st[kc + 3];
@@ -898,6 +926,7 @@ k_region_keys(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         if (__any(!(okA & okB))) {
             // a neighbour strip that sticks out of the staged range is clipped to it when the staged part provably holds the q window
             const u64k f = lw[wlo], l = lw[whi - 1];
+            K2STAT(4, !far && !(okA & okB));
             if (!okA & !far) { okA = (f >= (me & ~((1ull << 52) - 1ull)) - STRIP1) & (f < keyAL); tb = wlo; }
             if (!okB & !far) { okB = (l >= keyBH) & (l < (me & ~((1ull << 52) - 1ull)) + 2 * STRIP1); te = whi; }
         }
@@ -932,23 +961,33 @@ k_region_keys(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
             if (low >= minPts) c = low;
             else if (!capped && up < (int)l_next[low]) c = up;
             else {
-                const unsigned long long bal = __ballot(true);
-                const int slot = n3 + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
                 int na2 = na, nb2 = nb;
+                K2STAT(7, capped);
                 if (capped) {
                     // a window longer than the shallow search: its true end (clamped to the array: okA / okB say the window ends inside)
                     if (na >= K2K_HCAP) na2 = k2k_first_ge_clamped<12>(lw, ja, last, keyAH) - ja;
                     if (nb >= K2K_HCAP) nb2 = k2k_first_ge_clamped<12>(lw, jb, last, keyBH) - jb;
                 }
-                if (2 * slot + 1 < (h - lane) + 64 && na2 < 1024 && nb2 < 1024) {
+                // the slots are numbered over the lanes whose window sizes fit the entry: the deferred entries of a round are then the
+                // first ones of that numbering (no gaps in the list: phase 3 reads entries 0 .. n3 - 1)
+                const bool fits = (na2 < 1024) & (nb2 < 1024);
+                const unsigned long long bal = __ballot(fits);
+                const int slot = n3 + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                bool room = fits && 2 * slot + 1 < (h - lane) + 64;
+#ifdef CLOOPS_DEVEL
+                if (g.dbg & 8192) room = false;           // (developer knob: every walk in place)
+#endif
+                if (room) {
                     // (tix 10 bits | c 7 | na 10 ; ja 12 | jb 12 ... nb rides in the spare bits)
                     my_list[2 * slot] = (unsigned)tix | ((unsigned)c << 10) | ((unsigned)na2 << 17) | ((unsigned)(nb2 & 31) << 27);
                     my_list[2 * slot + 1] = (unsigned)ja | ((unsigned)jb << 12) | ((unsigned)(nb2 >> 5) << 24);
                     deferred = true;
-                } else c = walk(c, tix, ja, na2, jb, nb2);
+                    K2STAT(5, true);
+                } else { K2STAT(6, true); c = walk(c, tix, ja, na2, jb, nb2); }
             }
         } else {
             // a neighbour strip reaches outside the staged window (pile-up) or lies beyond the key clamp: global memory
+            K2STAT(3, true);
             const int pi = sa[t0 + tix], qlo = (int)qi - eps, qhi = (int)qi + eps;
             const int gtb = gtb0, ge = e - off, gte = gte0;
             if (gtb < b) {

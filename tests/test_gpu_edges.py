@@ -219,3 +219,85 @@ def test_walkers_beside_clusters_they_do_not_touch():
     for minPts in (30, 8):
         run_all(P[:, 0], P[:, 1], eps, minPts, variants=["v2", "v1"])
         run_all(P[:, 0], P[:, 1], eps, minPts, cut=8800, variants=["v2"])
+
+
+def _dense_blob(rng, x0, width, per, eps):
+    """half log-uniform background, half clusters, on `width` strips from x0 on (mean strip population per / width)"""
+    L = width * eps // 2
+    n1 = per // 2
+    bx = x0 + rng.integers(0, L, per - n1)
+    by = bx + np.exp(rng.uniform(np.log(10), np.log(40 * eps), per - n1)).astype(np.int64)
+    ncl = max(1, n1 // 60)
+    ax = x0 + rng.integers(0, L, ncl)
+    span = rng.integers(0, 30 * eps, ncl)
+    which = rng.integers(0, ncl, n1)
+    cx = np.abs(ax[which] + rng.normal(0, 0.1 * eps, n1)).astype(np.int64)
+    cy = np.abs(ax[which] + span[which] + rng.normal(0, 0.1 * eps, n1)).astype(np.int64)
+    return np.concatenate([bx, cx]), np.concatenate([by, cy]), L
+
+
+def _from_rotated(P, Q):
+    """(p = X + Y, q = Y - X) of equal parity -> X, Y"""
+    P = np.asarray(P, np.int64); Q = np.asarray(Q, np.int64)
+    Q = Q + ((P + Q) & 1)
+    return (P - Q) // 2, (P + Q) // 2
+
+
+@pytest.mark.parametrize("variant", ["v2", "v1"])
+def test_region_query_keys_across_a_gap_of_thousands_of_empty_strips(variant):
+    """the sorted-key region query packs `strip - first strip of the window` into 12 bits.  A dense blob (the MEAN strip population stays
+    above 40: the kernel's regime), more than 4095 empty strips, then 30 consecutive strips of 20 PETs each at nearly ONE distance: every
+    PET there has 20 neighbours in its strip and at most 40 in the two strips beside it -- nobody is core at minPts 70 -- but at the
+    clamp of the strip field no key says "same strip", and a test on the keys alone sees 600 PETs at one distance (found by
+    tools/fuzz_k2_keys.py; they are counted through the strip table)"""
+    rng = np.random.default_rng(29)
+    eps = 500
+    x1, y1, L = _dense_blob(rng, 1000, 250, 250000, eps)
+    p0 = ((2 * (1000 + L) + 80 * eps) // eps + 4300) * eps                 # first strip behind the gap (strips: p // eps)
+    t = np.repeat(np.arange(30), 20)
+    P = p0 + t * eps + 250 + rng.integers(0, 10, len(t))
+    x2, y2 = _from_rotated(P, 1000 + rng.integers(0, 10, len(t)))
+    X = np.concatenate([x1, x2]); Y = np.concatenate([y1, y2])
+    X, Y = np.minimum(X, Y), np.maximum(X, Y)
+    assert (250000 % 1024) + len(t) > 256                                   # the tile that holds the blob's last PETs holds most of them
+    p = rng.permutation(len(X))
+    X, Y = X[p], Y[p]
+    behind = (X + Y) >= p0
+    ch = api.Chromosome(X, Y)
+    try:
+        ch.set_count_thresholds([70, 35])
+        for m, cut in ((70, 0), (35, 0), (70, 400)):
+            got = ch.cluster(variant, eps, m, cut)
+            want = oracle.single_dbscan(variant, X, Y, eps, m, cut)["labels"]
+            if m == 70:
+                assert (want[behind] < 0).all()                            # (the construction: nobody behind the gap is clustered)
+            assert np.array_equal(got.labels, want), (m, cut)
+    finally:
+        ch.close()
+
+
+@pytest.mark.parametrize("level", [4, 3])
+def test_region_query_keys_beside_a_pile_up(level):
+    """a strip of 1300 PETs beside a strip of 48 PETs high in their strip (their neighbours one strip below are the pile-up's PETs that
+    lie higher still: a sixth of it), minPts 91: every one of the 48 needs its candidates walked, their q windows in the pile-up hold
+    300 to 1300 PETs -- walks deferred to the workgroup's list (window sizes of up to 1023 fit an entry) next to walks that must run
+    in place, in ONE wave: the slots of the list must not leave gaps (found by tools/fuzz_k2_keys.py)"""
+    rng = np.random.default_rng(26)
+    eps = 5000
+    x, y, L = _dense_blob(rng, 20000, 450, 60000, eps)
+    sp = (2 * (20000 + L) + 80 * eps) // eps + 8                          # the pile-up's strip: a few empty strips behind the blob
+    xp, yp = _from_rotated(sp * eps + rng.integers(0, eps, 1300), rng.integers(0, eps, 1300))
+    xq, yq = _from_rotated((sp + 1) * eps + rng.integers(int(0.7 * eps), int(0.95 * eps), 48), np.linspace(0.2 * eps, 1.9 * eps, 48).astype(np.int64))
+    X = np.concatenate([x, xp, xq]); Y = np.concatenate([y, yp, yq])
+    X, Y = np.minimum(X, Y), np.maximum(X, Y)
+    p = rng.permutation(len(X))
+    X, Y = X[p], Y[p]
+    ch = api.Chromosome(X, Y)
+    try:
+        ch.set_traversal(level)
+        ch.set_count_thresholds([91, 86])
+        for m, cut in ((91, 0), (86, 0), (91, 1500)):
+            got = ch.cluster("v2", eps, m, cut)
+            assert np.array_equal(got.labels, oracle.single_dbscan("v2", X, Y, eps, m, cut)["labels"]), (m, cut)
+    finally:
+        ch.close()
