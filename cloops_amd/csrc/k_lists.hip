@@ -1017,7 +1017,7 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
                 if (lane == leader) rep = true;
                 pending &= ~m;
             }
-            if (rep) { uf_unite(parent, A, B); ++st_un; }
+            if (rep && !L_ABL(1 << 15)) { uf_unite(parent, A, B); ++st_un; }      // (ablation bit 15: the walks without the union-find steps)
         }
 #ifdef CLOOPS_DEVEL
         LSTAT(12, in ? 1 : 0); LSTAT(13, st_it); LSTAT(14, st_touch); LSTAT(15, st_un); LSTAT(16, st_glb); LSTAT(17, st_jump);
