@@ -818,7 +818,7 @@ k_region_keys(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         const bool valid = (t0 + tix < M) & (qi >= g.qmin);
         // (a key of a later strip is above (rel, q + eps) whatever its q: q + eps < 2^28; one of an earlier strip, raised by eps, stays below)
         // (a PET at the strip_rel clamp shares its key's strip field with every strip behind it: no key test says "same strip" there)
-        const bool core = ((p_rr[u] < me + E24 + (1ull << 24)) | (p_ll[u] + E24 >= me)) & ((me >> 52) != (u64k)K2K_RELMAX);
+        const bool core = ((p_rr[u] < me + E24 + (1ull << 24)) | (p_ll[u] + E24 >= me)) & ((unsigned)(me >> 32) < ((unsigned)K2K_RELMAX << 20));
         if (valid & core) cnt[t0 + tix] = minPts;
         const bool hard = valid & !core;
         const unsigned long long bal = __ballot(hard);
@@ -847,7 +847,7 @@ k_region_keys(GridParams g, int ntiles, const int* __restrict__ sv, const int* _
         else if (m1 <= 64) { lo = k2k_first_ge<6>(lw, li - 63, keyL); hi = k2k_first_ge<6>(lw, li + 1, keyH); }
         else { lo = k2k_first_ge<7>(lw, li - 127, keyL); hi = k2k_first_ge<7>(lw, li + 1, keyH); }
         int c = hi - lo;
-        const bool clamped = act & ((me >> 52) == (u64k)K2K_RELMAX);
+        const bool clamped = act & ((unsigned)(me >> 32) >= ((unsigned)K2K_RELMAX << 20));
         if (__any(clamped)) {
             // at the strip_rel clamp (a window that spans more than 4 000 strips: a gap in the data) the own strip comes from the strip
             // table and global memory

@@ -27,7 +27,7 @@ for k in range(ncases):
     parts_x, parts_y = [], []
     nb = n // 2
     bx = rng.integers(0, L, nb)
-    by = bx + np.exp(rng.uniform(np.log(5), np.log(max(L, 10) * float(rng.choice([0.01, 1.0]))), nb)).astype(np.int64)
+    by = bx + np.exp(rng.uniform(np.log(5), np.log(max(max(L, 10) * float(rng.choice([0.01, 1.0])), 6.0)), nb)).astype(np.int64)
     parts_x.append(bx); parts_y.append(by)
     ncl = max(1, (n - nb) // int(rng.integers(10, 300)))
     ax = rng.integers(0, L, ncl); span = rng.integers(0, 40 * w, ncl)
