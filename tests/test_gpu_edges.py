@@ -301,3 +301,18 @@ def test_region_query_keys_beside_a_pile_up(level):
             assert np.array_equal(got.labels, oracle.single_dbscan("v2", X, Y, eps, m, cut)["labels"]), (m, cut)
     finally:
         ch.close()
+
+
+def test_region_query_falls_back_when_a_distance_leaves_the_key_field():
+    """the sorted-key region query holds q in 28 bits of its keys; a PET whose distance reaches 2^28 - eps (coordinates go up to 2^29)
+    sends the dense shapes back to the pair-predicate kernel (k_region_core): eps 2^20 keeps the mean strip population above 40 over
+    the 256 strips such a PET opens up -- same labels either way"""
+    rng = np.random.default_rng(5)
+    eps = 1 << 20
+    x, y, _ = _dense_blob(rng, 5000, 40, 30000, eps)
+    X = np.concatenate([x, [10, 20]]); Y = np.concatenate([y, [10 + (1 << 28) - 1000, 20 + (1 << 28) - 900]])
+    X, Y = np.minimum(X, Y), np.maximum(X, Y)
+    assert Y.max() < (1 << 29) and (Y - X).max() + eps + 1 >= (1 << 28)
+    p = rng.permutation(len(X))
+    run_all(X[p], Y[p], eps, 50, variants=["v2", "v1"])
+    run_all(X[p], Y[p], eps, 50, cut=300000, variants=["v2"])
