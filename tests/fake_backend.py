@@ -113,6 +113,11 @@ class FakeChromosome(object):
         dmid = (b[:, 2] + b[:, 3]) // 2 - (b[:, 0] + b[:, 1]) // 2
         return b[dmid >= final_cut].astype(np.int32)
 
+    def cand_finish_device(self, final_cut):
+        """the device form on the stand-in: (token, rows) -- the 'pointer' is only valid while the handle is alive"""
+        self._dev_table = self.cand_finish(final_cut, 0)
+        return id(self._dev_table), len(self._dev_table)
+
     def set_table_export(self, on=True):
         pass
 

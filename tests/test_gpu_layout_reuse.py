@@ -133,3 +133,32 @@ def test_fine_layout_on_chr21_edges():
         want = oracle.single_dbscan("v2", X, Y, eps, m, cut)["labels"]
         assert np.array_equal(got, want), (eps, m, cut)
     a.close()
+
+
+def test_sweep_plan_and_drop_indexes_leave_results_alone():
+    """cl_sweep_plan announces both lists of a sweep in one call (cLoops/pipe.py:247-248); cl_chrom_drop_indexes forgets every order and
+    count the handle has derived (what bench.py's cold_sweep_s pays for again): the labels of every run equal a plain handle's, before
+    and after the drop, and the plan makes the later runs of an eps re-use its words (region mode 2)"""
+    from cloops_amd.synth import synth_chrom
+    X, Y = synth_chrom(120000, 248956422 // 60, 17)
+    a = api.Chromosome(X, Y)
+    b = api.Chromosome(X, Y)
+    try:
+        b.set_count_reuse(False)
+        eps_list, mps = [3000, 4500, 6000], [30, 20]
+        for rnd in range(2):
+            a.sweep_plan(eps_list, mps)
+            cut = 0
+            for ep in eps_list:
+                for k, m in enumerate(mps):
+                    ra = a.cluster("v2", ep, m, cut)
+                    assert a.last_region_mode() == (0 if k == 0 else 2), (rnd, ep, m)
+                    rb = b.cluster("v2", ep, m, cut)
+                    assert np.array_equal(ra.labels, rb.labels), (rnd, ep, m, cut)
+                    cut += 350
+            a.sweep_plan([], [])
+            a.drop_indexes()                                  # the second round sorts everything again
+        with pytest.raises(Exception):
+            a.sweep_plan([3000, -1], [30])
+    finally:
+        a.close(); b.close()

@@ -271,3 +271,31 @@ def test_forced_cuts_replace_the_estimated_chain(cpu_pipe):
     assert forced[3][0]["n_inter"] == free[3][0]["n_inter"]          # the first step is the same work
     none = p.runSweepFast([f], [500, 1000], [5], cut=0, forced_cuts=[None, None])
     assert none[2] == free[2]
+
+
+def test_device_tables_are_consumed_under_the_sweeps_locks(monkeypatch, tmp_path):
+    """runSweepFast(finish_device=True, device_consumer=...): the consumer sees every chromosome's (pointer, rows) WHILE the residents are
+    pinned in the cache and their sweep locks are held -- nothing can evict, free or re-sweep a handle under the gather
+    (cLoops/pipe.py:119-127: the parent merges its workers' results; here the merge reads device memory of live handles)"""
+    monkeypatch.setattr(api, "Chromosome", fake_backend.FakeChromosome)
+    monkeypatch.setattr(api, "device_count", lambda: 1)
+    pipe.CACHE.clear()
+    fs = _write_many_jd(tmp_path, 3, n=600)
+    seen = {}
+
+    def consumer(dataI):
+        res = [pipe.CACHE.get(v["f"]) for v in dataI.values()]
+        seen["locked"] = all(r.sweep_lock.locked() for r in res)
+        seen["pinned"] = all(r.pins > 0 for r in res)
+        seen["rows"] = {k: (v["dev_rows"], v["n_rows"]) for k, v in dataI.items()}
+        return sum(v["n_rows"] for v in dataI.values())
+    try:
+        want = pipe.runSweepFast(fs, [800, 1200], [4, 3], cut=0)
+        got = pipe.runSweepFast(fs, [800, 1200], [4, 3], cut=0, finish_device=True, device_consumer=consumer)
+        assert seen["locked"] and seen["pinned"]
+        assert got[0].gathered == sum(len(v["boxes"]) for v in want[0].values())
+        assert {k: n for k, (_, n) in seen["rows"].items()} == {k: len(v["boxes"]) for k, v in want[0].items()}
+        assert got[1:3] == want[1:3]
+        assert not any(pipe.CACHE.get(f).sweep_lock.locked() for f in fs)
+    finally:
+        pipe.CACHE.clear()
