@@ -2212,7 +2212,7 @@ extern "C" void cl_set_count_thresholds(cl_chrom* c, const int32_t* min_pts, int
 extern "C" void cl_set_sort_index(cl_chrom* c, int mode) { if (c) c->sort_index_mode = mode > 0 ? 1 : (mode < 0 ? -1 : 0); }
 // One call for a sweep (cLoops/pipe.py:241-281: `for ep in eps: for m in minPts:`): everything the handle can prepare from knowing
 // both lists -- the q index from the first sort on and one fine sort for all layouts (several eps), counts bracketed for the minPts
-// list, layout / count reuse on, the default traversal.  n_eps = n_min_pts = 0 ends the plan (a later one-off run serves itself).
+// list.  n_eps = n_min_pts = 0 ends the plan (a later one-off run serves itself).
 extern "C" int cl_sweep_plan(cl_chrom* c, const int32_t* eps, int32_t n_eps, const int32_t* min_pts, int32_t n_min_pts)
 {
     if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
@@ -2220,9 +2220,8 @@ extern "C" int cl_sweep_plan(cl_chrom* c, const int32_t* eps, int32_t n_eps, con
     for (int k = 0; k < n_eps; ++k) if (eps[k] <= 0) return fail(CL_ERR_ARG, "cl_sweep_plan: eps must be positive");
     for (int k = 0; k < n_min_pts; ++k) if (min_pts[k] <= 0) return fail(CL_ERR_ARG, "cl_sweep_plan: minPts must be positive");
     if (c->slot[0].pending || c->slot[1].pending) return fail(CL_ERR_ARG, "cl_sweep_plan: a run is in flight");
-    if (!c->reuse_layout) cl_set_layout_reuse(c, 1);
-    if (!c->reuse_counts) cl_set_count_reuse(c, 1);
-    if (c->traversal != 4) cl_set_traversal(c, 4);
+    // (layout reuse, count reuse and the traversal level are left as they are: all three are on / 4 by default, and a caller that
+    //  switched one off -- the tests of the older levels, the measurements without re-use -- meant it)
     cl_set_count_thresholds(c, min_pts, n_min_pts);
     int distinct = 0;
     for (int k = 0; k < n_eps; ++k) { bool seen = false; for (int j = 0; j < k; ++j) seen |= eps[j] == eps[k]; distinct += seen ? 0 : 1; }

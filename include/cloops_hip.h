@@ -279,6 +279,8 @@ int cl_get_timing(const cl_chrom* c, cl_timing* out);
  * sorts its rows once for all announced eps (when they share a divisor), keeps the layout of an eps for its runs, makes the
  * neighbour counts of an eps once -- exact enough for every announced minPts -- and re-queries only the cut band of the later runs.
  * Results are identical with and without a plan; without one every run pays for itself.  n_eps = n_min_pts = 0 ends the plan.
+ * (The plan is the announcement of the two lists: cl_set_sort_index(1) + cl_set_eps_list + cl_set_count_thresholds.  Layout reuse,
+ * count reuse and the traversal level keep their values -- on / on / 4 unless the caller changed them.)
  * The cl_set_* entries below are the plan's parts, kept for tests and measurements (each documents what it switches); a caller
  * needs none of them. */
 int cl_sweep_plan(cl_chrom* c, const int32_t* eps, int32_t n_eps, const int32_t* min_pts, int32_t n_min_pts);
