@@ -58,7 +58,8 @@ def test_level4_makes_no_copy_for_reusing_runs():
             got = ch.cluster("v2", eps, m, cut)
             modes.append(ch.last_region_mode())
             assert np.array_equal(got.labels, _want("v2", X, Y, eps, m, cut)), (eps, m, cut)
-        assert modes == [0, 2, 2, 0, 1, 2], modes
+        if api.TRAVERSAL_OVERRIDE in (None, 4, "4"):         # (the suite run under CLOOPS_TRAVERSAL < 4 checks the labels only: the modes are level 4's)
+            assert modes == [0, 2, 2, 0, 1, 2], modes
     finally:
         ch.close()
 
@@ -85,6 +86,8 @@ def test_sweep_step_statistics_from_the_lists():
 def test_pairs_form_equals_row_aligned_labels(variant):
     """cl_cluster_pairs_async: the labels as the reference holds them -- (row, label) of the clustered points only
     (cDBSCAN2.py:186-191) -- reassemble to exactly the row-aligned labels of cl_cluster, run after run on two result slots"""
+    if api.TRAVERSAL_OVERRIDE is not None and int(api.TRAVERSAL_OVERRIDE) < 3:
+        pytest.skip("the pairs form needs the list form of a run (traversal level >= 3)")
     X, Y = synth_chrom(N, 46709983, 37)
     ref = api.Chromosome(X, Y)
     ch = api.Chromosome(X, Y)
