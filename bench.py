@@ -259,7 +259,7 @@ def main(argv=None):
     # K2 is timed inside a sweep on the largest local chromosome (chr1 on rank 0): HIP events on the library's stream -- in the
     # last WARM-UP sweep only: the event records between the kernels of that stream cost the sweep ~7 % (0.214 -> 0.230 s), so
     # the timed sweeps run without them (the roofline figure comes from the solo replay behind the timed region anyway)
-    probe_f = max(fs, key=lambda f: len(pipe.CACHE.get(f).d)) if fs else None
+    probe_f = max(fs, key=lambda f: len(pipe.CACHE.get(f))) if fs else None
     k2_log = []
 
     def probe(f, ep, m, cut_in, res):
@@ -344,7 +344,7 @@ def main(argv=None):
             # the same passes with the re-use switched off (every run its own full region query)
             r = pipe.CACHE.get(probe_f)
             settings = [(st["eps"], st["minPts"], st["cut_in"]) for st in steps]
-            line["roofline"] = roofline_block(k2_replay(r.chrom, settings, sorted(set(minpts_list)), 3), len(r.d))
+            line["roofline"] = roofline_block(k2_replay(r.chrom, settings, sorted(set(minpts_list)), 3), len(r))
             if k2_log:
                 line["roofline"]["in_sweep_avg_launch_ms"] = sum(max(t[3]["ms_region"] - t[3]["ms_bracket"], 1e-6) for t in k2_log) / len(k2_log)
                 line["roofline"]["in_sweep_source"] = "HIP events around K2 on chr1's stream during the last warm-up sweep (same work as a timed one; the event records between the kernels cost a sweep ~7 %, so the timed sweeps run without them)"
@@ -525,7 +525,7 @@ def with_labels_sweep(pipe, fs, steps, pets_per_sweep, reps=2):
     figure; and row-aligned int32 labels of every PET (`row_aligned`: the row-order scatter and 0.8 GB over PCIe per run).
     All chromosomes of a run are enqueued, then collected."""
     res = [pipe.CACHE.get(f) for f in fs]
-    res.sort(key=lambda r: -len(r.d))
+    res.sort(key=lambda r: -len(r))
 
     # the cuts are given (the chain of the timed sweeps), so consecutive runs are independent: a chromosome has two result slots, and
     # run k + 1 of every chromosome is enqueued before run k is collected -- its kernels execute while run k's labels cross PCIe
@@ -600,7 +600,7 @@ def scaling_proxy(pipe, lpt_assign, fs, sizes, steps, nranks, one_gpu_sweep_s, r
         # over the shared streams; the handles of the whole genome sit on the streams the 23-chromosome load balancing gave them,
         # which can put a share's chromosomes on one stream)
         copies = {}
-        for f in sorted(fr, key=lambda f: -len(pipe.CACHE.get(f).d)):
+        for f in sorted(fr, key=lambda f: -len(pipe.CACHE.get(f))):
             src = pipe.CACHE.get(f)
             name = "mem://rank_share/%s-%s" % (src.key[0], src.key[1])
             pipe.CACHE.put_chrom(name, pipe._make_chrom(src.X, src.Y, src.device), src.X, src.Y, ids=src.ids, key=src.key, device=src.device)

@@ -136,7 +136,33 @@ def _make_chrom(X, Y, device):
     ch.close = close_and_release
     return ch
 class _Resident(object):
-    __slots__ = ("key", "ids", "X", "Y", "d", "chrom", "device", "stamp", "lock", "pins", "sweep_lock", "replaced")
+    """a chromosome resident in HBM + its host copies.  `ids` (the row ids of cLoops/io.py:181-183) and `d` (the distances Y - X the
+    reference-shaped wrappers hand out, pipe.py:59-63) are made on FIRST USE: the sweep on the device needs neither, and for a 200 M-PET
+    genome they are 3.2 GB of int64 that took as long to fill as the upload itself."""
+    __slots__ = ("key", "_ids", "X", "Y", "_d", "chrom", "device", "stamp", "lock", "pins", "sweep_lock", "replaced")
+
+    @property
+    def ids(self):
+        if self._ids is None:
+            self._ids = np.arange(len(self.X), dtype=np.int64)
+        return self._ids
+
+    @ids.setter
+    def ids(self, v):
+        self._ids = v
+
+    @property
+    def d(self):
+        if self._d is None:
+            self._d = self.Y.astype(np.int64) - self.X.astype(np.int64)
+        return self._d
+
+    @d.setter
+    def d(self, v):
+        self._d = v
+
+    def __len__(self):
+        return len(self.X)
 
 
 class ChromCache(object):
@@ -209,8 +235,8 @@ class ChromCache(object):
         r.pins = 0
         r.X = np.ascontiguousarray(X)
         r.Y = np.ascontiguousarray(Y)
-        r.ids = np.arange(len(r.X), dtype=np.int64) if ids is None else np.asarray(ids)
-        r.d = r.Y.astype(np.int64) - r.X.astype(np.int64)
+        r.ids = None if ids is None else np.asarray(ids)
+        r.d = None
         r.chrom = _make_chrom(r.X, r.Y, device)
         r.chrom.set_device_labels(False)        # runs without a host destination (the sweep) skip the row-order scatter
         with self._lock:
@@ -235,8 +261,8 @@ class ChromCache(object):
         r.pins = 0
         r.X = np.ascontiguousarray(X)
         r.Y = np.ascontiguousarray(Y)
-        r.ids = np.arange(len(r.X), dtype=np.int64) if ids is None else np.asarray(ids)
-        r.d = r.Y.astype(np.int64) - r.X.astype(np.int64)
+        r.ids = None if ids is None else np.asarray(ids)
+        r.d = None
         r.chrom = chrom
         r.chrom.set_device_labels(False)
         with self._lock:
@@ -391,7 +417,7 @@ def _run_many(fs, eps, minPts, cut, fn):
     devs = _devices()
     if len(devs) <= 1 or len(fs) <= 1:
         return [fn(f, eps, minPts, cut, devs[0]) for f in fs]
-    sizes = [len(CACHE.get(f).d) if f.startswith("mem://") else os.path.getsize(f) for f in fs]
+    sizes = [len(CACHE.get(f)) if f.startswith("mem://") else os.path.getsize(f) for f in fs]
     parts = lpt_assign(sizes, len(devs))
     out = [None] * len(fs)
 
@@ -631,8 +657,8 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
                 device_consumer=None):
     cuts = [cut]
     steps = []
-    live = [(f, r) for f, r in zip(fs, res_all) if len(r.d)]
-    by_size = sorted(live, key=lambda fr: -len(fr[1].d))   # enqueue order: largest first (results are collected in file order)
+    live = [(f, r) for f, r in zip(fs, res_all) if len(r)]
+    by_size = sorted(live, key=lambda fr: -len(fr[1]))   # enqueue order: largest first (results are collected in file order)
     appended = {}                                        # f -> inter-ligation boxes appended on the device so far
     pool = ThreadPoolExecutor(max_workers=SWEEP_THREADS) if len(live) > 1 else None
     # the candidate buffer, the layout and the sort index of a handle are state of ONE sweep: a second sweep over the same
@@ -645,7 +671,7 @@ def _sweep_fast(fs, res_all, eps, minPts, cut, max_cut, log, variant, allsum, gs
         for r in held:
             r.lock.acquire()
         try:
-            STREAMS.rebalance([(r.chrom, len(r.d)) for _, r in live])
+            STREAMS.rebalance([(r.chrom, len(r)) for _, r in live])
         finally:
             for r in held:
                 r.lock.release()

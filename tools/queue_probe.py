@@ -41,7 +41,7 @@ for _ in range(3):
     res = pipe.runSweepFast(fs, eps, mps, cut=0)
 ts = (time.perf_counter() - t0) / 3
 steps = res[3]
-rs = sorted((pipe.CACHE.get(f) for f in fs), key=lambda r: -len(r.d))
+rs = sorted((pipe.CACHE.get(f) for f in fs), key=lambda r: -len(r))
 for r in rs:
     r.chrom.set_device_labels(True)
 
