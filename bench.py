@@ -441,12 +441,12 @@ def k2_replay(chrom, settings, served, passes=3):
 def roofline_block(replay, n_probe):
     """The region query (K2) on the probe chromosome, three ways:
       frac / achieved   AMORTISED over the runs of an eps the way the sweep executes it: the first run of an eps queries the whole
-                        base layout (k_region_core, counts bracketed for the sweep's minPts list), every run under a cut queries its
+                        base layout (k_region_keys, counts bracketed for the sweep's minPts list), every run under a cut queries its
                         cut band only (k_band, a kernel of its own between its own pair of events) and reads every other PET's word
                         in place: sum over the 12 runs of SURVEY 8d's algorithmic bytes N * 12 + (S + 2) * 4 / sum over the 12 runs
-                        of (k_region_core time + k_band time).  (Traversal levels <= 3 carry the words through the cut compaction
+                        of (k_region_keys time + k_band time).  (Traversal levels <= 3 carry the words through the cut compaction
                         instead: that cost = the difference of the sort-phase brackets against the pass without re-use.)
-      per_launch        the k_region_core launches that executed, each against the algorithmic bytes of the PETs it covered
+      per_launch        the k_region_keys launches that executed, each against the algorithmic bytes of the PETs it covered
       full_query        every run its own full query (cl_set_count_reuse(0)): the per-launch figure of rounds 1-3
     K2 is the only kernel between its two events; the bracket around an EMPTY kernel (event packets + dispatch gap, calibrated by
     the library) is taken out of every launch -- rocprofv3's kernel duration has no such term (profiles/README.md)."""
@@ -469,13 +469,13 @@ def roofline_block(replay, n_probe):
     tot = max(k2net + sum(carry), 1e-9)
     ach = b / (tot * 1e-3) / 1e9
     fb, _, fnet = agg(full)
-    # the launches of k_region_core that actually ran (the hardware figure next to the amortised one): bytes of the layout each covered
+    # the launches of k_region_keys that actually ran (the hardware figure next to the amortised one): bytes of the layout each covered
     launched = [r for r in rows if r[3].get("n_queried", 0) > 0 and net(r[3]) > 0]
     lb = sum(int(r[3]["n_queried"]) * 12 + int(r[3]["n_strips"]) * 4 for r in launched)
     lt = sum(net(r[3]) for r in launched)
     per_launch = {"launches": len(launched), "bytes": lb // max(1, len(launched)), "avg_launch_ms": lt / max(1, len(launched)),
                   "achieved": lb / max(lt * 1e-3, 1e-12) / 1e9, "frac": lb / max(lt * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
-                  "note": "the k_region_core launches that executed (one per eps: the whole base layout, counts bracketed for the sweep's minPts list), "
+                  "note": "the k_region_keys launches that executed (one per eps: the whole base layout, counts bracketed for the sweep's minPts list), "
                           "algorithmic bytes of the PETs each covered / its own duration"}
     per_eps = {}
     for ep in sorted({r[0] for r in rows}):
