@@ -324,6 +324,19 @@ k_layout_from_fine(int n, GridParams g, GridParams gf, int k, unsigned kmagic, i
     __shared__ int lq[LFF_CAP + LFF_PAD];
     const int t0 = blockIdx.x * LFF_T, t1 = min(n, t0 + LFF_T);
     if (t0 >= n) return;
+    // the tile's own PETs first: their loads depend on nothing but t0 and are in flight under the chain of dependent loads below
+    // (first / last strip -> table rows -> the staged runs)
+    constexpr int E = LFF_T / 256;
+    int q[E], spf[E], fbase[E], r[E], dst[E];
+    u32 row[E];
+    bool in[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = t0 + e * 256 + (int)threadIdx.x;
+        in[e] = i < t1;
+        const int ic = in[e] ? i : t0;
+        q[e] = fq[ic]; row[e] = frow[ic]; spf[e] = fsp[ic];
+    }
     // the strips (of width eps) the tile's first and last PET belong to are contiguous in the fine layout: [a, b) holds every run
     // any PET of the tile has to be ranked in
     const int sb_first = (((fsp[t0] >> gf.rbits) + gf.s0) / k) * k - gf.s0, sb_last = (((fsp[t1 - 1] >> gf.rbits) + gf.s0) / k) * k - gf.s0;
@@ -352,17 +365,6 @@ k_layout_from_fine(int n, GridParams g, GridParams gf, int k, unsigned kmagic, i
     __syncthreads();
     auto fst = [&](int f) { return slice ? lst[f - f_first] : fstrip[f]; };      // f in [f_first, f_end]
     // four PETs per thread, their searches side by side (every probe is a dependent round trip: four chains in flight)
-    constexpr int E = LFF_T / 256;
-    int q[E], spf[E], fbase[E], r[E], dst[E];
-    u32 row[E];
-    bool in[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = t0 + e * 256 + (int)threadIdx.x;
-        in[e] = i < t1;
-        const int ic = in[e] ? i : t0;
-        q[e] = fq[ic]; row[e] = frow[ic]; spf[e] = fsp[ic];
-    }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = t0 + e * 256 + (int)threadIdx.x;
