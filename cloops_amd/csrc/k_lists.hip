@@ -1466,6 +1466,19 @@ k_border_q(GridParams g, int ntiles, int npos, int kcap, const int* __restrict__
     if (w0 == w1) return;
     const int clo = max(cgrank[g0] - HC, 0), chi = min(cgrank[g1] + HC, C);
     if (threadIdx.x == 0) l_nq = 0;
+    // the first 256 walkers of the tile (usually all of them): record, then the rank index at its position and at both hints -- two
+    // dependent round trips that need nothing of the staged cores, issued in front of the staging loads instead of behind the barrier
+    int2 pf_me = make_int2(0, 0);
+    int pf_pos = 0, pf_enc = 0, pf_gr0 = 0, pf_gr1 = 0, pf_gr2 = 0;
+    unsigned long long pf_gm0 = 0, pf_gm1 = 0, pf_gm2 = 0;
+    {
+        const int h = w0 + (int)threadIdx.x;
+        if (h < w1) { pf_me = wpair[h]; pf_pos = wpos[h]; pf_enc = wenc[h]; }
+        const bool hinted = (unsigned)pf_enc != LH_NONE;
+        const int pa = hinted ? pf_pos - (int)((unsigned)pf_enc & 0xffffu) : pf_pos, pb = hinted ? pf_pos + (int)((unsigned)pf_enc >> 16) : pf_pos;
+        pf_gr0 = cgrank[pf_pos >> 6]; pf_gr1 = cgrank[pa >> 6]; pf_gr2 = cgrank[pb >> 6];
+        pf_gm0 = cmask[pf_pos >> 6]; pf_gm1 = cmask[pa >> 6]; pf_gm2 = cmask[pb >> 6];
+    }
     {
         // (every staging load of the thread in flight before the first LDS store: the rolled loop was a chain of round trips per tile)
         constexpr int SU = (WIN + 255) / 256;
@@ -1530,12 +1543,20 @@ k_border_q(GridParams g, int ntiles, int npos, int kcap, const int* __restrict__
         int ja = -1, jb = -1, r0 = -1, r1 = -1, r2 = -1, r3 = -1;
         int2 me = make_int2(0, 0);
         {
-            int pos = 0, enc = 0;
-            if (act) { me = wpair[h]; pos = wpos[h]; enc = wenc[h]; }
+            int pos = pf_pos, enc = pf_enc;
+            int gr0 = pf_gr0, gr1 = pf_gr1, gr2 = pf_gr2;
+            unsigned long long gm0 = pf_gm0, gm1 = pf_gm1, gm2 = pf_gm2;
+            me = pf_me;
+            if (i0 > 0) {                                 // (a tile with more than 256 walkers: the later rounds load behind the barrier)
+                pos = 0; enc = 0; me = make_int2(0, 0);
+                if (act) { me = wpair[h]; pos = wpos[h]; enc = wenc[h]; }
+            }
             const bool hinted = (unsigned)enc != LH_NONE;
             const int pa = hinted ? pos - (int)((unsigned)enc & 0xffffu) : pos, pb = hinted ? pos + (int)((unsigned)enc >> 16) : pos;
-            const int gr0 = cgrank[pos >> 6], gr1 = cgrank[pa >> 6], gr2 = cgrank[pb >> 6];
-            const unsigned long long gm0 = cmask[pos >> 6], gm1 = cmask[pa >> 6], gm2 = cmask[pb >> 6];
+            if (i0 > 0) {
+                gr0 = cgrank[pos >> 6]; gr1 = cgrank[pa >> 6]; gr2 = cgrank[pb >> 6];
+                gm0 = cmask[pos >> 6]; gm1 = cmask[pa >> 6]; gm2 = cmask[pb >> 6];
+            }
             const int c1 = gr0 + __popcll(gm0 & low_mask(pos & 63));
             ja = gr1 + __popcll(gm1 & low_mask(pa & 63));
             jb = gr2 + __popcll(gm2 & low_mask(pb & 63));
