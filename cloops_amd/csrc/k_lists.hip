@@ -808,6 +808,7 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
     const int lane = threadIdx.x & 63;
     const int nmask = ~(g.peps - 1);
     if (FUSE && threadIdx.x == 0) l_found = -1;
+    int pf_tb[NT / 256], pf_b[NT / 256];
     {
         // (every load of the thread in flight before the first LDS store: the rolled loop was WIN / 256 dependent round trips per tile)
         constexpr int SU = (WIN + 255) / 256;
@@ -819,6 +820,17 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
             const bool in = gi >= 0 && gi < C && u * 256 + (int)threadIdx.x < WIN;
             mv[u] = in ? cpair[gi] : (gi < 0 ? make_int2(0, INT_MIN) : make_int2(INT_MAX, INT_MAX));
             pvl[u] = (FUSE && lane == 0 && gi > 0 && gi < C) ? cpair[gi - 1] : make_int2(0, 0);      // the first lane of a wave reads its predecessor
+        }
+        // the rows of the cores-only strip table the thread's OWN cores will need for their windows (strip s-1 = [cstrip[s-1], cstrip[s])):
+        // requested as soon as their pairs are here, in flight while the tile makes its chains
+        if (HALO % 256 == 0) {
+#pragma unroll
+            for (int u2 = 0; u2 < NT / 256; ++u2) {
+                const int gi = t0 + u2 * 256 + (int)threadIdx.x;
+                const int s = mv[HALO / 256 + u2].y >> g.rbits;
+                const bool ok = gi < C && s > 0;
+                pf_tb[u2] = ok ? cstrip[s - 1] : 0; pf_b[u2] = ok ? cstrip[s] : 0;
+            }
         }
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
@@ -913,8 +925,9 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
             const int2 me = lw[i - base];
             A = lx[i - base];
             const int s = me.y >> g.rbits;
-            int tb = s > 0 ? cstrip[s - 1] : 0;
-            const int b = s > 0 ? cstrip[s] : 0;          // (strip 0 has nothing below: an empty range)
+            int tb, b;                                    // (strip 0 has nothing below: an empty range)
+            if (HALO % 256 == 0) { tb = u == 0 ? pf_tb[0] : pf_tb[NT / 256 - 1]; b = u == 0 ? pf_b[0] : pf_b[NT / 256 - 1]; }
+            else { tb = s > 0 ? cstrip[s - 1] : 0; b = s > 0 ? cstrip[s] : 0; }
             if (tb < b) {
                 const int qlo = me.x - g.eps, qhi = me.x + g.eps;
                 const int T = me.y - g.peps;             // every candidate lies one strip below: "within eps in p" is sp_j >= sp_i - peps
