@@ -42,61 +42,67 @@ __device__ __forceinline__ int tab_slot(int* keys, int key)
     }
     return -1;
 }
-// level 1 + insertion into the workgroup's LDS table (no barrier inside: may be called repeatedly)
-__device__ __forceinline__ void table_accumulate(const Table& t, TableLds& h, int lab, int x, int y)
+// Runs of equal values in the lanes of a wave, for a segmented reduction toward every run's LAST lane on the DPP network:
+// dist = lanes of the run in front of this lane, last = the run ends here.  (All 64 lanes must be active.)
+__device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }     // lane L <- lane L - 1 (lane 0 keeps its own)
+struct WaveRuns { int dist; bool last; };
+__device__ __forceinline__ WaveRuns wave_runs(int v)
 {
     const int lane = threadIdx.x & 63;
-    const unsigned long long pending = __ballot(lab >= 0);
-    if (!pending) return;
-    const int leader = __ffsll((long long)pending) - 1;
-    const int L = __builtin_amdgcn_readlane(lab, leader);
-    const unsigned long long m = __ballot(lab == L);
-    if (m == pending && __popcll(m) >= 16) {
-        // the wave lies inside one cluster: four reductions, one insertion
-        const bool mine = lab == L;
-        const int cm = __popcll(m);
-        int mnx = wave_min_i(mine ? x : INT_MAX), mxx = wave_max_i(mine ? x : INT_MIN);
-        int mny = wave_min_i(mine ? y : INT_MAX), mxy = wave_max_i(mine ? y : INT_MIN);
-        if (lane == leader) {
-            const int sl = tab_slot(h.key, L);
-            if (sl >= 0) {
-                atomicAdd(&h.cnt[sl], cm);
-                atomicMin(&h.mnx[sl], mnx); atomicMax(&h.mxx[sl], mxx);
-                atomicMin(&h.mny[sl], mny); atomicMax(&h.mxy[sl], mxy);
-            } else {
-                atomicAdd(&t.count[L], cm);
-                atomicMin(&t.minx[L], mnx); atomicMax(&t.maxx[L], mxx);
-                atomicMin(&t.miny[L], mny); atomicMax(&t.maxy[L], mxy);
-            }
-        }
-    } else {
-        // several clusters (and noise) in the wave.  Sorted order keeps a cluster's PETs of one strip in NEIGHBOURING lanes: the
-        // wave is cut into runs of equal labels, every run is reduced over its lanes (segmented shuffles: a lane takes the
-        // partial of the lane d further on while that lane still belongs to its run) and only the first lane of a run goes to
-        // the LDS table -- one set of atomics per run instead of one per PET, and no two lanes of a run on one LDS address.
-        const int prev = __shfl_up(lab, 1);
-        const bool brk = lane == 0 || prev != lab;
-        const unsigned long long B = __ballot(brk);
-        const unsigned long long rest = lane == 63 ? 0ull : (B >> (lane + 1));
-        const int nb = rest ? lane + __ffsll((long long)rest) : 64;        // first lane behind this lane's run
-        int mnx = x, mxx = x, mny = y, mxy = y;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int a = __shfl_down(mnx, d), b = __shfl_down(mxx, d), c = __shfl_down(mny, d), e = __shfl_down(mxy, d);
-            if (lane + d < nb) { mnx = min(mnx, a); mxx = max(mxx, b); mny = min(mny, c); mxy = max(mxy, e); }
-        }
-        if (brk && lab >= 0) {
-            const int cm = nb - lane;
-            const int sl = tab_slot(h.key, lab);
-            if (sl >= 0) {
-                atomicAdd(&h.cnt[sl], cm);
-                atomicMin(&h.mnx[sl], mnx); atomicMax(&h.mxx[sl], mxx);
-                atomicMin(&h.mny[sl], mny); atomicMax(&h.mxy[sl], mxy);
-            } else {
-                atomicAdd(&t.count[lab], cm);
-                atomicMin(&t.minx[lab], mnx); atomicMax(&t.maxx[lab], mxx);
-                atomicMin(&t.miny[lab], mny); atomicMax(&t.maxy[lab], mxy);
-            }
+    const int prev = wave_shr1(v);
+    const unsigned long long B = __ballot(lane == 0 || prev != v);
+    const int start = 63 - __clzll((long long)(B & (~0ull >> (63 - lane))));
+    WaveRuns r;
+    r.dist = lane - start;
+    r.last = lane == 63 || ((B >> (lane + 1)) & 1ull);
+    return r;
+}
+// one step of the segmented inclusive scan: lane L combines with the DPP source only if that lane belongs to its run.  A lane
+// the network gives nothing (row edge, masked row) reads its own value back, and min / max with oneself change nothing.
+#define SEG_STEP(ctrl, rowmask, cond, ...) seg_step_values<ctrl, rowmask>((cond), __VA_ARGS__)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ void seg_step_values(bool take, int& mn0, int& mx0, int& mn1, int& mx1)
+{
+    const int a = min(mn0, __builtin_amdgcn_update_dpp(mn0, mn0, CTRL, ROWMASK, 0xf, false));
+    const int b = max(mx0, __builtin_amdgcn_update_dpp(mx0, mx0, CTRL, ROWMASK, 0xf, false));
+    const int c = min(mn1, __builtin_amdgcn_update_dpp(mn1, mn1, CTRL, ROWMASK, 0xf, false));
+    const int d = max(mx1, __builtin_amdgcn_update_dpp(mx1, mx1, CTRL, ROWMASK, 0xf, false));
+    mn0 = take ? a : mn0; mx0 = take ? b : mx0; mn1 = take ? c : mn1; mx1 = take ? d : mx1;
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ void seg_step_min(bool take, int& m)
+{
+    const int a = min(m, __builtin_amdgcn_update_dpp(m, m, CTRL, ROWMASK, 0xf, false));
+    m = take ? a : m;
+}
+// level 1 + insertion into the workgroup's LDS table (no barrier inside: may be called repeatedly; by whole waves)
+__device__ __forceinline__ void table_accumulate(const Table& t, TableLds& h, int lab, int x, int y)
+{
+    if (!__any(lab >= 0)) return;
+    // Sorted order keeps a cluster's PETs of one strip in NEIGHBOURING lanes: the wave is cut into runs of equal labels (the
+    // inside of a large cluster: one run), every run is reduced toward its last lane -- row shifts, then the two row broadcasts,
+    // a lane taking a partial only from a lane of its own run -- and that lane alone goes to the LDS table: one set of atomics
+    // per run instead of one per PET, no two lanes of a run on one LDS address, and nothing through the LDS crossbar.
+    const int lane = threadIdx.x & 63;
+    const WaveRuns r = wave_runs(lab);
+    int mnx = x, mxx = x, mny = y, mxy = y;
+    SEG_STEP(0x111, 0xf, r.dist >= 1, mnx, mxx, mny, mxy);
+    SEG_STEP(0x112, 0xf, r.dist >= 2, mnx, mxx, mny, mxy);
+    SEG_STEP(0x114, 0xf, r.dist >= 4, mnx, mxx, mny, mxy);
+    SEG_STEP(0x118, 0xf, r.dist >= 8, mnx, mxx, mny, mxy);
+    SEG_STEP(0x142, 0xa, r.dist > (lane & 15), mnx, mxx, mny, mxy);            // row_bcast:15: the run began in front of this row
+    SEG_STEP(0x143, 0xc, r.dist > (lane & 31), mnx, mxx, mny, mxy);            // row_bcast:31: ... in front of this half
+    if (r.last && lab >= 0) {
+        const int cm = r.dist + 1;
+        const int sl = tab_slot(h.key, lab);
+        if (sl >= 0) {
+            atomicAdd(&h.cnt[sl], cm);
+            atomicMin(&h.mnx[sl], mnx); atomicMax(&h.mxx[sl], mxx);
+            atomicMin(&h.mny[sl], mny); atomicMax(&h.mxy[sl], mxy);
+        } else {
+            atomicAdd(&t.count[lab], cm);
+            atomicMin(&t.minx[lab], mnx); atomicMax(&t.maxx[lab], mxx);
+            atomicMin(&t.miny[lab], mny); atomicMax(&t.maxy[lab], mxy);
         }
     }
 }

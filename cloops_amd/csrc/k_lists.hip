@@ -132,7 +132,7 @@ k_classify(GridParams g, const int* __restrict__ sv, const int* __restrict__ sa,
         if (threadIdx.x == 0) l_hlast = -1;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int a = __shfl_up(q[u], 1), b = __shfl_up(sp[u], 1);
+            const int a = wave_shr1(q[u]), b = wave_shr1(sp[u]);      // (lane 0 reads its own value back: handled apart)
             if (lane != 0) { pq[u] = a; pp[u] = b; }
         }
     } else {
@@ -434,7 +434,7 @@ k_base_keys(GridParams g, int npos, const int* __restrict__ bq, const int* __res
     if (threadIdx.x == 0) l_hlast = -1;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const int a = __shfl_up(q[u], 1), b = __shfl_up(sp[u], 1);
+        const int a = wave_shr1(q[u]), b = wave_shr1(sp[u]);      // (lane 0 reads its own value back: handled apart)
         if (lane != 0) { pq[u] = a; pp[u] = b; }
         const int i = t0 + u * 256 + (int)threadIdx.x;
         const bool in = i < npos;
@@ -459,18 +459,19 @@ k_base_keys(GridParams g, int npos, const int* __restrict__ bq, const int* __res
             }
         if (i == min(t0 + LT, npos) - 1) l_hlast = pos[u];
     }
-    // a cell's PETs sit in neighbouring lanes: the wave is cut into runs of one cell, a run is reduced over its lanes (segmented
-    // shuffles) and its first lane alone goes to the cell's slot -- one LDS atomic per cell and wave instead of one per PET on one address
+    // a cell's PETs sit in neighbouring lanes: the wave is cut into runs of one cell, a run is reduced toward its last lane (on the
+    // DPP network) and that lane alone goes to the cell's slot -- one LDS atomic per cell and wave instead of one per PET on one address
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const int prev = __shfl_up(pos[u], 1);
-        const unsigned long long B = __ballot(lane == 0 || prev != pos[u]);
-        const unsigned long long rest = lane == 63 ? 0ull : (B >> (lane + 1));
-        const int nb = rest ? lane + __ffsll((long long)rest) : 64;        // first lane behind this lane's run
+        const WaveRuns w = wave_runs(pos[u]);
         int m = pos[u] >= t0 ? (int)row[u] : INT_MAX;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int a = __shfl_down(m, d); if (lane + d < nb) m = min(m, a); }
-        if (((B >> lane) & 1ull) && pos[u] >= t0) atomicMin(&lmin[pos[u] - t0], m);
+        seg_step_min<0x111, 0xf>(w.dist >= 1, m);
+        seg_step_min<0x112, 0xf>(w.dist >= 2, m);
+        seg_step_min<0x114, 0xf>(w.dist >= 4, m);
+        seg_step_min<0x118, 0xf>(w.dist >= 8, m);
+        seg_step_min<0x142, 0xa>(w.dist > (lane & 15), m);
+        seg_step_min<0x143, 0xc>(w.dist > (lane & 31), m);
+        if (w.last && pos[u] >= t0) atomicMin(&lmin[pos[u] - t0], m);
     }
     __syncthreads();
     const int tend = t0 + LT;
@@ -843,7 +844,7 @@ k_union_c(GridParams g, int ntiles, const int* __restrict__ lcnt, const int2* __
             else {
                 // does the staged core open a chain?  (entries in front of core 0 never do, entries behind the last core always.)  The
                 // predecessor's pair comes from the lane in front
-                int2 pv = make_int2(__shfl_up(me.x, 1), __shfl_up(me.y, 1));
+                int2 pv = make_int2(wave_shr1(me.x), wave_shr1(me.y));
                 if (lane == 0 && gi > 0 && gi < C) pv = pvl[u];
                 const bool o = gi <= 0 ? gi == 0 : (gi >= C || (pv.y & nmask) != (me.y & nmask) || pv.x < me.x - g.eps);
                 const unsigned long long ob = __ballot(o);
@@ -1163,40 +1164,25 @@ k_flatten_c(const int* __restrict__ lcnt, const int* __restrict__ chainid, const
     if (!(abl & (1 << 20)))
 #pragma unroll
     for (int e = 0; e < FLC_PER; ++e) {
-        const unsigned long long pending = __ballot(r[e] >= 0);
-        if (pending) {
-            const int leader = __ffsll((long long)pending) - 1;
-            const int R = __builtin_amdgcn_readlane(r[e], leader);
-            const unsigned long long m = __ballot(r[e] == R);
-            if (m == pending && __popcll(m) >= 16) {
-                // a wave of one component (the inside of a large cluster): one reduction, one insertion by its first lane
-                int mk = r[e] == R ? key[e] : INT_MAX;
-                mk = dpp_reduce_wave(mk, OpMin());
-                if (lane == leader) {
-                    const int sl = agg_slot(hkey, R);
-                    if (sl >= 0) { atomicMin(&hmin[sl], mk); atomicAdd(&hcnt[sl], __popcll(m)); }
-                    else { atomicMin(&compkey[R], mk); atomicAdd(&ncore[R], __popcll(m)); }
-                }
-            } else {
-                // cores follow each other in layout order: the cores of a component come in RUNS (chains; neighbouring chains of a
-                // cluster).  A run of equal roots is reduced inside the wave (segmented min over six shuffles, the length from
-                // the head flags) and its last lane alone goes to the table -- a handful of LDS atomics per wave instead of 64 pairs
-                const int rv = r[e];
-                const int prev = __shfl_up(rv, 1);
-                const unsigned long long hb = __ballot(lane == 0 || prev != rv);
-                const int start = 63 - __clzll((long long)(hb & (~0ull >> (63 - lane))));
-                const unsigned long long above = lane == 63 ? 0ull : (hb & (~0ull << (lane + 1)));
-                const int end = above ? __ffsll((long long)above) - 2 : 63;
-                int mk = key[e];
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(mk, d); if (lane - d >= start) mk = min(mk, v); }
-                if (lane == end && rv >= 0) {
-                    const int cntv = end - start + 1;
-                    const int sl = agg_slot(hkey, rv);
-                    if (sl >= 0) { if (mk != INT_MAX) atomicMin(&hmin[sl], mk); atomicAdd(&hcnt[sl], cntv); }
-                    else { if (mk != INT_MAX) atomicMin(&compkey[rv], mk); atomicAdd(&ncore[rv], cntv); }
-                }
-            }
+        if (!__any(r[e] >= 0)) continue;
+        // cores follow each other in layout order: the cores of a component come in RUNS (chains; neighbouring chains of a
+        // cluster; the inside of a large cluster: the whole wave).  A run of equal roots is reduced toward its last lane on the
+        // DPP network (wave_runs / seg_step_min of cl_table.h: row shifts, then the two row broadcasts) and that lane alone
+        // goes to the table -- a handful of LDS atomics per wave instead of 64 pairs
+        const int rv = r[e];
+        const WaveRuns w = wave_runs(rv);
+        int mk = key[e];
+        seg_step_min<0x111, 0xf>(w.dist >= 1, mk);
+        seg_step_min<0x112, 0xf>(w.dist >= 2, mk);
+        seg_step_min<0x114, 0xf>(w.dist >= 4, mk);
+        seg_step_min<0x118, 0xf>(w.dist >= 8, mk);
+        seg_step_min<0x142, 0xa>(w.dist > (lane & 15), mk);
+        seg_step_min<0x143, 0xc>(w.dist > (lane & 31), mk);
+        if (w.last && rv >= 0) {
+            const int cntv = w.dist + 1;
+            const int sl = agg_slot(hkey, rv);
+            if (sl >= 0) { if (mk != INT_MAX) atomicMin(&hmin[sl], mk); atomicAdd(&hcnt[sl], cntv); }
+            else { if (mk != INT_MAX) atomicMin(&compkey[rv], mk); atomicAdd(&ncore[rv], cntv); }
         }
     }
     __syncthreads();
