@@ -22,7 +22,10 @@ __device__ __forceinline__ int wave_max_i(int v) { return dpp_reduce_wave(v, OpM
 // Cluster table (pipe.py:78-102) by the two-level reduce-by-key above; called by all threads
 // of a BIGTPB workgroup (sorted order keeps a cluster's PETs in neighbouring lanes, so a wave
 // usually carries a handful of labels).
-#define TAB_H 512
+#ifndef TAB_BITS
+#define TAB_BITS 9
+#endif
+#define TAB_H (1 << TAB_BITS)
 struct TableLds { int key[TAB_H], cnt[TAB_H], mnx[TAB_H], mxx[TAB_H], mny[TAB_H], mxy[TAB_H]; };
 
 __device__ __forceinline__ void table_lds_init(TableLds& h)
@@ -34,7 +37,7 @@ __device__ __forceinline__ void table_lds_init(TableLds& h)
 }
 __device__ __forceinline__ int tab_slot(int* keys, int key)
 {
-    unsigned h = ((unsigned)key * 2654435761u) >> 23;            // 9 bits = log2(TAB_H)
+    unsigned h = ((unsigned)key * 2654435761u) >> (32 - TAB_BITS);
     for (int probe = 0; probe < 16; ++probe) {
         const int old = atomicCAS(&keys[h], -1, key);
         if (old == -1 || old == key) return (int)h;

@@ -1834,7 +1834,7 @@ k_emit_records_w(GridParams g, const int* __restrict__ lcnt, const unsigned long
 // caller has filled the array with -1: .labels of the reference holds clustered points only, cDBSCAN2.py:186-191); the
 // cluster table {minX, maxX, minY, maxY, count} by the two-level reduce-by-key of cl_table.h (pipe.py:78-102).
 #ifndef LF_CHUNKS
-#define LF_CHUNKS 4
+#define LF_CHUNKS 2           // (2048 items per workgroup: 8 -> 79 us, 4 -> 61, 2 -> 53, 1 -> 57 per chr1 run -- the flush of a workgroup's table is a tail nothing overlaps but other workgroups)
 #endif
 __global__ void __launch_bounds__(BIGTPB)
 k_final_lists(GridParams g, const int* __restrict__ lcnt, const int2* __restrict__ cpair, const int* __restrict__ cpos,
