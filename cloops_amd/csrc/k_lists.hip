@@ -592,7 +592,7 @@ k_make_lists_q(GridParams g, int npos, int bandq, const int* __restrict__ bq, co
     __shared__ int l_red[2][4];
     const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
     const int t0 = blk * LT;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;      // (a wave-uniform wv -- group words by scalar loads, 63 instead of 109 registers, 7 waves per SIMD instead of 4 -- measured 83 against 80 us: the kernel is bound by its bytes, not by what is in flight)
     // A tile is a chain of dependent round trips (masks -> keys / hints; tile sums -> places -> stores), and a chromosome is eight
     // rounds of resident workgroups: the loads are issued as early as their addresses are known -- q and sp of every position
     // with the masks (nearly every 64-byte line holds a listed PET anyway), keys / hints and the rows of the boundary cells as
@@ -1103,26 +1103,29 @@ __global__ void k_union_overflow(GridParams g, const int* __restrict__ counters,
 //   variant 1: key = smallest input row of a core = the component's start point (cDBSCAN.py:134-137)
 //   variant 2: key = smallest cellfirst over the cells holding its cores (cDBSCAN2.py:117-140)
 // both arrive as ckey[c] (k_make_lists); two-level reduce-by-key as in k_flatten (cloops_hip.hip)
+#ifndef FLC_TPB
+#define FLC_TPB BIGTPB
+#endif
 #ifndef FLC_PER
 #define FLC_PER 4          // cores per thread of k_flatten_c
 #endif
-__global__ void __launch_bounds__(BIGTPB)
+__global__ void __launch_bounds__(FLC_TPB)
 k_flatten_c(const int* __restrict__ lcnt, const int* __restrict__ chainid, const int* __restrict__ parent, const int* __restrict__ ckey,
             int* __restrict__ croot, int* __restrict__ compkey,
             int* __restrict__ ncore, int* __restrict__ rootlist, int* __restrict__ counters, int abl)
 {
     __shared__ int hkey[AGG_H], hmin[AGG_H], hcnt[AGG_H];
     __shared__ int l_nroot, l_rootbase;
-    if (threadIdx.x < AGG_H) { hkey[threadIdx.x] = -1; hmin[threadIdx.x] = INT_MAX; hcnt[threadIdx.x] = 0; }
+    for (int k = threadIdx.x; k < AGG_H; k += FLC_TPB) { hkey[k] = -1; hmin[k] = INT_MAX; hcnt[k] = 0; }
     if (threadIdx.x == 0) l_nroot = 0;
     __syncthreads();
     const int C = lcnt[0];
-    if ((int)blockIdx.x * BIGTPB * FLC_PER >= C) return;
+    if ((int)blockIdx.x * FLC_TPB * FLC_PER >= C) return;
     int ii[FLC_PER], r[FLC_PER], key[FLC_PER], x[FLC_PER];
     bool in[FLC_PER];
 #pragma unroll
     for (int e = 0; e < FLC_PER; ++e) {
-        ii[e] = (blockIdx.x * FLC_PER + e) * BIGTPB + (int)threadIdx.x;
+        ii[e] = (blockIdx.x * FLC_PER + e) * FLC_TPB + (int)threadIdx.x;
         in[e] = ii[e] < C;
         x[e] = in[e] ? chainid[ii[e]] : -1;
         key[e] = in[e] ? ckey[ii[e]] : INT_MAX;
@@ -1186,10 +1189,11 @@ k_flatten_c(const int* __restrict__ lcnt, const int* __restrict__ chainid, const
         }
     }
     __syncthreads();
-    if (threadIdx.x < AGG_H && hkey[threadIdx.x] >= 0) {
-        atomicMin(&compkey[hkey[threadIdx.x]], hmin[threadIdx.x]);
-        atomicAdd(&ncore[hkey[threadIdx.x]], hcnt[threadIdx.x]);
-    }
+    for (int k = threadIdx.x; k < AGG_H; k += FLC_TPB)
+        if (hkey[k] >= 0) {
+            atomicMin(&compkey[hkey[k]], hmin[k]);
+            atomicAdd(&ncore[hkey[k]], hcnt[k]);
+        }
     if (threadIdx.x == 0) l_rootbase = l_nroot ? atomicAdd(&counters[CTR_NROOT], l_nroot) : 0;
     __syncthreads();
 #pragma unroll
@@ -1833,10 +1837,13 @@ k_emit_records_w(GridParams g, const int* __restrict__ lcnt, const unsigned long
 // distance statistics K7 read: d = q + V0; noise never entered a list); labels[row] = label only for labelled items (the
 // caller has filled the array with -1: .labels of the reference holds clustered points only, cDBSCAN2.py:186-191); the
 // cluster table {minX, maxX, minY, maxY, count} by the two-level reduce-by-key of cl_table.h (pipe.py:78-102).
+#ifndef LF_TPB
+#define LF_TPB BIGTPB
+#endif
 #ifndef LF_CHUNKS
 #define LF_CHUNKS 2           // (2048 items per workgroup: 8 -> 79 us, 4 -> 61, 2 -> 53, 1 -> 57 per chr1 run -- the flush of a workgroup's table is a tail nothing overlaps but other workgroups)
 #endif
-__global__ void __launch_bounds__(BIGTPB)
+__global__ void __launch_bounds__(LF_TPB)
 k_final_lists(GridParams g, const int* __restrict__ lcnt, const int2* __restrict__ cpair, const int* __restrict__ cpos,
               const int* __restrict__ croot, const int2* __restrict__ wpair, const int* __restrict__ wpos,
               const int* __restrict__ wowner, const int* __restrict__ rlabel, const u32* __restrict__ srow,
@@ -1851,7 +1858,7 @@ k_final_lists(GridParams g, const int* __restrict__ lcnt, const int2* __restrict
     int2 pr[LF_CHUNKS];
 #pragma unroll
     for (int ch = 0; ch < LF_CHUNKS; ++ch) {
-        idx[ch] = (blockIdx.x * LF_CHUNKS + ch) * BIGTPB + threadIdx.x;
+        idx[ch] = (blockIdx.x * LF_CHUNKS + ch) * LF_TPB + threadIdx.x;
         const int k = idx[ch];
         own[ch] = -1; pos[ch] = 0; pr[ch] = make_int2(0, 0);
         if (k < C) { own[ch] = croot[k]; pr[ch] = cpair[k]; pos[ch] = (labels || pairs) ? cpos[k] : 0; }
@@ -1881,26 +1888,26 @@ k_final_lists(GridParams g, const int* __restrict__ lcnt, const int2* __restrict
         // compacted -- ONE counter bump per workgroup (a bump per wave put 120 k same-address atomics with a return value into a
         // chr1 run), 8 contiguous bytes per lane.  (Written straight into page-locked host memory the kernel ran at 20 GB/s of
         // PCIe and held the compute stream.)
-        __shared__ int l_pc[LF_CHUNKS * (BIGTPB / 64)];
+        __shared__ int l_pc[LF_CHUNKS * (LF_TPB / 64)];
         __shared__ int l_pbase;
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         unsigned long long bals[LF_CHUNKS];
 #pragma unroll
         for (int ch = 0; ch < LF_CHUNKS; ++ch) {
             bals[ch] = __ballot(lab[ch] >= 0);
-            if (lane == 0) l_pc[ch * (BIGTPB / 64) + wv] = __popcll(bals[ch]);
+            if (lane == 0) l_pc[ch * (LF_TPB / 64) + wv] = __popcll(bals[ch]);
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             int tot = 0;
-            for (int k = 0; k < LF_CHUNKS * (BIGTPB / 64); ++k) { const int v = l_pc[k]; l_pc[k] = tot; tot += v; }      // (exclusive, in place)
+            for (int k = 0; k < LF_CHUNKS * (LF_TPB / 64); ++k) { const int v = l_pc[k]; l_pc[k] = tot; tot += v; }      // (exclusive, in place)
             l_pbase = tot ? atomicAdd(pair_count, tot) : 0;
         }
         __syncthreads();
 #pragma unroll
         for (int ch = 0; ch < LF_CHUNKS; ++ch) {
             if (lab[ch] < 0) continue;
-            const int at = l_pbase + l_pc[ch * (BIGTPB / 64) + wv] + lane_rank(bals[ch]);
+            const int at = l_pbase + l_pc[ch * (LF_TPB / 64) + wv] + lane_rank(bals[ch]);
             if (at < pairs_cap) pairs[at] = make_int2((int)srow[pos[ch]], lab[ch]);
         }
     }
@@ -2119,7 +2126,7 @@ int lists_union_flatten(cl_chrom* c, const GridParams& g, int nm, const ListRun&
     }
 #endif
 #undef LU_ARGS
-    hipLaunchKernelGGL(k_flatten_c, dim3(nblocks(nm, BIGTPB * FLC_PER)), dim3(BIGTPB), 0, c->stream, L.lcnt, (const int*)c->chainflag.as<int>(),
+    hipLaunchKernelGGL(k_flatten_c, dim3(nblocks(nm, FLC_TPB * FLC_PER)), dim3(FLC_TPB), 0, c->stream, L.lcnt, (const int*)c->chainflag.as<int>(),
                        (const int*)c->parent.as<int>(), (const int*)L.ckey, croot_of(c),
                        c->compkey.as<int>(), c->ncore.as<int>(), c->rootlist.as<int>(), c->counters.as<int>(), (int)g.dbg2);
     HIP_TRY(hipGetLastError());
@@ -2190,7 +2197,7 @@ int lists_scatter_owner(cl_chrom* c, int nm, const ListRun& L)
 int lists_final(cl_chrom* c, const GridParams& g, int nm, const ListRun& L, bool rows, int* pair_count)
 {
     cl_chrom::Slot& sl = c->slot[c->cur];
-    hipLaunchKernelGGL(k_final_lists, dim3(nblocks(nm, BIGTPB * LF_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, L.lcnt, (const int2*)L.cpair, (const int*)L.cpos,
+    hipLaunchKernelGGL(k_final_lists, dim3(nblocks(nm, LF_TPB * LF_CHUNKS)), dim3(LF_TPB), 0, c->stream, g, L.lcnt, (const int2*)L.cpair, (const int*)L.cpos,
                        (const int*)croot_of(c), (const int2*)L.wpair, (const int*)L.wpos, (const int*)c->owner.as<int>(), (const int*)c->chainhead.as<int>(),
                        (const u32*)c->srow, (rows && !c->pairs_out) ? sl.labels.as<int>() : (int*)nullptr, sl.slab.as<int>(), c->l_dist.as<int>(), make_table(c),
                        c->pairs_out ? sl.pairs.as<int2>() : (int2*)nullptr, (int)std::min<long long>(c->pairs_cap, INT_MAX), pair_count);
