@@ -20,7 +20,9 @@
 #pragma once
 #include "cl_common.h"
 
+#ifndef KB_SB              // (strips per wave; 2 / 4 / 6 / 8 measured 35 / 23 / 20 / 19 us against 17 for 12 on a chr1 run: the cost is per wave, not per strip)
 #define KB_SB 12
+#endif
 #define KB_CAP 512
 
 // the band PETs of one wave's strips, 64 per round.  LDSP: the strip prefixes are staged in lw (else: global memory, base layout)
