@@ -592,7 +592,7 @@ k_make_lists_q(GridParams g, int npos, int bandq, const int* __restrict__ bq, co
     __shared__ int l_red[2][4];
     const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
     const int t0 = blk * LT;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;      // (a wave-uniform wv -- group words by scalar loads, 63 instead of 109 registers, 7 waves per SIMD instead of 4 -- measured 83 against 80 us: the kernel is bound by its bytes, not by what is in flight)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;      // (a wave-uniform wv -- group words by scalar loads, 63 instead of 109 registers, 7 waves per SIMD instead of 4 -- measured 83 against 80 us; q and sp read for LISTED positions only, behind the masks, with a band mask from k_classify_q: 82 + 6 us more in k_classify_q -- the kernel is bound neither by what is in flight nor by those bytes)
     // A tile is a chain of dependent round trips (masks -> keys / hints; tile sums -> places -> stores), and a chromosome is eight
     // rounds of resident workgroups: the loads are issued as early as their addresses are known -- q and sp of every position
     // with the masks (nearly every 64-byte line holds a listed PET anyway), keys / hints and the rows of the boundary cells as
