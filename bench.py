@@ -545,6 +545,22 @@ def with_labels_sweep(pipe, fs, steps, pets_per_sweep, reps=2):
             r.chrom.pairs_sync()
         return nlab
 
+    def sweep_mask():
+        nlab = 0
+        for k, st in enumerate(steps):
+            for r in res:
+                r.chrom.cluster_rowmask_async(VARIANT, st["eps"], st["minPts"], st["cut_in"], want_boxes=True)
+            if k > 0:
+                for r in res:
+                    nlab += int(r.chrom.wait_rowmask(defer=True)[2].shape[0])
+                for r in res:
+                    r.chrom.pairs_sync()
+        for r in res:
+            nlab += int(r.chrom.wait_rowmask(defer=True)[2].shape[0])
+        for r in res:
+            r.chrom.pairs_sync()
+        return nlab
+
     def sweep_rows():
         nlab = 0
         for k, st in enumerate(steps):
@@ -563,16 +579,22 @@ def with_labels_sweep(pipe, fs, steps, pets_per_sweep, reps=2):
         for _ in range(reps):
             k = fn()
         return (time.perf_counter() - t0) / reps, k
-    dt, nlab = timed(sweep_pairs)
+    dt_pairs, nlab_pairs = timed(sweep_pairs)
+    dt, nlab = timed(sweep_mask)
+    assert nlab == nlab_pairs, (nlab, nlab_pairs)
+    mask_bytes = len(steps) * sum(8 * ((len(r) + 63) // 64) for r in res)
     for r in res:
         r.chrom.set_device_labels(True)
     dt_rows, nrows = timed(sweep_rows)
     for r in res:
         r.chrom.set_device_labels(False)
     return {"sweep_wall_s": dt, "value": pets_per_sweep / dt, "unit": "PETs/s", "runs": len(steps), "labelled_pets_to_host_per_sweep": nlab,
-            "bytes_to_host_per_sweep": 8 * nlab,
-            "end_point": "(row, label) int32 pairs of every CLUSTERED PET (the reference's `.labels` holds nothing else) + the cluster table of every run in "
-                         "pinned host memory (SURVEY.md 8d(1)); cuts = the chain of the timed sweeps; no statistics / candidate work on the device",
+            "bytes_to_host_per_sweep": 4 * nlab + mask_bytes,
+            "end_point": "the CLUSTERED PETs of every run (the reference's `.labels` holds nothing else) as one bit per input row + their int32 labels in "
+                         "ascending row order (cl_cluster_rowmask_async) + the cluster table of every run in pinned host memory (SURVEY.md 8d(1)); "
+                         "cuts = the chain of the timed sweeps; no statistics / candidate work on the device",
+            "pairs": {"sweep_wall_s": dt_pairs, "value": pets_per_sweep / dt_pairs, "bytes_to_host_per_sweep": 8 * nlab_pairs,
+                      "end_point": "the same set as (row, label) int32 pairs in no particular order (cl_cluster_pairs_async): 8 bytes per clustered PET, PCIe-bound"},
             "row_aligned": {"sweep_wall_s": dt_rows, "value": pets_per_sweep / dt_rows, "labels_to_host_per_sweep": nrows, "bytes_to_host_per_sweep": 4 * nrows,
                             "end_point": "row-aligned int32 labels of EVERY PET (-1 = not clustered) + the cluster table of every run"}}
 

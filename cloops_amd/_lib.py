@@ -30,7 +30,7 @@ SYMBOLS = [
     "cl_get_timing", "cl_version", "cl_host_alloc", "cl_host_free", "cl_cluster_async", "cl_wait", "cl_boxes_host",
     "cl_dist_summary", "cl_dist_bin_hist", "cl_last_n_in", "cl_sig_counts", "cl_cluster_weighted",
     "cl_set_layout_reuse", "cl_set_sort_index", "cl_set_device_labels", "cl_set_table_export", "cl_cand_reset", "cl_cand_append", "cl_cand_finish", "cl_cluster_step_async", "cl_step_result",
-    "cl_set_count_reuse", "cl_set_count_floor", "cl_set_count_thresholds", "cl_set_eps_list", "cl_chrom_set_stream", "cl_last_region_mode", "cl_debug_arena_overcommit", "cl_chrom_subsample", "cl_stream_create", "cl_stream_destroy", "cl_set_traversal", "cl_cand_finish_device", "cl_cluster_pairs_async", "cl_last_n_labelled", "cl_set_pairs_defer", "cl_pairs_sync", "cl_sweep_plan", "cl_chrom_drop_indexes",
+    "cl_set_count_reuse", "cl_set_count_floor", "cl_set_count_thresholds", "cl_set_eps_list", "cl_chrom_set_stream", "cl_last_region_mode", "cl_debug_arena_overcommit", "cl_chrom_subsample", "cl_stream_create", "cl_stream_destroy", "cl_set_traversal", "cl_cand_finish_device", "cl_cluster_pairs_async", "cl_cluster_rowmask_async", "cl_last_n_labelled", "cl_set_pairs_defer", "cl_pairs_sync", "cl_sweep_plan", "cl_chrom_drop_indexes",
 ]
 
 
@@ -123,6 +123,8 @@ def load():
     lib.cl_cand_finish.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int64, i64p]
     lib.cl_cluster_pairs_async.restype = ctypes.c_int
     lib.cl_cluster_pairs_async.argtypes = [vp, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, ctypes.c_int64]
+    lib.cl_cluster_rowmask_async.restype = ctypes.c_int
+    lib.cl_cluster_rowmask_async.argtypes = [vp, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, ctypes.c_int64]
     lib.cl_set_pairs_defer.restype = None
     lib.cl_set_pairs_defer.argtypes = [vp, ctypes.c_int]
     lib.cl_pairs_sync.restype = ctypes.c_int

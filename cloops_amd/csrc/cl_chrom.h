@@ -142,6 +142,8 @@ struct cl_chrom {
     int2* pairs_out = nullptr;        // cl_cluster_pairs_async: (row, label) of every labelled PET, staged by the label kernel in the slot's
     long long pairs_cap = 0;          // device buffer and copied by cl_wait into the caller's page-locked buffer (their count: header word 6)
     bool pairs_defer = false, pairs_copy_pending = false;      // cl_set_pairs_defer / cl_pairs_sync
+    void* mask_out = nullptr;         // cl_cluster_rowmask_async: one bit per row + the labels of the set rows in row order, made on the device from the
+    long long mask_cap = 0;           // row-aligned labels (k_rowmask_count / k_rowmask_write) in the slot's `pairs` buffer, copied out by cl_wait like the pairs
     bool l4_make_base = false;        // level 4: the run makes the words of its eps -- K2 on the base layout, launched behind the band query
     bool l4_cut = false;              // level 4: the run has a cut (the per-strip tables of k_cut_strips apply)
     bool l4_band = false;             // ... and re-uses counts under another cut (the band's words are fresh: c->cnt, by run position)
@@ -179,6 +181,8 @@ struct cl_chrom {
         DevBuf pairs;                 // cl_cluster_pairs_async: (row, label) of the labelled PETs on the device (copied out by cl_wait: their number is
         int2* pairs_host = nullptr;   //   only known when the run has completed)
         long long pairs_host_cap = 0; //   the caller's capacity (pairs): cl_wait refuses a run that labelled more
+        void* mask_host = nullptr;    // cl_cluster_rowmask_async: the caller's buffer (mask words, then labels) and its capacity in labels
+        long long mask_host_cap = 0;
         bool exported = true;         // the table rows were stored to h_boxes
         bool step_valid = false;      // the run carried the sweep-step tail (classification, candidate append, distance summary)
         bool host_written = false;    // ... and its last kernel stored header + step output in pinned host memory itself
@@ -281,6 +285,7 @@ int lists_border(cl_chrom* c, const GridParams& g, int nm, const ListRun& L);
 int lists_emit_records(cl_chrom* c, const GridParams& g, int nm, const ListRun& L);
 int lists_scatter_owner(cl_chrom* c, int nm, const ListRun& L);
 int lists_final(cl_chrom* c, const GridParams& g, int nm, const ListRun& L, bool rows, int* pair_count);
+int lists_rowmask(cl_chrom* c, int* total);
 
 // kernels of k_sweep.hip that the step tail (finish_enqueue) launches
 __global__ void __launch_bounds__(256)

@@ -3413,6 +3413,20 @@ static int finish_wait(cl_chrom* c, int32_t* n_clusters, int32_t* max_label)
             else HIP_TRY(hipStreamSynchronize(c->aux_stream));
         }
     }
+    if (sl.mask_host) {
+        // cl_cluster_rowmask_async: ceil(n / 64) mask words, then one label per set bit (their number: header word 6), one copy
+        void* dst = sl.mask_host;
+        sl.mask_host = nullptr;
+        const long long kp = sl.h_hdr[6];
+        if (kp > sl.mask_host_cap)
+            return fail(CL_ERR_ARG, "cl_cluster_rowmask_async: the run labelled more PETs than capacity_labels (n always suffices)");
+        if (sl.h_hdr[1] == 0) {
+            const size_t nw = (size_t)((c->n + 63) / 64);
+            HIP_TRY(hipMemcpyAsync(dst, sl.pairs.p, nw * 8 + (size_t)kp * 4, hipMemcpyDeviceToHost, c->aux_stream));
+            if (c->pairs_defer) c->pairs_copy_pending = true;
+            else HIP_TRY(hipStreamSynchronize(c->aux_stream));
+        }
+    }
     if (sl.h_hdr[1] != 0)
         return fail(CL_ERR_HIP, sl.h_hdr[1] == 8 ? "internal: the number of PETs that passed the cut differs from the host's count"
                                 : sl.h_hdr[1] == 4 ? "internal: strip longer than the hybrid sort accepts"
@@ -3516,6 +3530,18 @@ extern "C" int cl_cluster_pairs_async(cl_chrom* c, int variant, int32_t eps, int
     c->pairs_cap = capacity_pairs;
     const int rc = cl_cluster_async(c, variant, eps, min_pts, cut, nullptr);
     c->pairs_out = nullptr; c->pairs_cap = 0;
+    return rc;
+}
+extern "C" int cl_cluster_rowmask_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut, void* pinned_out, int64_t capacity_labels)
+{
+    if (!c) return fail(CL_ERR_ARG, "null chromosome handle");
+    if (!pinned_out || capacity_labels <= 0) return fail(CL_ERR_ARG, "cl_cluster_rowmask_async: no output buffer");
+    if (variant != CL_VARIANT_CDBSCAN1 && variant != CL_VARIANT_CDBSCAN2) return fail(CL_ERR_ARG, "cl_cluster_rowmask_async: rotated variants only");
+    if (c->traversal < 3 || min_pts < 2 || min_pts > 128) return fail(CL_ERR_ARG, "cl_cluster_rowmask_async: needs the list form of the run (traversal level >= 3, minPts 2 .. 128)");
+    c->mask_out = pinned_out;
+    c->mask_cap = capacity_labels;
+    const int rc = cl_cluster_async(c, variant, eps, min_pts, cut, nullptr);
+    c->mask_out = nullptr; c->mask_cap = 0;
     return rc;
 }
 extern "C" void cl_set_pairs_defer(cl_chrom* c, int enabled) { if (c) c->pairs_defer = enabled != 0; }
@@ -3662,7 +3688,7 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
     c->init_nclr = nw + 1;
     // row-aligned labels only when somebody reads them: k_final_labels then writes the label (or -1) of every PET that
     // entered DBSCAN and only the rows removed by the cut filter need the -1 fill
-    const bool rows = labels_out != nullptr || c->device_labels || c->pairs_out != nullptr;
+    const bool rows = labels_out != nullptr || c->device_labels || c->pairs_out != nullptr || c->mask_out != nullptr;
     // how far the run works on lists (k_lists.hip; cl_set_traversal): 0 = tile kernels over every PET, 1 = K3 on the core list,
     // 2 = + the border rule on the walker list, 3 = + labels / table / distance list from the lists (only labelled PETs are
     // written: the row-aligned array is filled with -1 first)
@@ -3784,8 +3810,13 @@ static int run_rotated(cl_chrom* c, int variant, int eps, int minPts, int cut, i
         if (c->pairs_out && (rc = c->slot[c->cur].pairs.ensure((size_t)std::max<long long>(c->pairs_cap, 1) * 8))) return rc;
         if ((rc = lists_final(c, g, nm, L, rows, c->hdr.as<int>() + 16 * c->cur + 6))) return rc;
         cl_chrom::Slot& sl = c->slot[c->cur];
+        sl.mask_host = c->mask_out; sl.mask_host_cap = c->mask_cap;
+        // (cl_cluster_rowmask_async: the row-aligned labels the kernel above has just written -> mask words + labels in row order,
+        //  their number in header word 6 like the pairs')
+        if (c->mask_out && (rc = lists_rowmask(c, c->hdr.as<int>() + 16 * c->cur + 6))) return rc;
         sl.k7_lcnt = L.lcnt; sl.k7_sv = c->l_dist.as<int>();      // the distance statistics read the run's lists (K7Src::sorted == 2)
     } else {
+        if (c->mask_out) return fail(CL_ERR_ARG, "cl_cluster_rowmask_async: this run did not take the list form");
         if (level == 2 && (rc = lists_scatter_owner(c, nm, L))) return rc;
         if (!SKIP(8)) hipLaunchKernelGGL(k_final_labels, dim3(nblocks(nm, BIGTPB * FINAL_CHUNKS)), dim3(BIGTPB), 0, c->stream, g, strip, sv, sa, srow,
                        level == 2 ? c->l_aux.as<int>() : c->owner.as<int>(),

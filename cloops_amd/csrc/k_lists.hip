@@ -2205,6 +2205,99 @@ int lists_final(cl_chrom* c, const GridParams& g, int nm, const ListRun& L, bool
     return CL_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// cl_cluster_rowmask_async: the labels of a run as ONE BIT PER ROW + the labels of the set rows in row order
+// ------------------------------------------------------------------------------------------
+// The reference's `.labels` holds the clustered points only (cDBSCAN2.py:186-191).  As (row, label) pairs that is 8 bytes per
+// clustered PET over PCIe -- what bounds a label-inclusive sweep; as a bit per row and a label per set bit it is 4 bytes + 1/8
+// byte per row, and the rows come back sorted.  Made from the run's row-aligned labels (-1 = not clustered) in two passes over
+// 2048-row tiles: mask words + tile totals (+ the totals of 16-tile superblocks, one atomic nobody waits for), then the places.
+#define RM_T 2048
+__global__ void __launch_bounds__(256)
+k_rowmask_count(int n, const int* __restrict__ labels, unsigned long long* __restrict__ mask, int* __restrict__ tsum,
+                unsigned long long* __restrict__ sup, int* __restrict__ total)
+{
+    __shared__ int l_c[4];
+    const int t0 = (int)blockIdx.x * RM_T;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int lab[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int r = t0 + u * 256 + (int)threadIdx.x; lab[u] = r < n ? labels[r] : -1; }
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const unsigned long long bal = __ballot(lab[u] >= 0);
+        if (lane == 0 && t0 + u * 256 + wv * 64 < n) mask[(t0 >> 6) + u * 4 + wv] = bal;
+        cnt += __popcll(bal);
+    }
+    if (lane == 0) l_c[wv] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = l_c[0] + l_c[1] + l_c[2] + l_c[3];
+        tsum[blockIdx.x] = tot;
+        if (tot) { atomicAdd(&sup[blockIdx.x >> 4], (unsigned long long)tot); atomicAdd(total, tot); }
+    }
+}
+__global__ void __launch_bounds__(256)
+k_rowmask_write(int n, const int* __restrict__ labels, const unsigned long long* __restrict__ mask, const int* __restrict__ tsum,
+                const unsigned long long* __restrict__ sup, int* __restrict__ out, long long cap)
+{
+    __shared__ long long l_red[4];
+    __shared__ int l_goff[RM_T / 64];
+    const int blk = (int)blockIdx.x, t0 = blk * RM_T;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int lab[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int r = t0 + u * 256 + (int)threadIdx.x; lab[u] = r < n ? labels[r] : -1; }
+    // set rows in front of this tile: the superblocks in front of its own + the tiles of its own in front of it
+    long long pc = 0;
+    const int sb = blk >> 4;
+    for (int k = threadIdx.x; k < sb; k += 256) pc += (long long)sup[k];
+    if (threadIdx.x < 16) { const int k = sb * 16 + (int)threadIdx.x; if (k < blk) pc += tsum[k]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pc += __shfl_down(pc, o);
+    if (lane == 0) l_red[wv] = pc;
+    // the tile's 32 groups in row order: group k = u * 4 + wv holds rows t0 + 64 k ..
+    if (threadIdx.x < 64) {
+        const int k = lane & 31;
+        const int gi = (t0 >> 6) + k;
+        const int v = (lane < 32 && (long long)gi * 64 < n) ? __popcll(mask[gi]) : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) { const int t = __shfl_up(incl, d, 32); incl += k >= d ? t : 0; }
+        if (lane < 32) l_goff[k] = incl - v;
+    }
+    __syncthreads();
+    const long long base = l_red[0] + l_red[1] + l_red[2] + l_red[3];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const unsigned long long bal = __ballot(lab[u] >= 0);
+        if (lab[u] >= 0) {
+            const long long dst = base + l_goff[u * 4 + wv] + __popcll(bal & low_mask(lane));
+            if (dst < cap) out[dst] = lab[u];
+        }
+    }
+}
+// the slot's `pairs` buffer in this form: mask words | labels (capacity) | tile sums | superblock sums
+int lists_rowmask(cl_chrom* c, int* total)
+{
+    cl_chrom::Slot& sl = c->slot[c->cur];
+    const long long n = c->n;
+    const size_t nw = (size_t)((n + 63) / 64), ntile = (size_t)((n + RM_T - 1) / RM_T), nsup = ntile / 16 + 1;
+    const size_t cap = (size_t)std::max<long long>(c->mask_cap, 1);
+    const size_t o_lab = nw * 8, o_tsum = ((o_lab + cap * 4 + 255) / 256) * 256, o_sup = ((o_tsum + ntile * 4 + 255) / 256) * 256;
+    int rc = sl.pairs.ensure(o_sup + nsup * 8 + 256);
+    if (rc) return rc;
+    char* p = (char*)sl.pairs.p;
+    HIP_TRY(hipMemsetAsync(p + o_sup, 0, nsup * 8, c->stream));
+    hipLaunchKernelGGL(k_rowmask_count, dim3((unsigned)ntile), dim3(256), 0, c->stream, (int)n, (const int*)sl.labels.as<int>(), (unsigned long long*)p,
+                       (int*)(p + o_tsum), (unsigned long long*)(p + o_sup), total);
+    hipLaunchKernelGGL(k_rowmask_write, dim3((unsigned)ntile), dim3(256), 0, c->stream, (int)n, (const int*)sl.labels.as<int>(), (const unsigned long long*)p,
+                       (const int*)(p + o_tsum), (const unsigned long long*)(p + o_sup), (int*)(p + o_lab), (long long)c->mask_cap);
+    HIP_TRY(hipGetLastError());
+    return CL_OK;
+}
+
 #ifdef CLOOPS_DEVEL
 // developer build: one list kernel of the LAST run on its own, `reps` times between two events (its inputs are still in place;
 // CLOOPS_DBG2 ablations apply).  which: 0 k_classify, 1 k_make_lists, 2 k_chain_c, 3 k_union_c, 4 k_border_w, 5 k_final_lists

@@ -237,6 +237,16 @@ int cl_cand_reset(cl_chrom* c);
 int cl_cluster_pairs_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut, int32_t* pinned_pairs_out,
                            int64_t capacity_pairs);
 int64_t cl_last_n_labelled(const cl_chrom* c);
+/* The same set -- the clustered points and their cluster ids, what cDBSCAN(mat, eps, minPts).labels holds (cDBSCAN2.py:186-191,
+ * cDBSCAN.py:143-152) -- in its smallest form: ceil(n / 64) 64-bit mask words (bit r % 64 of word r / 64 set <=> input row r is
+ * clustered), followed by one int32 label per set bit in ASCENDING ROW ORDER.  4 bytes per clustered PET + n / 8 bytes cross PCIe
+ * instead of 8 bytes per clustered PET: the label-inclusive sweep is bound by that copy.  `pinned_out` (page-locked host memory:
+ * cl_host_alloc) must hold 8 * ceil(n / 64) + 4 * capacity_labels bytes; cl_wait copies the mask and exactly
+ * cl_last_n_labelled(c) labels (a run that labels MORE than capacity_labels PETs makes cl_wait return CL_ERR_ARG and copies
+ * nothing; n always suffices); cl_set_pairs_defer / cl_pairs_sync apply to this copy as well.  Same restrictions as
+ * cl_cluster_pairs_async. */
+int cl_cluster_rowmask_async(cl_chrom* c, int variant, int32_t eps, int32_t min_pts, int32_t cut, void* pinned_out,
+                             int64_t capacity_labels);
 /* cl_set_pairs_defer(c, 1): cl_wait of a pairs run returns with the copy of the pairs to the host still in flight (their number
  * is known: cl_last_n_labelled); cl_pairs_sync(c) completes it.  A host that collects many chromosomes waits for all of them
  * first and syncs afterwards, so that their copies cross PCIe side by side. */

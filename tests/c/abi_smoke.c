@@ -154,6 +154,27 @@ int main(void)
         CHECK(cl_cluster(c, CL_VARIANT_CDBSCAN2, 2000, 5, 0, lab, &nc, &ml));     /* the handle is still usable */
         printf("pairs capacity: refused\n");
     }
+    {
+        /* the same labels as one bit per row + the labels of the set rows in row order (cl_cluster_rowmask_async) */
+        const size_t nw = (size_t)((n + 63) / 64);
+        unsigned char* pin = (unsigned char*)cl_host_alloc((int64_t)(8 * nw + 4 * (size_t)n));
+        if (!pin) return 50;
+        CHECK(cl_cluster(c, CL_VARIANT_CDBSCAN2, 2000, 5, 0, lab, &nc, &ml));
+        CHECK(cl_cluster_rowmask_async(c, CL_VARIANT_CDBSCAN2, 2000, 5, 0, pin, n));
+        int32_t nc3 = 0, ml3 = -1;
+        CHECK(cl_wait(c, &nc3, &ml3));
+        const unsigned long long* mask = (const unsigned long long*)pin;
+        const int32_t* rl = (const int32_t*)(pin + 8 * nw);
+        int64_t k = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            const int set = (int)((mask[i >> 6] >> (i & 63)) & 1ull);
+            if (set != (lab[i] >= 0)) { fprintf(stderr, "rowmask: bit of row %lld\n", (long long)i); return 51; }
+            if (set && rl[k++] != lab[i]) { fprintf(stderr, "rowmask: label of row %lld\n", (long long)i); return 52; }
+        }
+        if (k != cl_last_n_labelled(c) || nc3 != nc) return 53;
+        cl_host_free(pin);
+        printf("rowmask: %lld labelled rows, bits and labels equal to cl_cluster\n", (long long)k);
+    }
     if (cl_cluster(c, 7, 2000, 5, 0, lab, &nc, &ml) != CL_ERR_ARG) return 8;          /* unknown variant */
     if (cl_cluster(c, CL_VARIANT_CDBSCAN2, 0, 5, 0, lab, &nc, &ml) != CL_ERR_ARG) return 9;   /* eps = 0 */
     cl_chrom_destroy(c);

@@ -114,3 +114,77 @@ def test_pairs_form_equals_row_aligned_labels(variant):
     finally:
         ch.close()
         ref.close()
+
+
+@pytest.mark.parametrize("variant", ["v2", "v1"])
+def test_rowmask_form_equals_row_aligned_labels(variant):
+    """cl_cluster_rowmask_async: one bit per row + the labels of the set rows in ascending row order -- the clustered points of
+    the reference's `.labels` (cDBSCAN2.py:186-191) -- reassemble to exactly the row-aligned labels of cl_cluster, run after run
+    on two result slots, with the copy deferred (cl_set_pairs_defer / cl_pairs_sync) and not"""
+    if api.TRAVERSAL_OVERRIDE is not None and int(api.TRAVERSAL_OVERRIDE) < 3:
+        pytest.skip("the row-mask form needs the list form of a run (traversal level >= 3)")
+    X, Y = synth_chrom(N + 37, 46709983, 41)               # (a last mask word that is not full)
+    ref = api.Chromosome(X, Y)
+    ch = api.Chromosome(X, Y)
+
+    def check(setting, defer):
+        e0, m0, c0 = setting
+        res, mask, labels = ch.wait_rowmask(defer=defer)
+        if defer:
+            ch.pairs_sync()
+        want = ref.cluster(variant, e0, m0, c0)
+        rows = ch.rows_of_mask(mask)
+        assert len(mask) == (len(X) + 63) // 64
+        assert np.array_equal(rows, np.flatnonzero(want.labels >= 0)), setting
+        assert np.array_equal(labels, want.labels[rows]), setting
+        assert res.n_clusters == want.n_clusters
+    try:
+        pending = []
+        for k, setting in enumerate(((2000, 5, 0), (5000, 20, 0), (5000, 10, 3000), (5000, 10, 4500), (800, 3, 0))):
+            ch.cluster_rowmask_async(variant, *setting)
+            pending.append(setting)
+            if len(pending) == 2:
+                check(pending.pop(0), defer=bool(k & 1))
+        while pending:
+            check(pending.pop(0), defer=False)
+    finally:
+        ch.close()
+        ref.close()
+
+
+def test_rowmask_form_on_tiny_and_empty_results():
+    """fewer rows than one mask word; a run that clusters nothing (all bits clear, no labels); a capacity below the labelled count
+    is an argument error at cl_wait, not an overrun"""
+    if api.TRAVERSAL_OVERRIDE is not None and int(api.TRAVERSAL_OVERRIDE) < 3:
+        pytest.skip("the row-mask form needs the list form of a run (traversal level >= 3)")
+    import ctypes
+    from cloops_amd import _lib
+    rng = np.random.default_rng(5)
+    X = np.sort(rng.integers(1000, 3000, 40)).astype(np.int32)
+    Y = (X + rng.integers(100, 400, 40)).astype(np.int32)
+    ch = api.Chromosome(X, Y)
+    try:
+        want = ch.cluster("v2", 500, 3, 0)
+        ch.cluster_rowmask_async("v2", 500, 3, 0)
+        res, mask, labels = ch.wait_rowmask()
+        rows = ch.rows_of_mask(mask)
+        assert len(mask) == 1 and np.array_equal(rows, np.flatnonzero(want.labels >= 0)) and np.array_equal(labels, want.labels[rows])
+        assert len(rows) > 0
+        ch.cluster_rowmask_async("v2", 1, 30, 0)               # nothing can cluster
+        res, mask, labels = ch.wait_rowmask()
+        assert res.n_clusters == 0 and int(mask[0]) == 0 and len(labels) == 0
+        # capacity below the labelled count: CL_ERR_ARG at cl_wait
+        lib = _lib.load()
+        p = lib.cl_host_alloc(8 + 4 * 40)
+        try:
+            _lib.check(lib.cl_cluster_rowmask_async(ch._h, api.VARIANTS["v2"], 500, 3, 0, ctypes.c_void_p(p), 1))
+            nc, ml = ctypes.c_int32(0), ctypes.c_int32(-1)
+            rc = lib.cl_wait(ch._h, ctypes.byref(nc), ctypes.byref(ml))
+            assert rc != 0 and b"capacity_labels" in lib.cl_last_error()
+        finally:
+            lib.cl_host_free(ctypes.c_void_p(p))
+        # the handle still works
+        again = ch.cluster("v2", 500, 3, 0)
+        assert np.array_equal(again.labels, want.labels)
+    finally:
+        ch.close()
