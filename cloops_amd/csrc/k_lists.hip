@@ -2215,7 +2215,7 @@ int lists_final(cl_chrom* c, const GridParams& g, int nm, const ListRun& L, bool
 #define RM_T 2048
 __global__ void __launch_bounds__(256)
 k_rowmask_count(int n, const int* __restrict__ labels, unsigned long long* __restrict__ mask, int* __restrict__ tsum,
-                unsigned long long* __restrict__ sup, int* __restrict__ total)
+                unsigned long long* __restrict__ sup)
 {
     __shared__ int l_c[4];
     const int t0 = (int)blockIdx.x * RM_T;
@@ -2235,12 +2235,12 @@ k_rowmask_count(int n, const int* __restrict__ labels, unsigned long long* __res
     if (threadIdx.x == 0) {
         const int tot = l_c[0] + l_c[1] + l_c[2] + l_c[3];
         tsum[blockIdx.x] = tot;
-        if (tot) { atomicAdd(&sup[blockIdx.x >> 4], (unsigned long long)tot); atomicAdd(total, tot); }
+        if (tot) atomicAdd(&sup[blockIdx.x >> 4], (unsigned long long)tot);      // (a bump of ONE total by every tile cost 80 us: 8 000 atomics on one address)
     }
 }
 __global__ void __launch_bounds__(256)
 k_rowmask_write(int n, const int* __restrict__ labels, const unsigned long long* __restrict__ mask, const int* __restrict__ tsum,
-                const unsigned long long* __restrict__ sup, int* __restrict__ out, long long cap)
+                const unsigned long long* __restrict__ sup, int* __restrict__ out, long long cap, int* __restrict__ total)
 {
     __shared__ long long l_red[4];
     __shared__ int l_goff[RM_T / 64];
@@ -2269,6 +2269,7 @@ k_rowmask_write(int n, const int* __restrict__ labels, const unsigned long long*
     }
     __syncthreads();
     const long long base = l_red[0] + l_red[1] + l_red[2] + l_red[3];
+    if (blk == (int)gridDim.x - 1 && threadIdx.x == 0) *total = (int)(base + tsum[blk]);      // the run's labelled PETs: header word 6
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const unsigned long long bal = __ballot(lab[u] >= 0);
@@ -2291,9 +2292,9 @@ int lists_rowmask(cl_chrom* c, int* total)
     char* p = (char*)sl.pairs.p;
     HIP_TRY(hipMemsetAsync(p + o_sup, 0, nsup * 8, c->stream));
     hipLaunchKernelGGL(k_rowmask_count, dim3((unsigned)ntile), dim3(256), 0, c->stream, (int)n, (const int*)sl.labels.as<int>(), (unsigned long long*)p,
-                       (int*)(p + o_tsum), (unsigned long long*)(p + o_sup), total);
+                       (int*)(p + o_tsum), (unsigned long long*)(p + o_sup));
     hipLaunchKernelGGL(k_rowmask_write, dim3((unsigned)ntile), dim3(256), 0, c->stream, (int)n, (const int*)sl.labels.as<int>(), (const unsigned long long*)p,
-                       (const int*)(p + o_tsum), (const unsigned long long*)(p + o_sup), (int*)(p + o_lab), (long long)c->mask_cap);
+                       (const int*)(p + o_tsum), (const unsigned long long*)(p + o_sup), (int*)(p + o_lab), (long long)c->mask_cap, total);
     HIP_TRY(hipGetLastError());
     return CL_OK;
 }
